@@ -1,0 +1,313 @@
+"""CPU oracle for the NLS / MSV / transforms half of the hot path.  TEST INFRASTRUCTURE ONLY.
+
+This is a NumPy float64 restatement of the reference's algorithms, written from their behaviour.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it; the
+product (``velocity_amd``) never does.
+
+Pinning: every function here is checked against the reference's own implementation (imported from
+``/root/reference`` in the build container by ``tests/gen_golden.py``) through the committed golden
+vectors in ``tests/golden/nls_golden.npz`` -- see ``tests/test_oracle_nls.py``.
+
+Conventions (reference: row-vector / MATLAB layout):
+  * intrinsics ``K = [[fx,0,0],[s,fy,0],[cx,cy,1]]``  (utils/images.py:148-151)
+  * camera frame ``b = pw @ R + t``                   (utils/common.py:58-64)
+  * pixel ``uv = (b @ K)[:, :2] / (b @ K)[:, 2:3]``    (utils/NLS.py:71-78, utils/common.py:145-147)
+"""
+import itertools
+import math
+
+import numpy as np
+
+FD_STEP = 1e-6  # forward-difference step, utils/NLS.py:110,149,218 ; utils/MSV.py:21
+
+
+# ----------------------------------------------------------------------------------------------------
+# small helpers (utils/common.py:13-39,145-147)
+# ----------------------------------------------------------------------------------------------------
+def l2(x, axis=None):
+    """Euclidean norm, utils/common.py:13-15."""
+    return np.sqrt((x * x).sum(axis))
+
+
+def rms(x, axis=None):
+    """Root mean square, utils/common.py:18-20."""
+    return np.sqrt((x * x).mean(axis))
+
+
+def hom1(x):
+    """Append a column of ones (utils/common.py:35-39)."""
+    return np.concatenate([x, np.ones((x.shape[0], 1), x.dtype)], axis=1)
+
+
+def hom0(x):
+    """Append a column of zeros (utils/common.py:28-32)."""
+    return np.concatenate([x, np.zeros((x.shape[0], 1), x.dtype)], axis=1)
+
+
+def dehom(q):
+    """Divide the first two columns by the third (pscale, utils/common.py:145-147)."""
+    return q[:, 0:2] / q[:, 2:3]
+
+
+def project_cam(b, K):
+    """Pixels of camera-frame points ``b`` (fzK, utils/NLS.py:71-78)."""
+    return dehom(b @ K)
+
+
+# ----------------------------------------------------------------------------------------------------
+# rotations (utils/transforms.py:7-23, 51-57)
+# ----------------------------------------------------------------------------------------------------
+def rpy_to_dcm(rpy):
+    """Roll/pitch/yaw -> direction-cosine matrix used as a RIGHT multiplier (transforms.py:7-23)."""
+    r, p, y = float(rpy[0]), float(rpy[1]), float(rpy[2])
+    sr, cr, sp, cp, sy, cy = math.sin(r), math.cos(r), math.sin(p), math.cos(p), math.sin(y), math.cos(y)
+    return np.array(
+        [
+            [cp * cy, sr * sp * cy - cr * sy, cr * sp * cy + sr * sy],
+            [cp * sy, sr * sp * sy + cr * cy, cr * sp * sy - sr * cy],
+            [-sp, sr * cp, cr * cp],
+        ]
+    )
+
+
+def dcm_to_rpy(R):
+    """Inverse of :func:`rpy_to_dcm` with the reference's atan/asin/atan2 choice (transforms.py:51-57)."""
+    return np.array([math.atan(R[2, 1] / R[2, 2]), math.asin(-R[2, 0]), math.atan2(R[1, 0], R[0, 0])])
+
+
+# ----------------------------------------------------------------------------------------------------
+# projections (utils/common.py:49-64, 122-126)
+# ----------------------------------------------------------------------------------------------------
+def world_to_image(K, R, t, pw):
+    """utils/common.py:58-64."""
+    cam = np.concatenate([R, np.asarray(t)[None]]) @ K
+    return dehom(hom1(pw) @ cam)
+
+
+def image_to_world(K, R, t, p):
+    """Back-project pixels onto the world plane Z=0 (utils/common.py:49-55)."""
+    H = np.concatenate([R[0:2, :], np.asarray(t)[None]]) @ K
+    q = hom1(p) @ np.linalg.inv(H)
+    return q[:, 0:2] / q[:, 2:3]
+
+
+def pixel_to_uvec(K, p):
+    """Unit rays through pixels (utils/common.py:122-126)."""
+    q = hom0(p - K[2, 0:2])
+    q[:, 2] = K[0, 0]
+    return q / np.sqrt((q * q).sum(1, keepdims=True))
+
+
+def plate_world_points(country="EU"):
+    """Licence-plate corner model (utils/common.py:150-156)."""
+    size = [0.3725, 0.1275, 0] if country == "Chile" else [0.520, 0.110, 0]
+    sign = np.array([[1, -1, 0], [1, 1, 0], [-1, 1, 0], [-1, -1, 0]], np.float32)
+    return sign * np.array(size, np.float32) / 2
+
+
+# ----------------------------------------------------------------------------------------------------
+# Levenberg-Marquardt core shared by all solvers (constant +I damping, forward differences)
+# ----------------------------------------------------------------------------------------------------
+def _lm_update(JT, r, gain):
+    """delta = inv(J^T J + I) J^T r * gain   (utils/NLS.py:121-122,173-174,235 ; utils/MSV.py:34-36)."""
+    A = JT @ JT.T + np.eye(JT.shape[0])
+    return np.linalg.inv(A) @ JT @ r * gain
+
+
+def nls_t(K, p, pw, x, return_info=False):
+    """3-DoF translation fit (fcnNLS_t, utils/NLS.py:102-129).
+
+    Step ramp min((0.2(i+1))^2, 1) (:122), stop rms(delta) < 1e-8 (:124), <= 30 iterations (:114).
+    Returns float32 like the reference (:129).
+    """
+    x = np.asarray(x, float).copy()
+    n = pw.shape[0]
+    z = p.reshape(-1)
+    steps = np.eye(3) * FD_STEP
+    it, converged = 0, False
+    for it in range(30):
+        b0 = pw + x
+        zhat = project_cam(b0, K).reshape(-1)
+        JT = np.stack([project_cam(b0 + steps[k], K).reshape(-1) for k in range(3)])
+        JT = (JT - zhat) / FD_STEP
+        delta = _lm_update(JT, z - zhat, min(((it + 1) * 0.2) ** 2, 1))
+        x = x + delta
+        if rms(delta) < 1e-8:
+            converged = True
+            break
+    out = x.astype(np.float32)
+    return (out, it + 1, converged) if return_info else out
+
+
+def nls_rt(K, p, pw, x, return_info=False):
+    """6-DoF pose fit, x=[roll,pitch,yaw,tx,ty,tz] (fcnNLS_Rt, utils/NLS.py:133-183)."""
+    x = np.asarray(x, float).copy()
+    z = p.reshape(-1)
+    steps = np.eye(3) * FD_STEP
+    it, converged = 0, False
+    for it in range(30):
+        ang, tr = x[:3], x[3:6]
+        a0 = pw @ rpy_to_dcm(ang)
+        zhat = project_cam(a0 + tr, K).reshape(-1)
+        rows = [project_cam(pw @ rpy_to_dcm(ang + steps[k]) + tr, K).reshape(-1) for k in range(3)]
+        rows += [project_cam(a0 + (tr + steps[k]), K).reshape(-1) for k in range(3)]
+        JT = (np.stack(rows) - zhat) / FD_STEP
+        delta = _lm_update(JT, z - zhat, min(((it + 1) * 0.2) ** 2, 1))
+        x = x + delta
+        if rms(delta) < 1e-8:
+            converged = True
+            break
+    R = rpy_to_dcm(x[:3]).astype(np.float32)
+    t = x[3:6].astype(np.float32)
+    return (R, t, it + 1, converged) if return_info else (R, t)
+
+
+def estimate_world_camera_pose(K, p, p3, t=np.array([0, 0, 1]), R=np.eye(3), findR=False):
+    """estimateWorldCameraPose, utils/NLS.py:9-33."""
+    x0 = np.concatenate((dcm_to_rpy(R), t))
+    if findR is True:
+        R, t = nls_rt(K.astype(float), p.astype(float), p3, x0)
+    else:
+        t = nls_t(K.astype(float), p.astype(float), p3, t)
+    p_proj = world_to_image(K, R, t, p3)
+    return t, R, rms(p - p_proj), p_proj
+
+
+# ----------------------------------------------------------------------------------------------------
+# multi-view triangulation (utils/MSV.py:8-49, 98-142, 146-175)
+# ----------------------------------------------------------------------------------------------------
+def two_view_intercept(A, U):
+    """Mean of pairwise closest-approach points over all frame pairs (fcn2vintercept, MSV.py:98-142).
+
+    A: [nf,3] ray origins; U: [3,nf,nv] unit ray directions.  Returns [nv,3].
+    """
+    _, nf, nv = U.shape
+    pairs = np.array(list(itertools.combinations(range(nf), 2)))
+    j, k = pairs[:, 0], pairs[:, 1]
+    dA = A[j] - A[k]  # [npairs,3]
+    uj, uk = U[:, j], U[:, k]  # [3,npairs,nv]
+    d = (uj * uk).sum(0)
+    e = (uj * dA.T[:, :, None]).sum(0)
+    f = (uk * dA.T[:, :, None]).sum(0)
+    g = 1 - d * d
+    s1 = (d * f - e) / g
+    t1 = (f - d * e) / g
+    num = (t1 * uk + s1 * uj).sum(1)  # [3,nv]
+    base = A.sum(0) * (nf - 1)
+    return ((num + base[:, None]) / (2 * len(pairs))).T.copy()
+
+
+def n_view_intercept(A, U):
+    """Least-squares intersection of nf rays per point (fcnNvintercept, MSV.py:146-175)."""
+    _, nf, nv = U.shape
+    out = np.zeros((nv, 3))
+    for i in range(nv):
+        S1 = np.zeros((3, 3))
+        S2 = np.zeros(3)
+        for f in range(nf):
+            u = U[:, f, i]
+            V = np.eye(3) - np.outer(u, u)
+            S1 += V
+            S2 += V @ A[f]
+        out[i] = np.linalg.inv(S1) @ S2
+    return out
+
+
+def msv1_t(K, P, B, vg, ii, return_info=False):
+    """LM over the last camera translation with re-triangulation inside (fcnMSV1_t, MSV.py:8-49)."""
+    nf = ii + 1
+    ng = int(vg.sum())
+    U = np.zeros((3, nf, ng))
+    for j in range(nf):
+        U[:, j] = pixel_to_uvec(K, P[0:2, vg, j].T).T
+    u0 = B[0, 0:3] - B[:nf, 0:3]
+    x = np.array([0, 0, 1]) - u0[nf - 2]
+    z = P[0:2, vg, ii].T.reshape(-1)
+    steps = np.eye(3) * FD_STEP
+    it, converged, b0 = 0, False, None
+    for it in range(1000):
+        b0 = two_view_intercept(np.vstack((u0[:-1], -x)), U) + x
+        zhat = project_cam(b0, K).reshape(-1)
+        JT = np.stack([project_cam(b0 + steps[k], K).reshape(-1) for k in range(3)])
+        JT = (JT - zhat) / FD_STEP
+        delta = _lm_update(JT, z - zhat, 1.0)
+        x = x + delta
+        if rms(delta) < 1e-8:
+            converged = True
+            break
+    out = x.astype(np.float32)
+    return (out, b0, it + 1, converged) if return_info else (out, b0)
+
+
+# ----------------------------------------------------------------------------------------------------
+# dense bundle adjustment (fcnNLS_batch, utils/NLS.py:186-250)
+# ----------------------------------------------------------------------------------------------------
+def ba_predict(x, K, nc, nt):
+    """zhat ordering [all u | all v], camera-major / track-minor (NLS.py:206-216)."""
+    pw = x[: nt * 3].reshape(nt, 3)
+    cams = [pw]
+    for c in range(nc):
+        ia = nt * 3 + c * 3
+        ib = ia + nc * 3
+        cams.append(pw @ rpy_to_dcm(x[ib : ib + 3]) + x[ia : ia + 3])
+    uv = project_cam(np.concatenate(cams, 0), K)
+    return np.concatenate([uv[:, 0], uv[:, 1]])
+
+
+def ba_pack(K, P, pw, cw):
+    """Track filter, measurement vector z and initial state x of fcnNLS_batch (NLS.py:190-203)."""
+    keep = np.isfinite(P[4]).sum(1) == P.shape[2]
+    P, pw = P[:, keep], pw[keep]
+    _, nt, nf = P.shape
+    nc = nf - 1
+    u = P[0].T.reshape(-1)  # camera-major, track-minor
+    v = P[1].T.reshape(-1)
+    z = np.concatenate([u, v]).astype(float)
+    bad = np.isnan(z)
+    z[bad] = 0
+    x = np.concatenate((pw, cw[1:], np.zeros((nc, 3)))).reshape(-1).astype(float)
+    return z, bad, x, nt, nc
+
+
+def ba_jacobian_fd(x, K, nc, nt, zhat):
+    """Dense forward-difference J^T [nx, nz] (NLS.py:228-233)."""
+    nx = x.size
+    JT = np.zeros((nx, zhat.size))
+    for j in range(nx):
+        x1 = x.copy()
+        x1[j] += FD_STEP
+        JT[j] = ba_predict(x1, K, nc, nt)
+    return (JT - zhat) / FD_STEP
+
+
+def nls_batch(K, P, pw, cw, max_iter=10, return_info=False):
+    """Dense full bundle adjustment over points and cameras 1..nc (fcnNLS_batch, NLS.py:186-250)."""
+    K = K.astype(float)
+    z, bad, x, nt, nc = ba_pack(K, P, pw, cw)
+    trace = []
+    for it in range(max_iter):
+        zhat = ba_predict(x, K, nc, nt)
+        zhat[bad] = 0
+        JT = ba_jacobian_fd(x, K, nc, nt, zhat)
+        delta = np.linalg.inv(JT @ JT.T + np.eye(x.size)) @ JT @ (z - zhat) * 0.9
+        x = x + delta
+        trace.append((rms(z - zhat), rms(delta)))
+        if rms(delta) < 1e-7:
+            break
+    j = nt * 3
+    pw_out = x[:j].reshape(nt, 3)
+    cw_out = np.concatenate((np.zeros((1, 3)), x[j : j + nc * 3].reshape(nc, 3)), 0)
+    if return_info:
+        return cw_out, pw_out, x, np.array(trace)
+    return cw_out, pw_out
+
+
+# ----------------------------------------------------------------------------------------------------
+# driver bookkeeping (vidExample.py:125-129,135-136,139,151-153,159-160)
+# ----------------------------------------------------------------------------------------------------
+def bookkeeping_step(vg, vp, v):
+    """vg[vg] = v ; vp &= vg ; returns (vg, vp, pose_sel) with pose_sel = vp[vg] (vidExample.py:135-139)."""
+    vg = vg.copy()
+    vg[vg] = v
+    vp = vp & vg
+    return vg, vp, vp[vg]

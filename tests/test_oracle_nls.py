@@ -1,0 +1,101 @@
+"""Pins oracle/nls_oracle.py against the reference's own outputs (tests/golden/nls_golden.npz,
+produced by tests/gen_golden.py running /root/reference's NumPy code)."""
+import numpy as np
+import pytest
+
+from oracle import nls_oracle as O
+
+
+def close(a, b, rtol=1e-12, atol=1e-12):
+    np.testing.assert_allclose(np.asarray(a, float), np.asarray(b, float), rtol=rtol, atol=atol)
+
+
+def test_rotations(golden):
+    for rpy, dcm, back in zip(golden["rot_rpy"], golden["rot_dcm"], golden["rot_rpy_back"]):
+        close(O.rpy_to_dcm(rpy), dcm)
+        close(O.dcm_to_rpy(O.rpy_to_dcm(rpy)), back)
+    # SURVEY Appendix C anchor
+    close(O.rpy_to_dcm([0.1, 0.2, 0.3])[0], [0.9362933636, -0.2750958473, 0.2183506631], rtol=0, atol=1e-9)
+
+
+def test_projection_helpers(golden):
+    K = golden["K32"].astype(float)
+    close(O.project_cam(golden["fzK_in"], K), golden["fzK_out"])
+    close(O.project_cam(golden["fzK_in"], K), [[1010.3473114014, 440.8053771973], [1209.7365570068, 665.1182785034]], rtol=0, atol=1e-9)
+    close(O.world_to_image(K, golden["w2i_R"], golden["w2i_t"], golden["fzK_in"]), golden["w2i_out"])
+    close(O.pixel_to_uvec(K, golden["uvec_in"]), golden["uvec_out"])
+    close(O.image_to_world(K, golden["i2w_R"], golden["i2w_t"], golden["i2w_in"]), golden["i2w_out"], rtol=1e-10)
+    assert np.array_equal(O.plate_world_points("Chile"), golden["plate_chile"])
+    assert np.array_equal(O.plate_world_points("EU"), golden["plate_eu"])
+
+
+@pytest.mark.parametrize("key", ["IMG_4134", "IMG_4119"])
+def test_plate_pose_real_corners(golden, key):
+    K32 = golden["K32"]
+    t, R, res, proj = O.estimate_world_camera_pose(K32, golden[f"plate_{key}_q"], O.plate_world_points("Chile"), findR=True)
+    close(t, golden[f"plate_{key}_t"], rtol=1e-6)
+    close(R, golden[f"plate_{key}_R"], rtol=0, atol=1e-6)
+    close(res, golden[f"plate_{key}_res"], rtol=1e-7)
+    close(proj, golden[f"plate_{key}_proj"], rtol=1e-7)
+
+
+def test_plate_pose_anchor_values(golden):
+    # SURVEY Appendix C
+    close(golden["plate_IMG_4134_res"], 0.60324794, rtol=1e-6)
+    close(golden["plate_IMG_4119_res"], 0.24922280, rtol=1e-6)
+    close(golden["plate_IMG_4134_t"], [1.5558778, 0.4673411, 3.6046615], rtol=1e-6)
+
+
+@pytest.mark.parametrize("n", [4, 64, 1000, 2000, 5000])
+def test_nls_t(golden, n):
+    K = golden["K32"].astype(float)
+    p, pw = golden[f"nlst_{n}_p"], golden[f"nlst_{n}_pw"]
+    t = O.nls_t(K, p.astype(float), pw, np.array([0, 0, 1]))
+    assert t.dtype == np.float32
+    close(t, golden[f"nlst_{n}_t"], rtol=2e-7)  # float32 outputs; f64 paths agree to ~1e-12
+    t2, R, res, proj = O.estimate_world_camera_pose(golden["K32"], p, pw, findR=False)
+    close(t2, golden[f"pose_{n}_t"], rtol=2e-7)
+    close(res, golden[f"pose_{n}_res"], rtol=1e-9)
+    close(proj, golden[f"pose_{n}_proj"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("n", [4, 64, 1000])
+def test_nls_rt(golden, n):
+    K = golden["K32"].astype(float)
+    p, pw = golden[f"nlsrt_{n}_p"], golden[f"nlsrt_{n}_pw"]
+    R, t = O.nls_rt(K, p.astype(float), pw, np.array([0, 0, 0, 0, 0, 1.0]))
+    close(R, golden[f"nlsrt_{n}_R"], rtol=0, atol=2e-7)
+    close(t, golden[f"nlsrt_{n}_t"], rtol=2e-6)
+
+
+def test_triangulation(golden):
+    close(O.two_view_intercept(golden["tri_A"], golden["tri_U"]), golden["tri_2v"], rtol=1e-11)
+    close(O.n_view_intercept(golden["tri_A"], golden["tri_U"]), golden["tri_nv"], rtol=1e-9)
+
+
+def test_msv1_t(golden):
+    x, b0 = O.msv1_t(golden["K32"], golden["msv_P"], golden["msv_B"], golden["msv_vg"], int(golden["msv_ii"]))
+    close(x, golden["msv_x"], rtol=2e-6)
+    close(b0, golden["msv_b0"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("nt,nf", [(20, 4), (50, 6)])
+def test_nls_batch(golden, nt, nf):
+    tag = f"ba_{nt}_{nf}"
+    cw, pw, x, trace = O.nls_batch(golden["K32"], golden[f"{tag}_P"].copy(), golden[f"{tag}_pw0"], golden[f"{tag}_cw0"], return_info=True)
+    assert pw.shape == (nt, 3)  # the 3 short tracks are filtered (NLS.py:190)
+    close(cw, golden[f"{tag}_cw"], rtol=1e-6, atol=1e-8)
+    close(pw, golden[f"{tag}_pw"], rtol=1e-6, atol=1e-8)
+    ref = golden[f"{tag}_trace"]  # parsed from the reference's printed %g trace
+    assert len(ref) == len(trace) == 10  # always exhausts its 10 iterations
+    close(trace[:, 0], ref[:, 0], rtol=2e-5)
+
+
+def test_bookkeeping(golden):
+    vg = np.ones(10, bool)
+    vp = np.array([1, 1, 1, 1, 0, 1, 0, 1, 1, 0], bool)
+    for v in (golden["bk_v1"], golden["bk_v2"]):
+        vg, vp, sel = O.bookkeeping_step(vg, vp, v)
+    assert np.array_equal(vg, golden["bk_vg"]) and np.array_equal(vp, golden["bk_vp"]) and np.array_equal(sel, golden["bk_sel"])
+    assert np.array_equal(np.nonzero(vg)[0], [0, 3, 4, 5, 6, 8, 9])
+    assert np.array_equal(np.nonzero(vg)[0][sel], np.nonzero(vp)[0])
