@@ -1,0 +1,758 @@
+/*
+ * CPU oracle for the KLT half of the hot path.  TEST INFRASTRUCTURE ONLY -- never linked into the product.
+ *
+ * Restates, in plain C, the algorithm behind the reference's tracker:
+ *     utils/KLT.py:37-51   cv2calcOpticalFlowPyrLK  (LK + forward-backward gate)
+ *     utils/KLT.py:55-95   KLTregional              (ROI crop / shift / affine remap, LK, map back)
+ *     utils/KLT.py:99-134  KLTmain                  (1/4-scale LK -> RANSAC -> ROI LK -> RANSAC affine -> fine LK)
+ *     utils/images.py:9-19 boundingRect
+ * All arithmetic of those functions lives in an un-pinned third-party dependency (requirements.txt:5,
+ * `opencv-python`, no version, absent from this image and from /root/reference).  What is restated here
+ * is OpenCV 4.x's PUBLISHED algorithm: pyrDown [1 4 6 4 1]^2/256 with REFLECT_101,
+ * un-normalised int16 Scharr derivatives, 14-bit fixed-point bilinear windows, the min-eigenvalue test,
+ * the Newton iteration with its two stop rules, remap's 5-bit fixed-point bilinear, nearest resize.
+ *
+ * PARITY UNPINNED: the reference holds no KLT test, golden vector or fixture and cv2 cannot run here, so this
+ * restatement is pinned only by analytic-flow ground truth (tests/test_oracle_klt.py) and by self-consistency.
+ * Deliberate, documented choices where OpenCV is build/SIMD dependent or not reproducible:
+ *   - window sums (A11,A12,A22,b1,b2,err) are accumulated EXACTLY in int64 and converted once to float
+ *     (OpenCV: float or int32-lane accumulation depending on the SIMD path) -> order independent;
+ *   - estimateAffine2D's RANSAC uses our own counter-based RNG (OpenCV's sequence is not reproducible
+ *     without its generator) and the LM refinement is replaced by the linear least-squares fit it
+ *     converges to; reductions use int64 fixed point so they are order independent;
+ *   - the two crashing lines of the reference (KLT.py:87, vidExample.py:134) follow SURVEY Appendix B intent.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -fopenmp -ffp-contract=off -shared).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define KO_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------------ */
+/* small helpers                                                                                     */
+/* ------------------------------------------------------------------------------------------------ */
+static inline int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+static inline int ifloor(float v) { return (int)floorf(v); }
+static inline int iround(float v) { return (int)lrintf(v); } /* round-half-even, like cvRound */
+static inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+typedef struct {
+    int w, h;      /* logical size */
+    int border;    /* padding on every side */
+    int stride;    /* elements per row of the padded buffer */
+    uint8_t *img;  /* padded, REFLECT_101 filled; pixel (x,y) at img[(y+border)*stride + x+border] */
+    int16_t *der;  /* padded interleaved (Ix,Iy), constant 0 outside; may be NULL */
+} level_t;
+
+static void level_free(level_t *L)
+{
+    free(L->img);
+    free(L->der);
+    L->img = NULL;
+    L->der = NULL;
+}
+
+/* copy a w x h image into a padded REFLECT_101 buffer */
+static void level_from_image(level_t *L, const uint8_t *src, int w, int h, ptrdiff_t sstride, int border)
+{
+    L->w = w; L->h = h; L->border = border; L->stride = w + 2 * border;
+    L->img = (uint8_t *)malloc((size_t)L->stride * (h + 2 * border));
+    L->der = NULL;
+#pragma omp parallel for schedule(static)
+    for (int y = -border; y < h + border; y++) {
+        const uint8_t *srow = src + (ptrdiff_t)reflect101(y, h) * sstride;
+        uint8_t *drow = L->img + (size_t)(y + border) * L->stride;
+        for (int x = -border; x < w + border; x++) drow[x + border] = srow[reflect101(x, w)];
+    }
+}
+
+/* pyrDown: dst (w+1)/2 x (h+1)/2, 5x5 [1 4 6 4 1]^2, REFLECT_101, (sum+128)>>8 */
+static void pyr_down_raw(const uint8_t *src, int w, int h, ptrdiff_t sstride, uint8_t *dst, int dw, int dh, ptrdiff_t dstride)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; y++) {
+        const uint8_t *r[5];
+        for (int k = 0; k < 5; k++) r[k] = src + (ptrdiff_t)reflect101(2 * y - 2 + k, h) * sstride;
+        for (int x = 0; x < dw; x++) {
+            int c[5];
+            for (int k = 0; k < 5; k++) c[k] = reflect101(2 * x - 2 + k, w);
+            int acc = 0;
+            static const int wv[5] = {1, 4, 6, 4, 1};
+            for (int k = 0; k < 5; k++) {
+                const uint8_t *row = r[k];
+                int hsum = row[c[0]] + 4 * row[c[1]] + 6 * row[c[2]] + 4 * row[c[3]] + row[c[4]];
+                acc += wv[k] * hsum;
+            }
+            dst[(ptrdiff_t)y * dstride + x] = (uint8_t)((acc + 128) >> 8);
+        }
+    }
+}
+
+KO_API void ko_pyr_down(const uint8_t *src, int w, int h, int sstride, uint8_t *dst)
+{
+    int dw = (w + 1) / 2, dh = (h + 1) / 2;
+    pyr_down_raw(src, w, h, sstride, dst, dw, dh, dw);
+}
+
+/* resize(fx=fy=0.25, INTER_NEAREST): dsize = round-half-even(src*0.25), sx = min(4x, W-1)  (KLT.py:111-113) */
+KO_API void ko_resize_quarter_dims(int w, int h, int *dw, int *dh)
+{
+    *dw = (int)lrint(w * 0.25);
+    *dh = (int)lrint(h * 0.25);
+}
+KO_API void ko_resize_quarter(const uint8_t *src, int w, int h, int sstride, uint8_t *dst)
+{
+    int dw, dh;
+    ko_resize_quarter_dims(w, h, &dw, &dh);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; y++) {
+        int sy = 4 * y < h - 1 ? 4 * y : h - 1;
+        for (int x = 0; x < dw; x++) {
+            int sx = 4 * x < w - 1 ? 4 * x : w - 1;
+            dst[(size_t)y * dw + x] = src[(ptrdiff_t)sy * sstride + sx];
+        }
+    }
+}
+
+/* Scharr derivative of the un-padded image with REFLECT_101 support, zero in the padding */
+static void level_make_deriv(level_t *L)
+{
+    int b = L->border, w = L->w, h = L->h, st = L->stride;
+    L->der = (int16_t *)calloc((size_t)st * (h + 2 * b) * 2, sizeof(int16_t));
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        /* rows/cols outside the image come from the REFLECT_101 padding (border >= 1) */
+        const uint8_t *r0 = L->img + (size_t)(y - 1 + b) * st + b;
+        const uint8_t *r1 = r0 + st, *r2 = r1 + st;
+        int16_t *d = L->der + ((size_t)(y + b) * st + b) * 2;
+        for (int x = 0; x < w; x++) {
+            /* vertical smooth [3 10 3] and vertical diff [-1 0 1] at columns x-1, x, x+1 */
+            int s_m = (r0[x - 1] + r2[x - 1]) * 3 + r1[x - 1] * 10;
+            int s_p = (r0[x + 1] + r2[x + 1]) * 3 + r1[x + 1] * 10;
+            int d_m = r2[x - 1] - r0[x - 1], d_c = r2[x] - r0[x], d_p = r2[x + 1] - r0[x + 1];
+            d[2 * x] = (int16_t)(s_p - s_m);
+            d[2 * x + 1] = (int16_t)((d_p + d_m) * 3 + d_c * 10);
+        }
+    }
+}
+
+/* pyramid with OpenCV's level truncation: stop when the NEXT level would be <= win in either dim */
+typedef struct { int nlevels; level_t lv[16]; } pyramid_t;
+
+static void pyramid_build(pyramid_t *P, const uint8_t *src, int w, int h, ptrdiff_t sstride, int win, int max_level, int with_deriv)
+{
+    P->nlevels = 0;
+    level_from_image(&P->lv[0], src, w, h, sstride, win);
+    int lw = w, lh = h;
+    for (int level = 0; level <= max_level; level++) {
+        if (level > 0) {
+            level_t *prev = &P->lv[level - 1];
+            uint8_t *tmp = (uint8_t *)malloc((size_t)lw * lh);
+            pyr_down_raw(prev->img + (size_t)prev->border * prev->stride + prev->border, prev->w, prev->h, prev->stride, tmp, lw, lh, lw);
+            level_from_image(&P->lv[level], tmp, lw, lh, lw, win);
+            free(tmp);
+        }
+        if (with_deriv) level_make_deriv(&P->lv[level]);
+        P->nlevels = level + 1;
+        lw = (lw + 1) / 2;
+        lh = (lh + 1) / 2;
+        if (lw <= win || lh <= win) break;
+    }
+}
+static void pyramid_free(pyramid_t *P)
+{
+    for (int i = 0; i < P->nlevels; i++) level_free(&P->lv[i]);
+    P->nlevels = 0;
+}
+
+KO_API int ko_pyramid_levels(int w, int h, int win, int max_level)
+{
+    int n = 0;
+    for (int level = 0; level <= max_level; level++) {
+        n = level + 1;
+        w = (w + 1) / 2;
+        h = (h + 1) / 2;
+        if (w <= win || h <= win) break;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* pyramidal Lucas-Kanade                                              */
+/* ------------------------------------------------------------------------------------------------ */
+#define W_BITS 14
+static const float FLT_SCALE = 1.f / (1 << 20);
+
+static inline void bilinear_weights(float a, float b, int *w00, int *w01, int *w10, int *w11)
+{
+    *w00 = iround((1.f - a) * (1.f - b) * (1 << W_BITS));
+    *w01 = iround(a * (1.f - b) * (1 << W_BITS));
+    *w10 = iround((1.f - a) * b * (1 << W_BITS));
+    *w11 = (1 << W_BITS) - *w00 - *w01 - *w10;
+}
+
+/* one point on one level; returns nothing, updates next[2], status, err */
+static void lk_point_level(const level_t *I, const level_t *J, int win, int level, int top_level, int max_count, double eps2,
+                           float min_eig_thr, const float prev_pt_full[2], float next[2], uint8_t *status, float *err,
+                           int16_t *Iwin, int16_t *dIwin)
+{
+    const float half = (win - 1) * 0.5f;
+    const float lscale = (float)(1. / (1 << level));
+    float px = prev_pt_full[0] * lscale, py = prev_pt_full[1] * lscale;
+    float nx, ny;
+    if (level == top_level) { nx = px; ny = py; }
+    else { nx = next[0] * 2.f; ny = next[1] * 2.f; }
+    next[0] = nx; next[1] = ny;
+
+    px -= half; py -= half;
+    int ipx = ifloor(px), ipy = ifloor(py);
+    if (ipx < -win || ipx >= I->w || ipy < -win || ipy >= I->h) {
+        if (level == 0) { *status = 0; *err = 0.f; }
+        return;
+    }
+    int w00, w01, w10, w11;
+    bilinear_weights(px - ipx, py - ipy, &w00, &w01, &w10, &w11);
+
+    const int sI = I->stride, sD = I->stride * 2, sJ = J->stride;
+    int64_t sA11 = 0, sA12 = 0, sA22 = 0;
+    for (int y = 0; y < win; y++) {
+        const uint8_t *src = I->img + (size_t)(y + ipy + I->border) * sI + ipx + I->border;
+        const int16_t *ds = I->der + ((size_t)(y + ipy + I->border) * sI + ipx + I->border) * 2;
+        for (int x = 0; x < win; x++) {
+            int iv = descale(src[x] * w00 + src[x + 1] * w01 + src[x + sI] * w10 + src[x + sI + 1] * w11, W_BITS - 5);
+            int ix = descale(ds[2 * x] * w00 + ds[2 * x + 2] * w01 + ds[2 * x + sD] * w10 + ds[2 * x + sD + 2] * w11, W_BITS);
+            int iy = descale(ds[2 * x + 1] * w00 + ds[2 * x + 3] * w01 + ds[2 * x + sD + 1] * w10 + ds[2 * x + sD + 3] * w11, W_BITS);
+            Iwin[y * win + x] = (int16_t)iv;
+            dIwin[2 * (y * win + x)] = (int16_t)ix;
+            dIwin[2 * (y * win + x) + 1] = (int16_t)iy;
+            sA11 += (int64_t)ix * ix;
+            sA12 += (int64_t)ix * iy;
+            sA22 += (int64_t)iy * iy;
+        }
+    }
+    float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
+    if (minEig < min_eig_thr || D < 1.1920929e-07f) {
+        if (level == 0) *status = 0;
+        return;
+    }
+    D = 1.f / D;
+
+    nx -= half; ny -= half;
+    float pdx = 0.f, pdy = 0.f;
+    for (int j = 0; j < max_count; j++) {
+        int inx = ifloor(nx), iny = ifloor(ny);
+        if (inx < -win || inx >= J->w || iny < -win || iny >= J->h) {
+            if (level == 0) *status = 0;
+            break;
+        }
+        bilinear_weights(nx - inx, ny - iny, &w00, &w01, &w10, &w11);
+        int64_t sb1 = 0, sb2 = 0;
+        for (int y = 0; y < win; y++) {
+            const uint8_t *jp = J->img + (size_t)(y + iny + J->border) * sJ + inx + J->border;
+            for (int x = 0; x < win; x++) {
+                int diff = descale(jp[x] * w00 + jp[x + 1] * w01 + jp[x + sJ] * w10 + jp[x + sJ + 1] * w11, W_BITS - 5) - Iwin[y * win + x];
+                sb1 += (int64_t)diff * dIwin[2 * (y * win + x)];
+                sb2 += (int64_t)diff * dIwin[2 * (y * win + x) + 1];
+            }
+        }
+        float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+        float dx = (A12 * b2 - A22 * b1) * D;
+        float dy = (A12 * b1 - A11 * b2) * D;
+        nx += dx; ny += dy;
+        next[0] = nx + half; next[1] = ny + half;
+        if ((double)dx * dx + (double)dy * dy <= eps2) break;
+        if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+            next[0] -= dx * 0.5f; next[1] -= dy * 0.5f;
+            break;
+        }
+        pdx = dx; pdy = dy;
+    }
+
+    if (*status && level == 0) {
+        float fx = next[0] - half, fy = next[1] - half;
+        int inx = ifloor(fx), iny = ifloor(fy);
+        if (inx < -win || inx >= J->w || iny < -win || iny >= J->h) { *status = 0; return; }
+        bilinear_weights(fx - inx, fy - iny, &w00, &w01, &w10, &w11);
+        int64_t se = 0;
+        for (int y = 0; y < win; y++) {
+            const uint8_t *jp = J->img + (size_t)(y + iny + J->border) * sJ + inx + J->border;
+            for (int x = 0; x < win; x++) {
+                int diff = descale(jp[x] * w00 + jp[x + 1] * w01 + jp[x + sJ] * w10 + jp[x + sJ + 1] * w11, W_BITS - 5) - Iwin[y * win + x];
+                se += diff < 0 ? -diff : diff;
+            }
+        }
+        *err = (float)se * (1.f / (float)(32 * win * win));
+    }
+}
+
+static void criteria_clamp(int *max_count, double *eps)
+{
+    if (*max_count < 0) *max_count = 0;
+    if (*max_count > 100) *max_count = 100;
+    if (*eps < 0) *eps = 0;
+    if (*eps > 10) *eps = 10;
+    *eps = *eps * *eps;
+}
+
+static void lk_run(const pyramid_t *PI, const pyramid_t *PJ, const float *prev_pts, int n, int win, int max_count, double eps,
+                   float *next_pts, uint8_t *status, float *err)
+{
+    criteria_clamp(&max_count, &eps);
+    int nl = PI->nlevels < PJ->nlevels ? PI->nlevels : PJ->nlevels;
+#pragma omp parallel
+    {
+        int16_t *Iwin = (int16_t *)malloc(sizeof(int16_t) * win * win);
+        int16_t *dIwin = (int16_t *)malloc(sizeof(int16_t) * win * win * 2);
+#pragma omp for schedule(dynamic, 16)
+        for (int i = 0; i < n; i++) {
+            status[i] = 1;
+            err[i] = 0.f;
+            float nxt[2] = {0.f, 0.f};
+            for (int level = nl - 1; level >= 0; level--)
+                lk_point_level(&PI->lv[level], &PJ->lv[level], win, level, nl - 1, max_count, eps, 1e-4f, prev_pts + 2 * i, nxt,
+                               &status[i], &err[i], Iwin, dIwin);
+            next_pts[2 * i] = nxt[0];
+            next_pts[2 * i + 1] = nxt[1];
+        }
+        free(Iwin);
+        free(dIwin);
+    }
+}
+
+/* cv2.calcOpticalFlowPyrLK(prev, next, pts, None, winSize=(win,win), maxLevel, criteria=(EPS|COUNT, max_count, eps)) */
+KO_API void ko_pyr_lk(const uint8_t *prev, const uint8_t *next, int w, int h, int pstride, int nstride, const float *prev_pts, int n,
+                      int win, int max_level, int max_count, double eps, float *next_pts, uint8_t *status, float *err)
+{
+    pyramid_t PI, PJ;
+    pyramid_build(&PI, prev, w, h, pstride, win, max_level, 1);
+    pyramid_build(&PJ, next, w, h, nstride, win, max_level, 0);
+    lk_run(&PI, &PJ, prev_pts, n, win, max_count, eps, next_pts, status, err);
+    pyramid_free(&PI);
+    pyramid_free(&PJ);
+}
+
+/* cv2calcOpticalFlowPyrLK (KLT.py:37-51): forward LK; if fbt >= 0 backward LK from the results and
+ * v = v & v2 & (||p1 - p1'|| < fbt), the norm and compare in float32 (common.py:13-15). */
+KO_API void ko_lk_fb(const uint8_t *im1, const uint8_t *im2, int w, int h, int stride1, int stride2, const float *p1, int n, int win,
+                     int max_level, int max_count, double eps, float fbt, float *p2, uint8_t *v, float *err, float *fbe_out)
+{
+    pyramid_t P1, P2;
+    int fb = fbt >= 0.f;
+    pyramid_build(&P1, im1, w, h, stride1, win, max_level, 1);
+    pyramid_build(&P2, im2, w, h, stride2, win, max_level, fb);
+    lk_run(&P1, &P2, p1, n, win, max_count, eps, p2, v, err);
+    if (fb) {
+        float *p1b = (float *)malloc(sizeof(float) * 2 * n);
+        uint8_t *v2 = (uint8_t *)malloc(n);
+        float *e2 = (float *)malloc(sizeof(float) * n);
+        lk_run(&P2, &P1, p2, n, win, max_count, eps, p1b, v2, e2);
+        for (int i = 0; i < n; i++) {
+            float dx = p1[2 * i] - p1b[2 * i], dy = p1[2 * i + 1] - p1b[2 * i + 1];
+            float fbe = sqrtf(dx * dx + dy * dy);
+            if (fbe_out) fbe_out[i] = fbe;
+            v[i] = (uint8_t)(v[i] && v2[i] && (fbe < fbt));
+        }
+        free(p1b); free(v2); free(e2);
+    }
+    pyramid_free(&P1);
+    pyramid_free(&P2);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* boundingRect (images.py:9-19 over cv2.boundingRect of float points)                               */
+/* ------------------------------------------------------------------------------------------------ */
+KO_API void ko_bounding_rect(const float *p, int n, int imw, int imh, int bx, int by, int roi[4])
+{
+    float mnx = p[0], mxx = p[0], mny = p[1], mxy = p[1];
+    for (int i = 1; i < n; i++) {
+        float x = p[2 * i], y = p[2 * i + 1];
+        if (x < mnx) mnx = x;
+        if (x > mxx) mxx = x;
+        if (y < mny) mny = y;
+        if (y > mxy) mxy = y;
+    }
+    int x0 = ifloor(mnx), y0 = ifloor(mny);
+    int bw = ifloor(mxx) - x0 + 1, bh = ifloor(mxy) - y0 + 1;
+    int x1 = x0 + bw + bx, y1 = y0 + bh + by;
+    x0 -= bx; y0 -= by;
+    if (x0 < 1) x0 = 1;
+    if (y0 < 1) y0 = 1;
+    if (x1 > imw) x1 = imw;
+    if (y1 > imh) y1 = imh;
+    roi[0] = x0; roi[1] = x1; roi[2] = y0; roi[3] = y1;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* affine remap of a ROI (KLT.py:70-73): map coords in float32, remap INTER_LINEAR, constant-0 border */
+/* ------------------------------------------------------------------------------------------------ */
+KO_API void ko_remap_affine(const uint8_t *im, int w, int h, int stride, const float T[6] /* 3x2 row-major */, int x0, int x1, int y0,
+                            int y1, uint8_t *dst /* (y1-y0) x (x1-x0) */)
+{
+    int rw = x1 - x0;
+#pragma omp parallel for schedule(static)
+    for (int yy = y0; yy < y1; yy++) {
+        float y = (float)yy;
+        for (int xx = x0; xx < x1; xx++) {
+            float x = (float)xx;
+            float mx = (x * T[0] + y * T[2]) + T[4];
+            float my = (x * T[1] + y * T[3]) + T[5];
+            int fx = iround(mx * 32.f), fy = iround(my * 32.f);
+            int sx = fx >> 5, sy = fy >> 5, ax = fx & 31, ay = fy & 31;
+            int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+            int s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+            int inx0 = sx >= 0 && sx < w, inx1 = sx + 1 >= 0 && sx + 1 < w;
+            int iny0 = sy >= 0 && sy < h, iny1 = sy + 1 >= 0 && sy + 1 < h;
+            if (iny0 && inx0) s00 = im[(ptrdiff_t)sy * stride + sx];
+            if (iny0 && inx1) s01 = im[(ptrdiff_t)sy * stride + sx + 1];
+            if (iny1 && inx0) s10 = im[(ptrdiff_t)(sy + 1) * stride + sx];
+            if (iny1 && inx1) s11 = im[(ptrdiff_t)(sy + 1) * stride + sx + 1];
+            dst[(size_t)(yy - y0) * rw + (xx - x0)] = (uint8_t)((s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11 + (1 << 14)) >> 15);
+        }
+    }
+}
+
+/* shifted crop with zero padding outside the frame (KLT.py:65-68, Appendix B intent) */
+KO_API void ko_crop_shift(const uint8_t *im, int w, int h, int stride, int x0, int x1, int y0, int y1, int dx, int dy, uint8_t *dst)
+{
+    int rw = x1 - x0;
+    for (int yy = y0; yy < y1; yy++)
+        for (int xx = x0; xx < x1; xx++) {
+            int sx = xx + dx, sy = yy + dy;
+            dst[(size_t)(yy - y0) * rw + (xx - x0)] = (sx >= 0 && sx < w && sy >= 0 && sy < h) ? im[(ptrdiff_t)sy * stride + sx] : 0;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* deterministic RANSAC affine (stands in for cv2.estimateAffine2D, KLT.py:116,127)                  */
+/* ------------------------------------------------------------------------------------------------ */
+#define RANSAC_MAX_ITERS 2000
+#define RANSAC_THRESH 3.0
+#define RANSAC_CONF 0.99
+#define RANSAC_SEED 0x2545F491u
+
+static inline uint32_t mix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+static inline uint32_t ransac_draw(uint32_t hyp, uint32_t k, uint32_t attempt, uint32_t m)
+{
+    uint32_t h = mix32(RANSAC_SEED ^ mix32(hyp * 0x9E3779B9u + k * 0x7F4A7C15u + attempt * 0x94D049BBu + 1u));
+    return (uint32_t)(((uint64_t)h * m) >> 32);
+}
+
+/* log(x) for x > 0 from plain arithmetic only, so CPU and GPU agree bit for bit */
+static double det_log(double x)
+{
+    union { double d; uint64_t u; } c;
+    c.d = x;
+    int e = (int)((c.u >> 52) & 0x7FF) - 1023;
+    c.u = (c.u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull; /* m in [1,2) */
+    double m = c.d;
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0), s2 = s * s, acc = 0.0;
+    for (int k = 12; k >= 0; k--) acc = acc * s2 + 1.0 / (double)(2 * k + 1);
+    return (double)e * 0.6931471805599453 + 2.0 * s * acc;
+}
+
+static int ransac_update_iters(double conf, double ep, int max_iters)
+{
+    double num = 1.0 - conf;
+    if (num < 2.2250738585072014e-308) num = 2.2250738585072014e-308;
+    double wgt = 1.0 - ep;
+    double denom = 1.0 - wgt * wgt * wgt;
+    if (denom < 2.2250738585072014e-308) return 0;
+    num = det_log(num);
+    denom = det_log(denom);
+    if (denom >= 0 || -num >= max_iters * (-denom)) return max_iters;
+    return (int)lrint(num / denom);
+}
+
+static int collinear(const double a[2], const double b[2], const double c[2])
+{
+    double dx1 = b[0] - a[0], dy1 = b[1] - a[1], dx2 = c[0] - a[0], dy2 = c[1] - a[1];
+    return fabs(dx1 * dy2 - dy1 * dx2) <= 1.1920929e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2));
+}
+
+/* affine from three pairs; returns 0 when the sample is degenerate */
+static int affine_from3(const float *from, const float *to, const int id[3], double M[6])
+{
+    double f[3][2], t[3][2];
+    for (int k = 0; k < 3; k++) {
+        f[k][0] = from[2 * id[k]]; f[k][1] = from[2 * id[k] + 1];
+        t[k][0] = to[2 * id[k]];   t[k][1] = to[2 * id[k] + 1];
+    }
+    if (collinear(f[0], f[1], f[2]) || collinear(t[0], t[1], t[2])) return 0;
+    double ax = f[0][0] - f[2][0], ay = f[0][1] - f[2][1], bx = f[1][0] - f[2][0], by = f[1][1] - f[2][1];
+    double det = ax * by - bx * ay;
+    if (det == 0.0) return 0;
+    for (int r = 0; r < 2; r++) {
+        double u0 = t[0][r] - t[2][r], u1 = t[1][r] - t[2][r];
+        double a = (u0 * by - u1 * ay) / det;
+        double b = (ax * u1 - bx * u0) / det;
+        M[3 * r] = a;
+        M[3 * r + 1] = b;
+        M[3 * r + 2] = (t[2][r] - a * f[2][0]) - b * f[2][1];
+    }
+    return 1;
+}
+
+static inline int is_inlier(const double M[6], float x, float y, float u, float v)
+{
+    double ex = ((M[0] * x + M[1] * y) + M[2]) - u;
+    double ey = ((M[3] * x + M[4] * y) + M[5]) - v;
+    float e = (float)(ex * ex + ey * ey);
+    return e <= (float)(RANSAC_THRESH * RANSAC_THRESH);
+}
+
+static int hypothesis(const float *from, const float *to, int m, uint32_t hyp, double M[6])
+{
+    int id[3];
+    for (int k = 0; k < 3; k++) {
+        int ok = 0;
+        for (uint32_t a = 0; a < 16 && !ok; a++) {
+            id[k] = (int)ransac_draw(hyp, (uint32_t)k, a, (uint32_t)m);
+            ok = 1;
+            for (int q = 0; q < k; q++) ok &= id[q] != id[k];
+        }
+        if (!ok) return 0;
+    }
+    return affine_from3(from, to, id, M);
+}
+
+static int64_t fixq(double v, int bits) { return (int64_t)llrint(ldexp(v, bits)); }
+
+/* from/to: m compacted pairs.  Out: M (2x3 row-major, float64), inl (m bytes).  Returns 1 on success. */
+KO_API int ko_ransac_affine(const float *from, const float *to, int m, double Mout[6], uint8_t *inl, int *iters_used)
+{
+    for (int i = 0; i < m; i++) inl[i] = 0;
+    if (iters_used) *iters_used = 0;
+    if (m < 3) return 0;
+    int *counts = (int *)malloc(sizeof(int) * RANSAC_MAX_ITERS);
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int hyp = 0; hyp < RANSAC_MAX_ITERS; hyp++) {
+        double M[6];
+        int c = 0;
+        if (hypothesis(from, to, m, (uint32_t)hyp, M))
+            for (int i = 0; i < m; i++) c += is_inlier(M, from[2 * i], from[2 * i + 1], to[2 * i], to[2 * i + 1]);
+        counts[hyp] = c;
+    }
+    int niters = RANSAC_MAX_ITERS, best = -1, best_count = 0, it;
+    for (it = 0; it < niters; it++) {
+        int c = counts[it];
+        if (c > (best_count > 2 ? best_count : 2)) {
+            best = it;
+            best_count = c;
+            niters = ransac_update_iters(RANSAC_CONF, (double)(m - c) / m, niters);
+        }
+    }
+    free(counts);
+    if (iters_used) *iters_used = it;
+    if (best < 0) return 0;
+    double M[6];
+    hypothesis(from, to, m, (uint32_t)best, M);
+    for (int i = 0; i < m; i++) inl[i] = (uint8_t)is_inlier(M, from[2 * i], from[2 * i + 1], to[2 * i], to[2 * i + 1]);
+
+    /* least-squares refit on the inliers; every sum is an exact int64 fixed-point sum (order independent) */
+    int64_t sx = 0, sy = 0, su = 0, sv = 0;
+    for (int i = 0; i < m; i++)
+        if (inl[i]) {
+            sx += fixq(from[2 * i], 32); sy += fixq(from[2 * i + 1], 32);
+            su += fixq(to[2 * i], 32);   sv += fixq(to[2 * i + 1], 32);
+        }
+    double cnt = (double)best_count;
+    double mx = ldexp((double)sx, -32) / cnt, my = ldexp((double)sy, -32) / cnt;
+    double mu = ldexp((double)su, -32) / cnt, mv = ldexp((double)sv, -32) / cnt;
+    int64_t q[9] = {0};
+    for (int i = 0; i < m; i++)
+        if (inl[i]) {
+            double x = from[2 * i] - mx, y = from[2 * i + 1] - my, u = to[2 * i] - mu, v = to[2 * i + 1] - mv;
+            q[0] += fixq(x * x, 20); q[1] += fixq(x * y, 20); q[2] += fixq(y * y, 20);
+            q[3] += fixq(x * u, 20); q[4] += fixq(y * u, 20);
+            q[5] += fixq(x * v, 20); q[6] += fixq(y * v, 20);
+        }
+    double Sxx = ldexp((double)q[0], -20), Sxy = ldexp((double)q[1], -20), Syy = ldexp((double)q[2], -20);
+    double Sxu = ldexp((double)q[3], -20), Syu = ldexp((double)q[4], -20), Sxv = ldexp((double)q[5], -20), Syv = ldexp((double)q[6], -20);
+    double det = Sxx * Syy - Sxy * Sxy;
+    if (best_count >= 3 && det > 1e-9 * (Sxx + Syy) * (Sxx + Syy) && det > 0) {
+        double a = (Sxu * Syy - Syu * Sxy) / det, b = (Sxx * Syu - Sxy * Sxu) / det;
+        double d = (Sxv * Syy - Syv * Sxy) / det, e = (Sxx * Syv - Sxy * Sxv) / det;
+        M[0] = a; M[1] = b; M[2] = (mu - a * mx) - b * my;
+        M[3] = d; M[4] = e; M[5] = (mv - d * mx) - e * my;
+    }
+    for (int k = 0; k < 6; k++) Mout[k] = M[k];
+    return 1;
+}
+
+/* mean of (p - p0) over valid points, float32 differences summed exactly in 2^-32 fixed point (KLT.py:121-123) */
+static void mean_translation(const float *p0, const float *p, const uint8_t *v, int n, double out[2], int *count)
+{
+    int64_t sx = 0, sy = 0;
+    int c = 0;
+    for (int i = 0; i < n; i++)
+        if (v[i]) {
+            float dx = p[2 * i] - p0[2 * i], dy = p[2 * i + 1] - p0[2 * i + 1];
+            sx += fixq((double)dx, 32); sy += fixq((double)dy, 32);
+            c++;
+        }
+    *count = c;
+    out[0] = c ? ldexp((double)sx, -32) / (double)c : 0.0;
+    out[1] = c ? ldexp((double)sy, -32) / (double)c : 0.0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* KLTregional / KLTmain                                                                             */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int win, max_level, max_count;
+    double eps;
+} lk_params_t;
+
+/* KLTregional (KLT.py:55-95).  T: 3x2 row-major float32.  p,v sized n. roi out = x0,x1,y0,y1 */
+static void klt_regional(const uint8_t *im0, const uint8_t *im, int w, int h, int stride0, int stride, const float *p0, int n,
+                         const float T[6], const lk_params_t *lk, float fbt, int translate, float *p, uint8_t *v, int roi[4],
+                         uint8_t *warp_out)
+{
+    ko_bounding_rect(p0, n, w, h, 50, 50, roi);
+    int x0 = roi[0], x1 = roi[1], y0 = roi[2], y1 = roi[3], rw = x1 - x0, rh = y1 - y0;
+    float *p0r = (float *)malloc(sizeof(float) * 2 * n), *pa = (float *)malloc(sizeof(float) * 2 * n);
+    float *err = (float *)malloc(sizeof(float) * n);
+    float fx0 = (float)x0, fy0 = (float)y0;
+    for (int i = 0; i < n; i++) { p0r[2 * i] = p0[2 * i] - fx0; p0r[2 * i + 1] = p0[2 * i + 1] - fy0; }
+    uint8_t *warped = (uint8_t *)malloc((size_t)rw * rh);
+    int dx = 0, dy = 0;
+    if (translate) {
+        dx = (int)T[4]; dy = (int)T[5]; /* truncation toward zero, KLT.py:66-67 */
+        ko_crop_shift(im, w, h, stride, x0, x1, y0, y1, dx, dy, warped);
+    } else {
+        ko_remap_affine(im, w, h, stride, T, x0, x1, y0, y1, warped);
+    }
+    if (warp_out) memcpy(warp_out, warped, (size_t)rw * rh);
+    ko_lk_fb(im0 + (ptrdiff_t)y0 * stride0 + x0, warped, rw, rh, stride0, rw, p0r, n, lk->win, lk->max_level, lk->max_count, lk->eps, fbt,
+             pa, v, err, NULL);
+    for (int i = 0; i < n; i++) {
+        float ax = pa[2 * i] + fx0, ay = pa[2 * i + 1] + fy0;
+        if (translate) { p[2 * i] = ax + (float)dx; p[2 * i + 1] = ay + (float)dy; }
+        else { p[2 * i] = (ax * T[0] + ay * T[2]) + T[4]; p[2 * i + 1] = (ax * T[1] + ay * T[3]) + T[5]; }
+    }
+    free(p0r); free(pa); free(err); free(warped);
+}
+
+static int compact_pairs(const float *a, const float *b, const uint8_t *v, int n, float *ca, float *cb, int *idx)
+{
+    int m = 0;
+    for (int i = 0; i < n; i++)
+        if (v[i]) {
+            ca[2 * m] = a[2 * i]; ca[2 * m + 1] = a[2 * i + 1];
+            cb[2 * m] = b[2 * i]; cb[2 * m + 1] = b[2 * i + 1];
+            idx[m++] = i;
+        }
+    return m;
+}
+
+typedef struct {        /* optional stage outputs for stage-by-stage parity tests (any pointer may be NULL) */
+    float *p_small;     /* n x 2 : stage-1 LK result scaled back to full resolution */
+    uint8_t *v_small;   /* n     : after the RANSAC inlier gate */
+    double *T_trans;    /* 2     : mean translation */
+    int *roi;           /* 4     : x0,x1,y0,y1 */
+    float *p_coarse;    /* n x 2 : stage-2 result */
+    uint8_t *v_coarse;  /* n */
+    double *T23;        /* 6     : 2x3 affine */
+    uint8_t *warped;    /* ROI-sized warp of stage 3 (caller allocates w*h) */
+    float *p_fine;      /* n x 2 : stage-3 result for ALL points */
+    int *flags;         /* 1     : bit0 = coarse-affine failure (KLT.py:128-130) */
+} klt_stages_t;
+
+/* KLTmain (KLT.py:99-134).  lk_*: coarse = (15, 4, 10, 0.1), fine = (51, 0, 30, 0.001) in the reference (:106-107).
+ * im0_small may be NULL (computed then).  Outputs: p_all n x 2 (all points), v n, im_small (dw x dh). */
+KO_API int ko_klt_main(const uint8_t *im, const uint8_t *im0, const uint8_t *im0_small, int w, int h, int stride, int stride0,
+                       const float *p0, int n, int cw, int cl, int cc, double ce, int fw, int fl, int fc, double fe,
+                       float *p_all, uint8_t *v, uint8_t *im_small, klt_stages_t *st)
+{
+    lk_params_t lkc = {cw, cl, cc, ce}, lkf = {fw, fl, fc, fe};
+    int dw, dh, flags = 0;
+    ko_resize_quarter_dims(w, h, &dw, &dh);
+    ko_resize_quarter(im, w, h, stride, im_small);
+    uint8_t *small0 = NULL;
+    if (!im0_small) {
+        small0 = (uint8_t *)malloc((size_t)dw * dh);
+        ko_resize_quarter(im0, w, h, stride0, small0);
+        im0_small = small0;
+    }
+    float *ps = (float *)malloc(sizeof(float) * 2 * n), *p = (float *)malloc(sizeof(float) * 2 * n);
+    float *err = (float *)malloc(sizeof(float) * n);
+    float *ca = (float *)malloc(sizeof(float) * 2 * n), *cb = (float *)malloc(sizeof(float) * 2 * n);
+    int *idx = (int *)malloc(sizeof(int) * n);
+    uint8_t *inl = (uint8_t *)malloc(n > 0 ? n : 1);
+
+    /* 1. coarse LK on the quarter-scale frame (KLT.py:114-117) */
+    for (int i = 0; i < 2 * n; i++) ps[i] = p0[i] * 0.25f;
+    ko_lk_fb(im0_small, im_small, dw, dh, dw, dw, ps, n, lkc.win, lkc.max_level, lkc.max_count, lkc.eps, -1.f, p, v, err, NULL);
+    for (int i = 0; i < 2 * n; i++) p[i] = p[i] / 0.25f;
+    double M[6];
+    int m = compact_pairs(p0, p, v, n, ca, cb, idx);
+    if (ko_ransac_affine(ca, cb, m, M, inl, NULL)) {
+        for (int k = 0; k < m; k++) v[idx[k]] = inl[k];
+    } else {
+        for (int i = 0; i < n; i++) v[i] = 0;
+    }
+    if (st && st->p_small) memcpy(st->p_small, p, sizeof(float) * 2 * n);
+    if (st && st->v_small) memcpy(st->v_small, v, n);
+
+    /* 2. translation-compensated coarse LK on the full-resolution ROI (KLT.py:121-124) */
+    double tr[2];
+    int cnt;
+    mean_translation(p0, p, v, n, tr, &cnt);
+    if (st && st->T_trans) { st->T_trans[0] = tr[0]; st->T_trans[1] = tr[1]; }
+    float T[6] = {1.f, 0.f, 0.f, 1.f, (float)tr[0], (float)tr[1]};
+    int roi[4];
+    klt_regional(im0, im, w, h, stride0, stride, p0, n, T, &lkc, 1.0f, 1, p, v, roi, NULL);
+    if (st && st->roi) memcpy(st->roi, roi, sizeof(roi));
+    if (st && st->p_coarse) memcpy(st->p_coarse, p, sizeof(float) * 2 * n);
+    if (st && st->v_coarse) memcpy(st->v_coarse, v, n);
+
+    /* affine from the survivors (KLT.py:126-130); the SURF fallback is out of scope -> keep the translation */
+    int nv = 0;
+    for (int i = 0; i < n; i++) nv += v[i];
+    int ok = 0;
+    if (nv > 10) {
+        m = compact_pairs(p0, p, v, n, ca, cb, idx);
+        ok = ko_ransac_affine(ca, cb, m, M, inl, NULL);
+    }
+    if (!ok) {
+        flags |= 1;
+        M[0] = 1; M[1] = 0; M[2] = tr[0]; M[3] = 0; M[4] = 1; M[5] = tr[1];
+    }
+    if (st && st->T23) memcpy(st->T23, M, sizeof(M));
+
+    /* 3. fine LK on the affine-warped ROI (KLT.py:133): T = T23.T as float32, 3x2 row-major */
+    float Tf[6] = {(float)M[0], (float)M[3], (float)M[1], (float)M[4], (float)M[2], (float)M[5]};
+    klt_regional(im0, im, w, h, stride0, stride, p0, n, Tf, &lkf, 0.3f, 0, p_all, v, roi, st ? st->warped : NULL);
+    if (st && st->p_fine) memcpy(st->p_fine, p_all, sizeof(float) * 2 * n);
+    if (st && st->flags) *st->flags = flags;
+
+    free(ps); free(p); free(err); free(ca); free(cb); free(idx); free(inl); free(small0);
+    return flags;
+}
+
+/* thin exported wrapper so tests can call KLTregional alone */
+KO_API void ko_klt_regional(const uint8_t *im0, const uint8_t *im, int w, int h, int stride0, int stride, const float *p0, int n,
+                            const float T[6], int win, int max_level, int max_count, double eps, float fbt, int translate, float *p,
+                            uint8_t *v, int roi[4], uint8_t *warp_out)
+{
+    lk_params_t lk = {win, max_level, max_count, eps};
+    klt_regional(im0, im, w, h, stride0, stride, p0, n, T, &lk, fbt, translate, p, v, roi, warp_out);
+}
+
+KO_API double ko_det_log(double x) { return det_log(x); }

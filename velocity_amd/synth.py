@@ -1,0 +1,102 @@
+"""Deterministic synthetic inputs for tests and bench: hash-noise frames under a known
+affine motion, jittered-grid tracks, plane-scene pose data.  Pure torch ops, so the same code renders on
+the CPU (tests) and on the GPU (bench, frames generated directly in HBM).  Not part of the hot path.
+"""
+import math
+
+import numpy as np
+import torch
+
+M32 = 0xFFFFFFFF
+K_1080P = np.array([[1993.8924560546875, 0, 0], [0, 1993.8924560546875, 0], [960.5, 540.5, 1]], np.float32)
+
+
+def _hash01(ix, iy, seed):
+    """32-bit integer hash of lattice coordinates -> float64 in [0,1)."""
+    h = (ix * 0x9E3779B1 + iy * 0x85EBCA77 + seed * 0xC2B2AE3D) & M32
+    h = h ^ (h >> 15)
+    h = (h * 0x2C1B3C6D) & M32
+    h = h ^ (h >> 12)
+    h = (h * 0x297A2D39) & M32
+    h = h ^ (h >> 15)
+    return h.to(torch.float64) / 4294967296.0
+
+
+def _value_noise(u, v, cell, seed):
+    x, y = u / cell, v / cell
+    x0, y0 = torch.floor(x), torch.floor(y)
+    fx, fy = x - x0, y - y0
+    sx, sy = fx * fx * (3 - 2 * fx), fy * fy * (3 - 2 * fy)
+    ix, iy = x0.to(torch.int64) + 100000, y0.to(torch.int64) + 100000
+    a, b = _hash01(ix, iy, seed), _hash01(ix + 1, iy, seed)
+    c, d = _hash01(ix, iy + 1, seed), _hash01(ix + 1, iy + 1, seed)
+    top = a + (b - a) * sx
+    bot = c + (d - c) * sx
+    return top + (bot - top) * sy
+
+
+def texture(u, v, seed=0xC0FFEE):
+    """Continuous multi-octave value-noise texture in [0,1] evaluated at real coordinates (u,v)."""
+    cells = (3.0, 8.0, 24.0, 72.0)
+    amps = (0.22, 0.28, 0.28, 0.22)
+    t = torch.zeros_like(u)
+    for k, (c, a) in enumerate(zip(cells, amps)):
+        t = t + a * _value_noise(u, v, c, seed + 17 * k)
+    return t
+
+
+class AffineMotion:
+    """x_k = c + s^k R(theta k)(x_0 - c) + k (tx, ty): frame k of a sequence, analytic ground truth."""
+
+    def __init__(self, width, height, s=0.995, theta_deg=0.05, tx=11.0, ty=-2.5):
+        self.c = np.array([(width - 1) / 2.0, (height - 1) / 2.0])
+        self.s, self.theta, self.t = s, math.radians(theta_deg), np.array([tx, ty], float)
+
+    def matrix(self, k):
+        """2x3 matrix A_k with x_k = A_k [x_0; 1]."""
+        sk, th = self.s ** k, self.theta * k
+        L = sk * np.array([[math.cos(th), -math.sin(th)], [math.sin(th), math.cos(th)]])
+        b = self.c - L @ self.c + k * self.t
+        return np.concatenate([L, b[:, None]], 1)
+
+    def apply(self, k, pts):
+        A = self.matrix(k)
+        return pts @ A[:, :2].T + A[:, 2]
+
+    def inverse(self, k):
+        A = self.matrix(k)
+        Li = np.linalg.inv(A[:, :2])
+        return np.concatenate([Li, (-Li @ A[:, 2])[:, None]], 1)
+
+
+def render_frame(width, height, motion, k, seed=0xC0FFEE, device="cpu"):
+    """uint8 [H,W] frame k: texture sampled at A_k^-1 (x,y), stretched to [16,240]."""
+    Ai = motion.inverse(k)
+    ys, xs = torch.meshgrid(torch.arange(height, dtype=torch.float64, device=device),
+                            torch.arange(width, dtype=torch.float64, device=device), indexing="ij")
+    u = Ai[0, 0] * xs + Ai[0, 1] * ys + Ai[0, 2]
+    v = Ai[1, 0] * xs + Ai[1, 1] * ys + Ai[1, 2]
+    t = texture(u, v, seed)
+    t = torch.clamp((t - 0.5) * 2.2 + 0.5, 0.0, 1.0)
+    return torch.clamp(torch.round(16.0 + 224.0 * t), 0, 255).to(torch.uint8)
+
+
+def grid_tracks(n, width, height, seed=1, frac=0.8):
+    """n float32 points on a jittered grid inside the central frac x frac of the frame."""
+    w, h = width * frac, height * frac
+    cols = max(1, int(math.ceil(math.sqrt(n * w / h))))
+    rows = int(math.ceil(n / cols))
+    idx = torch.arange(n, dtype=torch.int64)
+    gx, gy = (idx % cols).to(torch.float64), (idx // cols).to(torch.float64)
+    jx, jy = _hash01(idx, idx * 0 + 7, seed), _hash01(idx, idx * 0 + 13, seed)
+    x = (width - w) / 2 + (gx + 0.15 + 0.7 * jx) * (w / cols)
+    y = (height - h) / 2 + (gy + 0.15 + 0.7 * jy) * (h / rows)
+    return torch.stack([x, y], 1).to(torch.float32).numpy()
+
+
+def plane_pose_scene(p_pixels, K=K_1080P, depth=3.6):
+    """World points on the plane Z=0 seen at translation (0,0,depth): back-projection of the tracks (vidExample.py:119)."""
+    K = K.astype(float)
+    x = (p_pixels[:, 0].astype(float) - K[2, 0]) / K[0, 0] * depth
+    y = (p_pixels[:, 1].astype(float) - K[2, 1]) / K[1, 1] * depth
+    return np.stack([x, y, np.zeros_like(x)], 1)
