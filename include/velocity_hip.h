@@ -1,0 +1,124 @@
+/*
+ * libvelocity_hip -- C ABI of the MI355X-native KLT + NLS hot path of ultralytics/velocity.
+ *
+ * The reference has no FFI / plugin interface: its boundary is the set of Python call sites in vidExample.py
+ * (SURVEY.md section 8b).  Every entry point below names the reference function (file:line) it replaces; the Python
+ * binding a maintainer would add is velocity_amd/_lib.py (ctypes) and is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is marked "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on it, inputs are
+ *     borrowed and never modified, outputs are caller-allocated;
+ *   - images are uint8, pixel (x,y) at base[y*stride + x]; points are float32 (x,y) pairs; poses follow the
+ *     reference's row-vector layout (uv1 ~ [X Y Z] @ K, X_cam = X_w @ R + t, affine [x y 1] @ T with T 3x2);
+ *   - return value 0 = success, otherwise a hipError_t (or a negative vh error); vh_last_error() describes it.
+ *     Numerical non-convergence is NOT an error: like the reference (NLS.py:126-127,178-179; KLT.py:129) the call
+ *     succeeds and reports it through an info/flags output so the host shim can print the same warning.
+ */
+#ifndef VELOCITY_HIP_H
+#define VELOCITY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VH_API __attribute__((visibility("default")))
+
+typedef struct vh_ctx vh_ctx;         /* device workspace for `batch` independent video streams               */
+typedef struct vh_session vh_session; /* per-frame tracker state of `batch` streams (vidExample.py loop body) */
+
+/* Lucas-Kanade parameters: cv2 winSize=(win,win), maxLevel, criteria=(EPS|COUNT, max_count, eps)  (KLT.py:106-107) */
+typedef struct {
+    int win;
+    int max_level;
+    int max_count;
+    double eps;
+} vh_lk_params;
+
+/* device pointers to the intermediate results of the last vh_klt_main call of one stream (parity tests) */
+typedef struct {
+    const float* p_small;     /* n x 2  stage-1 result at full resolution (KLT.py:114-115)  */
+    const uint8_t* v_small;   /* n      after the RANSAC inlier gate (KLT.py:117)           */
+    const double* t_trans;    /* 2      mean translation (KLT.py:121-123)                   */
+    const int* roi;           /* 4      x0,x1,y0,y1 (KLT.py:60)                             */
+    const float* p_coarse;    /* n x 2  stage-2 result (KLT.py:124)                         */
+    const uint8_t* v_coarse;  /* n                                                          */
+    const double* t23;        /* 6      2x3 affine (KLT.py:127)                             */
+    const uint8_t* warped;    /* ROI-sized affine warp, row stride = roi width (KLT.py:73)  */
+    const int* flags;         /* 1      bit0: coarse-affine failure (KLT.py:128-130)        */
+} vh_klt_stages;
+
+VH_API int vh_version(void);
+VH_API const char* vh_last_error(void);
+
+/* ---- workspace ------------------------------------------------------------------------------------------------ */
+VH_API int vh_ctx_create(vh_ctx** out, int batch, int max_w, int max_h, int max_pts);
+VH_API void vh_ctx_destroy(vh_ctx* ctx);
+
+/* ---- image stages (K1, K2, K8, K9) ---------------------------------------------------------------------------- */
+/* cv2.resize(im, (0,0), fx=.25, fy=.25, INTER_NEAREST), utils/KLT.py:111-113.  dst: round(h/4) x round(w/4), dense */
+VH_API int vh_resize_quarter(vh_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream);
+/* cv2.pyrDown as used inside cv2.calcOpticalFlowPyrLK (KLT.py:45,48).  dst: (h+1)/2 x (w+1)/2, dense */
+VH_API int vh_pyr_down(vh_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream);
+/* meshgrid + affine + cv2.remap(INTER_LINEAR), utils/KLT.py:70-73.  T: host, 3x2 row-major float32.  dst dense ROI */
+VH_API int vh_remap_affine(vh_ctx* ctx, const uint8_t* im, int w, int h, int stride, const float* T_host, int x0, int x1, int y0,
+                           int y1, uint8_t* dst, void* stream);
+/* im[y0+dy:y1+dy, x0+dx:x1+dx] with zero padding outside the frame, utils/KLT.py:65-68 (SURVEY App. B intent) */
+VH_API int vh_crop_shift(vh_ctx* ctx, const uint8_t* im, int w, int h, int stride, int x0, int x1, int y0, int y1, int dx, int dy,
+                         uint8_t* dst, void* stream);
+/* boundingRect(x, imshape, border), utils/images.py:9-19.  roi_out: device int[4] = x0,x1,y0,y1 */
+VH_API int vh_bounding_rect(vh_ctx* ctx, const float* p, int n, int imw, int imh, int bx, int by, int* roi_out, void* stream);
+
+/* ---- tracker -------------------------------------------------------------------------------------------------- */
+/* cv2calcOpticalFlowPyrLK(im1, im2, p1, None, fbt, **lk), utils/KLT.py:37-51.  fbt < 0 means fbt=None.
+ * Outputs: p2 n x 2, v n (uint8 0/1), err n (may be NULL), fbe n (may be NULL). */
+VH_API int vh_pyr_lk(vh_ctx* ctx, const uint8_t* im1, const uint8_t* im2, int w, int h, int stride1, int stride2, const float* p1,
+                     int n, const vh_lk_params* lk_host, float fbt, float* p2, uint8_t* v, float* err, float* fbe, void* stream);
+/* cv2.estimateAffine2D(from[valid], to[valid], method=RANSAC), utils/KLT.py:116,127 (deterministic stand-in, see
+ * DESIGN.md).  valid may be NULL (all).  Outputs: M device double[6] (2x3), inl device uint8[n], status device int[1]. */
+VH_API int vh_ransac_affine(vh_ctx* ctx, const float* from, const float* to, const uint8_t* valid, int n, double* M, uint8_t* inl,
+                            int* status, void* stream);
+/* KLTmain(im, im0, im0_small, p0), utils/KLT.py:99-134, for stream slot `slot` of the workspace.
+ * im0_small may be NULL.  Outputs: p_all n x 2 (every point; the shim returns p_all[v]), v n, im_small
+ * round(h/4) x round(w/4), flags device int[1] (bit0: "KLT coarse-affine failure", KLT.py:129). */
+VH_API int vh_klt_main(vh_ctx* ctx, int slot, const uint8_t* im, const uint8_t* im0, const uint8_t* im0_small, int w, int h, int stride,
+                       int stride0, const float* p0, int n, const vh_lk_params* coarse_host, const vh_lk_params* fine_host,
+                       float* p_all, uint8_t* v, uint8_t* im_small, int* flags, void* stream);
+VH_API int vh_klt_stage_ptrs(vh_ctx* ctx, int slot, vh_klt_stages* out_host);
+/* KLTregional(im0, im, p0, T, lk, fbt, translateFlag), utils/KLT.py:55-95.  T_host: 3x2 row-major float32 (host).
+ * Outputs: p_out n x 2 (frame coordinates), v_out n, roi_out device int[4] = x0,x1,y0,y1 (may be NULL). */
+VH_API int vh_klt_regional(vh_ctx* ctx, const uint8_t* im0, const uint8_t* im, int w, int h, int stride0, int stride, const float* p0,
+                           int n, const float* T_host, const vh_lk_params* lk_host, float fbt, int translate, float* p_out,
+                           uint8_t* v_out, int* roi_out, void* stream);
+
+/* ---- NLS pose (K11-K13) ---------------------------------------------------------------------------------------- */
+/* estimateWorldCameraPose(K, p, p3, t, R, findR), utils/NLS.py:9-33 -> fcnNLS_t (:102-129) / fcnNLS_Rt (:133-183).
+ * K_host: 9 floats (MATLAB layout), x0_host: 6 doubles [rpy(R), t], R_host: 9 doubles.
+ * Outputs: t_out float[3]; R_out double[9] (findR: float32-rounded rpy2dcm, else R); res_out double[1] = rms(p - p_proj);
+ * p_proj double[n x 2] (may be NULL); info int[2] = {iterations, converged}. */
+VH_API int vh_pose(vh_ctx* ctx, const float* K_host, const float* p, const double* pw, int n, const double* x0_host,
+                   const double* R_host, int findR, float* t_out, double* R_out, double* res_out, double* p_proj, int* info,
+                   void* stream);
+/* world2image(K, R, t, pw), utils/common.py:58-64.  C_host = [R; t] @ K (4x3 row-major, host).  out n x 2 */
+VH_API int vh_world2image(vh_ctx* ctx, const double* C_host, const double* pw, int n, double* out, void* stream);
+/* image2world(K, R, t, p), utils/common.py:49-55.  Hi_host = inv([R[0:2]; t] @ K) (3x3, host).  out n x 2 */
+VH_API int vh_image2world(vh_ctx* ctx, const double* Hi_host, const double* p, int n, double* out, void* stream);
+/* pixel2uvec(K, p), utils/common.py:122-126.  out n x 3 */
+VH_API int vh_pixel2uvec(vh_ctx* ctx, double cx, double cy, double f, const double* p, int n, double* out, void* stream);
+
+/* ---- triangulation (K15, K16) ---------------------------------------------------------------------------------- */
+/* fcn2vintercept(A, U), utils/MSV.py:98-142.  A [nf,3], U [3,nf,nv], out [nv,3] (all device, float64) */
+VH_API int vh_two_view_intercept(vh_ctx* ctx, const double* A, const double* U, int nf, int nv, double* out, void* stream);
+/* fcnMSV1_t(K, P, B, vg, ii), utils/MSV.py:8-49.  P float32 [5,N0,nhist], B float32 [nhist,14], ids = nonzero(vg)
+ * (int32, ng entries).  f32_rays: K and P were float32 on the caller's side (numpy then builds the rays in float32).
+ * Outputs: x_out float[3], b0 double[ng x 3], info int[2]; U_scratch double[3*(ii+1)*ng]. */
+VH_API int vh_msv1_t(vh_ctx* ctx, const float* K_host, const float* P, const float* B, const int* ids, int ng, int N0, int nhist,
+                     int ii, int f32_rays, double* U_scratch, float* x_out, double* b0, int* info, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VELOCITY_HIP_H */

@@ -1,0 +1,214 @@
+"""GPU parity: HIP KLT path (through the C ABI, via the reference-named shims) vs the CPU oracle on the same
+seeded inputs.  Bit-exact for every integer/bool/float32 output (the arithmetic is integer/fixed-point by design)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import klt_oracle as KO  # noqa: E402  (checker only)
+from velocity_amd import synth  # noqa: E402
+
+CV_COARSE = dict(winSize=(15, 15), maxLevel=4, criteria=(3, 10, 0.1))  # utils/KLT.py:106
+CV_FINE = dict(winSize=(51, 51), maxLevel=0, criteria=(3, 30, 0.001))  # utils/KLT.py:107
+
+
+@pytest.fixture(scope="module")
+def seq():
+    W, H = 960, 540
+    m = synth.AffineMotion(W, H, tx=5.5, ty=-1.25)
+    f0 = synth.render_frame(W, H, m, 0).numpy()
+    f1 = synth.render_frame(W, H, m, 1).numpy()
+    p0 = synth.grid_tracks(600, W, H)
+    return W, H, m, f0, f1, p0
+
+
+def _lib():
+    from velocity_amd import _lib as L
+    import ctypes as C
+    import torch
+
+    return L, C, torch
+
+
+def test_resize_quarter_bit_exact():
+    L, C, torch = _lib()
+    rng = np.random.default_rng(0)
+    for (h, w) in ((1080, 1920), (273, 483), (541, 959), (16, 18)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        ws = L.workspace(w, h, 1)
+        t = torch.from_numpy(img).cuda()
+        exp = KO.resize_quarter(img)
+        out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
+        L.check(ws.lib.vh_resize_quarter(ws.handle, L.dptr(t), w, h, w, L.dptr(out), L.stream_ptr()))
+        assert np.array_equal(out.cpu().numpy(), exp)
+
+
+def test_pyr_down_bit_exact_incl_views_and_odd_sizes():
+    L, C, torch = _lib()
+    rng = np.random.default_rng(1)
+    for (h, w) in ((1080, 1920), (135, 241), (17, 30), (68, 120), (33, 1), (5, 7)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        ws = L.workspace(w, h, 1)
+        t = torch.from_numpy(img).cuda()
+        exp = KO.pyr_down(img)
+        out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
+        L.check(ws.lib.vh_pyr_down(ws.handle, L.dptr(t), w, h, w, L.dptr(out), L.stream_ptr()))
+        assert np.array_equal(out.cpu().numpy(), exp), (h, w)
+    # strided view like im0[y0:y1, x0:x1]
+    img = rng.integers(0, 256, (300, 400), dtype=np.uint8)
+    t = torch.from_numpy(img).cuda()
+    view = t[7:250, 13:377]
+    exp = KO.pyr_down(img[7:250, 13:377])
+    out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
+    ws = L.workspace(400, 300, 1)
+    L.check(ws.lib.vh_pyr_down(ws.handle, C.c_void_p(view.data_ptr()), 364, 243, 400, L.dptr(out), L.stream_ptr()))
+    assert np.array_equal(out.cpu().numpy(), exp)
+
+
+def test_remap_and_crop_shift_bit_exact():
+    L, C, torch = _lib()
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (270, 480), dtype=np.uint8)
+    t = torch.from_numpy(img).cuda()
+    ws = L.workspace(480, 270, 1)
+    roi = (3, 471, 1, 262)
+    for T in ([[1, 0], [0, 1], [0, 0]], [[0.995, 0.0009], [-0.0009, 0.995], [8.13, -0.32]], [[1.01, 0.02], [-0.03, 0.98], [-25.5, 14.25]]):
+        Tf = np.asarray(T, np.float32).reshape(6)
+        exp = KO.remap_affine(img, Tf, roi)
+        out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
+        L.check(ws.lib.vh_remap_affine(ws.handle, L.dptr(t), 480, 270, 480, Tf.ctypes.data_as(L.f32p), *roi, L.dptr(out), L.stream_ptr()))
+        assert np.array_equal(out.cpu().numpy(), exp)
+    for dx, dy in ((0, 0), (11, -2), (-30, 40), (500, 0)):
+        exp = KO.crop_shift(img, roi, dx, dy)
+        out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
+        L.check(ws.lib.vh_crop_shift(ws.handle, L.dptr(t), 480, 270, 480, *roi, dx, dy, L.dptr(out), L.stream_ptr()))
+        assert np.array_equal(out.cpu().numpy(), exp)
+
+
+def test_bounding_rect_matches():
+    from velocity_amd.images import boundingRect
+
+    rng = np.random.default_rng(3)
+    for n in (1, 4, 300, 5000):
+        p = rng.uniform(-20, 2000, (n, 2)).astype(np.float32)
+        for border in ((0, 0), (50, 50), (700, 500)):
+            assert boundingRect(p, (1080, 1920), border) == KO.bounding_rect(p, (1080, 1920), border)
+
+
+@pytest.mark.parametrize("lk", [CV_COARSE, dict(winSize=(21, 21), maxLevel=3, criteria=(3, 30, 0.01)), CV_FINE,
+                                dict(winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.1))])
+@pytest.mark.parametrize("fbt", [None, 1.0, 0.3])
+def test_pyr_lk_bit_exact(seq, lk, fbt):
+    from velocity_amd.KLT import cv2calcOpticalFlowPyrLK
+
+    W, H, m, f0, f1, p0 = seq
+    rng = np.random.default_rng(4)
+    # regular tracks + points near / beyond the borders (status bookkeeping, REFLECT_101 path)
+    edge = np.concatenate([rng.uniform(-30, 40, (40, 2)), rng.uniform([W - 40, H - 40], [W + 30, H + 30], (40, 2)),
+                           np.stack([rng.uniform(0, W, 40), rng.uniform(-10, 10, 40)], 1)]).astype(np.float32)
+    pts = np.concatenate([p0, edge])
+    kw = dict(win=lk["winSize"][0], max_level=lk["maxLevel"], max_count=lk["criteria"][1], eps=lk["criteria"][2])
+    p2, v, err = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=fbt, **lk)
+    e2, ev, eerr = KO.lk_fb(f0, f1, pts, fbt=fbt, **kw)
+    assert v.dtype == bool and p2.dtype == np.float32 and err.shape == (len(pts), 1)
+    assert np.array_equal(v, ev)
+    assert np.array_equal(p2, e2)
+    assert np.array_equal(err.ravel(), eerr)
+    assert v[: len(p0)].mean() > 0.9
+
+
+def test_pyr_lk_textureless_and_small_images():
+    from velocity_amd.KLT import cv2calcOpticalFlowPyrLK
+
+    flat = np.full((120, 160), 128, np.uint8)
+    pts = np.array([[40.0, 40.0], [100.5, 60.25]], np.float32)
+    p2, v, err = cv2calcOpticalFlowPyrLK(flat, flat, pts, **CV_COARSE)
+    e2, ev, _ = KO.lk_fb(flat, flat, pts, fbt=None)
+    assert not v.any() and np.array_equal(v, ev) and np.array_equal(p2, e2)
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (40, 52), dtype=np.uint8)
+    b = np.roll(a, 1, axis=1)
+    pts = rng.uniform(5, 35, (50, 2)).astype(np.float32)
+    p2, v, err = cv2calcOpticalFlowPyrLK(a, b, pts, fbt=1.0, **CV_COARSE)  # window (15) vs 52x40 image: level truncation
+    e2, ev, eerr = KO.lk_fb(a, b, pts, fbt=1.0)
+    assert np.array_equal(v, ev) and np.array_equal(p2, e2) and np.array_equal(err.ravel(), eerr)
+
+
+def test_ransac_affine_bit_exact():
+    from velocity_amd.KLT import estimateAffine2D
+
+    rng = np.random.default_rng(6)
+    for m, nbad in ((400, 80), (2000, 900), (12, 3), (3, 0)):
+        src = rng.uniform(0, 1900, (m, 2)).astype(np.float32)
+        A = np.array([[0.99, -0.02, 7.5], [0.02, 0.99, -3.25]])
+        dst = (src @ A[:, :2].T + A[:, 2] + rng.normal(0, 0.05, (m, 2))).astype(np.float32)
+        bad = rng.choice(m, nbad, replace=False)
+        dst[bad] += rng.uniform(20, 80, (nbad, 2)).astype(np.float32)
+        M, inl = estimateAffine2D(src, dst)
+        eM, einl, _ = KO.ransac_affine(src, dst)
+        assert (M is None) == (eM is None)
+        assert np.array_equal(inl.ravel().astype(bool), einl)
+        if M is not None:
+            assert np.array_equal(M, eM)  # float64, bit for bit
+    assert estimateAffine2D(src[:2], dst[:2])[0] is None
+    line = np.stack([np.arange(50), np.arange(50)], 1).astype(np.float32)
+    assert estimateAffine2D(line, line)[0] is None
+
+
+def test_klt_regional_bit_exact(seq):
+    from velocity_amd.KLT import KLTregional
+
+    W, H, m, f0, f1, p0 = seq
+    T = np.array([[1, 0], [0, 1], [5.6, -1.3]])
+    p, v = KLTregional(f0, f1, p0, T, CV_COARSE, fbt=1, translateFlag=True)
+    ep, ev, roi, _ = KO.klt_regional(f0, f1, p0, T, KO.LK_COARSE, fbt=1.0, translate=True)
+    assert np.array_equal(v, ev) and np.array_equal(p, ep)
+    A = m.matrix(1)
+    T23T = A.T
+    p, v = KLTregional(f0, f1, p0, T23T, CV_FINE, fbt=0.3)
+    ep, ev, roi, _ = KO.klt_regional(f0, f1, p0, T23T, KO.LK_FINE, fbt=0.3, translate=False)
+    assert np.array_equal(v, ev) and np.array_equal(p, ep)
+    # shift that leaves the frame -> zero-padded crop path
+    pts = np.concatenate([p0, np.array([[3.0, 3.0], [W - 3.0, H - 3.0]], np.float32)])
+    T = np.array([[1, 0], [0, 1], [-40.2, 33.7]])
+    p, v = KLTregional(f0, f1, pts, T, CV_COARSE, fbt=1, translateFlag=True)
+    ep, ev, roi, _ = KO.klt_regional(f0, f1, pts, T, KO.LK_COARSE, fbt=1.0, translate=True)
+    assert np.array_equal(v, ev) and np.array_equal(p, ep)
+
+
+@pytest.mark.parametrize("coarse_levels", [4, 2])
+def test_klt_main_bit_exact_all_stages(seq, coarse_levels):
+    from velocity_amd import KLT
+
+    W, H, m, f0, f1, p0 = seq
+    lkc = dict(max_level=coarse_levels)
+    p, v, small, p_all, flags = KLT.KLTmain(f1, f0, None, p0, lk_coarse=lkc, return_all=True)
+    ep, ev, esmall, S = KO.klt_main(f1, f0, None, p0, lk_coarse=lkc, stages=True)
+    G = KLT.klt_stages(len(p0))
+    assert np.array_equal(small, esmall)
+    assert np.array_equal(G["p_small"], S["p_small"]) and np.array_equal(G["v_small"], S["v_small"])
+    assert np.array_equal(G["T_trans"], S["T_trans"])
+    assert np.array_equal(G["roi"], S["roi"])
+    assert np.array_equal(G["p_coarse"], S["p_coarse"]) and np.array_equal(G["v_coarse"], S["v_coarse"])
+    assert np.array_equal(G["T23"], S["T23"])
+    assert np.array_equal(G["warped"], S["warped"])
+    assert flags == S["flags"] == 0
+    assert np.array_equal(v, ev) and np.array_equal(p_all, S["p_all"]) and np.array_equal(p, ep)
+    gt = m.apply(1, p0.astype(float))
+    e = np.linalg.norm(p_all - gt, axis=1)[v]
+    assert v.mean() > 0.98 and np.median(e) < 0.02
+    # cached quarter-scale previous frame (KLT.py:112-113)
+    p_b, v_b, _ = KLT.KLTmain(f1, f0, KO.resize_quarter(f0), p0, lk_coarse=lkc)
+    assert np.array_equal(p_b, p) and np.array_equal(v_b, v)
+
+
+def test_klt_main_failure_path_matches(seq):
+    """Unrelated frames: few survivors -> 'coarse-affine failure' branch (KLT.py:126-130) must agree with the oracle."""
+    from velocity_amd import KLT
+
+    W, H, m, f0, f1, p0 = seq
+    other = synth.render_frame(W, H, synth.AffineMotion(W, H), 0, seed=12345).numpy()
+    p, v, small, p_all, flags = KLT.KLTmain(other, f0, None, p0[:200], return_all=True)
+    ep, ev, esmall, S = KO.klt_main(other, f0, None, p0[:200], stages=True)
+    assert flags == S["flags"]
+    assert np.array_equal(v, ev) and np.array_equal(p_all, S["p_all"])

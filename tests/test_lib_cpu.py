@@ -1,0 +1,58 @@
+"""CPU-side checks of the product's boundary: the C-ABI library loads without a GPU and exports every symbol
+include/velocity_hip.h declares; the host shims mirror the reference's call signatures; no CPU fallback exists."""
+import inspect
+import os
+
+import numpy as np
+import pytest
+
+from velocity_amd import _lib
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.load()
+    syms = _lib.declared_symbols()
+    assert len(syms) >= 20 and len(set(syms)) == len(syms)
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/velocity_hip.h but not exported"
+        assert s in _lib._SIGS, f"{s} has no ctypes signature in velocity_amd/_lib.py"
+    assert L.vh_version() >= 100
+
+
+def test_shims_mirror_reference_signatures():
+    from velocity_amd import KLT, MSV, NLS, common, images, transforms
+
+    def params(f):
+        return list(inspect.signature(f).parameters)
+
+    assert params(KLT.KLTmain)[:4] == ["im", "im0", "im0_small", "p0"]  # utils/KLT.py:99
+    assert params(KLT.KLTregional) == ["im0", "im", "p0", "T", "lk_param", "fbt", "translateFlag"]  # KLT.py:55
+    assert params(KLT.cv2calcOpticalFlowPyrLK) == ["im1", "im2", "p1", "p2hat", "fbt", "lk_param"]  # KLT.py:37
+    assert params(NLS.estimateWorldCameraPose) == ["K", "p", "p3", "t", "R", "findR"]  # NLS.py:9
+    assert params(NLS.fcnNLS_t) == ["K", "p", "pw", "x"] and params(NLS.fcnNLS_Rt) == ["K", "p", "pw", "x"]
+    assert params(MSV.fcnMSV1_t) == ["K", "P", "B", "vg", "ii"] and params(MSV.fcn2vintercept) == ["A", "U"]
+    assert params(images.boundingRect) == ["x", "imshape", "border"]
+    assert params(common.world2image) == ["K", "R", "t", "pw"] and params(common.image2world) == ["K", "R", "t", "p"]
+    R = transforms.rpy2dcm([0.1, 0.2, 0.3])
+    np.testing.assert_allclose(transforms.dcm2rpy(R), [0.1, 0.2, 0.3], atol=1e-15)
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from velocity_amd import NLS
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        NLS.fcnNLS_t(np.eye(3), np.zeros((4, 2)), np.zeros((4, 3)), [0, 0, 1])
+
+
+def test_product_never_imports_oracle():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "velocity_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                for bad in ("import oracle", "from oracle", "oracle/", "klt_oracle", "nls_oracle"):
+                    assert bad not in src, f"{f} references the oracle ({bad})"

@@ -1,0 +1,176 @@
+"""ctypes binding of libvelocity_hip.so (C ABI in include/velocity_hip.h) + the device workspace.
+
+PyTorch is used only as plumbing: device allocations (torch tensors), the current HIP stream and host<->device
+copies.  There is NO CPU fallback: if the HIP library is missing, or no GPU is visible, every op raises.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvelocity_hip.so")
+_lib = None
+_lock = threading.Lock()
+
+u8p, f32p, f64p, i32p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+
+
+class LKParams(C.Structure):
+    """vh_lk_params: winSize, maxLevel, criteria (utils/KLT.py:106-107)."""
+
+    _fields_ = [("win", C.c_int), ("max_level", C.c_int), ("max_count", C.c_int), ("eps", C.c_double)]
+
+
+class KltStages(C.Structure):
+    _fields_ = [(k, vp) for k in ("p_small", "v_small", "t_trans", "roi", "p_coarse", "v_coarse", "t23", "warped", "flags")]
+
+
+LK_COARSE = dict(win=15, max_level=4, max_count=10, eps=0.1)  # utils/KLT.py:106
+LK_FINE = dict(win=51, max_level=0, max_count=30, eps=0.001)  # utils/KLT.py:107
+
+_SIGS = {
+    "vh_version": (C.c_int, []),
+    "vh_last_error": (C.c_char_p, []),
+    "vh_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vh_ctx_destroy": (None, [vp]),
+    "vh_resize_quarter": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "vh_pyr_down": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "vh_remap_affine": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "vh_crop_shift": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "vh_bounding_rect": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "vh_pyr_lk": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(LKParams), C.c_float, vp, vp, vp, vp, vp]),
+    "vh_ransac_affine": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]),
+    "vh_klt_main": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(LKParams),
+                              C.POINTER(LKParams), vp, vp, vp, vp, vp]),
+    "vh_klt_stage_ptrs": (C.c_int, [vp, C.c_int, C.POINTER(KltStages)]),
+    "vh_klt_regional": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, f32p, C.POINTER(LKParams), C.c_float, C.c_int,
+                                  vp, vp, vp, vp]),
+    "vh_pose": (C.c_int, [vp, f32p, vp, vp, C.c_int, f64p, f64p, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "vh_world2image": (C.c_int, [vp, f64p, vp, C.c_int, vp, vp]),
+    "vh_image2world": (C.c_int, [vp, f64p, vp, C.c_int, vp, vp]),
+    "vh_pixel2uvec": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp, vp]),
+    "vh_two_view_intercept": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "vh_msv1_t": (C.c_int, [vp, f32p, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+}
+
+
+def load():
+    """Load the HIP library (no GPU needed for loading).  Raises if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950). velocity_amd has no CPU fallback."
+                )
+            L = C.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGS.items():
+                fn = getattr(L, name)  # AttributeError here = header/library mismatch
+                fn.restype, fn.argtypes = res, args
+            _lib = L
+    return _lib
+
+
+def declared_symbols():
+    """Every VH_API symbol include/velocity_hip.h declares."""
+    import re
+
+    hdr = open(os.path.join(_HERE, "..", "include", "velocity_hip.h")).read()
+    return re.findall(r"VH_API\s+[\w\s\*]+?\b(vh_\w+)\(", hdr)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().vh_last_error().decode(errors="replace")
+        raise RuntimeError(f"libvelocity_hip {what} failed (rc={rc}): {msg}")
+
+
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("velocity_amd needs a visible MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    return torch
+
+
+def stream_ptr():
+    torch = torch_cuda()
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def to_dev(a, dtype=None):
+    """numpy array / torch tensor -> contiguous CUDA tensor of `dtype` (a torch dtype)."""
+    torch = torch_cuda()
+    if isinstance(a, torch.Tensor):
+        t = a if a.is_cuda else a.cuda()
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def img_dev(a):
+    """uint8 2-D image -> (cuda tensor, h, w, row stride).  Tensors with unit column stride are used in place (views)."""
+    torch = torch_cuda()
+    if isinstance(a, torch.Tensor):
+        assert a.dtype == torch.uint8 and a.dim() == 2
+        t = a if a.is_cuda else a.cuda()
+        if t.stride(1) != 1:
+            t = t.contiguous()
+        return t, t.shape[0], t.shape[1], t.stride(0)
+    a = np.asarray(a)
+    assert a.dtype == np.uint8 and a.ndim == 2
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t, t.shape[0], t.shape[1], t.stride(0)
+
+
+class Workspace:
+    """vh_ctx: device scratch for `batch` streams of at most max_w x max_h pixels and max_pts tracks."""
+
+    def __init__(self, batch=1, max_w=1920, max_h=1080, max_pts=4096):
+        self.lib = load()
+        torch_cuda()
+        self.batch, self.max_w, self.max_h, self.max_pts = batch, max_w, max_h, max_pts
+        h = C.c_void_p()
+        check(self.lib.vh_ctx_create(C.byref(h), batch, max_w, max_h, max_pts), "vh_ctx_create")
+        self.handle = h
+
+    def fits(self, w, h, n):
+        return w <= self.max_w and h <= self.max_h and n <= self.max_pts
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.vh_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_default_ws = None
+
+
+def workspace(w=0, h=0, n=0):
+    """Process-wide default workspace, grown on demand."""
+    global _default_ws
+    if _default_ws is None or not _default_ws.fits(w, h, n):
+        old = _default_ws
+        mw = max(w, old.max_w if old else 1920)
+        mh = max(h, old.max_h if old else 1080)
+        mp = max(n, old.max_pts if old else 8192)
+        torch_cuda().cuda.synchronize()
+        _default_ws = Workspace(1, mw, mh, mp)
+    return _default_ws
+
+
+def lk_params(d):
+    return LKParams(int(d["win"]), int(d["max_level"]), int(d["max_count"]), float(d["eps"]))

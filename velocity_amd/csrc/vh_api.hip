@@ -1,0 +1,747 @@
+// C-ABI entry points (include/velocity_hip.h), the device workspace, and the KLTmain stage pipeline
+// (utils/KLT.py:99-134).  Data-dependent quantities (track count, ROI, shift, transforms, pyramid level sizes) never
+// leave the GPU: small "glue" kernels write the job descriptors of the next stage into the per-stream workspace, and
+// every image / track kernel is launched over the maximum extent and reads its extent from there.  A frame is thus a
+// fixed sequence of launches with no host round trip (hipGraph-capturable), for any number of streams per launch.
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/velocity_hip.h"
+#include "vh_kernels.hpp"
+#include "vh_nls.hpp"
+
+// ---------------------------------------------------------------------------------------------------------------
+// error reporting
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void vh_set_error(const char* what, hipError_t e, const char* file, int line)
+{
+    snprintf(g_err, sizeof(g_err), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+}
+static int vh_fail(int code, const char* msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+#define VH_LAUNCH_CHECK() VH_CHECK(hipGetLastError())
+
+extern "C" VH_API int vh_version(void) { return 100; }
+extern "C" VH_API const char* vh_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-stream device workspace
+// ---------------------------------------------------------------------------------------------------------------
+struct StreamBufs {  // fixed after vh_ctx_create
+    uint8_t* small0[2];                    // quarter-scale frames (ping-pong) when the caller passes none
+    uint8_t* small_lv[2][VH_MAX_LEVELS];   // quarter-scale pyramid levels >= 1 (ping-pong)
+    uint8_t* roi_lv[2][VH_MAX_LEVELS];     // ROI pyramid levels >= 1 of the previous (0) / current (1) frame
+    uint8_t* warp;                         // shifted crop (stage 2) / affine-warped ROI (stage 3)
+    float* p_small;
+    float* p_coarse;
+    uint8_t* v_small;
+    uint8_t* v_coarse;
+    uint8_t* v_all;                        // all-ones mask for the stateless RANSAC entry
+    uint8_t* inl;
+    int* idx;
+    int* counts;
+};
+
+struct KltIO {  // one KLTmain call (KLT.py:99)
+    const uint8_t* im;
+    const uint8_t* im0;
+    const uint8_t* im0_small;  // may be null
+    const float* p0;
+    const int* n_ptr;          // device count (null -> n)
+    float* p_all;
+    uint8_t* v;
+    uint8_t* im_small;         // may be null (internal buffer)
+    int* flags;                // may be null
+    int w, h, stride, stride0, n;
+    int reuse_prev_small;      // 1: small_lv[1 - pp] already holds the pyramid of im0_small (session mode)
+    vh_lk_params coarse, fine;
+    float fbt_coarse, fbt_fine;  // 1.0, 0.3 (KLT.py:124,133)
+};
+
+struct StreamWS {
+    LKJob lk;
+    WarpJob warp;
+    RansacJob ransac;
+    PyrBuild pb[2];
+    ImgDesc rs_src[2], rs_dst[2];  // quarter-scale resize table: [0] current frame, [1] previous frame
+    KltIO io;
+    StreamBufs bufs;
+    double M[6];
+    double t_trans[2];
+    int roi[4];
+    int dxy[2];
+    int n, m, rstatus, flags, pp, pad;
+};
+
+struct vh_ctx {
+    int batch, max_w, max_h, max_pts, sw, sh;
+    char* arena;
+    size_t arena_bytes;
+    StreamWS* d_ws;
+    StreamBufs* h_bufs;  // host copy of every stream's buffer table
+    double* d_small;     // 64 doubles of scratch for host-provided small matrices
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" VH_API int vh_ctx_create(vh_ctx** out, int batch, int max_w, int max_h, int max_pts)
+{
+    if (!out || batch < 1 || max_w < 4 || max_h < 4 || max_pts < 1) return vh_fail(-1, "vh_ctx_create: bad arguments");
+    vh_ctx* c = new (std::nothrow) vh_ctx();
+    if (!c) return vh_fail(-1, "vh_ctx_create: out of host memory");
+    c->batch = batch; c->max_w = max_w; c->max_h = max_h; c->max_pts = max_pts;
+    c->sw = (int)lrint(max_w * 0.25); c->sh = (int)lrint(max_h * 0.25);
+    // carve plan (computed twice: size, then pointers)
+    StreamBufs* hb = new StreamBufs[batch];
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    size_t ws_off = carve(sizeof(StreamWS) * batch);
+    size_t small_off = carve(sizeof(double) * 64);
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) {
+            c->arena_bytes = off;
+            hipError_t e = hipMalloc((void**)&c->arena, off);
+            if (e != hipSuccess) { delete[] hb; delete c; vh_set_error("hipMalloc(arena)", e, __FILE__, __LINE__); return (int)e; }
+            e = hipMemset(c->arena, 0, off);
+            if (e != hipSuccess) { (void)hipFree(c->arena); delete[] hb; delete c; vh_set_error("hipMemset(arena)", e, __FILE__, __LINE__); return (int)e; }
+            off = 0;
+            carve(sizeof(StreamWS) * batch);
+            carve(sizeof(double) * 64);
+        }
+        char* base = pass ? c->arena : nullptr;
+        for (int b = 0; b < batch; b++) {
+            StreamBufs& B = hb[b];
+            for (int k = 0; k < 2; k++) {
+                B.small0[k] = (uint8_t*)(base + carve((size_t)c->sw * c->sh));
+                int w = c->sw, h = c->sh;
+                for (int l = 1; l < VH_MAX_LEVELS; l++) {
+                    w = (w + 1) / 2; h = (h + 1) / 2;
+                    B.small_lv[k][l] = (uint8_t*)(base + carve((size_t)w * h));
+                }
+                B.small_lv[k][0] = nullptr;
+                w = max_w; h = max_h;
+                for (int l = 1; l < VH_MAX_LEVELS; l++) {
+                    w = (w + 1) / 2; h = (h + 1) / 2;
+                    B.roi_lv[k][l] = (uint8_t*)(base + carve((size_t)w * h));
+                }
+                B.roi_lv[k][0] = nullptr;
+            }
+            B.warp = (uint8_t*)(base + carve((size_t)max_w * max_h));
+            B.p_small = (float*)(base + carve(sizeof(float) * 2 * max_pts));
+            B.p_coarse = (float*)(base + carve(sizeof(float) * 2 * max_pts));
+            B.v_small = (uint8_t*)(base + carve(max_pts));
+            B.v_coarse = (uint8_t*)(base + carve(max_pts));
+            B.v_all = (uint8_t*)(base + carve(max_pts));
+            B.inl = (uint8_t*)(base + carve(max_pts));
+            B.idx = (int*)(base + carve(sizeof(int) * max_pts));
+            B.counts = (int*)(base + carve(sizeof(int) * VH_RANSAC_ITERS));
+        }
+    }
+    c->d_ws = (StreamWS*)(c->arena + ws_off);
+    c->d_small = (double*)(c->arena + small_off);
+    hipError_t e = hipSuccess;
+    for (int b = 0; b < batch && e == hipSuccess; b++) {
+        e = hipMemcpy(&c->d_ws[b].bufs, &hb[b], sizeof(StreamBufs), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(hb[b].v_all, 1, max_pts);
+    }
+    if (e != hipSuccess) { (void)hipFree(c->arena); delete[] hb; delete c; vh_set_error("hipMemcpy(bufs)", e, __FILE__, __LINE__); return (int)e; }
+    c->h_bufs = hb;
+    *out = c;
+    return 0;
+}
+
+extern "C" VH_API void vh_ctx_destroy(vh_ctx* c)
+{
+    if (!c) return;
+    (void)hipFree(c->arena);
+    delete[] c->h_bufs;
+    delete c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device helpers shared by the glue kernels
+// ---------------------------------------------------------------------------------------------------------------
+__device__ void fill_pyramid(PyrDesc& P, const uint8_t* lv0, int w, int h, int stride, uint8_t* const* lvbuf, int win, int max_level)
+{
+    // OpenCV truncation: keep level L, stop when level L+1 would be <= win in either dimension
+    int n = 0;
+    for (int level = 0; level <= max_level && level < VH_MAX_LEVELS; level++) {
+        ImgDesc& d = P.lv[level];
+        if (level == 0) { d.p = lv0; d.w = w; d.h = h; d.stride = stride; }
+        else { d.p = lvbuf[level]; d.w = w; d.h = h; d.stride = w; }
+        n = level + 1;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+        if (w <= win || h <= win) break;
+    }
+    P.nlevels = n;
+}
+
+__device__ void clamp_criteria(const vh_lk_params& lk, int& max_count, double& eps2)
+{
+    max_count = min(max(lk.max_count, 0), 100);
+    double e = fmin(fmax(lk.eps, 0.0), 10.0);
+    eps2 = e * e;
+}
+
+__device__ void fill_lk_common(LKJob& J, const vh_lk_params& lk, const float* p_in, const int* n_ptr, int n)
+{
+    J.p_in = p_in; J.n_ptr = n_ptr; J.n = n;
+    J.win = lk.win; J.max_level = lk.max_level;
+    clamp_criteria(lk, J.max_count, J.eps2);
+    J.err_out = nullptr; J.fbe_out = nullptr; J.praw_out = nullptr;
+}
+
+// ---- stage 0: descriptors of the quarter-scale stage (KLT.py:110-114) -------------------------------------------
+__global__ void k_klt_setup(StreamWS* ws_all)
+{
+    if (threadIdx.x != 0) return;
+    StreamWS& ws = ws_all[blockIdx.x];
+    const KltIO& io = ws.io;
+    const StreamBufs& B = ws.bufs;
+    const int n = io.n_ptr ? *io.n_ptr : io.n;
+    ws.n = n;
+    ws.flags = 0;
+    const int dw = __double2int_rn(io.w * 0.25), dh = __double2int_rn(io.h * 0.25);
+    const int cur = ws.pp & 1, prev = 1 - cur;
+    uint8_t* small_cur = io.im_small ? io.im_small : B.small0[cur];
+    const uint8_t* small_prev = io.im0_small ? io.im0_small : B.small0[prev];
+    // resize table
+    ws.rs_src[0] = ImgDesc{io.im, io.w, io.h, io.stride, 0};
+    ws.rs_dst[0] = ImgDesc{small_cur, dw, dh, dw, 0};
+    const bool need_prev = io.im0_small == nullptr;
+    ws.rs_src[1] = ImgDesc{io.im0, io.w, io.h, io.stride0, 0};
+    ws.rs_dst[1] = ImgDesc{B.small0[prev], need_prev ? dw : 0, need_prev ? dh : 0, dw, 0};
+    // job A: LK on the quarter-scale pair, points scaled by 1/4, no backward pass
+    LKJob& J = ws.lk;
+    fill_pyramid(J.I, small_prev, dw, dh, dw, B.small_lv[prev], io.coarse.win, io.coarse.max_level);
+    fill_pyramid(J.J, small_cur, dw, dh, dw, B.small_lv[cur], io.coarse.win, io.coarse.max_level);
+    ws.pb[0] = PyrBuild{&J.I, io.reuse_prev_small ? 0 : 1, 0};
+    ws.pb[1] = PyrBuild{&J.J, 1, 0};
+    fill_lk_common(J, io.coarse, io.p0, nullptr, n);
+    J.p_out = B.p_small; J.v_out = B.v_small;
+    J.fbt = -1.f;
+    J.in_scale = 0.25f; J.in_off[0] = 0.f; J.in_off[1] = 0.f;
+    J.out_mode = VH_OUT_SCALE; J.out_scale = 0.25f;
+    // RANSAC 1: inliers gate the status (KLT.py:116-117)
+    RansacJob& R = ws.ransac;
+    R.from = io.p0; R.to = B.p_small; R.valid = B.v_small; R.n_ptr = nullptr; R.n = n;
+    R.min_valid = 0; R.gate_valid = 1;
+    R.idx = B.idx; R.counts = B.counts; R.m_out = &ws.m; R.M = ws.M; R.inl = B.inl; R.status = &ws.rstatus;
+}
+
+// ---- stage 1 -> 2: mean translation, ROI, shifted crop, job B (KLT.py:121-124, 55-68) ---------------------------
+__device__ __forceinline__ float block_min_f(float v, float* sh, bool is_max)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(v, o, 64);
+        v = is_max ? fmaxf(v, t) : fminf(v, t);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int k = 1; k < 4; k++) r = is_max ? fmaxf(r, sh[k]) : fminf(r, sh[k]);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_klt_glue1(StreamWS* ws_all)
+{
+    StreamWS& ws = ws_all[blockIdx.x];
+    const KltIO& io = ws.io;
+    const StreamBufs& B = ws.bufs;
+    const int n = ws.n, tid = threadIdx.x;
+    __shared__ long long sh_i[3 * 4];
+    __shared__ float sh_f[4];
+    long long s[3] = {0, 0, 0};
+    float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
+    for (int i = tid; i < n; i += 256) {
+        const float x0 = io.p0[2 * i], y0 = io.p0[2 * i + 1];
+        mnx = fminf(mnx, x0); mxx = fmaxf(mxx, x0); mny = fminf(mny, y0); mxy = fmaxf(mxy, y0);
+        if (B.v_small[i]) {
+            const float dx = __fsub_rn(B.p_small[2 * i], x0), dy = __fsub_rn(B.p_small[2 * i + 1], y0);
+            s[0] += vh_fixq((double)dx, 32); s[1] += vh_fixq((double)dy, 32); s[2] += 1;
+        }
+    }
+    // block reductions
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int k = 0; k < 3; k++) s[k] = vh_wave_sum_i64(s[k]);
+        if (lane == 0) for (int k = 0; k < 3; k++) sh_i[k * 4 + wave] = s[k];
+        __syncthreads();
+        for (int k = 0; k < 3; k++) s[k] = sh_i[k * 4] + sh_i[k * 4 + 1] + sh_i[k * 4 + 2] + sh_i[k * 4 + 3];
+    }
+    mnx = block_min_f(mnx, sh_f, false); mny = block_min_f(mny, sh_f, false);
+    mxx = block_min_f(mxx, sh_f, true);  mxy = block_min_f(mxy, sh_f, true);
+    if (tid != 0) return;
+
+    const double cnt = (double)s[2];
+    const double tx = s[2] ? __ddiv_rn(ldexp((double)s[0], -32), cnt) : 0.0;
+    const double ty = s[2] ? __ddiv_rn(ldexp((double)s[1], -32), cnt) : 0.0;
+    ws.t_trans[0] = tx; ws.t_trans[1] = ty;
+    // boundingRect(p0, im.shape, border=(50,50))  (images.py:9-19, KLT.py:60)
+    int x0 = vh_floor(mnx), y0 = vh_floor(mny);
+    const int bw = vh_floor(mxx) - x0 + 1, bh = vh_floor(mxy) - y0 + 1;
+    int x1 = x0 + bw + 50, y1 = y0 + bh + 50;
+    x0 -= 50; y0 -= 50;
+    x0 = max(x0, 1); y0 = max(y0, 1); x1 = min(x1, io.w); y1 = min(y1, io.h);
+    if (n == 0) { x0 = 1; y0 = 1; x1 = 1; y1 = 1; }
+    ws.roi[0] = x0; ws.roi[1] = x1; ws.roi[2] = y0; ws.roi[3] = y1;
+    const int rw = max(x1 - x0, 0), rh = max(y1 - y0, 0);
+    const int dx = (int)(float)tx, dy = (int)(float)ty;  // T.astype(float32)[2].__int__()  (KLT.py:58,66-67)
+    ws.dxy[0] = dx; ws.dxy[1] = dy;
+    // shifted crop: a view when it stays inside the frame, a zero-padded copy otherwise
+    WarpJob& W = ws.warp;
+    W.src = ImgDesc{io.im, io.w, io.h, io.stride, 0};
+    W.dst = B.warp; W.dst_stride = rw;
+    W.x0 = x0; W.x1 = x1; W.y0 = y0; W.y1 = y1; W.dx = dx; W.dy = dy;
+    const bool inside = x0 + dx >= 0 && x1 + dx <= io.w && y0 + dy >= 0 && y1 + dy <= io.h;
+    W.mode = (inside || n == 0) ? -1 : 0;
+    LKJob& J = ws.lk;
+    const vh_lk_params& lk = io.coarse;
+    fill_pyramid(J.I, io.im0 + (size_t)y0 * io.stride0 + x0, rw, rh, io.stride0, B.roi_lv[0], lk.win, lk.max_level);
+    if (inside) fill_pyramid(J.J, io.im + (ptrdiff_t)(y0 + dy) * io.stride + (x0 + dx), rw, rh, io.stride, B.roi_lv[1], lk.win, lk.max_level);
+    else fill_pyramid(J.J, B.warp, rw, rh, rw, B.roi_lv[1], lk.win, lk.max_level);
+    ws.pb[0] = PyrBuild{&J.I, 1, 0};
+    ws.pb[1] = PyrBuild{&J.J, 1, 0};
+    fill_lk_common(J, lk, io.p0, nullptr, n);
+    J.p_out = B.p_coarse; J.v_out = B.v_coarse;
+    J.fbt = io.fbt_coarse;
+    J.in_scale = 1.f; J.in_off[0] = (float)x0; J.in_off[1] = (float)y0;
+    J.out_mode = VH_OUT_TRANSLATE; J.out_off[0] = (float)dx; J.out_off[1] = (float)dy;
+    // RANSAC 2: affine from the survivors, only when more than 10 of them (KLT.py:126-127)
+    RansacJob& R = ws.ransac;
+    R.to = B.p_coarse; R.valid = B.v_coarse; R.min_valid = 10; R.gate_valid = 0;
+}
+
+// ---- stage 2 -> 3: affine (or fallback), remap job, job C (KLT.py:126-133) ---------------------------------------
+__global__ void k_klt_glue2(StreamWS* ws_all)
+{
+    if (threadIdx.x != 0) return;
+    StreamWS& ws = ws_all[blockIdx.x];
+    const KltIO& io = ws.io;
+    const StreamBufs& B = ws.bufs;
+    double M[6];
+    if (ws.rstatus) {
+        for (int k = 0; k < 6; k++) M[k] = ws.M[k];
+    } else {
+        // "KLT coarse-affine failure" (KLT.py:128-130): the SURF fallback is out of scope -> keep the translation
+        ws.flags |= 1;
+        M[0] = 1; M[1] = 0; M[2] = ws.t_trans[0]; M[3] = 0; M[4] = 1; M[5] = ws.t_trans[1];
+        for (int k = 0; k < 6; k++) ws.M[k] = M[k];
+    }
+    const float T[6] = {(float)M[0], (float)M[3], (float)M[1], (float)M[4], (float)M[2], (float)M[5]};  // T23.T.astype(float32)
+    const int x0 = ws.roi[0], x1 = ws.roi[1], y0 = ws.roi[2], y1 = ws.roi[3];
+    const int rw = max(x1 - x0, 0), rh = max(y1 - y0, 0);
+    WarpJob& W = ws.warp;
+    W.mode = ws.n > 0 ? 1 : -1;
+    W.dst = B.warp; W.dst_stride = rw;
+    for (int k = 0; k < 6; k++) W.T[k] = T[k];
+    LKJob& J = ws.lk;
+    const vh_lk_params& lk = io.fine;
+    fill_pyramid(J.I, io.im0 + (size_t)y0 * io.stride0 + x0, rw, rh, io.stride0, B.roi_lv[0], lk.win, lk.max_level);
+    fill_pyramid(J.J, B.warp, rw, rh, rw, B.roi_lv[1], lk.win, lk.max_level);
+    ws.pb[0] = PyrBuild{&J.I, 1, 0};
+    ws.pb[1] = PyrBuild{&J.J, 1, 0};
+    fill_lk_common(J, lk, io.p0, nullptr, ws.n);
+    J.p_out = io.p_all; J.v_out = io.v;
+    J.fbt = io.fbt_fine;
+    J.in_scale = 1.f; J.in_off[0] = (float)x0; J.in_off[1] = (float)y0;
+    J.out_mode = VH_OUT_AFFINE;
+    for (int k = 0; k < 6; k++) J.T[k] = T[k];
+    if (io.flags) *io.flags = ws.flags;
+}
+
+static int run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine)
+{
+    StreamWS* ws = c->d_ws + slot;
+    const size_t st = sizeof(StreamWS);
+    const int lvl_c = min(coarse.max_level, VH_MAX_LEVELS - 1), lvl_f = min(fine.max_level, VH_MAX_LEVELS - 1);
+    hipLaunchKernelGGL(k_klt_setup, dim3(count), dim3(64), 0, s, ws);
+    vh_launch_resize_quarter(&ws->rs_src[0], &ws->rs_dst[0], st, 2, count, c->sw, c->sh, s);
+    for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->sw, c->sh, s);
+    int r = vh_launch_lk(&ws->lk, st, count, c->max_pts, coarse.win, s);
+    if (r) return vh_fail(r, "vh_launch_lk failed (window too large for LDS?)");
+    vh_launch_ransac(&ws->ransac, st, count, c->max_pts, s);
+    hipLaunchKernelGGL(k_klt_glue1, dim3(count), dim3(256), 0, s, ws);
+    vh_launch_roi_warp(&ws->warp, st, count, c->max_w, c->max_h, s);
+    for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->max_w, c->max_h, s);
+    r = vh_launch_lk(&ws->lk, st, count, c->max_pts, coarse.win, s);
+    if (r) return vh_fail(r, "vh_launch_lk failed");
+    vh_launch_ransac(&ws->ransac, st, count, c->max_pts, s);
+    hipLaunchKernelGGL(k_klt_glue2, dim3(count), dim3(64), 0, s, ws);
+    vh_launch_roi_warp(&ws->warp, st, count, c->max_w, c->max_h, s);
+    for (int l = 0; l < lvl_f; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->max_w, c->max_h, s);
+    r = vh_launch_lk(&ws->lk, st, count, c->max_pts, fine.win, s);
+    if (r) return vh_fail(r, "vh_launch_lk failed");
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_klt_main(vh_ctx* c, int slot, const uint8_t* im, const uint8_t* im0, const uint8_t* im0_small, int w, int h,
+                                  int stride, int stride0, const float* p0, int n, const vh_lk_params* coarse, const vh_lk_params* fine,
+                                  float* p_all, uint8_t* v, uint8_t* im_small, int* flags, void* stream)
+{
+    if (!c || slot < 0 || slot >= c->batch) return vh_fail(-1, "vh_klt_main: bad slot");
+    if (w > c->max_w || h > c->max_h || n > c->max_pts || n < 0) return vh_fail(-1, "vh_klt_main: frame or point count exceeds the workspace");
+    if (!coarse || !fine || coarse->win < 3 || fine->win < 3) return vh_fail(-1, "vh_klt_main: bad LK parameters");
+    KltIO io;
+    memset(&io, 0, sizeof(io));
+    io.im = im; io.im0 = im0; io.im0_small = im0_small; io.p0 = p0; io.n_ptr = nullptr; io.p_all = p_all; io.v = v;
+    io.im_small = im_small; io.flags = flags; io.w = w; io.h = h; io.stride = stride; io.stride0 = stride0; io.n = n;
+    io.reuse_prev_small = 0; io.coarse = *coarse; io.fine = *fine; io.fbt_coarse = 1.0f; io.fbt_fine = 0.3f;
+    hipStream_t s = (hipStream_t)stream;
+    VH_CHECK(vh_store(&c->d_ws[slot].io, io, s));
+    return run_klt_main(c, slot, 1, s, *coarse, *fine);
+}
+
+extern "C" VH_API int vh_klt_stage_ptrs(vh_ctx* c, int slot, vh_klt_stages* out)
+{
+    if (!c || !out || slot < 0 || slot >= c->batch) return vh_fail(-1, "vh_klt_stage_ptrs: bad arguments");
+    const StreamBufs& B = c->h_bufs[slot];
+    StreamWS* ws = c->d_ws + slot;
+    out->p_small = B.p_small; out->v_small = B.v_small; out->t_trans = ws->t_trans; out->roi = ws->roi;
+    out->p_coarse = B.p_coarse; out->v_coarse = B.v_coarse; out->t23 = ws->M; out->warped = B.warp; out->flags = &ws->flags;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stateless image entry points (use slot 0 of the workspace for their descriptors)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" VH_API int vh_resize_quarter(vh_ctx* c, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream)
+{
+    if (!c) return vh_fail(-1, "null ctx");
+    hipStream_t s = (hipStream_t)stream;
+    const int dw = (int)lrint(w * 0.25), dh = (int)lrint(h * 0.25);
+    StreamWS* ws = c->d_ws;
+    VH_CHECK(vh_store(&ws->rs_src[0], ImgDesc{src, w, h, stride, 0}, s));
+    VH_CHECK(vh_store(&ws->rs_dst[0], ImgDesc{dst, dw, dh, dw, 0}, s));
+    vh_launch_resize_quarter(&ws->rs_src[0], &ws->rs_dst[0], sizeof(StreamWS), 1, 1, dw, dh, s);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_pyr_down(vh_ctx* c, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream)
+{
+    if (!c) return vh_fail(-1, "null ctx");
+    hipStream_t s = (hipStream_t)stream;
+    StreamWS* ws = c->d_ws;
+    PyrDesc P;
+    memset(&P, 0, sizeof(P));
+    P.nlevels = 2;
+    P.lv[0] = ImgDesc{src, w, h, stride, 0};
+    P.lv[1] = ImgDesc{dst, (w + 1) / 2, (h + 1) / 2, (w + 1) / 2, 0};
+    VH_CHECK(vh_store(&ws->lk.I, P, s));
+    VH_CHECK(vh_store(&ws->pb[0], PyrBuild{&ws->lk.I, 1, 0}, s));
+    VH_CHECK(vh_store(&ws->pb[1], PyrBuild{nullptr, 0, 0}, s));
+    vh_launch_pyr_down_ws(&ws->pb[0], sizeof(StreamWS), 1, 0, w, h, s);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+static int run_warp(vh_ctx* c, const WarpJob& job, hipStream_t s)
+{
+    StreamWS* ws = c->d_ws;
+    VH_CHECK(vh_store(&ws->warp, job, s));
+    vh_launch_roi_warp(&ws->warp, sizeof(StreamWS), 1, job.x1 - job.x0, job.y1 - job.y0, s);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_remap_affine(vh_ctx* c, const uint8_t* im, int w, int h, int stride, const float* T, int x0, int x1, int y0,
+                                      int y1, uint8_t* dst, void* stream)
+{
+    if (!c || x1 <= x0 || y1 <= y0) return vh_fail(-1, "vh_remap_affine: bad arguments");
+    WarpJob J;
+    memset(&J, 0, sizeof(J));
+    J.src = ImgDesc{im, w, h, stride, 0}; J.dst = dst; J.dst_stride = x1 - x0; J.mode = 1;
+    J.x0 = x0; J.x1 = x1; J.y0 = y0; J.y1 = y1;
+    for (int k = 0; k < 6; k++) J.T[k] = T[k];
+    return run_warp(c, J, (hipStream_t)stream);
+}
+
+extern "C" VH_API int vh_crop_shift(vh_ctx* c, const uint8_t* im, int w, int h, int stride, int x0, int x1, int y0, int y1, int dx, int dy,
+                                    uint8_t* dst, void* stream)
+{
+    if (!c || x1 <= x0 || y1 <= y0) return vh_fail(-1, "vh_crop_shift: bad arguments");
+    WarpJob J;
+    memset(&J, 0, sizeof(J));
+    J.src = ImgDesc{im, w, h, stride, 0}; J.dst = dst; J.dst_stride = x1 - x0; J.mode = 0;
+    J.x0 = x0; J.x1 = x1; J.y0 = y0; J.y1 = y1; J.dx = dx; J.dy = dy;
+    return run_warp(c, J, (hipStream_t)stream);
+}
+
+__global__ __launch_bounds__(256) void k_bounding_rect(const float* p, int n, int imw, int imh, int bx, int by, int* roi)
+{
+    __shared__ float sh_f[4];
+    float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float x = p[2 * i], y = p[2 * i + 1];
+        mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+    }
+    mnx = block_min_f(mnx, sh_f, false); mny = block_min_f(mny, sh_f, false);
+    mxx = block_min_f(mxx, sh_f, true);  mxy = block_min_f(mxy, sh_f, true);
+    if (threadIdx.x == 0) {
+        int x0 = vh_floor(mnx), y0 = vh_floor(mny);
+        const int bw = vh_floor(mxx) - x0 + 1, bh = vh_floor(mxy) - y0 + 1;
+        int x1 = x0 + bw + bx, y1 = y0 + bh + by;
+        x0 -= bx; y0 -= by;
+        roi[0] = max(x0, 1); roi[1] = min(x1, imw); roi[2] = max(y0, 1); roi[3] = min(y1, imh);
+    }
+}
+
+extern "C" VH_API int vh_bounding_rect(vh_ctx* c, const float* p, int n, int imw, int imh, int bx, int by, int* roi_out, void* stream)
+{
+    if (!c || n < 1) return vh_fail(-1, "vh_bounding_rect: bad arguments");
+    hipLaunchKernelGGL(k_bounding_rect, dim3(1), dim3(256), 0, (hipStream_t)stream, p, n, imw, imh, bx, by, roi_out);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stateless tracker entry points
+// ---------------------------------------------------------------------------------------------------------------
+static void host_fill_pyramid(PyrDesc& P, const uint8_t* lv0, int w, int h, int stride, uint8_t* const* lvbuf, int win, int max_level)
+{
+    int n = 0;
+    for (int level = 0; level <= max_level && level < VH_MAX_LEVELS; level++) {
+        ImgDesc& d = P.lv[level];
+        if (level == 0) { d.p = lv0; d.w = w; d.h = h; d.stride = stride; }
+        else { d.p = lvbuf[level]; d.w = w; d.h = h; d.stride = w; }
+        d.pad = 0;
+        n = level + 1;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+        if (w <= win || h <= win) break;
+    }
+    P.nlevels = n;
+}
+
+extern "C" VH_API int vh_pyr_lk(vh_ctx* c, const uint8_t* im1, const uint8_t* im2, int w, int h, int stride1, int stride2, const float* p1,
+                                int n, const vh_lk_params* lk, float fbt, float* p2, uint8_t* v, float* err, float* fbe, void* stream)
+{
+    if (!c || !lk || lk->win < 3) return vh_fail(-1, "vh_pyr_lk: bad arguments");
+    if (w > c->max_w || h > c->max_h || n > c->max_pts) return vh_fail(-1, "vh_pyr_lk: image or point count exceeds the workspace");
+    if (n <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const StreamBufs& B = c->h_bufs[0];
+    LKJob J;
+    memset(&J, 0, sizeof(J));
+    host_fill_pyramid(J.I, im1, w, h, stride1, B.roi_lv[0], lk->win, lk->max_level);
+    host_fill_pyramid(J.J, im2, w, h, stride2, B.roi_lv[1], lk->win, lk->max_level);
+    J.p_in = p1; J.p_out = p2; J.v_out = v; J.err_out = err; J.fbe_out = fbe; J.n = n;
+    J.win = lk->win; J.max_level = lk->max_level;
+    J.max_count = lk->max_count < 0 ? 0 : (lk->max_count > 100 ? 100 : lk->max_count);
+    double e = lk->eps < 0 ? 0 : (lk->eps > 10 ? 10 : lk->eps);
+    J.eps2 = e * e;
+    J.fbt = fbt;
+    J.in_scale = 1.f; J.out_mode = VH_OUT_SCALE; J.out_scale = 1.f;
+    StreamWS* ws = c->d_ws;
+    VH_CHECK(vh_store(&ws->lk, J, s));
+    VH_CHECK(vh_store(&ws->pb[0], PyrBuild{&ws->lk.I, 1, 0}, s));
+    VH_CHECK(vh_store(&ws->pb[1], PyrBuild{&ws->lk.J, 1, 0}, s));
+    const int lv = lk->max_level < VH_MAX_LEVELS - 1 ? lk->max_level : VH_MAX_LEVELS - 1;
+    for (int l = 0; l < lv; l++) vh_launch_pyr_down_ws(&ws->pb[0], sizeof(StreamWS), 1, l, w, h, s);
+    int r = vh_launch_lk(&ws->lk, sizeof(StreamWS), 1, n, lk->win, s);
+    if (r) return vh_fail(r, "vh_launch_lk failed (window too large for LDS?)");
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_ransac_affine(vh_ctx* c, const float* from, const float* to, const uint8_t* valid, int n, double* M, uint8_t* inl,
+                                       int* status, void* stream)
+{
+    if (!c || n < 0 || n > c->max_pts) return vh_fail(-1, "vh_ransac_affine: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const StreamBufs& B = c->h_bufs[0];
+    RansacJob R;
+    memset(&R, 0, sizeof(R));
+    R.from = from; R.to = to; R.valid = const_cast<uint8_t*>(valid ? valid : B.v_all); R.n = n; R.min_valid = 0; R.gate_valid = 0;
+    R.idx = B.idx; R.counts = B.counts; R.m_out = &c->d_ws[0].m; R.M = M; R.inl = inl; R.status = status;
+    VH_CHECK(vh_store(&c->d_ws[0].ransac, R, s));
+    vh_launch_ransac(&c->d_ws[0].ransac, sizeof(StreamWS), 1, n, s);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+// KLTregional (KLT.py:55-95) as one device-side pipeline: bbox -> ROI -> crop/remap -> LK fwd/bwd -> map back
+struct RegionalIO {
+    const uint8_t* im0;
+    const uint8_t* im;
+    const float* p0;
+    float* p_out;
+    uint8_t* v_out;
+    int* roi_out;
+    int w, h, stride0, stride, n, translate;
+    vh_lk_params lk;
+    float fbt;
+    float T[6];
+};
+
+__global__ __launch_bounds__(256) void k_regional_setup(StreamWS* ws_p, RegionalIO io)
+{
+    StreamWS& ws = *ws_p;
+    const StreamBufs& B = ws.bufs;
+    __shared__ float sh_f[4];
+    float mnx = 3.0e38f, mny = 3.0e38f, mxx = -3.0e38f, mxy = -3.0e38f;
+    for (int i = threadIdx.x; i < io.n; i += 256) {
+        const float x = io.p0[2 * i], y = io.p0[2 * i + 1];
+        mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+    }
+    mnx = block_min_f(mnx, sh_f, false); mny = block_min_f(mny, sh_f, false);
+    mxx = block_min_f(mxx, sh_f, true);  mxy = block_min_f(mxy, sh_f, true);
+    if (threadIdx.x != 0) return;
+    int x0 = vh_floor(mnx), y0 = vh_floor(mny);
+    const int bw = vh_floor(mxx) - x0 + 1, bh = vh_floor(mxy) - y0 + 1;
+    int x1 = min(x0 + bw + 50, io.w), y1 = min(y0 + bh + 50, io.h);
+    x0 = max(x0 - 50, 1); y0 = max(y0 - 50, 1);
+    const int rw = max(x1 - x0, 0), rh = max(y1 - y0, 0);
+    if (io.roi_out) { io.roi_out[0] = x0; io.roi_out[1] = x1; io.roi_out[2] = y0; io.roi_out[3] = y1; }
+    ws.roi[0] = x0; ws.roi[1] = x1; ws.roi[2] = y0; ws.roi[3] = y1;
+    WarpJob& W = ws.warp;
+    W.src = ImgDesc{io.im, io.w, io.h, io.stride, 0};
+    W.dst = B.warp; W.dst_stride = rw;
+    W.x0 = x0; W.x1 = x1; W.y0 = y0; W.y1 = y1;
+    LKJob& J = ws.lk;
+    fill_pyramid(J.I, io.im0 + (size_t)y0 * io.stride0 + x0, rw, rh, io.stride0, B.roi_lv[0], io.lk.win, io.lk.max_level);
+    fill_lk_common(J, io.lk, io.p0, nullptr, io.n);
+    J.p_out = io.p_out; J.v_out = io.v_out; J.fbt = io.fbt;
+    J.in_scale = 1.f; J.in_off[0] = (float)x0; J.in_off[1] = (float)y0;
+    if (io.translate) {
+        const int dx = (int)io.T[4], dy = (int)io.T[5];
+        W.dx = dx; W.dy = dy;
+        const bool inside = x0 + dx >= 0 && x1 + dx <= io.w && y0 + dy >= 0 && y1 + dy <= io.h;
+        W.mode = inside ? -1 : 0;
+        if (inside) fill_pyramid(J.J, io.im + (ptrdiff_t)(y0 + dy) * io.stride + (x0 + dx), rw, rh, io.stride, B.roi_lv[1], io.lk.win, io.lk.max_level);
+        else fill_pyramid(J.J, B.warp, rw, rh, rw, B.roi_lv[1], io.lk.win, io.lk.max_level);
+        J.out_mode = VH_OUT_TRANSLATE; J.out_off[0] = (float)dx; J.out_off[1] = (float)dy;
+    } else {
+        W.mode = 1;
+        for (int k = 0; k < 6; k++) { W.T[k] = io.T[k]; J.T[k] = io.T[k]; }
+        fill_pyramid(J.J, B.warp, rw, rh, rw, B.roi_lv[1], io.lk.win, io.lk.max_level);
+        J.out_mode = VH_OUT_AFFINE;
+    }
+    ws.pb[0] = PyrBuild{&J.I, 1, 0};
+    ws.pb[1] = PyrBuild{&J.J, 1, 0};
+}
+
+extern "C" VH_API int vh_klt_regional(vh_ctx* c, const uint8_t* im0, const uint8_t* im, int w, int h, int stride0, int stride, const float* p0,
+                                      int n, const float* T_host, const vh_lk_params* lk, float fbt, int translate, float* p_out,
+                                      uint8_t* v_out, int* roi_out, void* stream)
+{
+    if (!c || !lk || !T_host || lk->win < 3 || n < 1) return vh_fail(-1, "vh_klt_regional: bad arguments");
+    if (w > c->max_w || h > c->max_h || n > c->max_pts) return vh_fail(-1, "vh_klt_regional: image or point count exceeds the workspace");
+    hipStream_t s = (hipStream_t)stream;
+    RegionalIO io;
+    memset(&io, 0, sizeof(io));
+    io.im0 = im0; io.im = im; io.p0 = p0; io.p_out = p_out; io.v_out = v_out; io.roi_out = roi_out;
+    io.w = w; io.h = h; io.stride0 = stride0; io.stride = stride; io.n = n; io.translate = translate; io.lk = *lk; io.fbt = fbt;
+    for (int k = 0; k < 6; k++) io.T[k] = T_host[k];
+    StreamWS* ws = c->d_ws;
+    hipLaunchKernelGGL(k_regional_setup, dim3(1), dim3(256), 0, s, ws, io);
+    vh_launch_roi_warp(&ws->warp, sizeof(StreamWS), 1, w, h, s);
+    const int lv = lk->max_level < VH_MAX_LEVELS - 1 ? lk->max_level : VH_MAX_LEVELS - 1;
+    for (int l = 0; l < lv; l++) vh_launch_pyr_down_ws(&ws->pb[0], sizeof(StreamWS), 1, l, w, h, s);
+    int r = vh_launch_lk(&ws->lk, sizeof(StreamWS), 1, n, lk->win, s);
+    if (r) return vh_fail(r, "vh_launch_lk failed (window too large for LDS?)");
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// NLS / MSV entry points
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_store_doubles(double* dst, const double* src_dummy, int n, double v0, double v1, double v2, double v3, double v4, double v5,
+                                double v6, double v7, double v8, double v9, double v10, double v11)
+{
+    const double v[12] = {v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11};
+    if (threadIdx.x < n) dst[threadIdx.x] = v[threadIdx.x];
+}
+static int store_doubles(double* dst, const double* host, int n, hipStream_t s)
+{
+    double v[12] = {0};
+    for (int k = 0; k < n && k < 12; k++) v[k] = host[k];
+    hipLaunchKernelGGL(k_store_doubles, dim3(1), dim3(64), 0, s, dst, (const double*)nullptr, n, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8],
+                       v[9], v[10], v[11]);
+    return (int)hipGetLastError();
+}
+
+struct PoseSlot {  // lives in the workspace arena right behind d_small (one per stateless call)
+    PoseJob job;
+};
+
+extern "C" VH_API int vh_pose(vh_ctx* c, const float* K, const float* p, const double* pw, int n, const double* x0, const double* R,
+                              int findR, float* t_out, double* R_out, double* res_out, double* p_proj, int* info, void* stream)
+{
+    if (!c || !K || !x0 || !R || n < 0) return vh_fail(-1, "vh_pose: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    PoseJob J;
+    memset(&J, 0, sizeof(J));
+    for (int k = 0; k < 9; k++) { J.K[k] = (double)K[k]; J.R[k] = R[k]; }
+    for (int k = 0; k < 6; k++) J.x0[k] = x0[k];
+    J.p = p; J.pw = pw; J.n = n; J.mode = findR ? 1 : 0;
+    J.t_out = t_out; J.R_out = R_out; J.res_out = res_out; J.p_proj = p_proj; J.info_out = info;
+    // the job descriptor is parked in the LKJob area of slot 0 (never live at the same time on one stream)
+    static_assert(sizeof(PoseJob) <= sizeof(LKJob), "PoseJob must fit in the LKJob slot");
+    PoseJob* d = reinterpret_cast<PoseJob*>(&c->d_ws[0].lk);
+    VH_CHECK(vh_store(d, J, s));
+    vh_launch_pose(d, sizeof(PoseJob), 1, J.mode, s);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_world2image(vh_ctx* c, const double* C_host, const double* pw, int n, double* out, void* stream)
+{
+    if (!c || !C_host) return vh_fail(-1, "vh_world2image: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int r = store_doubles(c->d_small, C_host, 12, s);
+    if (r) return r;
+    vh_launch_world2image(c->d_small, pw, n, out, s);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_image2world(vh_ctx* c, const double* Hi_host, const double* p, int n, double* out, void* stream)
+{
+    if (!c || !Hi_host) return vh_fail(-1, "vh_image2world: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int r = store_doubles(c->d_small + 16, Hi_host, 9, s);
+    if (r) return r;
+    vh_launch_image2world(c->d_small + 16, p, n, out, s);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_pixel2uvec(vh_ctx* c, double cx, double cy, double f, const double* p, int n, double* out, void* stream)
+{
+    if (!c) return vh_fail(-1, "null ctx");
+    vh_launch_pixel2uvec(cx, cy, f, p, n, out, (hipStream_t)stream);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_two_view_intercept(vh_ctx* c, const double* A, const double* U, int nf, int nv, double* out, void* stream)
+{
+    if (!c || nf < 2 || nf > 16) return vh_fail(-1, "vh_two_view_intercept: nf must be in [2,16]");
+    vh_launch_two_view(A, U, nf, nv, out, (hipStream_t)stream);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_msv1_t(vh_ctx* c, const float* K, const float* P, const float* B, const int* ids, int ng, int N0, int nhist, int ii,
+                                int f32_rays, double* U_scratch, float* x_out, double* b0, int* info, void* stream)
+{
+    if (!c || !K || ii < 1 || ii + 1 > 16 || ii + 1 > nhist) return vh_fail(-1, "vh_msv1_t: need 2 <= ii+1 <= min(16, nhist)");
+    MsvJob J;
+    memset(&J, 0, sizeof(J));
+    for (int k = 0; k < 9; k++) J.K[k] = (double)K[k];
+    J.P = P; J.B = B; J.ids = ids; J.ng = ng; J.N0 = N0; J.nhist = nhist; J.nf = ii + 1; J.max_iter = 1000; J.f32_rays = f32_rays;
+    J.U = U_scratch; J.b0 = b0; J.x_out = x_out; J.info_out = info;
+    vh_launch_msv1(J, (hipStream_t)stream);
+    VH_LAUNCH_CHECK();
+    return 0;
+}

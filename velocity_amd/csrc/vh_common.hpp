@@ -1,0 +1,106 @@
+// Shared device/host definitions for libvelocity_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VH_MAX_LEVELS 8
+#define VH_WAVE 64
+
+#define VH_CHECK(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            vh_set_error(#expr, _e, __FILE__, __LINE__);                                       \
+            return (int)_e ? (int)_e : -1;                                                     \
+        }                                                                                      \
+    } while (0)
+
+void vh_set_error(const char* what, hipError_t e, const char* file, int line);
+
+// ---- image / pyramid descriptors (device resident; dims may be data dependent) -------------------------------
+struct ImgDesc {
+    const uint8_t* p;  // pixel (x,y) at p[y*stride + x]
+    int w, h, stride;
+    int pad;
+};
+
+struct PyrDesc {
+    int nlevels;  // levels actually present (OpenCV truncation rule applied)
+    int pad;
+    ImgDesc lv[VH_MAX_LEVELS];
+};
+
+// how LK maps its result back to frame coordinates (KLT.py:86-89,114-115)
+enum { VH_OUT_SCALE = 0, VH_OUT_TRANSLATE = 1, VH_OUT_AFFINE = 2 };
+
+// One pyramidal-LK call (cv2calcOpticalFlowPyrLK, KLT.py:37-51) for one video stream.
+struct LKJob {
+    PyrDesc I, J;        // previous / next image pyramids
+    const float* p_in;   // n x 2 points in frame coordinates
+    float* p_out;        // n x 2 mapped-back result
+    uint8_t* v_out;      // n     status (after the forward-backward gate when fbt >= 0)
+    float* err_out;      // n     LK err of the forward pass (may be null)
+    float* fbe_out;      // n     forward-backward error (may be null)
+    float* praw_out;     // n x 2 un-mapped forward result in LK image coordinates (may be null)
+    const int* n_ptr;    // device count of points (null -> n)
+    int n;
+    int win, max_level, max_count;
+    double eps2;         // criteria epsilon, already clamped and squared
+    float fbt;           // < 0: no backward pass
+    float in_scale;      // p = p_in * in_scale - in_off   (in float32, as the reference does)
+    float in_off[2];
+    int out_mode;
+    float out_scale;     // VH_OUT_SCALE:     p_out = p / out_scale
+    float out_off[2];    // VH_OUT_TRANSLATE: p_out = (p + in_off) + out_off ; VH_OUT_AFFINE: [p + in_off, 1] @ T
+    float T[6];          // 3x2 row-major float32
+};
+
+// ---- device helpers -------------------------------------------------------------------------------------------
+__device__ __forceinline__ int vh_reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+__device__ __forceinline__ int vh_floor(float v) { return (int)floorf(v); }
+__device__ __forceinline__ int vh_round(float v) { return __float2int_rn(v); }  // round-half-even (cvRound)
+__device__ __forceinline__ int vh_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ long long vh_wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int lo = __shfl_xor((int)(v & 0xffffffffll), o, 64);
+        int hi = __shfl_xor((int)(v >> 32), o, 64);
+        v += ((long long)hi << 32) | (unsigned int)lo;
+    }
+    return v;
+}
+__device__ __forceinline__ double vh_wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int vh_wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// fixed-point conversion used by every order-independent reduction: round-half-even of v * 2^bits
+__device__ __forceinline__ long long vh_fixq(double v, int bits) { return __double2ll_rn(ldexp(v, bits)); }
+
+// stream-ordered upload of a small POD (<= 3 KiB) without hipMemcpy: the blob travels as a kernel argument
+template <typename T>
+__global__ void vh_k_store(T* dst, T value)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = value;
+}
+template <typename T>
+static inline hipError_t vh_store(T* dst, const T& value, hipStream_t s)
+{
+    hipLaunchKernelGGL(vh_k_store<T>, dim3(1), dim3(64), 0, s, dst, value);
+    return hipGetLastError();
+}

@@ -1,0 +1,275 @@
+// Deterministic RANSAC affine + least-squares refit (K6): stands in for cv2.estimateAffine2D(method=RANSAC)
+// (utils/KLT.py:116,127).  OpenCV's RNG sequence cannot be reproduced without its generator, so the
+// sample of hypothesis h comes from a counter-based hash; all VH_RANSAC_ITERS hypotheses are scored in parallel (one
+// wavefront each) and a single thread then replays OpenCV's sequential "best so far + adaptive iteration count" rule
+// over the scores, which gives exactly the result of the sequential algorithm.  The refit sums are exact int64
+// fixed-point sums, so the result does not depend on reduction order.
+#include "vh_kernels.hpp"
+
+#define RANSAC_THRESH2 9.0f
+#define RANSAC_CONF 0.99
+#define RANSAC_SEED 0x2545F491u
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t ransac_draw(uint32_t hyp, uint32_t k, uint32_t attempt, uint32_t m)
+{
+    const uint32_t h = mix32(RANSAC_SEED ^ mix32(hyp * 0x9E3779B9u + k * 0x7F4A7C15u + attempt * 0x94D049BBu + 1u));
+    return (uint32_t)(((uint64_t)h * m) >> 32);
+}
+
+// log(x), x > 0, from plain IEEE arithmetic only (bit-identical on host and device)
+__device__ double det_log(double x)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((u >> 52) & 0x7FF) - 1023;
+    u = (u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m = __longlong_as_double((long long)u);
+    if (m > 1.4142135623730951) { m = __dmul_rn(m, 0.5); e += 1; }
+    const double s = __ddiv_rn(__dsub_rn(m, 1.0), __dadd_rn(m, 1.0)), s2 = __dmul_rn(s, s);
+    double acc = 0.0;
+    for (int k = 12; k >= 0; k--) acc = __dadd_rn(__dmul_rn(acc, s2), __ddiv_rn(1.0, (double)(2 * k + 1)));
+    return __dadd_rn(__dmul_rn((double)e, 0.6931471805599453), __dmul_rn(__dmul_rn(2.0, s), acc));
+}
+
+__device__ int ransac_update_iters(double conf, double ep, int max_iters)
+{
+    double num = __dsub_rn(1.0, conf);
+    if (num < 2.2250738585072014e-308) num = 2.2250738585072014e-308;
+    const double wgt = __dsub_rn(1.0, ep);
+    double denom = __dsub_rn(1.0, __dmul_rn(__dmul_rn(wgt, wgt), wgt));
+    if (denom < 2.2250738585072014e-308) return 0;
+    num = det_log(num);
+    denom = det_log(denom);
+    if (denom >= 0 || -num >= __dmul_rn((double)max_iters, -denom)) return max_iters;
+    return __double2int_rn(__ddiv_rn(num, denom));
+}
+
+__device__ __forceinline__ bool collinear(const double* a, const double* b, const double* c)
+{
+    const double dx1 = __dsub_rn(b[0], a[0]), dy1 = __dsub_rn(b[1], a[1]), dx2 = __dsub_rn(c[0], a[0]), dy2 = __dsub_rn(c[1], a[1]);
+    const double lhs = fabs(__dsub_rn(__dmul_rn(dx1, dy2), __dmul_rn(dy1, dx2)));
+    const double rhs = __dmul_rn(1.1920929e-07, __dadd_rn(__dadd_rn(__dadd_rn(fabs(dx1), fabs(dy1)), fabs(dx2)), fabs(dy2)));
+    return lhs <= rhs;
+}
+
+// hypothesis `hyp` over the m compacted pairs; returns false when the sample is degenerate
+__device__ bool ransac_hypothesis(const float* from, const float* to, const int* idx, int m, uint32_t hyp, double* M)
+{
+    int id[3];
+    for (int k = 0; k < 3; k++) {
+        bool ok = false;
+        for (uint32_t a = 0; a < 16 && !ok; a++) {
+            id[k] = (int)ransac_draw(hyp, (uint32_t)k, a, (uint32_t)m);
+            ok = true;
+            for (int q = 0; q < k; q++) ok = ok && (id[q] != id[k]);
+        }
+        if (!ok) return false;
+    }
+    double f[3][2], t[3][2];
+    for (int k = 0; k < 3; k++) {
+        const int i = idx[id[k]];
+        f[k][0] = from[2 * i]; f[k][1] = from[2 * i + 1];
+        t[k][0] = to[2 * i];   t[k][1] = to[2 * i + 1];
+    }
+    if (collinear(f[0], f[1], f[2]) || collinear(t[0], t[1], t[2])) return false;
+    const double ax = __dsub_rn(f[0][0], f[2][0]), ay = __dsub_rn(f[0][1], f[2][1]);
+    const double bx = __dsub_rn(f[1][0], f[2][0]), by = __dsub_rn(f[1][1], f[2][1]);
+    const double det = __dsub_rn(__dmul_rn(ax, by), __dmul_rn(bx, ay));
+    if (det == 0.0) return false;
+    for (int r = 0; r < 2; r++) {
+        const double u0 = __dsub_rn(t[0][r], t[2][r]), u1 = __dsub_rn(t[1][r], t[2][r]);
+        const double a = __ddiv_rn(__dsub_rn(__dmul_rn(u0, by), __dmul_rn(u1, ay)), det);
+        const double b = __ddiv_rn(__dsub_rn(__dmul_rn(ax, u1), __dmul_rn(bx, u0)), det);
+        M[3 * r] = a;
+        M[3 * r + 1] = b;
+        M[3 * r + 2] = __dsub_rn(__dsub_rn(t[2][r], __dmul_rn(a, f[2][0])), __dmul_rn(b, f[2][1]));
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool is_inlier(const double* M, float x, float y, float u, float v)
+{
+    const double ex = __dsub_rn(__dadd_rn(__dadd_rn(__dmul_rn(M[0], x), __dmul_rn(M[1], y)), M[2]), (double)u);
+    const double ey = __dsub_rn(__dadd_rn(__dadd_rn(__dmul_rn(M[3], x), __dmul_rn(M[4], y)), M[5]), (double)v);
+    const float e = (float)__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey));
+    return e <= RANSAC_THRESH2;
+}
+
+__device__ __forceinline__ const RansacJob& rjob(const void* tab, size_t stride, int b)
+{
+    return *reinterpret_cast<const RansacJob*>(reinterpret_cast<const char*>(tab) + (size_t)b * stride);
+}
+
+// block-wide sum of NV int64 values; result valid in every thread
+template <int NV>
+__device__ void block_sum_i64(long long* v, long long* sh /* [NV * 4] */)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = vh_wave_sum_i64(v[k]);
+    __syncthreads();
+    if (lane == 0)
+        for (int k = 0; k < NV; k++) sh[k * 4 + wave] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = sh[k * 4] + sh[k * 4 + 1] + sh[k * 4 + 2] + sh[k * 4 + 3];
+}
+
+// ---- 1. compaction index list of the valid pairs (order preserving) ---------------------------------------------
+__global__ __launch_bounds__(256) void k_ransac_compact(const void* tab, size_t stride)
+{
+    const RansacJob& J = rjob(tab, stride, blockIdx.x);
+    const int n = J.n_ptr ? *J.n_ptr : J.n;
+    __shared__ int wcount[4];
+    __shared__ int base;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int c = 0; c < n; c += 256) {
+        const int i = c + tid;
+        const bool f = i < n && J.valid[i] != 0;
+        const unsigned long long bal = __ballot(f);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int q = 0; q < wave; q++) off += wcount[q];
+        if (f) J.idx[off + pre] = i;
+        __syncthreads();
+        if (tid == 0) base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    if (tid == 0) *J.m_out = base;
+}
+
+// ---- 2. score every hypothesis: one wavefront per hypothesis ----------------------------------------------------
+__global__ __launch_bounds__(256) void k_ransac_score(const void* tab, size_t stride)
+{
+    const RansacJob& J = rjob(tab, stride, blockIdx.y);
+    const int m = *J.m_out;
+    const int hyp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (hyp >= VH_RANSAC_ITERS) return;
+    if (m < 3 || m <= J.min_valid) {
+        if (lane == 0) J.counts[hyp] = 0;
+        return;
+    }
+    double M[6];
+    int c = 0;
+    if (ransac_hypothesis(J.from, J.to, J.idx, m, (uint32_t)hyp, M)) {
+        for (int k = lane; k < m; k += 64) {
+            const int i = J.idx[k];
+            c += is_inlier(M, J.from[2 * i], J.from[2 * i + 1], J.to[2 * i], J.to[2 * i + 1]) ? 1 : 0;
+        }
+    }
+    c = vh_wave_sum_i32(c);
+    if (lane == 0) J.counts[hyp] = c;
+}
+
+// ---- 3. sequential selection rule, inlier mask, least-squares refit ---------------------------------------------
+__global__ __launch_bounds__(256) void k_ransac_select(const void* tab, size_t stride)
+{
+    const RansacJob& J = rjob(tab, stride, blockIdx.x);
+    const int n = J.n_ptr ? *J.n_ptr : J.n;
+    const int m = *J.m_out;
+    const int tid = threadIdx.x;
+    __shared__ int s_best, s_count;
+    __shared__ double s_M[6];
+    __shared__ long long s_red[9 * 4];
+    if (tid == 0) {
+        int best = -1, best_count = 0;
+        if (m >= 3 && m > J.min_valid) {
+            int niters = VH_RANSAC_ITERS;
+            for (int it = 0; it < niters; it++) {
+                const int c = J.counts[it];
+                if (c > max(best_count, 2)) {
+                    best = it;
+                    best_count = c;
+                    niters = ransac_update_iters(RANSAC_CONF, __ddiv_rn((double)(m - c), (double)m), niters);
+                }
+            }
+        }
+        s_best = best;
+        s_count = best_count;
+        if (best >= 0) {
+            double M[6];
+            ransac_hypothesis(J.from, J.to, J.idx, m, (uint32_t)best, M);
+            for (int k = 0; k < 6; k++) s_M[k] = M[k];
+        }
+    }
+    __syncthreads();
+    const int best = s_best;
+    if (best < 0) {
+        for (int i = tid; i < n; i += 256) {
+            J.inl[i] = 0;
+            if (J.gate_valid) J.valid[i] = 0;
+        }
+        if (tid == 0) *J.status = 0;
+        return;
+    }
+    double M[6];
+    for (int k = 0; k < 6; k++) M[k] = s_M[k];
+
+    // inlier mask + first fixed-point pass (means), 2^-32 resolution
+    long long s1[4] = {0, 0, 0, 0};
+    for (int i = tid; i < n; i += 256) {
+        bool in = false;
+        if (J.valid[i]) {
+            const float x = J.from[2 * i], y = J.from[2 * i + 1], u = J.to[2 * i], v = J.to[2 * i + 1];
+            in = is_inlier(M, x, y, u, v);
+            if (in) {
+                s1[0] += vh_fixq((double)x, 32); s1[1] += vh_fixq((double)y, 32);
+                s1[2] += vh_fixq((double)u, 32); s1[3] += vh_fixq((double)v, 32);
+            }
+        }
+        J.inl[i] = in ? 1 : 0;
+    }
+    block_sum_i64<4>(s1, s_red);
+    const double cnt = (double)s_count;
+    const double mx = __ddiv_rn(ldexp((double)s1[0], -32), cnt), my = __ddiv_rn(ldexp((double)s1[1], -32), cnt);
+    const double mu = __ddiv_rn(ldexp((double)s1[2], -32), cnt), mv = __ddiv_rn(ldexp((double)s1[3], -32), cnt);
+    __syncthreads();  // J.inl written by this block is re-read below (same thread reads its own entries)
+
+    long long q[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < n; i += 256) {
+        if (J.inl[i]) {
+            const double x = __dsub_rn((double)J.from[2 * i], mx), y = __dsub_rn((double)J.from[2 * i + 1], my);
+            const double u = __dsub_rn((double)J.to[2 * i], mu), v = __dsub_rn((double)J.to[2 * i + 1], mv);
+            q[0] += vh_fixq(__dmul_rn(x, x), 20); q[1] += vh_fixq(__dmul_rn(x, y), 20); q[2] += vh_fixq(__dmul_rn(y, y), 20);
+            q[3] += vh_fixq(__dmul_rn(x, u), 20); q[4] += vh_fixq(__dmul_rn(y, u), 20);
+            q[5] += vh_fixq(__dmul_rn(x, v), 20); q[6] += vh_fixq(__dmul_rn(y, v), 20);
+        }
+    }
+    block_sum_i64<7>(q, s_red);
+    if (J.gate_valid)
+        for (int i = tid; i < n; i += 256) J.valid[i] = J.inl[i];
+    if (tid == 0) {
+        const double Sxx = ldexp((double)q[0], -20), Sxy = ldexp((double)q[1], -20), Syy = ldexp((double)q[2], -20);
+        const double Sxu = ldexp((double)q[3], -20), Syu = ldexp((double)q[4], -20);
+        const double Sxv = ldexp((double)q[5], -20), Syv = ldexp((double)q[6], -20);
+        const double det = __dsub_rn(__dmul_rn(Sxx, Syy), __dmul_rn(Sxy, Sxy));
+        const double tr = __dadd_rn(Sxx, Syy);
+        if (s_count >= 3 && det > __dmul_rn(__dmul_rn(1e-9, tr), tr) && det > 0) {
+            const double a = __ddiv_rn(__dsub_rn(__dmul_rn(Sxu, Syy), __dmul_rn(Syu, Sxy)), det);
+            const double b = __ddiv_rn(__dsub_rn(__dmul_rn(Sxx, Syu), __dmul_rn(Sxy, Sxu)), det);
+            const double d = __ddiv_rn(__dsub_rn(__dmul_rn(Sxv, Syy), __dmul_rn(Syv, Sxy)), det);
+            const double e = __ddiv_rn(__dsub_rn(__dmul_rn(Sxx, Syv), __dmul_rn(Sxy, Sxv)), det);
+            M[0] = a; M[1] = b; M[2] = __dsub_rn(__dsub_rn(mu, __dmul_rn(a, mx)), __dmul_rn(b, my));
+            M[3] = d; M[4] = e; M[5] = __dsub_rn(__dsub_rn(mv, __dmul_rn(d, mx)), __dmul_rn(e, my));
+        }
+        for (int k = 0; k < 6; k++) J.M[k] = M[k];
+        *J.status = 1;
+    }
+}
+
+void vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
+{
+    (void)max_n;
+    hipLaunchKernelGGL(k_ransac_compact, dim3(batch), dim3(256), 0, s, job_tab, tab_stride);
+    hipLaunchKernelGGL(k_ransac_score, dim3((VH_RANSAC_ITERS + 3) / 4, batch), dim3(256), 0, s, job_tab, tab_stride);
+    hipLaunchKernelGGL(k_ransac_select, dim3(batch), dim3(256), 0, s, job_tab, tab_stride);
+}

@@ -1,0 +1,34 @@
+"""Counterparts of the hot-path helpers of utils/images.py: boundingRect (:9-19), insidebbox (:22-27), K construction (:120-151)."""
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+
+def boundingRect(x, imshape, border=(0, 0)):
+    """Integer box around float32 points +/- border, clamped to [1,W] x [1,H] (utils/images.py:9-19) -> (x0, x1, y0, y1)."""
+    torch = L.torch_cuda()
+    p = L.to_dev(x, torch.float32).reshape(-1, 2)
+    ws = L.workspace(0, 0, p.shape[0])
+    roi = torch.zeros(4, dtype=torch.int32, device="cuda")
+    L.check(ws.lib.vh_bounding_rect(ws.handle, L.dptr(p), p.shape[0], int(imshape[1]), int(imshape[0]), int(border[0]), int(border[1]),
+                                    L.dptr(roi), L.stream_ptr()), "vh_bounding_rect")
+    return tuple(int(v) for v in roi.cpu().numpy())
+
+
+def insidebbox(x, box):
+    """Points strictly inside box=(x0,x1,y0,y1) (utils/images.py:22-27)."""
+    x0, x1, y0, y1 = box
+    x = np.asarray(x)
+    return (x[:, 0] > x0) & (x[:, 0] < x1) & (x[:, 1] > y0) & (x[:, 1] < y1)
+
+
+def intrinsic_matrix_iphone6s_video(width=3840, height=2160, halve=True):
+    """K of getCameraParams for 4K iPhone 6s video (utils/images.py:120-122,143,148-151), halved like vidExample.py:35-39."""
+    ratio = math.sqrt(4032**2 + 3024**2) / math.sqrt(3840**2 + 2160**2)
+    f = 3486 * ratio
+    K = np.array([[f, 0, 0], [0, f, 0], [width / 2 + 0.5, height / 2 + 0.5, 1]], np.float32)
+    if halve:
+        K[:2, :2] /= 2
+    return K
