@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py -- tracked frames/s of the KLT + NLS hot path on MI355X (BASELINE.json metric).
+
+One "step" = one tracked frame for every resident stream: KLTmain (3-stage pyramidal LK + 2 RANSAC + affine ROI
+warp) + estimateWorldCameraPose(findR=False) + the track-state bookkeeping, all device resident (vh_session_step),
+frames already in HBM when the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--config c2|c3] [--params baseline|ref]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): every rank tracks its own S
+streams (weak scaling, no data-path collective) and all-gathers the packed track state every 30 frames (config C4).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CONFIGS = {
+    # BASELINE.json configs[1] / configs[2]
+    "c2": dict(w=1920, h=1080, n=2000, levels=3, name="C2 synthetic 1080p@30fps, 2000 KLT tracks, 3 pyramid levels"),
+    "c3": dict(w=3840, h=2160, n=5000, levels=4, name="C3 synthetic 4K@30fps, 5000 KLT tracks, 4 pyramid levels"),
+}
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s (int32/f32 VALU)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VH_BENCH_STREAMS", 8)), help="video streams resident per GPU")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--params", default="baseline", choices=["baseline", "ref"],
+                    help="baseline: coarse stages use the config's pyramid depth; ref: exactly utils/KLT.py:106-107 (maxLevel=4)")
+    ap.add_argument("--ring", type=int, default=60, help="distinct synthetic frames kept in HBM (one motion period)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables)")
+    ap.add_argument("--exchange-every", type=int, default=30)
+    return ap.parse_args()
+
+
+def make_ring(cfg, ring, device, seed):
+    """`ring` frames of a periodic plane motion + the tracks / world points of frame 0."""
+    from velocity_amd import synth
+
+    W, H = cfg["w"], cfg["h"]
+    K = synth.K_1080P.copy()
+    if W != 1920:
+        K[:2, :2] *= W / 1920.0
+        K[2, 0], K[2, 1] = W / 2 + 0.5, H / 2 + 0.5
+    m = synth.PlaneMotion(K, z0=3.6, traj=synth.oscillating_traj(period=float(ring)))
+    frames = torch.stack([synth.render_frame(W, H, m, k, seed=seed, device=device) for k in range(ring)])
+    p0 = synth.grid_tracks(cfg["n"], W, H, seed=(seed & 0xFF) + 1)
+    return K, m, frames, p0
+
+
+def cpu_baseline(cfg, K, frames, p0, p3, vp, lkc, lkf, budget_s):
+    """The oracle's frame loop (C restatement, OpenMP over points, all host cores) on the first frames of stream 0."""
+    from oracle import klt_oracle
+    from oracle.session_oracle import SessionOracle
+
+    klt_oracle.build(native=True)
+    host = [frames[k].cpu().numpy() for k in range(min(len(frames), 40))]
+    orc = SessionOracle(K, host[0], p0, p3, vp, np.float32([0, 0, 3.6]), nhist=len(host) + 1, lk_coarse=lkc, lk_fine=lkf, msv_frame=0, native=True)
+    orc.step(host[1], np.float32(1 / 30), 1)  # warm-up (page faults, thread pool)
+    t0, done = time.perf_counter(), 0
+    for k in range(2, len(host)):
+        orc.step(host[k], np.float32(k / 30), k)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="tracked frames/s", cores=os.cpu_count(), kind="port",
+                sample=f"{done} frames of stream 0 ({cfg['w']}x{cfg['h']}, {cfg['n']} tracks), oracle C/OpenMP KLT + NumPy NLS, {dt:.1f} s")
+
+
+def main():
+    a = parse()
+    cfg = CONFIGS[a.config]
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from velocity_amd import _lib as L
+    from velocity_amd import dist as vdist
+    from velocity_amd.driver import TrackerSession
+
+    S, N, W, H = a.streams, cfg["n"], cfg["w"], cfg["h"]
+    lvl = cfg["levels"] - 1 if a.params == "baseline" else 4
+    lkc, lkf = dict(max_level=lvl), dict()
+    nhist = a.warmup + a.steps + 3
+    K, motion, frames, p0 = make_ring(cfg, a.ring, dev, seed=0xC0FFEE + 7919 * rank)
+    p3 = motion.world_points(p0)
+    vp = (np.abs(p0[:, 0] - W / 2) < W * 0.1) & (np.abs(p0[:, 1] - H / 2) < H * 0.1)  # "plate" box until the MSV frame
+    ses = TrackerSession(K, W, H, N, nhist=nhist, batch=S, lk_coarse=lkc, lk_fine=lkf, msv_frame=5)
+    # streams of one rank share the ring but run at different phases, so every launch sees S different frame pairs
+    phase = [(7 * b) % a.ring for b in range(S)]
+    base_ptr = frames.data_ptr()
+    fbytes = W * H
+    for b in range(S):
+        ses.init_stream(b, frames[phase[b]], motion.apply(phase[b], p0.astype(float)).astype(np.float32), p3 + motion.t(phase[b]), vp,
+                        np.float32([0, 0, 0]))
+    tables = torch.empty((a.ring, S), dtype=torch.int64)
+    for k in range(a.ring):
+        for b in range(S):
+            tables[k, b] = base_ptr + ((phase[b] + k) % a.ring) * fbytes
+    tables = tables.to(dev)
+    ex = vdist.TrackStateExchange(S, N, every=a.exchange_every, device=dev) if world > 1 else None
+
+    def run(first, count):
+        for i in range(first, first + count):
+            ses.step(frames_table=tables[i % a.ring], time_s=i / 30.0, frame_no=i)
+            if ex is not None and ex.due(i):
+                ex.wait()
+                L.check(ses.lib.vh_session_pack_state(ses.handle, L.dptr(ex.local), L.stream_ptr()), "vh_session_pack_state")
+                ex.start()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(1, a.warmup)
+    barrier()
+    L.check(ses.lib.vh_profile_begin(ses.ws.handle, 3 * a.steps + 8), "vh_profile_begin")
+    barrier()
+    t0 = time.perf_counter()
+    run(1 + a.warmup, a.steps)
+    if ex is not None:
+        ex.wait()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms_sum, launches = (C.c_double * 3)(), (C.c_int * 3)()
+    iters, setups = (C.c_ulonglong * 3)(), (C.c_ulonglong * 3)()
+    L.check(ses.lib.vh_profile_end(ses.ws.handle, ms_sum, launches, iters, setups), "vh_profile_end")
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # health of the tracked state (a bench that lost its tracks would be measuring nothing)
+    st = ses.state(0)
+    alive = st["n_cur"] / N
+    truth = motion.t((phase[0] + a.warmup + a.steps) % a.ring) - motion.t(phase[0])
+
+    if rank == 0:
+        total_frames = S * world * a.steps
+        value = total_frames / elapsed
+        # dominant kernel = the fine LK launch (stage 2): algorithmic gather bytes per launch (KLT track solve row)
+        wf = 51
+        us_fine = 1e3 * ms_sum[2] / max(launches[2], 1)
+        bytes_fine = 2 * N * S * 1 * ((wf + 2) ** 2 + (wf + 1) ** 2)
+        achieved = bytes_fine / (us_fine * 1e-6) / 1e9 if us_fine > 0 else 0.0
+        it_f = iters[2] / max(launches[2], 1)
+        su_f = setups[2] / max(launches[2], 1)
+        ops_fine = wf * wf * (47.0 * su_f + 12.0 * it_f)  # SURVEY §8d op model: 47 op/px set-up, 12 op/px per Newton iteration
+        roof = dict(bound="hbm", kernel="k_lk (fine stage: 51x51 window, level 0, fwd+bwd)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, us_per_launch=round(us_fine, 2),
+                    alg_bytes_per_launch=bytes_fine,
+                    valu=dict(model_gops_per_launch=round(ops_fine / 1e9, 4), achieved_tops=round(ops_fine / (us_fine * 1e-6) / 1e12, 3) if us_fine > 0 else 0,
+                              peak_tops=round(VALU_PEAK_TOPS, 1), frac=round(ops_fine / (us_fine * 1e-6) / 1e12 / VALU_PEAK_TOPS, 4) if us_fine > 0 else 0,
+                              newton_iters_per_track_dir=round(it_f / (2 * N * S), 2)),
+                    note="track solve is VALU/LDS bound (SURVEY §8d); the HBM figure prices its algorithmic gather bytes",
+                    lk_us_per_launch=[round(1e3 * ms_sum[k] / max(launches[k], 1), 2) for k in range(3)])
+        out = dict(metric="tracked frames/sec (KLT 2000 tracks + NLS pose, 1080p)" if a.config == "c2" else "tracked frames/sec (KLT 5000 tracks + NLS pose, 4K)",
+                   value=round(value, 2), unit="frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                   ms_per_step=round(1e3 * elapsed / a.steps, 4), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="i32+f32 (KLT) / f64 (NLS)",
+                   data="synthetic",
+                   config=dict(workload=cfg["name"] + f"; {S} independent streams resident per GPU, one launch sequence per step",
+                               params=a.params, coarse=dict(L.LK_COARSE, **lkc), fine=dict(L.LK_FINE), streams_per_gpu=S, tracks=N,
+                               parallelism=f"streams x{world} (1 rank per GPU" + (f", RCCL all-gather of track state every {a.exchange_every} frames)" if world > 1 else ")")),
+                   per_stream_fps=round(value / (S * world), 2), tracks_alive_frac=round(alive, 4),
+                   pose_t=[round(float(x), 5) for x in st["t"]], pose_t_truth=[round(float(x), 5) for x in truth], rms_residual_px=round(st["res"], 5),
+                   roofline=roof)
+        if a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(cfg, K, frames, p0, p3, vp, lkc, lkf, a.cpu_seconds)
+            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

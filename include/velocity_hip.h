@@ -53,6 +53,8 @@ typedef struct {
 
 VH_API int vh_version(void);
 VH_API const char* vh_last_error(void);
+/* utility: synchronous device -> host copy of a raw device pointer (used to read the stage pointers below) */
+VH_API int vh_copy_to_host(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 
 /* ---- workspace ------------------------------------------------------------------------------------------------ */
 VH_API int vh_ctx_create(vh_ctx** out, int batch, int max_w, int max_h, int max_pts);
@@ -117,6 +119,49 @@ VH_API int vh_two_view_intercept(vh_ctx* ctx, const double* A, const double* U, 
  * Outputs: x_out float[3], b0 double[ng x 3], info int[2]; U_scratch double[3*(ii+1)*ng]. */
 VH_API int vh_msv1_t(vh_ctx* ctx, const float* K_host, const float* P, const float* B, const int* ids, int ng, int N0, int nhist,
                      int ii, int f32_rays, double* U_scratch, float* x_out, double* b0, int* info, void* stream);
+
+
+/* ---- tracker session: the frame loop body of vidExample.py:133-160 on the device, for ctx->batch streams ------- */
+/* device pointers into the state of one stream (read with vh_copy_to_host / torch) */
+typedef struct {
+    const uint8_t* vg;      /* N0      global validity mask (vidExample.py:125,135)            */
+    const uint8_t* vp;      /* N0      pose-track mask (vidExample.py:126,136,160)             */
+    const float* p;         /* n_cur x 2 compacted current points                              */
+    const int* ids;         /* n_cur   global ids of the rows of p                             */
+    const double* p3;       /* N0 x 3  world points                                            */
+    const float* P;         /* [5,N0,nhist] history (vidExample.py:128-129,151-153)            */
+    const float* B;         /* [nhist,14]  (vidExample.py:44,142-146)                          */
+    const float* S;         /* [nhist,9]   (vidExample.py:45,164)                              */
+    const int* n_cur;
+    const int* n_pose;
+    const float* t;         /* 3       last pose translation                                   */
+    const double* res;      /* 1       last rms reprojection residual                          */
+    const int* frame_i;
+    const int* klt_flags;
+    const int* pose_info;   /* 2       iterations, converged                                   */
+    const int* sel_pw;      /* n_pose  global ids of the pose tracks                           */
+    const double* p_proj;   /* n_pose x 2                                                      */
+} vh_session_view;
+
+/* K_host: 9 floats.  n0 = number of initial tracks, nhist = number of frames of history (P, B, S rows),
+ * msv_frame = frame index at which fcnMSV1_t re-triangulates (vidExample.py:155; <= 0 disables). */
+VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, int nhist, int w, int h, const float* K_host,
+                             const vh_lk_params* coarse_host, const vh_lk_params* fine_host, int msv_frame);
+VH_API void vh_session_destroy(vh_session* s);
+/* frame-0 state of stream `slot` (vidExample.py:116-131): p n0 x 2, p3 n0 x 3, vp n0 (device); t0_host = plate pose t */
+VH_API int vh_session_init(vh_session* s, int slot, const uint8_t* frame0, int stride, const float* p, const double* p3,
+                           const uint8_t* vp, const float* t0_host, float time0, float frame_no, float res0, void* stream);
+/* one frame for every stream: frames_dev = device array of ctx->batch frame pointers (dense, w x h) */
+VH_API int vh_session_step(vh_session* s, const uint8_t* const* frames_dev, float time_s, float frame_no, void* stream);
+VH_API int vh_session_ptrs(vh_session* s, int slot, vh_session_view* out_host);
+/* Packed track state of every stream for the cross-GPU exchange (RCCL all-gather, DESIGN.md "multi-GPU"):
+ * out = device float32 [batch][8 + 3*n0]: {n_cur, n_pose, frame_i, klt_flags, t[3], res | p (n0 x 2) | ids (n0, int32 bits)} */
+VH_API int vh_session_pack_state(vh_session* s, float* out, void* stream);
+
+/* ---- measurement aids (bench.py): HIP-event timing of the LK launches + Newton-iteration statistics ------------- */
+VH_API int vh_profile_begin(vh_ctx* ctx, int max_launches);
+/* all outputs host arrays of 3 (KLTmain stage 0: quarter scale, 1: coarse ROI, 2: fine) */
+VH_API int vh_profile_end(vh_ctx* ctx, double* ms_sum, int* launches, unsigned long long* iters, unsigned long long* setups);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,77 @@
+"""world_size-2 gloo test of the N>1 path: stream sharding + the all-gather of the packed track state."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from velocity_amd import dist as vd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_record(stream_id, n0):
+    rng = np.random.default_rng(stream_id)
+    n = n0 - stream_id - 1
+    rec = np.zeros(vd.record_words(n0), np.float32)
+    rec[0:4] = (n, n // 2, 7, 0)
+    rec[4:7] = (0.1 * stream_id, 0.2, 3.6)
+    rec[7] = 0.25 + stream_id
+    p = rng.uniform(0, 1000, (n, 2)).astype(np.float32)
+    rec[vd.HEADER : vd.HEADER + 2 * n] = p.ravel()
+    ids = np.full(n0, -1, np.int32)
+    ids[:n] = np.sort(rng.choice(n0, n, replace=False))
+    rec[vd.HEADER + 2 * n0 :] = ids.view(np.float32)
+    return rec, p, ids[:n]
+
+
+def _worker(rank, world, port, n0, total_streams, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = vd.shard_streams(total_streams, world, rank)
+    ex = vd.TrackStateExchange(len(mine), n0, every=30, device="cpu")
+    for j, sid in enumerate(mine):
+        ex.local[j] = torch.from_numpy(_fake_record(sid, n0)[0])
+    assert ex.due(30) and not ex.due(31)
+    ex.start()
+    g = ex.wait()
+    ok = True
+    for r in range(world):
+        for j, sid in enumerate(vd.shard_streams(total_streams, world, r)):
+            rec, p, ids = _fake_record(sid, n0)
+            st = vd.unpack_state(g[r, j], n0)
+            ok &= st["n_cur"] == len(p) and np.array_equal(st["p"], p) and np.array_equal(st["ids"], ids)
+            ok &= abs(st["res"] - (0.25 + sid)) < 1e-6 and st["frame_i"] == 7
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_streams_partition():
+    for total, world in ((8, 8), (8, 2), (7, 4), (3, 8), (16, 1)):
+        parts = [vd.shard_streams(total, world, r) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(total))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_track_state_all_gather_world2():
+    world, n0, total = 2, 64, 4
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), n0, total, out), nprocs=world, join=True)
+    assert all(out[r] for r in range(world)), dict(out)
+
+
+def test_single_process_exchange():
+    ex = vd.TrackStateExchange(2, 16, every=5, device="cpu")
+    ex.local[1] = torch.from_numpy(_fake_record(1, 16)[0])
+    ex.start()
+    st = vd.unpack_state(ex.wait()[0, 1], 16)
+    assert st["n_cur"] == 14 and st["frame_i"] == 7

@@ -1,0 +1,85 @@
+"""GPU parity of the device-resident frame loop (vidExample.py:133-160 on vh_session_step) vs oracle/session_oracle.py:
+bit-exact track-index bookkeeping (vg, vp, compaction, history P rows 0,1,4), <= 1e-4 rel on pose / residual / speed."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.session_oracle import SessionOracle  # noqa: E402 (checker only)
+from velocity_amd import synth  # noqa: E402
+
+
+def _scene(W, H, n0, nframes, seed):
+    K = synth.K_1080P.copy()
+    K[0, 0] = K[1, 1] = 700.0
+    K[2, 0], K[2, 1] = W / 2 + 0.5, H / 2 + 0.5
+    m = synth.PlaneMotion(K, z0=3.6)
+    frames = [synth.render_frame(W, H, m, k, seed=seed).numpy() for k in range(nframes)]
+    p = synth.grid_tracks(n0, W, H, seed=seed & 0xFF)
+    # a few hopeless tracks (window far outside the frame) so the masks and the compaction actually change
+    p[::37] = np.float32([-40.0, -40.0])
+    p3 = m.world_points(p)
+    vp = (p[:, 0] > W * 0.3) & (p[:, 0] < W * 0.7) & (p[:, 1] > H * 0.3) & (p[:, 1] < H * 0.7)
+    return frames, p, p3, vp, K
+
+
+@pytest.mark.parametrize("msv_frame", [5, 0])
+def test_session_matches_reference_loop(msv_frame):
+    import torch
+
+    from velocity_amd.driver import TrackerSession
+
+    W, H, n0, nframes = 640, 360, 400, 9
+    frames, p, p3, vp, K = _scene(W, H, n0, nframes, 0xC0FFEE)
+    t0 = np.float32([1.5, 0.45, 3.6])
+    orc = SessionOracle(K, frames[0], p, p3, vp, t0, time0=0.0, frame_no=0, res0=0.5, nhist=nframes, msv_frame=msv_frame)
+    ses = TrackerSession(K, W, H, n0, nhist=nframes, batch=1, msv_frame=msv_frame)
+    ses.init_stream(0, frames[0], p, p3, vp, t0, time0=0.0, frame_no=0, res0=0.5)
+    for i in range(1, nframes):
+        ts = np.float32(i / 29.97)
+        orc.step(frames[i], ts, i)
+        ses.step([torch.from_numpy(frames[i]).cuda()], time_s=ts, frame_no=i)
+        st = ses.state(0)
+        assert np.array_equal(st["vg"], orc.vg), f"vg differs at frame {i}"
+        assert np.array_equal(st["vp"], orc.vp), f"vp differs at frame {i}"
+        assert np.array_equal(st["ids"], np.nonzero(orc.vg)[0])
+        assert np.array_equal(st["p"], orc.p), f"compacted points differ at frame {i}"
+        np.testing.assert_allclose(st["t"], orc.t, rtol=1e-5)
+        np.testing.assert_allclose(st["res"], orc.residuals, rtol=1e-6)
+    st = ses.state(0)
+    assert st["frame_i"] == nframes - 1
+    # history: rows 0,1 (tracked xy) and 4 (frame index) bit-exact incl. the NaN padding; rows 2,3 (projections) to tolerance
+    for r in (0, 1, 4):
+        assert np.array_equal(st["P"][r], orc.P[r], equal_nan=True)
+    assert np.array_equal(np.isnan(st["P"][2:4]), np.isnan(orc.P[2:4]))
+    np.testing.assert_allclose(np.nan_to_num(st["P"][2:4]), np.nan_to_num(orc.P[2:4]), rtol=1e-5)
+    np.testing.assert_allclose(st["B"], orc.B, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(st["S"][1:, [0, 2, 4, 5]], orc.S[1:, [0, 2, 4, 5]], rtol=0, atol=0)
+    np.testing.assert_allclose(st["S"][1:, [3, 6, 7, 8]], orc.S[1:, [3, 6, 7, 8]], rtol=1e-4)  # residual, dx, distance, speed
+    np.testing.assert_allclose(st["p3"], orc.p3, rtol=1e-4, atol=1e-5)
+    assert st["vg"].sum() < n0  # the hopeless tracks were dropped -> compaction really happened
+
+
+def test_session_batch_streams_are_independent():
+    import torch
+
+    from velocity_amd.driver import TrackerSession
+
+    W, H, n0, nframes, B = 480, 270, 200, 5, 3
+    scenes = [_scene(W, H, n0, nframes, 1000 + 77 * b) for b in range(B)]
+    t0 = np.float32([1.5, 0.45, 3.6])
+    ses = TrackerSession(scenes[0][4], W, H, n0, nhist=nframes, batch=B, msv_frame=0)
+    orcs = []
+    for b, (frames, p, p3, vp, K) in enumerate(scenes):
+        ses.init_stream(b, frames[0], p, p3, vp, t0)
+        orcs.append(SessionOracle(K, frames[0], p, p3, vp, t0, nhist=nframes, msv_frame=0))
+    for i in range(1, nframes):
+        ts = np.float32(i / 30.0)
+        ses.step([torch.from_numpy(scenes[b][0][i]).cuda() for b in range(B)], time_s=ts, frame_no=i)
+        for b in range(B):
+            orcs[b].step(scenes[b][0][i], ts, i)
+    for b in range(B):
+        st = ses.state(b)
+        assert np.array_equal(st["vg"], orcs[b].vg) and np.array_equal(st["vp"], orcs[b].vp)
+        assert np.array_equal(st["p"], orcs[b].p)
+        np.testing.assert_allclose(st["t"], orcs[b].t, rtol=1e-5)

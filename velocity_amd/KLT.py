@@ -146,9 +146,7 @@ def klt_stages(n):
     def rd(ptr, count, dtype):
         out = np.empty(count, dtype)
         if count:
-            rc = torch.cuda.cudart().cudaMemcpy(out.ctypes.data, ptr, out.nbytes, 2)  # D2H
-            if int(rc) != 0:
-                raise RuntimeError(f"cudaMemcpy failed: {rc}")
+            L.check(ws.lib.vh_copy_to_host(out.ctypes.data, ptr, out.nbytes, L.stream_ptr()), "vh_copy_to_host")
         return out
 
     roi = rd(st.roi, 4, np.int32)

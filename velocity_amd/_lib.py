@@ -27,12 +27,18 @@ class KltStages(C.Structure):
     _fields_ = [(k, vp) for k in ("p_small", "v_small", "t_trans", "roi", "p_coarse", "v_coarse", "t23", "warped", "flags")]
 
 
+class SessionView(C.Structure):
+    _fields_ = [(k, vp) for k in ("vg", "vp", "p", "ids", "p3", "P", "B", "S", "n_cur", "n_pose", "t", "res", "frame_i", "klt_flags",
+                                  "pose_info", "sel_pw", "p_proj")]
+
+
 LK_COARSE = dict(win=15, max_level=4, max_count=10, eps=0.1)  # utils/KLT.py:106
 LK_FINE = dict(win=51, max_level=0, max_count=30, eps=0.001)  # utils/KLT.py:107
 
 _SIGS = {
     "vh_version": (C.c_int, []),
     "vh_last_error": (C.c_char_p, []),
+    "vh_copy_to_host": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "vh_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]),
     "vh_ctx_destroy": (None, [vp]),
     "vh_resize_quarter": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
@@ -52,6 +58,14 @@ _SIGS = {
     "vh_image2world": (C.c_int, [vp, f64p, vp, C.c_int, vp, vp]),
     "vh_pixel2uvec": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp, vp]),
     "vh_two_view_intercept": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "vh_session_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(LKParams), C.POINTER(LKParams), C.c_int]),
+    "vh_session_destroy": (None, [vp]),
+    "vh_session_init": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, f32p, C.c_float, C.c_float, C.c_float, vp]),
+    "vh_session_step": (C.c_int, [vp, vp, C.c_float, C.c_float, vp]),
+    "vh_session_ptrs": (C.c_int, [vp, C.c_int, C.POINTER(SessionView)]),
+    "vh_session_pack_state": (C.c_int, [vp, vp, vp]),
+    "vh_profile_begin": (C.c_int, [vp, C.c_int]),
+    "vh_profile_end": (C.c_int, [vp, f64p, i32p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "vh_msv1_t": (C.c_int, [vp, f32p, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
 }
 

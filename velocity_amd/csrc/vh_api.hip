@@ -8,9 +8,7 @@
 
 #include <new>
 
-#include "../../include/velocity_hip.h"
-#include "vh_kernels.hpp"
-#include "vh_nls.hpp"
+#include "vh_ws.hpp"
 
 // ---------------------------------------------------------------------------------------------------------------
 // error reporting
@@ -20,7 +18,7 @@ void vh_set_error(const char* what, hipError_t e, const char* file, int line)
 {
     snprintf(g_err, sizeof(g_err), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
 }
-static int vh_fail(int code, const char* msg)
+int vh_fail(int code, const char* msg)
 {
     snprintf(g_err, sizeof(g_err), "%s", msg);
     return code;
@@ -28,65 +26,13 @@ static int vh_fail(int code, const char* msg)
 #define VH_LAUNCH_CHECK() VH_CHECK(hipGetLastError())
 
 extern "C" VH_API int vh_version(void) { return 100; }
+extern "C" VH_API int vh_copy_to_host(void* dst_host, const void* src_dev, size_t bytes, void* stream)
+{
+    VH_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    VH_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
 extern "C" VH_API const char* vh_last_error(void) { return g_err; }
-
-// ---------------------------------------------------------------------------------------------------------------
-// per-stream device workspace
-// ---------------------------------------------------------------------------------------------------------------
-struct StreamBufs {  // fixed after vh_ctx_create
-    uint8_t* small0[2];                    // quarter-scale frames (ping-pong) when the caller passes none
-    uint8_t* small_lv[2][VH_MAX_LEVELS];   // quarter-scale pyramid levels >= 1 (ping-pong)
-    uint8_t* roi_lv[2][VH_MAX_LEVELS];     // ROI pyramid levels >= 1 of the previous (0) / current (1) frame
-    uint8_t* warp;                         // shifted crop (stage 2) / affine-warped ROI (stage 3)
-    float* p_small;
-    float* p_coarse;
-    uint8_t* v_small;
-    uint8_t* v_coarse;
-    uint8_t* v_all;                        // all-ones mask for the stateless RANSAC entry
-    uint8_t* inl;
-    int* idx;
-    int* counts;
-};
-
-struct KltIO {  // one KLTmain call (KLT.py:99)
-    const uint8_t* im;
-    const uint8_t* im0;
-    const uint8_t* im0_small;  // may be null
-    const float* p0;
-    const int* n_ptr;          // device count (null -> n)
-    float* p_all;
-    uint8_t* v;
-    uint8_t* im_small;         // may be null (internal buffer)
-    int* flags;                // may be null
-    int w, h, stride, stride0, n;
-    int reuse_prev_small;      // 1: small_lv[1 - pp] already holds the pyramid of im0_small (session mode)
-    vh_lk_params coarse, fine;
-    float fbt_coarse, fbt_fine;  // 1.0, 0.3 (KLT.py:124,133)
-};
-
-struct StreamWS {
-    LKJob lk;
-    WarpJob warp;
-    RansacJob ransac;
-    PyrBuild pb[2];
-    ImgDesc rs_src[2], rs_dst[2];  // quarter-scale resize table: [0] current frame, [1] previous frame
-    KltIO io;
-    StreamBufs bufs;
-    double M[6];
-    double t_trans[2];
-    int roi[4];
-    int dxy[2];
-    int n, m, rstatus, flags, pp, pad;
-};
-
-struct vh_ctx {
-    int batch, max_w, max_h, max_pts, sw, sh;
-    char* arena;
-    size_t arena_bytes;
-    StreamWS* d_ws;
-    StreamBufs* h_bufs;  // host copy of every stream's buffer table
-    double* d_small;     // 64 doubles of scratch for host-provided small matrices
-};
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -160,6 +106,9 @@ extern "C" VH_API void vh_ctx_destroy(vh_ctx* c)
 {
     if (!c) return;
     (void)hipFree(c->arena);
+    for (int k = 0; k < 2 * c->prof_cap; k++) (void)hipEventDestroy(c->prof_ev[k]);
+    delete[] c->prof_ev;
+    delete[] c->prof_stage;
     delete[] c->h_bufs;
     delete c;
 }
@@ -191,7 +140,7 @@ __device__ void clamp_criteria(const vh_lk_params& lk, int& max_count, double& e
 
 __device__ void fill_lk_common(LKJob& J, const vh_lk_params& lk, const float* p_in, const int* n_ptr, int n)
 {
-    J.p_in = p_in; J.n_ptr = n_ptr; J.n = n;
+    J.p_in = p_in; J.n_ptr = n_ptr; J.n = n; J.stats = nullptr;
     J.win = lk.win; J.max_level = lk.max_level;
     clamp_criteria(lk, J.max_count, J.eps2);
     J.err_out = nullptr; J.fbe_out = nullptr; J.praw_out = nullptr;
@@ -228,6 +177,7 @@ __global__ void k_klt_setup(StreamWS* ws_all)
     J.fbt = -1.f;
     J.in_scale = 0.25f; J.in_off[0] = 0.f; J.in_off[1] = 0.f;
     J.out_mode = VH_OUT_SCALE; J.out_scale = 0.25f;
+    J.stats = ws.lk_stats[0];
     // RANSAC 1: inliers gate the status (KLT.py:116-117)
     RansacJob& R = ws.ransac;
     R.from = io.p0; R.to = B.p_small; R.valid = B.v_small; R.n_ptr = nullptr; R.n = n;
@@ -314,6 +264,7 @@ __global__ __launch_bounds__(256) void k_klt_glue1(StreamWS* ws_all)
     J.fbt = io.fbt_coarse;
     J.in_scale = 1.f; J.in_off[0] = (float)x0; J.in_off[1] = (float)y0;
     J.out_mode = VH_OUT_TRANSLATE; J.out_off[0] = (float)dx; J.out_off[1] = (float)dy;
+    J.stats = ws.lk_stats[1];
     // RANSAC 2: affine from the survivors, only when more than 10 of them (KLT.py:126-127)
     RansacJob& R = ws.ransac;
     R.to = B.p_coarse; R.valid = B.v_coarse; R.min_valid = 10; R.gate_valid = 0;
@@ -354,10 +305,23 @@ __global__ void k_klt_glue2(StreamWS* ws_all)
     J.in_scale = 1.f; J.in_off[0] = (float)x0; J.in_off[1] = (float)y0;
     J.out_mode = VH_OUT_AFFINE;
     for (int k = 0; k < 6; k++) J.T[k] = T[k];
+    J.stats = ws.lk_stats[2];
     if (io.flags) *io.flags = ws.flags;
 }
 
-static int run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine)
+static int launch_lk_profiled(vh_ctx* c, int stage, const void* tab, size_t st, int count, int win, hipStream_t s)
+{
+    const bool on = c->prof_on && c->prof_n < c->prof_cap;
+    if (on) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], s);
+    const int r = vh_launch_lk(tab, st, count, c->max_pts, win, s);
+    if (on) {
+        (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s);
+        c->prof_stage[c->prof_n++] = stage;
+    }
+    return r;
+}
+
+int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine)
 {
     StreamWS* ws = c->d_ws + slot;
     const size_t st = sizeof(StreamWS);
@@ -365,21 +329,62 @@ static int run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_
     hipLaunchKernelGGL(k_klt_setup, dim3(count), dim3(64), 0, s, ws);
     vh_launch_resize_quarter(&ws->rs_src[0], &ws->rs_dst[0], st, 2, count, c->sw, c->sh, s);
     for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->sw, c->sh, s);
-    int r = vh_launch_lk(&ws->lk, st, count, c->max_pts, coarse.win, s);
+    int r = launch_lk_profiled(c, 0, &ws->lk, st, count, coarse.win, s);
     if (r) return vh_fail(r, "vh_launch_lk failed (window too large for LDS?)");
     vh_launch_ransac(&ws->ransac, st, count, c->max_pts, s);
     hipLaunchKernelGGL(k_klt_glue1, dim3(count), dim3(256), 0, s, ws);
     vh_launch_roi_warp(&ws->warp, st, count, c->max_w, c->max_h, s);
     for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->max_w, c->max_h, s);
-    r = vh_launch_lk(&ws->lk, st, count, c->max_pts, coarse.win, s);
+    r = launch_lk_profiled(c, 1, &ws->lk, st, count, coarse.win, s);
     if (r) return vh_fail(r, "vh_launch_lk failed");
     vh_launch_ransac(&ws->ransac, st, count, c->max_pts, s);
     hipLaunchKernelGGL(k_klt_glue2, dim3(count), dim3(64), 0, s, ws);
     vh_launch_roi_warp(&ws->warp, st, count, c->max_w, c->max_h, s);
     for (int l = 0; l < lvl_f; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->max_w, c->max_h, s);
-    r = vh_launch_lk(&ws->lk, st, count, c->max_pts, fine.win, s);
+    r = launch_lk_profiled(c, 2, &ws->lk, st, count, fine.win, s);
     if (r) return vh_fail(r, "vh_launch_lk failed");
     VH_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- optional HIP-event timing of the LK launches + iteration statistics (bench.py's roofline leg) ---------------
+extern "C" VH_API int vh_profile_begin(vh_ctx* c, int max_launches)
+{
+    if (!c || max_launches < 1) return vh_fail(-1, "vh_profile_begin: bad arguments");
+    if (c->prof_cap < max_launches) {
+        for (int k = 0; k < 2 * c->prof_cap; k++) (void)hipEventDestroy(c->prof_ev[k]);
+        delete[] c->prof_ev;
+        delete[] c->prof_stage;
+        c->prof_ev = new hipEvent_t[2 * max_launches];
+        c->prof_stage = new int[max_launches];
+        for (int k = 0; k < 2 * max_launches; k++) VH_CHECK(hipEventCreate(&c->prof_ev[k]));
+        c->prof_cap = max_launches;
+    }
+    c->prof_n = 0;
+    c->prof_on = 1;
+    VH_CHECK(hipDeviceSynchronize());
+    for (int b = 0; b < c->batch; b++) VH_CHECK(hipMemset(c->d_ws[b].lk_stats, 0, sizeof(c->d_ws[b].lk_stats)));
+    return 0;
+}
+
+// ms_sum[3], launches[3], iters[3], setups[3]: per KLTmain stage (0: quarter scale, 1: coarse ROI, 2: fine), summed over streams
+extern "C" VH_API int vh_profile_end(vh_ctx* c, double* ms_sum, int* launches, unsigned long long* iters, unsigned long long* setups)
+{
+    if (!c) return vh_fail(-1, "null ctx");
+    c->prof_on = 0;
+    VH_CHECK(hipDeviceSynchronize());
+    for (int k = 0; k < 3; k++) { ms_sum[k] = 0; launches[k] = 0; iters[k] = 0; setups[k] = 0; }
+    for (int k = 0; k < c->prof_n; k++) {
+        float ms = 0.f;
+        VH_CHECK(hipEventElapsedTime(&ms, c->prof_ev[2 * k], c->prof_ev[2 * k + 1]));
+        ms_sum[c->prof_stage[k]] += ms;
+        launches[c->prof_stage[k]]++;
+    }
+    for (int b = 0; b < c->batch; b++) {
+        unsigned long long st[3][2];
+        VH_CHECK(hipMemcpy(st, c->d_ws[b].lk_stats, sizeof(st), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 3; k++) { iters[k] += st[k][0]; setups[k] += st[k][1]; }
+    }
     return 0;
 }
 
@@ -397,7 +402,7 @@ extern "C" VH_API int vh_klt_main(vh_ctx* c, int slot, const uint8_t* im, const 
     io.reuse_prev_small = 0; io.coarse = *coarse; io.fine = *fine; io.fbt_coarse = 1.0f; io.fbt_fine = 0.3f;
     hipStream_t s = (hipStream_t)stream;
     VH_CHECK(vh_store(&c->d_ws[slot].io, io, s));
-    return run_klt_main(c, slot, 1, s, *coarse, *fine);
+    return vh_run_klt_main(c, slot, 1, s, *coarse, *fine);
 }
 
 extern "C" VH_API int vh_klt_stage_ptrs(vh_ctx* c, int slot, vh_klt_stages* out)

@@ -43,6 +43,7 @@ struct LKJob {
     float* fbe_out;      // n     forward-backward error (may be null)
     float* praw_out;     // n x 2 un-mapped forward result in LK image coordinates (may be null)
     const int* n_ptr;    // device count of points (null -> n)
+    unsigned long long* stats;  // may be null: [0] += Newton iterations, [1] += template set-ups (profiling aid)
     int n;
     int win, max_level, max_count;
     double eps2;         // criteria epsilon, already clamped and squared
@@ -62,6 +63,9 @@ __device__ __forceinline__ int vh_reflect101(int i, int n)
     while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
     return i;
 }
+// correctly rounded float32 sqrt (HIP's __fsqrt_rn is the approximate native instruction; sqrtf is IEEE under the
+// default -fhip-fp32-correctly-rounded-divide-sqrt)
+__device__ __forceinline__ float vh_sqrtf(float v) { return __builtin_sqrtf(v); }
 __device__ __forceinline__ int vh_floor(float v) { return (int)floorf(v); }
 __device__ __forceinline__ int vh_round(float v) { return __float2int_rn(v); }  // round-half-even (cvRound)
 __device__ __forceinline__ int vh_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }

@@ -90,7 +90,8 @@ __device__ __forceinline__ int search_sample(const ImgDesc& im, int gx, int gy, 
 
 // One point on one level.  All control flow is wave-uniform.
 __device__ void lk_level(const ImgDesc& I, const ImgDesc& J, int win, int level, int top_level, int max_count, double eps2,
-                         float p0x, float p0y, float& nxo, float& nyo, int& status, float& err, short* ldsI, int* ldsD, int lane)
+                         float p0x, float p0y, float& nxo, float& nyo, int& status, float& err, short* ldsI, int* ldsD, int lane,
+                         int& n_iter, int& n_setup)
 {
     const float half = (float)(win - 1) * 0.5f;
     const float lscale = (float)(1. / (double)(1 << level));
@@ -111,6 +112,7 @@ __device__ void lk_level(const ImgDesc& I, const ImgDesc& J, int win, int level,
     const int xinc = 64 % win, yinc = 64 / win;
     const int x_first = lane % win, y_first = lane / win;
 
+    n_setup++;
     long long sA11 = 0, sA12 = 0, sA22 = 0;
     {
         const bool interior = ipx >= 1 && ipy >= 1 && ipx + win + 1 <= I.w - 1 && ipy + win + 1 <= I.h - 1;
@@ -135,7 +137,7 @@ __device__ void lk_level(const ImgDesc& I, const ImgDesc& J, int win, int level,
     float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
     const float dA = __fsub_rn(A11, A22);
     const float disc = __fadd_rn(__fmul_rn(dA, dA), __fmul_rn(__fmul_rn(4.f, A12), A12));
-    const float minEig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11), __fsqrt_rn(disc)), (float)(2 * win * win));
+    const float minEig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11), vh_sqrtf(disc)), (float)(2 * win * win));
     if (minEig < 1e-4f || D < 1.1920929e-07f) {
         if (level == 0) status = 0;
         return;
@@ -152,6 +154,7 @@ __device__ void lk_level(const ImgDesc& I, const ImgDesc& J, int win, int level,
         }
         w = bilinear_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny));
         const bool interior = inx >= 0 && iny >= 0 && inx + win <= J.w - 1 && iny + win <= J.h - 1;
+        n_iter++;
         long long sb1 = 0, sb2 = 0;
         int x = x_first, y = y_first, k = 0;
         for (int i = lane; i < npx; i += 64, k++) {
@@ -200,14 +203,14 @@ __device__ void lk_level(const ImgDesc& I, const ImgDesc& J, int win, int level,
 }
 
 __device__ void lk_track(const PyrDesc& PI, const PyrDesc& PJ, int win, int max_count, double eps2, float px, float py, float& ox,
-                         float& oy, int& status, float& err, short* ldsI, int* ldsD, int lane)
+                         float& oy, int& status, float& err, short* ldsI, int* ldsD, int lane, int& n_iter, int& n_setup)
 {
     const int nl = min(PI.nlevels, PJ.nlevels);
     status = 1;
     err = 0.f;
     ox = 0.f; oy = 0.f;
     for (int level = nl - 1; level >= 0; level--)
-        lk_level(PI.lv[level], PJ.lv[level], win, level, nl - 1, max_count, eps2, px, py, ox, oy, status, err, ldsI, ldsD, lane);
+        lk_level(PI.lv[level], PJ.lv[level], win, level, nl - 1, max_count, eps2, px, py, ox, oy, status, err, ldsI, ldsD, lane, n_iter, n_setup);
 }
 
 // grid = (max points, batch), block = one wavefront
@@ -228,15 +231,15 @@ __global__ __launch_bounds__(64) void k_lk(const void* job_tab, size_t tab_strid
     const float py = __fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]);
 
     float fx, fy, err;
-    int st;
-    lk_track(job.I, job.J, job.win, job.max_count, job.eps2, px, py, fx, fy, st, err, ldsI, ldsD, lane);
+    int st, n_iter = 0, n_setup = 0;
+    lk_track(job.I, job.J, job.win, job.max_count, job.eps2, px, py, fx, fy, st, err, ldsI, ldsD, lane, n_iter, n_setup);
     float fbe = 0.f;
     if (job.fbt >= 0.f) {
         float bx, by, e2;
         int st2;
-        lk_track(job.J, job.I, job.win, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, ldsI, ldsD, lane);
+        lk_track(job.J, job.I, job.win, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, ldsI, ldsD, lane, n_iter, n_setup);
         const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
-        fbe = __fsqrt_rn(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
+        fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
         st = st && st2 && (fbe < job.fbt);
     }
     if (lane == 0) {
@@ -260,6 +263,10 @@ __global__ __launch_bounds__(64) void k_lk(const void* job_tab, size_t tab_strid
         if (job.err_out) job.err_out[pt] = err;
         if (job.fbe_out) job.fbe_out[pt] = fbe;
         if (job.praw_out) { job.praw_out[2 * pt] = fx; job.praw_out[2 * pt + 1] = fy; }
+        if (job.stats) {
+            atomicAdd(&job.stats[0], (unsigned long long)n_iter);
+            atomicAdd(&job.stats[1], (unsigned long long)n_setup);
+        }
     }
 }
 

@@ -48,7 +48,7 @@ __device__ __forceinline__ void uvec_f64(double pu, double pv, double cx, double
 __device__ __forceinline__ void uvec_f32(float pu, float pv, float cx, float cy, float f, double* r)
 {
     const float a = __fsub_rn(pu, cx), b = __fsub_rn(pv, cy);
-    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b)), __fmul_rn(f, f)));
+    const float nrm = vh_sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b)), __fmul_rn(f, f)));
     r[0] = (double)__fdiv_rn(a, nrm); r[1] = (double)__fdiv_rn(b, nrm); r[2] = (double)__fdiv_rn(f, nrm);
 }
 

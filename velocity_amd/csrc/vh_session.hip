@@ -1,0 +1,383 @@
+// Tracker session: the body of the reference's frame loop (vidExample.py:133-160) for `batch` independent video
+// streams, entirely on the device -- KLTmain, the track-state bookkeeping (K19: vg[vg]=v, vp&=vg, stream compaction,
+// pose-track selection, NaN-padded history P), estimateWorldCameraPose(findR=False), the B/S result records and, at
+// the MSV frame, fcnMSV1_t.  One step = a fixed sequence of launches over all streams, no host round trip.
+#include <math.h>
+#include <string.h>
+
+#include <new>
+
+#include "vh_ws.hpp"
+
+struct SessStream {  // device resident, one per video stream
+    // track state (vidExample.py:125-129)
+    uint8_t* vg;     // N0  global validity of the initial tracks
+    uint8_t* vp;     // N0  tracks used for the pose fit
+    float* p_cur;    // n_cur x 2 compacted current points
+    int* ids;        // n_cur global ids of the compacted rows (= nonzero(vg))
+    double* p3;      // N0 x 3 world points
+    float* P;        // [5, N0, nhist] history, NaN padded
+    float* B;        // [nhist, 14]
+    float* S;        // [nhist, 9]
+    // per-frame scratch
+    float* p_all;    // KLTmain output before compaction
+    uint8_t* v;      // KLTmain status
+    int* sel_p;      // pose rows of p_cur      (p[vp[vg]], vidExample.py:139)
+    int* sel_pw;     // pose rows of p3         (p3[vp])
+    double* p_proj;  // n_pose x 2
+    double* msv_U;   // 3*16*N0 scratch of fcnMSV1_t
+    double* msv_b0;  // N0 x 3
+    uint8_t* small[2];
+    const uint8_t* im0;
+    PoseJob pose;
+    double K[9];
+    double res;
+    float t[3];
+    float msv_x[3];
+    float r_total, t0;
+    int pose_info[2], msv_info[2];
+    int N0, nhist, n_cur, n_pose, frame_i, pp, klt_flags, w, h, stride;
+};
+
+struct vh_session {
+    vh_ctx* ctx;
+    int batch, N0, nhist, w, h, msv_frame;
+    vh_lk_params coarse, fine;
+    char* arena;
+    SessStream* d_ss;
+    SessStream* h_ss;  // host mirror of the pointer fields
+    int steps;
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+#define SESS_CHECK() VH_CHECK(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_sess_prepare(SessStream* ss_all, StreamWS* ws_all, const uint8_t* const* frames, vh_lk_params coarse, vh_lk_params fine)
+{
+    if (threadIdx.x != 0) return;
+    SessStream& S = ss_all[blockIdx.x];
+    StreamWS& ws = ws_all[blockIdx.x];
+    KltIO& io = ws.io;
+    io.im = frames[blockIdx.x];
+    io.im0 = S.im0;
+    io.im0_small = S.small[1 - S.pp];
+    io.im_small = S.small[S.pp];
+    io.p0 = S.p_cur;
+    io.n_ptr = &S.n_cur;
+    io.n = 0;
+    io.p_all = S.p_all;
+    io.v = S.v;
+    io.flags = &S.klt_flags;
+    io.w = S.w; io.h = S.h; io.stride = S.stride; io.stride0 = S.stride;
+    io.reuse_prev_small = S.frame_i >= 1 ? 1 : 0;  // the previous step built the pyramid of what is now im0_small
+    io.coarse = coarse; io.fine = fine;
+    io.fbt_coarse = 1.0f; io.fbt_fine = 0.3f;
+    ws.pp = S.pp;
+}
+
+// order-preserving compaction helper: returns the number of selected items; dst index via callback
+template <typename F, typename G>
+__device__ int block_compact(int n, F pred, G emit, int* wcount /* [4] */, int* base /* [1] */)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) *base = 0;
+    __syncthreads();
+    for (int c = 0; c < n; c += 256) {
+        const int i = c + tid;
+        const bool f = i < n && pred(i);
+        const unsigned long long bal = __ballot(f);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int off = *base;
+        for (int q = 0; q < wave; q++) off += wcount[q];
+        if (f) emit(i, off + pre);
+        __syncthreads();
+        if (tid == 0) *base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    return *base;
+}
+
+// vg[vg] = v ; vp &= vg ; p = p[v] ; pose selection p[vp[vg]] / p3[vp]   (vidExample.py:134-139)
+__global__ __launch_bounds__(256) void k_sess_book_a(SessStream* ss_all)
+{
+    SessStream& S = ss_all[blockIdx.x];
+    const int tid = threadIdx.x, n = S.n_cur, N0 = S.N0;
+    __shared__ int wcount[4], base;
+    for (int r = tid; r < n; r += 256) S.vg[S.ids[r]] = S.v[r];
+    __syncthreads();
+    for (int g = tid; g < N0; g += 256) S.vp[g] = S.vp[g] & S.vg[g];
+    __syncthreads();
+    // compaction: reads of ids happen chunk-wise before the writes of the same chunk; destinations never pass the source
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        if (tid == 0) base = 0;
+        __syncthreads();
+        for (int c = 0; c < n; c += 256) {
+            const int i = c + tid;
+            const bool f = i < n && S.v[i] != 0;
+            const int id = i < n ? S.ids[i] : 0;
+            const float px = f ? S.p_all[2 * i] : 0.f, py = f ? S.p_all[2 * i + 1] : 0.f;
+            const unsigned long long bal = __ballot(f);
+            const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wcount[wave] = __popcll(bal);
+            __syncthreads();
+            int off = base;
+            for (int q = 0; q < wave; q++) off += wcount[q];
+            if (f) { S.ids[off + pre] = id; S.p_cur[2 * (off + pre)] = px; S.p_cur[2 * (off + pre) + 1] = py; }
+            __syncthreads();
+            if (tid == 0) base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+            __syncthreads();
+        }
+    }
+    const int n_new = base;
+    __syncthreads();
+    const int n_pose = block_compact(
+        n_new, [&](int k) { return S.vp[S.ids[k]] != 0; },
+        [&](int k, int j) { S.sel_p[j] = k; S.sel_pw[j] = S.ids[k]; }, wcount, &base);
+    if (tid == 0) {
+        S.n_cur = n_new;
+        S.n_pose = n_pose;
+    }
+}
+
+// results records B, S and history P (vidExample.py:142-146, 151-153, 164); then advance the frame state
+__global__ __launch_bounds__(256) void k_sess_book_b(SessStream* ss_all, const uint8_t* const* frames, float time_s, float frame_no)
+{
+    SessStream& S = ss_all[blockIdx.x];
+    const int tid = threadIdx.x, i = S.frame_i + 1, nh = S.nhist, N0 = S.N0;
+    if (i < nh) {
+        for (int k = tid; k < S.n_cur; k += 256) {
+            const int g = S.ids[k];
+            S.P[((size_t)0 * N0 + g) * nh + i] = S.p_cur[2 * k];
+            S.P[((size_t)1 * N0 + g) * nh + i] = S.p_cur[2 * k + 1];
+            S.P[((size_t)4 * N0 + g) * nh + i] = (float)i;
+        }
+        for (int j = tid; j < S.n_pose; j += 256) {
+            const int g = S.sel_pw[j];
+            S.P[((size_t)2 * N0 + g) * nh + i] = (float)S.p_proj[2 * j];
+            S.P[((size_t)3 * N0 + g) * nh + i] = (float)S.p_proj[2 * j + 1];
+        }
+    }
+    if (tid == 0) {
+        if (i < nh) {
+            float* B = S.B;
+            B[14 * i + 12] = time_s;
+            B[14 * i + 13] = frame_no;
+            const float dt = __fsub_rn(B[14 * i + 12], B[14 * (i - 1) + 12]);
+            // dr = norm(t + B[0,0:3] - B[i-1,0:3]) in float32 (vidExample.py:143)
+            float ss = 0.f;
+            for (int c = 0; c < 3; c++) {
+                const float d = __fsub_rn(__fadd_rn(S.t[c], B[c]), B[14 * (i - 1) + c]);
+                ss = __fadd_rn(ss, __fmul_rn(d, d));
+            }
+            const float dr = vh_sqrtf(ss);
+            S.r_total = __fadd_rn(S.r_total, dr);
+            for (int c = 0; c < 3; c++) {
+                B[14 * i + 3 + c] = S.t[c];
+                B[14 * i + c] = __fadd_rn(B[c], S.t[c]);
+            }
+            float* R = S.S + 9 * i;
+            R[0] = (float)i; R[1] = 0.f; R[2] = (float)S.n_cur; R[3] = (float)S.res; R[4] = dt;
+            R[5] = __fsub_rn(B[14 * i + 12], S.t0); R[6] = dr; R[7] = S.r_total;
+            R[8] = __fmul_rn(__fdiv_rn(dr, dt), 3.6f);
+        }
+        S.im0 = frames[blockIdx.x];
+        S.pp ^= 1;
+        S.frame_i = i;
+    }
+}
+
+// p3[vg] = p3hat - t ; vp = vg   (vidExample.py:159-160)
+__global__ __launch_bounds__(256) void k_sess_after_msv(SessStream* ss_all)
+{
+    SessStream& S = ss_all[blockIdx.x];
+    for (int k = threadIdx.x; k < S.n_cur; k += 256) {
+        const int g = S.ids[k];
+        for (int c = 0; c < 3; c++) S.p3[3 * g + c] = S.msv_b0[3 * k + c] - (double)S.t[c];
+    }
+    for (int g = threadIdx.x; g < S.N0; g += 256) S.vp[g] = S.vg[g];
+}
+
+// frame-0 initialisation (vidExample.py:125-131, 151-153)
+__global__ __launch_bounds__(256) void k_sess_init(SessStream* ss, const float* p, const double* p3, const uint8_t* vp, const uint8_t* frame0,
+                                                   float t0x, float t0y, float t0z, float time0, float frame_no, float res0)
+{
+    SessStream& S = *ss;
+    const int tid = threadIdx.x, N0 = S.N0, nh = S.nhist;
+    const float nanv = __int_as_float(0x7fc00000);
+    for (size_t q = tid; q < (size_t)5 * N0 * nh; q += 256) S.P[q] = nanv;
+    for (int q = tid; q < nh * 14; q += 256) S.B[q] = 0.f;
+    for (int q = tid; q < nh * 9; q += 256) S.S[q] = 0.f;
+    __syncthreads();
+    for (int g = tid; g < N0; g += 256) {
+        S.vg[g] = 1;
+        S.vp[g] = vp[g] ? 1 : 0;
+        S.ids[g] = g;
+        S.p_cur[2 * g] = p[2 * g]; S.p_cur[2 * g + 1] = p[2 * g + 1];
+        for (int c = 0; c < 3; c++) S.p3[3 * g + c] = p3[3 * g + c];
+        S.P[((size_t)0 * N0 + g) * nh] = p[2 * g];
+        S.P[((size_t)1 * N0 + g) * nh] = p[2 * g + 1];
+        if (vp[g]) { S.P[((size_t)2 * N0 + g) * nh] = p[2 * g]; S.P[((size_t)3 * N0 + g) * nh] = p[2 * g + 1]; }  // p_ = p[vp]
+        S.P[((size_t)4 * N0 + g) * nh] = 0.f;
+    }
+    if (tid == 0) {
+        S.n_cur = N0; S.n_pose = 0; S.frame_i = 0; S.pp = 0; S.klt_flags = 0;
+        S.B[0] = t0x; S.B[1] = t0y; S.B[2] = t0z; S.B[12] = time0; S.B[13] = frame_no;
+        S.t[0] = t0x; S.t[1] = t0y; S.t[2] = t0z;
+        S.t0 = time0; S.r_total = 0.f; S.res = (double)res0;
+        S.S[0] = 0.f; S.S[2] = (float)N0; S.S[3] = res0; S.S[4] = nanv; S.S[8] = nanv;
+        S.im0 = frame0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, int nhist, int w, int h, const float* K_host,
+                                        const vh_lk_params* coarse, const vh_lk_params* fine, int msv_frame)
+{
+    if (!out || !ctx || !K_host || !coarse || !fine || n0 < 1 || nhist < 2) return vh_fail(-1, "vh_session_create: bad arguments");
+    if (n0 > ctx->max_pts || w > ctx->max_w || h > ctx->max_h) return vh_fail(-1, "vh_session_create: exceeds the workspace");
+    vh_session* s = new (std::nothrow) vh_session();
+    if (!s) return vh_fail(-1, "out of host memory");
+    s->ctx = ctx; s->batch = ctx->batch; s->N0 = n0; s->nhist = nhist; s->w = w; s->h = h; s->msv_frame = msv_frame;
+    s->coarse = *coarse; s->fine = *fine; s->steps = 0;
+    const int dw = (int)lrint(w * 0.25), dh = (int)lrint(h * 0.25);
+    s->h_ss = new SessStream[s->batch];
+    memset(s->h_ss, 0, sizeof(SessStream) * s->batch);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) {
+            hipError_t e = hipMalloc((void**)&s->arena, off);
+            if (e != hipSuccess) { delete[] s->h_ss; delete s; vh_set_error("hipMalloc(session)", e, __FILE__, __LINE__); return (int)e; }
+            (void)hipMemset(s->arena, 0, off);
+            off = 0;
+        }
+        char* base = pass ? s->arena : nullptr;
+        s->d_ss = (SessStream*)(base + carve(sizeof(SessStream) * s->batch));
+        for (int b = 0; b < s->batch; b++) {
+            SessStream& S = s->h_ss[b];
+            S.vg = (uint8_t*)(base + carve(n0)); S.vp = (uint8_t*)(base + carve(n0));
+            S.p_cur = (float*)(base + carve(sizeof(float) * 2 * n0)); S.ids = (int*)(base + carve(sizeof(int) * n0));
+            S.p3 = (double*)(base + carve(sizeof(double) * 3 * n0));
+            S.P = (float*)(base + carve(sizeof(float) * 5 * (size_t)n0 * nhist));
+            S.B = (float*)(base + carve(sizeof(float) * 14 * nhist)); S.S = (float*)(base + carve(sizeof(float) * 9 * nhist));
+            S.p_all = (float*)(base + carve(sizeof(float) * 2 * n0)); S.v = (uint8_t*)(base + carve(n0));
+            S.sel_p = (int*)(base + carve(sizeof(int) * n0)); S.sel_pw = (int*)(base + carve(sizeof(int) * n0));
+            S.p_proj = (double*)(base + carve(sizeof(double) * 2 * n0));
+            S.msv_U = (double*)(base + carve(sizeof(double) * 3 * 16 * n0)); S.msv_b0 = (double*)(base + carve(sizeof(double) * 3 * n0));
+            S.small[0] = (uint8_t*)(base + carve((size_t)dw * dh)); S.small[1] = (uint8_t*)(base + carve((size_t)dw * dh));
+        }
+    }
+    for (int b = 0; b < s->batch; b++) {
+        SessStream& S = s->h_ss[b];
+        SessStream* d = s->d_ss + b;
+        for (int k = 0; k < 9; k++) S.K[k] = (double)K_host[k];
+        S.N0 = n0; S.nhist = nhist; S.w = w; S.h = h; S.stride = w;
+        PoseJob& J = S.pose;
+        for (int k = 0; k < 9; k++) { J.K[k] = S.K[k]; J.R[k] = (k % 4 == 0) ? 1.0 : 0.0; }
+        J.x0[0] = J.x0[1] = J.x0[2] = 0; J.x0[3] = 0; J.x0[4] = 0; J.x0[5] = 1;  // always restarted from t=[0,0,1] (NLS.py:9)
+        J.p = S.p_cur; J.pw = S.p3; J.p_sel = S.sel_p; J.pw_sel = S.sel_pw; J.n_ptr = &d->n_pose; J.n = 0; J.mode = 0;
+        J.t_out = d->t; J.R_out = nullptr; J.res_out = &d->res; J.p_proj = S.p_proj; J.info_out = d->pose_info;
+    }
+    hipError_t e = hipMemcpy(s->d_ss, s->h_ss, sizeof(SessStream) * s->batch, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(s->arena); delete[] s->h_ss; delete s; vh_set_error("hipMemcpy(session)", e, __FILE__, __LINE__); return (int)e; }
+    *out = s;
+    return 0;
+}
+
+extern "C" VH_API void vh_session_destroy(vh_session* s)
+{
+    if (!s) return;
+    (void)hipFree(s->arena);
+    delete[] s->h_ss;
+    delete s;
+}
+
+extern "C" VH_API int vh_session_init(vh_session* s, int slot, const uint8_t* frame0, int stride, const float* p, const double* p3,
+                                      const uint8_t* vp, const float* t0_host, float time0, float frame_no, float res0, void* stream)
+{
+    if (!s || slot < 0 || slot >= s->batch || !t0_host) return vh_fail(-1, "vh_session_init: bad arguments");
+    if (stride != s->w) return vh_fail(-1, "vh_session_init: frames must be dense (stride == width)");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sess_init, dim3(1), dim3(256), 0, st, s->d_ss + slot, p, p3, vp, frame0, t0_host[0], t0_host[1], t0_host[2], time0,
+                       frame_no, res0);
+    // quarter-scale copy of frame 0 = im0_small of the first step (pp starts at 0 -> previous index 1)
+    int r = vh_resize_quarter(s->ctx, frame0, s->w, s->h, stride, s->h_ss[slot].small[1], stream);
+    if (r) return r;
+    SESS_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_session_step(vh_session* s, const uint8_t* const* frames_dev, float time_s, float frame_no, void* stream)
+{
+    if (!s || !frames_dev) return vh_fail(-1, "vh_session_step: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    vh_ctx* c = s->ctx;
+    const int nb = s->batch;
+    hipLaunchKernelGGL(k_sess_prepare, dim3(nb), dim3(64), 0, st, s->d_ss, c->d_ws, frames_dev, s->coarse, s->fine);
+    int r = vh_run_klt_main(c, 0, nb, st, s->coarse, s->fine);
+    if (r) return r;
+    hipLaunchKernelGGL(k_sess_book_a, dim3(nb), dim3(256), 0, st, s->d_ss);
+    vh_launch_pose(&s->d_ss[0].pose, sizeof(SessStream), nb, 0, st);
+    hipLaunchKernelGGL(k_sess_book_b, dim3(nb), dim3(256), 0, st, s->d_ss, frames_dev, time_s, frame_no);
+    s->steps++;
+    if (s->steps == s->msv_frame && s->msv_frame >= 1 && s->msv_frame + 1 <= 16 && s->msv_frame < s->nhist) {
+        for (int b = 0; b < nb; b++) {
+            const SessStream& H = s->h_ss[b];
+            MsvJob J;
+            memset(&J, 0, sizeof(J));
+            for (int k = 0; k < 9; k++) J.K[k] = H.K[k];
+            J.P = H.P; J.B = H.B; J.ids = H.ids; J.ng_ptr = &s->d_ss[b].n_cur; J.ng = 0; J.N0 = s->N0; J.nhist = s->nhist;
+            J.nf = s->msv_frame + 1; J.max_iter = 1000; J.f32_rays = 1;
+            J.U = H.msv_U; J.b0 = H.msv_b0; J.x_out = s->d_ss[b].msv_x; J.info_out = s->d_ss[b].msv_info;
+            vh_launch_msv1(J, st);
+        }
+        hipLaunchKernelGGL(k_sess_after_msv, dim3(nb), dim3(256), 0, st, s->d_ss);
+    }
+    SESS_CHECK();
+    return 0;
+}
+
+// packed track state of every stream for the cross-GPU exchange (K20): per stream a record of 8 + 3*N0 float32 words
+// [n_cur, n_pose, frame_i, klt_flags, t0, t1, t2, res | p (N0 x 2, zero padded) | ids (N0 int32 bit patterns, -1 padded)]
+__global__ __launch_bounds__(256) void k_sess_pack(const SessStream* ss_all, float* out, int rec)
+{
+    const SessStream& S = ss_all[blockIdx.x];
+    float* o = out + (size_t)blockIdx.x * rec;
+    const int N0 = S.N0, n = S.n_cur;
+    if (threadIdx.x == 0) {
+        o[0] = (float)n; o[1] = (float)S.n_pose; o[2] = (float)S.frame_i; o[3] = (float)S.klt_flags;
+        o[4] = S.t[0]; o[5] = S.t[1]; o[6] = S.t[2]; o[7] = (float)S.res;
+    }
+    for (int k = threadIdx.x; k < N0; k += 256) {
+        o[8 + 2 * k] = k < n ? S.p_cur[2 * k] : 0.f;
+        o[8 + 2 * k + 1] = k < n ? S.p_cur[2 * k + 1] : 0.f;
+        o[8 + 2 * N0 + k] = __int_as_float(k < n ? S.ids[k] : -1);
+    }
+}
+
+extern "C" VH_API int vh_session_pack_state(vh_session* s, float* out, void* stream)
+{
+    if (!s || !out) return vh_fail(-1, "vh_session_pack_state: bad arguments");
+    hipLaunchKernelGGL(k_sess_pack, dim3(s->batch), dim3(256), 0, (hipStream_t)stream, s->d_ss, out, 8 + 3 * s->N0);
+    SESS_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_session_ptrs(vh_session* s, int slot, vh_session_view* out)
+{
+    if (!s || !out || slot < 0 || slot >= s->batch) return vh_fail(-1, "vh_session_ptrs: bad arguments");
+    const SessStream& H = s->h_ss[slot];
+    SessStream* d = s->d_ss + slot;
+    out->vg = H.vg; out->vp = H.vp; out->p = H.p_cur; out->ids = H.ids; out->p3 = H.p3; out->P = H.P; out->B = H.B; out->S = H.S;
+    out->n_cur = &d->n_cur; out->n_pose = &d->n_pose; out->t = d->t; out->res = &d->res; out->frame_i = &d->frame_i;
+    out->klt_flags = &d->klt_flags; out->pose_info = d->pose_info; out->sel_pw = H.sel_pw; out->p_proj = H.p_proj;
+    return 0;
+}

@@ -1,0 +1,96 @@
+"""Device-resident counterpart of the reference's frame loop (vidExample.py:75-171): TrackerSession keeps the track
+state of `batch` video streams on the GPU and advances all of them one frame per step() through vh_session_step.
+Inputs are torch CUDA uint8 frames (dense, H x W); results (P, B, S, masks, points) are read back on demand."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class TrackerSession:
+    def __init__(self, K, width, height, n0, nhist=20, batch=1, lk_coarse=None, lk_fine=None, msv_frame=5):
+        torch = L.torch_cuda()
+        self.torch = torch
+        self.batch, self.w, self.h, self.n0, self.nhist = batch, width, height, n0, nhist
+        self.ws = L.Workspace(batch, width, height, n0)
+        self.lib = self.ws.lib
+        self.K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+        self.lkc = L.lk_params(dict(L.LK_COARSE, **(lk_coarse or {})))
+        self.lkf = L.lk_params(dict(L.LK_FINE, **(lk_fine or {})))
+        h = C.c_void_p()
+        L.check(self.lib.vh_session_create(C.byref(h), self.ws.handle, n0, nhist, width, height, self.K32.ctypes.data_as(L.f32p),
+                                           C.byref(self.lkc), C.byref(self.lkf), int(msv_frame)), "vh_session_create")
+        self.handle = h
+        self._frames = torch.zeros(batch, dtype=torch.int64, device="cuda")  # device table of frame pointers
+        self._keep = [None] * batch
+        self._init_keep = []
+
+    def init_stream(self, slot, frame0, p, p3, vp, t0, time0=0.0, frame_no=0.0, res0=0.0):
+        """Frame-0 state (vidExample.py:116-131): points p [n0,2], world points p3 [n0,3], pose mask vp, plate pose t0."""
+        torch = self.torch
+        f0 = frame0 if isinstance(frame0, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frame0))
+        f0 = f0.cuda().contiguous()
+        assert f0.shape == (self.h, self.w) and f0.dtype == torch.uint8
+        pd = L.to_dev(np.asarray(p, np.float32), torch.float32)
+        p3d = L.to_dev(np.asarray(p3, np.float64), torch.float64)
+        vpd = L.to_dev(np.asarray(vp).astype(np.uint8), torch.uint8)
+        assert pd.shape == (self.n0, 2) and p3d.shape == (self.n0, 3) and vpd.shape == (self.n0,)
+        t0 = np.ascontiguousarray(np.asarray(t0, np.float32).reshape(3))
+        L.check(self.lib.vh_session_init(self.handle, slot, L.dptr(f0), self.w, L.dptr(pd), L.dptr(p3d), L.dptr(vpd), t0.ctypes.data_as(L.f32p),
+                                         float(time0), float(frame_no), float(res0), L.stream_ptr()), "vh_session_init")
+        self._keep[slot] = f0
+        self._init_keep.append((pd, p3d, vpd))
+
+    def set_frames(self, frames):
+        """frames: list of `batch` CUDA uint8 [H,W] tensors (kept alive until the next call replaces them)."""
+        torch = self.torch
+        ptrs = []
+        for f in frames:
+            assert f.is_cuda and f.dtype == torch.uint8 and f.shape == (self.h, self.w) and f.is_contiguous()
+            ptrs.append(f.data_ptr())
+        self._prev_keep = self._keep
+        self._keep = list(frames)
+        self._frames.copy_(torch.tensor(ptrs, dtype=torch.int64), non_blocking=False)
+
+    def step(self, frames=None, time_s=0.0, frame_no=0.0, frames_table=None):
+        """One frame for every stream.  Either `frames` (list of tensors) or `frames_table` (int64 CUDA tensor of pointers)."""
+        if frames is not None:
+            self.set_frames(frames)
+        tab = self._frames if frames_table is None else frames_table
+        L.check(self.lib.vh_session_step(self.handle, L.dptr(tab), float(time_s), float(frame_no), L.stream_ptr()), "vh_session_step")
+
+    def view(self, slot=0):
+        v = L.SessionView()
+        L.check(self.lib.vh_session_ptrs(self.handle, slot, C.byref(v)), "vh_session_ptrs")
+        return v
+
+    def _rd(self, ptr, count, dtype):
+        out = np.empty(count, dtype)
+        if count:
+            L.check(self.lib.vh_copy_to_host(out.ctypes.data, ptr, out.nbytes, L.stream_ptr()), "vh_copy_to_host")
+        return out
+
+    def state(self, slot=0):
+        """Host copy of the stream state: dict(vg, vp, p, P, B, S, p3, t, res, n_cur, n_pose, frame_i, klt_flags)."""
+        v = self.view(slot)
+        n0, nh = self.n0, self.nhist
+        n_cur = int(self._rd(v.n_cur, 1, np.int32)[0])
+        n_pose = int(self._rd(v.n_pose, 1, np.int32)[0])
+        return dict(
+            vg=self._rd(v.vg, n0, np.uint8).astype(bool), vp=self._rd(v.vp, n0, np.uint8).astype(bool),
+            p=self._rd(v.p, 2 * n_cur, np.float32).reshape(n_cur, 2), ids=self._rd(v.ids, n_cur, np.int32),
+            P=self._rd(v.P, 5 * n0 * nh, np.float32).reshape(5, n0, nh), B=self._rd(v.B, nh * 14, np.float32).reshape(nh, 14),
+            S=self._rd(v.S, nh * 9, np.float32).reshape(nh, 9), p3=self._rd(v.p3, 3 * n0, np.float64).reshape(n0, 3),
+            t=self._rd(v.t, 3, np.float32), res=float(self._rd(v.res, 1, np.float64)[0]), n_cur=n_cur, n_pose=n_pose,
+            frame_i=int(self._rd(v.frame_i, 1, np.int32)[0]), klt_flags=int(self._rd(v.klt_flags, 1, np.int32)[0]),
+            pose_info=self._rd(v.pose_info, 2, np.int32))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.torch.cuda.synchronize()
+                self.lib.vh_session_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

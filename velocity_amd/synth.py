@@ -69,6 +69,48 @@ class AffineMotion:
         return np.concatenate([Li, (-Li @ A[:, 2])[:, None]], 1)
 
 
+class PlaneMotion:
+    """Fronto-parallel textured plane at depth z0 (frame-0 camera coordinates) seen by a camera whose scene-relative
+    translation at frame k is t_k = traj(k) -- the reference's own model (vidExample.py:119: every feature on the
+    plate plane; pose = translation only).  Image motion: x_k = c + (x_0 - c) z0/(z0+tz) + f (tx,ty)/(z0+tz)."""
+
+    def __init__(self, K, z0=3.6, traj=None):
+        K = np.asarray(K, float)
+        self.f = np.array([K[0, 0], K[1, 1]])
+        self.c = np.array([K[2, 0], K[2, 1]])
+        self.z0 = float(z0)
+        self.traj = traj or (lambda k: np.array([0.02 * k, 0.005 * k, 0.10 * k]))
+
+    def t(self, k):
+        return np.asarray(self.traj(k), float)
+
+    def matrix(self, k):
+        tx, ty, tz = self.t(k)
+        s = self.z0 / (self.z0 + tz)
+        b = self.c * (1 - s) + self.f * np.array([tx, ty]) / (self.z0 + tz)
+        return np.array([[s, 0, b[0]], [0, s, b[1]]])
+
+    def apply(self, k, pts):
+        A = self.matrix(k)
+        return pts @ A[:, :2].T + A[:, 2]
+
+    def inverse(self, k):
+        A = self.matrix(k)
+        Li = np.linalg.inv(A[:, :2])
+        return np.concatenate([Li, (-Li @ A[:, 2])[:, None]], 1)
+
+    def world_points(self, p_pixels):
+        """Frame-0 camera-frame 3-D points of pixels on the plane (the reference's p3, vidExample.py:119)."""
+        xy = (np.asarray(p_pixels, float) - self.c) / self.f * self.z0
+        return np.concatenate([xy, np.full((len(xy), 1), self.z0)], 1)
+
+
+def oscillating_traj(period=60.0, ax=0.19, ay=0.04, az=0.25):
+    """Bounded periodic scene motion for long benchmark sequences (max ~11 px/frame at 1080p, z0 = 3.6 m)."""
+    w = 2 * math.pi / period
+    return lambda k: np.array([ax * math.sin(w * k), ay * math.sin(2 * w * k), az * (1 - math.cos(w * k))])
+
+
 def render_frame(width, height, motion, k, seed=0xC0FFEE, device="cpu"):
     """uint8 [H,W] frame k: texture sampled at A_k^-1 (x,y), stretched to [16,240]."""
     Ai = motion.inverse(k)
