@@ -108,8 +108,8 @@ def main():
     nhist = a.warmup + a.steps + 3
     K, motion, frames, p0 = make_ring(cfg, a.ring, dev, seed=0xC0FFEE + 7919 * rank)
     p3 = motion.world_points(p0)
-    vp = (np.abs(p0[:, 0] - W / 2) < W * 0.1) & (np.abs(p0[:, 1] - H / 2) < H * 0.1)  # "plate" box until the MSV frame
-    ses = TrackerSession(K, W, H, N, nhist=nhist, batch=S, lk_coarse=lkc, lk_fine=lkf, msv_frame=5)
+    vp = np.ones(N, bool)  # every valid track takes part in the pose fit (the state after vidExample.py:160)
+    ses = TrackerSession(K, W, H, N, nhist=nhist, batch=S, lk_coarse=lkc, lk_fine=lkf, msv_frame=0)
     # streams of one rank share the ring but run at different phases, so every launch sees S different frame pairs
     phase = [(7 * b) % a.ring for b in range(S)]
     base_ptr = frames.data_ptr()

@@ -158,6 +158,9 @@ VH_API int vh_session_ptrs(vh_session* s, int slot, vh_session_view* out_host);
  * out = device float32 [batch][8 + 3*n0]: {n_cur, n_pose, frame_i, klt_flags, t[3], res | p (n0 x 2) | ids (n0, int32 bits)} */
 VH_API int vh_session_pack_state(vh_session* s, float* out, void* stream);
 
+/* test hook: 1 routes every LK window through the per-sample kernel instead of the strip kernel (both are bit-identical) */
+VH_API void vh_debug_force_generic_lk(int on);
+
 /* ---- measurement aids (bench.py): HIP-event timing of the LK launches + Newton-iteration statistics ------------- */
 VH_API int vh_profile_begin(vh_ctx* ctx, int max_launches);
 /* all outputs host arrays of 3 (KLTmain stage 0: quarter scale, 1: coarse ROI, 2: fine) */

@@ -117,6 +117,25 @@ def test_pyr_lk_bit_exact(seq, lk, fbt):
     assert v[: len(p0)].mean() > 0.9
 
 
+def test_strip_and_per_sample_lk_kernels_agree(seq):
+    """Both device implementations of the track solve (strip kernel, per-sample kernel) are bit-identical."""
+    from velocity_amd import _lib as L
+    from velocity_amd.KLT import cv2calcOpticalFlowPyrLK
+
+    W, H, m, f0, f1, p0 = seq
+    rng = np.random.default_rng(9)
+    pts = np.concatenate([p0, rng.uniform(-20, 30, (60, 2)).astype(np.float32), rng.uniform([W - 30, H - 30], [W + 20, H + 20], (60, 2)).astype(np.float32)])
+    for lk in (CV_COARSE, CV_FINE, dict(winSize=(9, 9), maxLevel=3, criteria=(3, 20, 0.03)), dict(winSize=(31, 31), maxLevel=1, criteria=(3, 20, 0.03))):
+        a = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=0.5, **lk)
+        L.load().vh_debug_force_generic_lk(1)
+        try:
+            b = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=0.5, **lk)
+        finally:
+            L.load().vh_debug_force_generic_lk(0)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
 def test_pyr_lk_textureless_and_small_images():
     from velocity_amd.KLT import cv2calcOpticalFlowPyrLK
 

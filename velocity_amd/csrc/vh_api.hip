@@ -25,7 +25,9 @@ int vh_fail(int code, const char* msg)
 }
 #define VH_LAUNCH_CHECK() VH_CHECK(hipGetLastError())
 
-extern "C" VH_API int vh_version(void) { return 100; }
+extern "C" VH_API int vh_version(void) { return 101; }
+void vh_lk_force_generic(int on);
+extern "C" VH_API void vh_debug_force_generic_lk(int on) { vh_lk_force_generic(on); }
 extern "C" VH_API int vh_copy_to_host(void* dst_host, const void* src_dev, size_t bytes, void* stream)
 {
     VH_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));

@@ -270,9 +270,439 @@ __global__ __launch_bounds__(64) void k_lk(const void* job_tab, size_t tab_strid
     }
 }
 
+
+// =================================================================================================================
+// v2: strip kernel.  One lane handles a horizontal strip of 4 window samples: the 4x7 (set-up) / 2x5 (iteration)
+// pixel block of a strip comes from 3 aligned dword loads per row + v_alignbyte, the bilinear / gradient dot products
+// run on v_dot2_i32_i16 with packed int16 pairs, the template lives in LDS as lane-private packed int16 quads
+// (conflict-free ds_read_b64), and the exact wave sums are DPP row reductions of 16-bit halves (order independent).
+// Integer arithmetic is identical to the per-sample kernel above, so results are bit-identical.
+// =================================================================================================================
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int dpp_row_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);  // row_mirror
+    return v;
+}
+// exact wave-wide sum of per-lane int32 partials (|v| < 2^31) as int64, uniform result
+__device__ __forceinline__ long long wave_sum_i32_wide(int v)
+{
+    int lo = dpp_row_sum(v & 0xffff), hi = dpp_row_sum(v >> 16);
+    const int lo_t = __builtin_amdgcn_readlane(lo, 0) + __builtin_amdgcn_readlane(lo, 16) + __builtin_amdgcn_readlane(lo, 32) +
+                     __builtin_amdgcn_readlane(lo, 48);
+    const int hi_t = __builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) + __builtin_amdgcn_readlane(hi, 32) +
+                     __builtin_amdgcn_readlane(hi, 48);
+    return (long long)hi_t * 65536ll + (long long)lo_t;
+}
+
+__device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
+__device__ __forceinline__ short2v as_s2(unsigned v) { return __builtin_bit_cast(short2v, v); }
+__device__ __forceinline__ int dot2(unsigned a, unsigned b, int c) { return __builtin_amdgcn_sdot2(as_s2(a), as_s2(b), c, false); }
+
+// NR rows x 8 bytes starting at pixel (gx, gy): lo = bytes 0..3, hi = bytes 4..7 of every row (interior fast path)
+template <int NR>
+__device__ __forceinline__ void load_rows_fast(const ImgDesc& im, int gx, int gy, unsigned* lo, unsigned* hi)
+{
+    const uint8_t* base = im.p + (ptrdiff_t)gy * im.stride + gx;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(base + (ptrdiff_t)r * im.stride);
+        const unsigned sh = (unsigned)(a & 3);
+        const unsigned* ap = reinterpret_cast<const unsigned*>(a - sh);
+        const unsigned d0 = ap[0], d1 = ap[1], d2 = ap[2];
+        lo[r] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        hi[r] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    }
+}
+// the same block through REFLECT_101 byte loads (windows that touch the border)
+template <int NR, int NC>
+__device__ __forceinline__ void load_rows_slow(const ImgDesc& im, int gx, int gy, unsigned* lo, unsigned* hi)
+{
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        unsigned l = 0, h = 0;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const unsigned v = (unsigned)pix_r(im, gx + c, gy + r);
+            if (c < 4) l |= v << (8 * c);
+            else h |= v << (8 * (c - 4));
+        }
+        lo[r] = l; hi[r] = h;
+    }
+}
+__device__ __forceinline__ int byte_of(unsigned lo, unsigned hi, int c) { return c < 4 ? (int)((lo >> (8 * c)) & 0xff) : (int)((hi >> (8 * (c - 4))) & 0xff); }
+
+struct StripWeights {
+    unsigned wt, wb;  // packed (w00,w01), (w10,w11)
+    int w00, w01, w10, w11;
+};
+__device__ __forceinline__ StripWeights strip_weights(const Win& w)
+{
+    StripWeights s;
+    s.w00 = w.w00; s.w01 = w.w01; s.w10 = w.w10; s.w11 = w.w11;
+    s.wt = pack16(w.w00, w.w01); s.wb = pack16(w.w10, w.w11);
+    return s;
+}
+
+// bilinear x32 samples of the 4 strip positions from 2 rows (lo,hi): returns packed pairs (v0,v1), (v2,v3)
+__device__ __forceinline__ void strip_bilinear(const unsigned* lo, const unsigned* hi, const StripWeights& w, unsigned& p01, unsigned& p23)
+{
+    int v[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        // packed horizontal neighbours (b_c, b_{c+1}) of both rows
+        unsigned t, b;
+        if (c < 3) {
+            const unsigned sel = 0x0c000c00u + (unsigned)c + ((unsigned)(c + 1) << 16);
+            t = __builtin_amdgcn_perm(0u, lo[0], sel);
+            b = __builtin_amdgcn_perm(0u, lo[1], sel);
+        } else {
+            t = __builtin_amdgcn_perm(hi[0], lo[0], 0x0c040c03u);
+            b = __builtin_amdgcn_perm(hi[1], lo[1], 0x0c040c03u);
+        }
+        v[c] = dot2(b, w.wb, dot2(t, w.wt, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+    }
+    p01 = pack16(v[0], v[1]);
+    p23 = pack16(v[2], v[3]);
+}
+
+
+// set-up of one strip from its 4x7 pixel block: template samples (x32), Scharr gradients, structure-tensor partials
+template <bool FAST>
+__device__ __forceinline__ void strip_setup(const unsigned* lo, const unsigned* hi, const Win& w0, const ImgDesc& I, int ipx, int ipy, int x,
+                                            int y, int cnt, uint2* tI, uint2* tX, uint2* tY, int slot, int& a11, int& a12, int& a22)
+{
+    constexpr bool fast = FAST;
+            // vertical [3 10 3] smooth / [-1 0 1] difference for the two derivative rows, 7 columns
+            int sm[2][7], df[2][7];
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int c = 0; c < 7; c++) {
+                    const int t = byte_of(lo[r], hi[r], c), m = byte_of(lo[r + 1], hi[r + 1], c), b = byte_of(lo[r + 2], hi[r + 2], c);
+                    sm[r][c] = (t + b) * 3 + m * 10;
+                    df[r][c] = b - t;
+                }
+            int gx[2][5], gy[2][5];
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    gx[r][c] = sm[r][c + 2] - sm[r][c];
+                    gy[r][c] = (df[r][c] + df[r][c + 2]) * 3 + df[r][c + 1] * 10;
+                    if (!fast) {  // the derivative image is constant 0 outside the level
+                        const int ax = ipx + x + c, ay = ipy + y + r;
+                        if (ax < 0 || ax >= I.w || ay < 0 || ay >= I.h) { gx[r][c] = 0; gy[r][c] = 0; }
+                    }
+                }
+            int iv[4], ix[4], iy[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int q00 = byte_of(lo[1], hi[1], c + 1), q01 = byte_of(lo[1], hi[1], c + 2);
+                const int q10 = byte_of(lo[2], hi[2], c + 1), q11 = byte_of(lo[2], hi[2], c + 2);
+                iv[c] = vh_descale(q00 * w0.w00 + q01 * w0.w01 + q10 * w0.w10 + q11 * w0.w11, W_BITS - 5);
+                ix[c] = vh_descale(gx[0][c] * w0.w00 + gx[0][c + 1] * w0.w01 + gx[1][c] * w0.w10 + gx[1][c + 1] * w0.w11, W_BITS);
+                iy[c] = vh_descale(gy[0][c] * w0.w00 + gy[0][c + 1] * w0.w01 + gy[1][c] * w0.w10 + gy[1][c + 1] * w0.w11, W_BITS);
+                if (c >= cnt) { iv[c] = 0; ix[c] = 0; iy[c] = 0; }
+            }
+            const uint2 vI = make_uint2(pack16(iv[0], iv[1]), pack16(iv[2], iv[3]));
+            const uint2 vX = make_uint2(pack16(ix[0], ix[1]), pack16(ix[2], ix[3]));
+            const uint2 vY = make_uint2(pack16(iy[0], iy[1]), pack16(iy[2], iy[3]));
+            tI[slot] = vI; tX[slot] = vX; tY[slot] = vY;
+            a11 = dot2(vX.y, vX.y, dot2(vX.x, vX.x, a11));
+            a12 = dot2(vX.y, vY.y, dot2(vX.x, vY.x, a12));
+            a22 = dot2(vY.y, vY.y, dot2(vY.x, vY.x, a22));
+}
+
+template <int WIN_T>
+__device__ void lk_level_strip(const ImgDesc& I, const ImgDesc& J, int win_rt, int level, int top_level, int max_count, double eps2,
+                               float p0x, float p0y, float& nxo, float& nyo, int& status, float& err, uint2* tI, uint2* tX, uint2* tY,
+                               int lane, int& n_iter, int& n_setup)
+{
+    const int win = WIN_T ? WIN_T : win_rt;
+    const int spr = (win + 3) >> 2;   // strips per window row
+    const int nstrips = spr * win;
+    const float half = (float)(win - 1) * 0.5f;
+    const float lscale = (float)(1. / (double)(1 << level));
+    float px = __fmul_rn(p0x, lscale), py = __fmul_rn(p0y, lscale);
+    float nx, ny;
+    if (level == top_level) { nx = px; ny = py; }
+    else { nx = __fmul_rn(nxo, 2.f); ny = __fmul_rn(nyo, 2.f); }
+    nxo = nx; nyo = ny;
+
+    px = __fsub_rn(px, half); py = __fsub_rn(py, half);
+    const int ipx = vh_floor(px), ipy = vh_floor(py);
+    if (ipx < -win || ipx >= I.w || ipy < -win || ipy >= I.h) {
+        if (level == 0) { status = 0; err = 0.f; }
+        return;
+    }
+    const Win w0 = bilinear_weights(__fsub_rn(px, (float)ipx), __fsub_rn(py, (float)ipy));
+    n_setup++;
+    // strip coordinates of this lane: s = lane + 64 k -> (row, 4*col); advanced incrementally
+    const int j_first = lane % spr, y_first = lane / spr;
+    const int jinc = 64 % spr, yinc = 64 / spr;
+
+    int a11 = 0, a12 = 0, a22 = 0;
+    {
+        // fast path needs the 4x8-byte block [ipx-1 .. ipx+win+5] x [ipy-1 .. ipy+win+1] (+ dword slack) inside the level
+        const bool fast = ipx >= 4 && ipy >= 1 && ipx + win + 12 <= I.w && ipy + win + 2 <= I.h;
+        if constexpr (WIN_T != 0 && ((((WIN_T + 3) >> 2) * WIN_T + 63) / 64) <= 2) {
+            constexpr int SPR = (WIN_T + 3) >> 2, NS = SPR * WIN_T, KMAX = (NS + 63) / 64, G = KMAX < 3 ? KMAX : 3;
+#pragma unroll
+            for (int kb = 0; kb < KMAX; kb += G) {
+                unsigned lo[G][4], hi[G][4];
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const int k = kb + g, s = lane + 64 * k;
+                    if (k < KMAX && s < NS) {
+                        const int y = s / SPR, x = 4 * (s - y * SPR);
+                        if (fast) load_rows_fast<4>(I, ipx + x - 1, ipy + y - 1, lo[g], hi[g]);
+                        else load_rows_slow<4, 7>(I, ipx + x - 1, ipy + y - 1, lo[g], hi[g]);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const int k = kb + g, s = lane + 64 * k;
+                    if (k < KMAX && s < NS) {
+                        const int y = s / SPR, x = 4 * (s - y * SPR), cnt = min(4, WIN_T - x);
+                        if (fast) strip_setup<true>(lo[g], hi[g], w0, I, ipx, ipy, x, y, cnt, tI, tX, tY, k * 64 + lane, a11, a12, a22);
+                        else strip_setup<false>(lo[g], hi[g], w0, I, ipx, ipy, x, y, cnt, tI, tX, tY, k * 64 + lane, a11, a12, a22);
+                    }
+                }
+            }
+        } else {
+            int j = j_first, y = y_first, k = 0;
+            for (int s = lane; s < nstrips; s += 64, k++) {
+                const int x = 4 * j, cnt = min(4, win - x);
+                unsigned lo[4], hi[4];
+                if (fast) {
+                    load_rows_fast<4>(I, ipx + x - 1, ipy + y - 1, lo, hi);
+                    strip_setup<true>(lo, hi, w0, I, ipx, ipy, x, y, cnt, tI, tX, tY, k * 64 + lane, a11, a12, a22);
+                } else {
+                    load_rows_slow<4, 7>(I, ipx + x - 1, ipy + y - 1, lo, hi);
+                    strip_setup<false>(lo, hi, w0, I, ipx, ipy, x, y, cnt, tI, tX, tY, k * 64 + lane, a11, a12, a22);
+                }
+                j += jinc; y += yinc;
+                if (j >= spr) { j -= spr; y++; }
+            }
+        }
+    }
+    const long long sA11 = wave_sum_i32_wide(a11), sA12 = wave_sum_i32_wide(a12), sA22 = wave_sum_i32_wide(a22);
+    const float A11 = __fmul_rn((float)sA11, LK_FLT_SCALE), A12 = __fmul_rn((float)sA12, LK_FLT_SCALE), A22 = __fmul_rn((float)sA22, LK_FLT_SCALE);
+    float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
+    const float dA = __fsub_rn(A11, A22);
+    const float disc = __fadd_rn(__fmul_rn(dA, dA), __fmul_rn(__fmul_rn(4.f, A12), A12));
+    const float minEig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11), vh_sqrtf(disc)), (float)(2 * win * win));
+    if (minEig < 1e-4f || D < 1.1920929e-07f) {
+        if (level == 0) status = 0;
+        return;
+    }
+    D = __fdiv_rn(1.f, D);
+
+    nx = __fsub_rn(nx, half); ny = __fsub_rn(ny, half);
+    float pdx = 0.f, pdy = 0.f;
+    for (int it = 0; it < max_count; it++) {
+        const int inx = vh_floor(nx), iny = vh_floor(ny);
+        if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) {
+            if (level == 0) status = 0;
+            break;
+        }
+        const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny)));
+        const bool fast = inx >= 3 && iny >= 0 && inx + win + 12 <= J.w && iny + win + 1 <= J.h;
+        n_iter++;
+        int b1 = 0, b2 = 0;
+        if constexpr (WIN_T != 0 && ((((WIN_T + 3) >> 2) * WIN_T + 63) / 64) <= 2) {
+            // small compile-time window: fully unrolled, all loads of a group of strips issued before the first use so a
+            // Newton iteration pays the memory latency once per group instead of once per strip
+            constexpr int SPR = (WIN_T + 3) >> 2, NS = SPR * WIN_T, KMAX = (NS + 63) / 64, G = KMAX < 6 ? KMAX : 6;
+#pragma unroll
+            for (int kb = 0; kb < KMAX; kb += G) {
+                unsigned lo[G][2], hi[G][2];
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const int k = kb + g, s = lane + 64 * k;
+                    if (k < KMAX && s < NS) {
+                        const int y = s / SPR, j = s - y * SPR;
+                        if (fast) load_rows_fast<2>(J, inx + 4 * j, iny + y, lo[g], hi[g]);
+                        else load_rows_slow<2, 5>(J, inx + 4 * j, iny + y, lo[g], hi[g]);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const int k = kb + g, s = lane + 64 * k;
+                    if (k < KMAX && s < NS) {
+                        unsigned p01, p23;
+                        strip_bilinear(lo[g], hi[g], w, p01, p23);
+                        const uint2 vI = tI[k * 64 + lane], vX = tX[k * 64 + lane], vY = tY[k * 64 + lane];
+                        const unsigned d01 = __builtin_bit_cast(unsigned, as_s2(p01) - as_s2(vI.x));
+                        const unsigned d23 = __builtin_bit_cast(unsigned, as_s2(p23) - as_s2(vI.y));
+                        b1 = dot2(d23, vX.y, dot2(d01, vX.x, b1));
+                        b2 = dot2(d23, vY.y, dot2(d01, vY.x, b2));
+                    }
+                }
+            }
+        } else {
+            int j = j_first, y = y_first, k = 0;
+            for (int s = lane; s < nstrips; s += 64, k++) {
+                unsigned lo[2], hi[2];
+                if (fast) load_rows_fast<2>(J, inx + 4 * j, iny + y, lo, hi);
+                else load_rows_slow<2, 5>(J, inx + 4 * j, iny + y, lo, hi);
+                unsigned p01, p23;
+                strip_bilinear(lo, hi, w, p01, p23);
+                const uint2 vI = tI[k * 64 + lane], vX = tX[k * 64 + lane], vY = tY[k * 64 + lane];
+                const unsigned d01 = __builtin_bit_cast(unsigned, as_s2(p01) - as_s2(vI.x));
+                const unsigned d23 = __builtin_bit_cast(unsigned, as_s2(p23) - as_s2(vI.y));
+                // unused samples of the last strip of a row carry Ix = Iy = 0, so they add nothing
+                b1 = dot2(d23, vX.y, dot2(d01, vX.x, b1));
+                b2 = dot2(d23, vY.y, dot2(d01, vY.x, b2));
+                j += jinc; y += yinc;
+                if (j >= spr) { j -= spr; y++; }
+            }
+        }
+        const long long sb1 = wave_sum_i32_wide(b1), sb2 = wave_sum_i32_wide(b2);
+        const float fb1 = __fmul_rn((float)sb1, LK_FLT_SCALE), fb2 = __fmul_rn((float)sb2, LK_FLT_SCALE);
+        const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
+        const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
+        nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
+        nxo = __fadd_rn(nx, half); nyo = __fadd_rn(ny, half);
+        if (__dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy)) <= eps2) break;
+        if (it > 0 && fabsf(__fadd_rn(dx, pdx)) < 0.01f && fabsf(__fadd_rn(dy, pdy)) < 0.01f) {
+            nxo = __fsub_rn(nxo, __fmul_rn(dx, 0.5f));
+            nyo = __fsub_rn(nyo, __fmul_rn(dy, 0.5f));
+            break;
+        }
+        pdx = dx; pdy = dy;
+    }
+
+    if (status && level == 0) {
+        const float fx = __fsub_rn(nxo, half), fy = __fsub_rn(nyo, half);
+        const int inx = vh_floor(fx), iny = vh_floor(fy);
+        if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) { status = 0; return; }
+        const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny)));
+        const bool fast = inx >= 3 && iny >= 0 && inx + win + 12 <= J.w && iny + win + 1 <= J.h;
+        int se = 0;
+        int j = j_first, y = y_first, k = 0;
+        for (int s = lane; s < nstrips; s += 64, k++) {
+            const int cnt = min(4, win - 4 * j);
+            unsigned lo[2], hi[2];
+            if (fast) load_rows_fast<2>(J, inx + 4 * j, iny + y, lo, hi);
+            else load_rows_slow<2, 5>(J, inx + 4 * j, iny + y, lo, hi);
+            unsigned p01, p23;
+            strip_bilinear(lo, hi, w, p01, p23);
+            const uint2 vI = tI[k * 64 + lane];
+            const short2v d01 = as_s2(p01) - as_s2(vI.x), d23 = as_s2(p23) - as_s2(vI.y);
+            const int d[4] = {d01.x, d01.y, d23.x, d23.y};
+#pragma unroll
+            for (int c = 0; c < 4; c++) se += c < cnt ? (d[c] < 0 ? -d[c] : d[c]) : 0;
+            j += jinc; y += yinc;
+            if (j >= spr) { j -= spr; y++; }
+        }
+        const long long sse = wave_sum_i32_wide(se);
+        err = __fmul_rn((float)sse, __fdiv_rn(1.f, (float)(32 * win * win)));
+    }
+}
+
+template <int WIN_T>
+__device__ void lk_track_strip(const PyrDesc& PI, const PyrDesc& PJ, int win, int max_count, double eps2, float px, float py, float& ox,
+                               float& oy, int& status, float& err, uint2* tI, uint2* tX, uint2* tY, int lane, int& n_iter, int& n_setup)
+{
+    const int nl = min(PI.nlevels, PJ.nlevels);
+    status = 1;
+    err = 0.f;
+    ox = 0.f; oy = 0.f;
+    for (int level = nl - 1; level >= 0; level--)
+        lk_level_strip<WIN_T>(PI.lv[level], PJ.lv[level], win, level, nl - 1, max_count, eps2, px, py, ox, oy, status, err, tI, tX, tY, lane,
+                              n_iter, n_setup);
+}
+
+template <int WIN_T>
+__global__ __launch_bounds__(64) void k_lk_strip(const void* job_tab, size_t tab_stride)
+{
+    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
+    const int n = job.n_ptr ? *job.n_ptr : job.n;
+    const int pt = blockIdx.x;
+    if (pt >= n) return;
+    const int lane = threadIdx.x;
+    const int win = WIN_T ? WIN_T : job.win;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int kmax = (((win + 3) >> 2) * win + 63) / 64;
+    uint2* tI = reinterpret_cast<uint2*>(smem);
+    uint2* tX = tI + kmax * 64;
+    uint2* tY = tX + kmax * 64;
+
+    const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];
+    const float px = __fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]);
+    const float py = __fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]);
+
+    float fx, fy, err;
+    int st, n_iter = 0, n_setup = 0;
+    lk_track_strip<WIN_T>(job.I, job.J, win, job.max_count, job.eps2, px, py, fx, fy, st, err, tI, tX, tY, lane, n_iter, n_setup);
+    float fbe = 0.f;
+    if (job.fbt >= 0.f) {
+        float bx, by, e2;
+        int st2;
+        lk_track_strip<WIN_T>(job.J, job.I, win, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, tI, tX, tY, lane, n_iter, n_setup);
+        const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
+        fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
+        st = st && st2 && (fbe < job.fbt);
+    }
+    if (lane == 0) {
+        float ox, oy;
+        if (job.out_mode == VH_OUT_SCALE) {
+            ox = __fdiv_rn(fx, job.out_scale);
+            oy = __fdiv_rn(fy, job.out_scale);
+        } else {
+            const float ax = __fadd_rn(fx, job.in_off[0]), ay = __fadd_rn(fy, job.in_off[1]);
+            if (job.out_mode == VH_OUT_TRANSLATE) {
+                ox = __fadd_rn(ax, job.out_off[0]);
+                oy = __fadd_rn(ay, job.out_off[1]);
+            } else {
+                ox = __fadd_rn(__fadd_rn(__fmul_rn(ax, job.T[0]), __fmul_rn(ay, job.T[2])), job.T[4]);
+                oy = __fadd_rn(__fadd_rn(__fmul_rn(ax, job.T[1]), __fmul_rn(ay, job.T[3])), job.T[5]);
+            }
+        }
+        job.p_out[2 * pt] = ox;
+        job.p_out[2 * pt + 1] = oy;
+        job.v_out[pt] = (uint8_t)(st != 0);
+        if (job.err_out) job.err_out[pt] = err;
+        if (job.fbe_out) job.fbe_out[pt] = fbe;
+        if (job.praw_out) { job.praw_out[2 * pt] = fx; job.praw_out[2 * pt + 1] = fy; }
+        if (job.stats) {
+            atomicAdd(&job.stats[0], (unsigned long long)n_iter);
+            atomicAdd(&job.stats[1], (unsigned long long)n_setup);
+        }
+    }
+}
+
+template <int WIN_T>
+static int launch_strip(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s)
+{
+    const int kmax = (((win + 3) >> 2) * win + 63) / 64;
+    const size_t lds = (size_t)kmax * 64 * 24;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lk_strip<WIN_T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_lk_strip<WIN_T>, dim3(max_n, batch), dim3(64), lds, s, job_tab, tab_stride);
+    return 0;
+}
+
+static int g_lk_force_generic = 0;  // test hook: route every window through the per-sample kernel
+void vh_lk_force_generic(int on) { g_lk_force_generic = on; }
+
 int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s)
 {
     if (max_n <= 0) return 0;
+    if (!g_lk_force_generic && win <= 63) {
+        // int32 per-lane partial sums are exact up to 16 strips per lane (win <= 63)
+        if (win == 15) return launch_strip<15>(job_tab, tab_stride, batch, max_n, win, s);
+        if (win == 51) return launch_strip<51>(job_tab, tab_stride, batch, max_n, win, s);
+        return launch_strip<0>(job_tab, tab_stride, batch, max_n, win, s);
+    }
     const int kmax = (win * win + 63) / 64;
     const size_t lds = (size_t)kmax * 64 * 6;
     if (lds > 160 * 1024) return -2;
