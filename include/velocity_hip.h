@@ -121,6 +121,16 @@ VH_API int vh_msv1_t(vh_ctx* ctx, const float* K_host, const float* P, const flo
                      int ii, int f32_rays, double* U_scratch, float* x_out, double* b0, int* info, void* stream);
 
 
+/* ---- bundle adjustment (K14) ------------------------------------------------------------------------------------- */
+/* fcnNLS_batch(K, P, pw, cw), utils/NLS.py:186-250: dense LM over tie points and cameras 1..nc, +I damping, step 0.9.
+ * The host shim applies the track filter and packs z / x exactly as NLS.py:190-203 does:
+ *   z [2*nt*(nc+1)] float64 = [all u | all v], camera-major / track-minor;  x [3 nt + 6 nc] = points | cam pos | cam rpy.
+ * x is updated in place.  trace [max_iter][2] = (rms(z - zhat), rms(delta)) per iteration (what NLS.py:238 prints),
+ * info int[2] = {iterations, converged}.  workspace: vh_nls_batch_workspace(nt, nc) bytes of device memory. */
+VH_API size_t vh_nls_batch_workspace(int nt, int nc);
+VH_API int vh_nls_batch(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
+                        int* info, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- tracker session: the frame loop body of vidExample.py:133-160 on the device, for ctx->batch streams ------- */
 /* device pointers into the state of one stream (read with vh_copy_to_host / torch) */
 typedef struct {

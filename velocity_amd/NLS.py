@@ -61,3 +61,45 @@ def fzK(a, K):
     from .common import world2image
 
     return world2image(K, np.eye(3), np.zeros(3), a)
+
+
+def fcnNLS_batch(K, P, pw, cw, max_iter=10, return_info=False):
+    """Dense full bundle adjustment over tie points and cameras 1..nc (utils/NLS.py:186-250) -> (cw [nc+1,3], pw [nt,3]).
+
+    The track filter, the measurement ordering and the state layout are the reference's (NLS.py:190-203); the
+    iterations (forward-difference Jacobian, damped normal equations, x += 0.9 delta) run on the device.
+    """
+    torch = L.torch_cuda()
+    P = np.asarray(P)
+    pw = np.asarray(pw, np.float64)
+    cw = np.asarray(cw, np.float64)
+    keep = np.isfinite(P[4]).sum(1) == P.shape[2]  # NLS.py:190
+    P, pw = P[:, keep], pw[keep]
+    _, nt, nf = P.shape
+    nc = nf - 1
+    z = np.concatenate([P[0].T.reshape(-1), P[1].T.reshape(-1)]).astype(np.float64)  # NLS.py:198-199
+    z[np.isnan(z)] = 0
+    x0 = np.concatenate((pw, cw[1:], np.zeros((nc, 3)))).reshape(-1)  # NLS.py:202-203
+    K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+    zd = L.to_dev(z, torch.float64)
+    xd = L.to_dev(x0, torch.float64).clone()
+    trace = torch.zeros((max_iter, 2), dtype=torch.float64, device="cuda")
+    info = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ws = L.workspace()
+    nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    L.check(ws.lib.vh_nls_batch(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, int(max_iter), L.dptr(trace), L.dptr(info),
+                                L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch")
+    info = info.cpu().numpy()
+    x = xd.cpu().numpy()
+    tr = trace.cpu().numpy()[: info[0]]
+    for i, (f, xr) in enumerate(tr):
+        print(f"{i:g}: f={f:g}, x={xr}")  # NLS.py:238 (without the wall-time column)
+    if not info[1]:
+        print("WARNING: fcnNLS_batch() reaching max iterations!")  # NLS.py:242
+    j = nt * 3
+    pw_out = x[:j].reshape(nt, 3)
+    cw_out = np.concatenate((np.zeros((1, 3)), x[j : j + nc * 3].reshape(nc, 3)), 0)
+    if return_info:
+        return cw_out, pw_out, x, tr
+    return cw_out, pw_out

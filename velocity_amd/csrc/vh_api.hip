@@ -8,6 +8,7 @@
 
 #include <new>
 
+#include "vh_ba.hpp"
 #include "vh_ws.hpp"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -750,5 +751,26 @@ extern "C" VH_API int vh_msv1_t(vh_ctx* c, const float* K, const float* P, const
     J.U = U_scratch; J.b0 = b0; J.x_out = x_out; J.info_out = info;
     vh_launch_msv1(J, (hipStream_t)stream);
     VH_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bundle adjustment entry points
+// ---------------------------------------------------------------------------------------------------------------
+static int ba_parts(int nt) { int p = nt / 16; return p < 1 ? 1 : (p > 256 ? 256 : p); }
+
+extern "C" VH_API size_t vh_nls_batch_workspace(int nt, int nc) { return vh_ba_workspace_bytes(nt, nc, ba_parts(nt)); }
+
+extern "C" VH_API int vh_nls_batch(vh_ctx* c, const float* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
+                                   int* info, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!c || !K_host || nt < 1 || nc < 1 || max_iter < 1) return vh_fail(-1, "vh_nls_batch: bad arguments");
+    if (6 * nc > 256) return vh_fail(-1, "vh_nls_batch: at most 42 free cameras");
+    if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch: workspace too small");
+    BaProblem P;
+    for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
+    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt);
+    int r = vh_ba_run(P, (hipStream_t)stream);
+    if (r) return vh_fail(r, "vh_ba_run failed");
     return 0;
 }

@@ -1,0 +1,38 @@
+// Bundle-adjustment job descriptors (internal).
+#pragma once
+#include "vh_common.hpp"
+
+struct BaJob {  // passed by value to every BA kernel
+    double K[9];
+    const double* z;  // [2 * nt * (nc+1)] measurements, [all u | all v], camera-major / track-minor (NLS.py:198-199)
+    double* x;        // [3 nt + 6 nc] state: points | camera positions | camera rpy (NLS.py:203)
+    double* camR;     // [(nc+1)][4][9] R(rpy) and its three forward-difference neighbours
+    double* r;        // [m][2] residuals z - zhat
+    double* Jp;       // [m][2][3] d(u,v)/d(point)
+    double* Jc;       // [m][2][6] d(u,v)/d(camera pos, rpy)
+    double* tp;       // [nt][3]  (U+I)^-1 gp
+    double* Y;        // [nt][6 nc][3]  (U+I)^-1 W
+    double* Spart;    // [nparts][(6 nc)^2]
+    double* Rpart;    // [nparts][6 nc]
+    double* Sfull;    // [6 nc][6 nc + 1]
+    double* dc;       // [6 nc]
+    double* acc;      // [2] sum r^2, sum delta^2
+    double* trace;    // [max_iter][2] rms(z - zhat), rms(delta) (what NLS.py:238 prints)
+    int* info;        // [2] iterations, converged
+    int* done;
+    unsigned* ticket;
+    int nt, nc;
+};
+
+struct BaProblem {
+    double K[9];
+    const double* z;
+    double* x;
+    double* trace;
+    int* info;
+    void* workspace;
+    int nt, nc, max_iter, nparts;
+};
+
+size_t vh_ba_workspace_bytes(int nt, int nc, int nparts);
+int vh_ba_run(const BaProblem& P, hipStream_t s);
