@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--ring", type=int, default=60, help="distinct synthetic frames kept in HBM (one motion period)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables)")
     ap.add_argument("--exchange-every", type=int, default=30)
+    ap.add_argument("--no-ba", action="store_true", help="skip the BA (config 5) leg")
     return ap.parse_args()
 
 
@@ -69,18 +70,62 @@ def cpu_baseline(cfg, K, frames, p0, p3, vp, lkc, lkf, budget_s):
     from oracle.session_oracle import SessionOracle
 
     klt_oracle.build(native=True)
-    host = [frames[k].cpu().numpy() for k in range(min(len(frames), 40))]
-    orc = SessionOracle(K, host[0], p0, p3, vp, np.float32([0, 0, 3.6]), nhist=len(host) + 1, lk_coarse=lkc, lk_fine=lkf, msv_frame=0, native=True)
+    host = [frames[k].cpu().numpy() for k in range(len(frames))]  # the periodic ring; the CPU loop walks it cyclically
+    max_frames = 2000
+    orc = SessionOracle(K, host[0], p0, p3, vp, np.float32([0, 0, 3.6]), nhist=max_frames + 2, lk_coarse=lkc, lk_fine=lkf, msv_frame=0, native=True)
     orc.step(host[1], np.float32(1 / 30), 1)  # warm-up (page faults, thread pool)
     t0, done = time.perf_counter(), 0
-    for k in range(2, len(host)):
-        orc.step(host[k], np.float32(k / 30), k)
+    for k in range(2, max_frames):
+        orc.step(host[k % len(host)], np.float32(k / 30), k)
         done += 1
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
     return dict(value=done / dt, unit="tracked frames/s", cores=os.cpu_count(), kind="port",
                 sample=f"{done} frames of stream 0 ({cfg['w']}x{cfg['h']}, {cfg['n']} tracks), oracle C/OpenMP KLT + NumPy NLS, {dt:.1f} s")
+
+
+def bench_ba(nt=5000, nf=20, repeats=3):
+    """BASELINE config 5: sliding-window BA, 20 keyframes x 5000 full-length tracks, 10 LM iterations (fcnNLS_batch)."""
+    from velocity_amd import _lib as L
+    from velocity_amd import synth
+
+    rng = np.random.default_rng(5)
+    K = synth.K_1080P
+    X = np.stack([rng.uniform(-3, 3, nt), rng.uniform(-1.5, 1.5, nt), rng.uniform(9, 14, nt)], 1)
+    cams = np.stack([[0.05 * k, 0.0, 0.37 * k] for k in range(nf)])
+    Kd = K.astype(float)
+    z_u, z_v = [], []
+    for k in range(nf):
+        q = (X + cams[k]) @ Kd
+        uv = q[:, :2] / q[:, 2:3] + rng.normal(0, 0.1, (nt, 2))
+        z_u.append(uv[:, 0].astype(np.float32))
+        z_v.append(uv[:, 1].astype(np.float32))
+    z = np.concatenate([np.concatenate(z_u), np.concatenate(z_v)]).astype(np.float64)
+    nc = nf - 1
+    x0 = np.concatenate([(X + rng.normal(0, 0.05, X.shape)).ravel(), (cams[1:] + rng.normal(0, 0.02, (nc, 3))).ravel(), np.zeros(3 * nc)])
+    ws = L.workspace()
+    zd = L.to_dev(z, torch.float64)
+    nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    trace = torch.zeros((10, 2), dtype=torch.float64, device="cuda")
+    info = torch.zeros(2, dtype=torch.int32, device="cuda")
+    K32 = np.ascontiguousarray(K.reshape(9))
+    best = None
+    for _ in range(repeats + 1):
+        xd = L.to_dev(x0, torch.float64).clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        L.check(ws.lib.vh_nls_batch(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, 10, L.dptr(trace), L.dptr(info),
+                                    L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch")
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    its = int(info.cpu()[0])
+    tr = trace.cpu().numpy()
+    return dict(workload=f"C5 BA: {nf} keyframes x {nt} tracks (nx={3 * nt + 6 * nc}, nz={2 * nt * nf}), {its} LM iterations",
+                iters_per_s=round(its / best, 2), ms_per_iter=round(1e3 * best / its, 3), rms_residual_first=round(float(tr[0, 0]), 4),
+                rms_residual_last=round(float(tr[its - 1, 0]), 4), method="compact FD Jacobian + point-block Schur complement (f64)")
 
 
 def main():
@@ -190,6 +235,8 @@ def main():
                    per_stream_fps=round(value / (S * world), 2), tracks_alive_frac=round(alive, 4),
                    pose_t=[round(float(x), 5) for x in st["t"]], pose_t_truth=[round(float(x), 5) for x in truth], rms_residual_px=round(st["res"], 5),
                    roofline=roof)
+        if not a.no_ba:
+            out["ba"] = bench_ba()
         if a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, K, frames, p0, p3, vp, lkc, lkf, a.cpu_seconds)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -26,6 +26,7 @@ struct RansacJob {
     int* idx;             // scratch n    : compacted index list
     int* counts;          // scratch VH_RANSAC_ITERS : inliers per hypothesis
     int* m_out;           // scratch 1    : number of valid pairs
+    int* bound;           // scratch 1    : upper bound of the hypotheses the sequential rule can still reach
     double* M;            // out 6        : 2x3 row-major affine
     uint8_t* inl;         // out n        : inlier mask over ALL points (0 where !valid)
     int* status;          // out 1        : 1 = model found

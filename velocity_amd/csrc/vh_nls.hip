@@ -9,7 +9,8 @@
 
 #define FD_STEP 1e-6
 
-// block-wide sum of NV doubles, result broadcast to every thread.  sh: [NV * NLS_WAVES]
+// block-wide sum of NV doubles; the result is valid in THREAD 0 only (the lane that does the dense solve).
+// sh: [NV * NLS_WAVES]
 template <int NV, int NLS_WAVES>
 __device__ void block_sum_f64(double* v, double* sh)
 {
@@ -20,11 +21,13 @@ __device__ void block_sum_f64(double* v, double* sh)
     if (lane == 0)
         for (int k = 0; k < NV; k++) sh[k * NLS_WAVES + wave] = v[k];
     __syncthreads();
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-        double s = 0.0;
-        for (int q = 0; q < NLS_WAVES; q++) s += sh[k * NLS_WAVES + q];
-        v[k] = s;
+        for (int k = 0; k < NV; k++) {
+            double s = 0.0;
+            for (int q = 0; q < NLS_WAVES; q++) s += sh[k * NLS_WAVES + q];
+            v[k] = s;
+        }
     }
 }
 
@@ -50,6 +53,27 @@ __device__ __forceinline__ void uvec_f32(float pu, float pv, float cx, float cy,
     const float a = __fsub_rn(pu, cx), b = __fsub_rn(pv, cy);
     const float nrm = vh_sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b)), __fmul_rn(f, f)));
     r[0] = (double)__fdiv_rn(a, nrm); r[1] = (double)__fdiv_rn(b, nrm); r[2] = (double)__fdiv_rn(f, nrm);
+}
+
+
+// Residual point + forward-difference rows of the translation Jacobian (fcnNLS_t / fcnMSV1_t: b0 + dx e_k re-projected,
+// NLS.py:119-120).  (b + dx e_k) @ K = q + dx K[k,:], so the three perturbed projections reuse q; one reciprocal per
+// projection.  Same forward-difference values as the reference up to float64 rounding (~1e-16 rel).
+__device__ __forceinline__ void fd_rows_t(const double* K, double b0, double b1, double b2, double& u, double& v, double* ju, double* jv)
+{
+    const double q0 = b0 * K[0] + b1 * K[3] + b2 * K[6];
+    const double q1 = b0 * K[1] + b1 * K[4] + b2 * K[7];
+    const double q2 = b0 * K[2] + b1 * K[5] + b2 * K[8];
+    const double iq = 1.0 / q2;
+    u = q0 * iq;
+    v = q1 * iq;
+    const double inv_dx = 1.0 / FD_STEP;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double ik = 1.0 / (q2 + FD_STEP * K[3 * k + 2]);
+        ju[k] = ((q0 + FD_STEP * K[3 * k]) * ik - u) * inv_dx;
+        jv[k] = ((q1 + FD_STEP * K[3 * k + 1]) * ik - v) * inv_dx;
+    }
 }
 
 __device__ void rpy2dcm(const double* rpy, double* C)  // transforms.py:7-23
@@ -142,6 +166,22 @@ __global__ __launch_bounds__(NLS_THREADS) void k_pose(const void* tab, size_t st
     }
     __syncthreads();
 
+    // the points of this thread stay in registers across the LM iterations (n <= PPT * NLS_THREADS), so an iteration
+    // is arithmetic + one reduction, not a chain of dependent global loads
+    constexpr int PPT = 4;
+    const bool cached = MODE == 0 && n <= PPT * NLS_THREADS;
+    double cw[PPT][3], cz[PPT][2];
+    if (cached) {
+#pragma unroll
+        for (int q = 0; q < PPT; q++) {
+            const int i = tid + q * NLS_THREADS;
+            if (i < n) {
+                const int ip = J.p_sel ? J.p_sel[i] : i, iw = J.pw_sel ? J.pw_sel[i] : i;
+                cw[q][0] = J.pw[3 * iw]; cw[q][1] = J.pw[3 * iw + 1]; cw[q][2] = J.pw[3 * iw + 2];
+                cz[q][0] = (double)J.p[2 * ip]; cz[q][1] = (double)J.p[2 * ip + 1];
+            }
+        }
+    }
     const int max_iter = 30;
     int converged = 0;
     if (n > 0) {
@@ -152,14 +192,22 @@ __global__ __launch_bounds__(NLS_THREADS) void k_pose(const void* tab, size_t st
             if (MODE == 0) {
                 const double x0 = s_x[0], x1 = s_x[1], x2 = s_x[2];
                 double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (cached) {
+#pragma unroll
+                    for (int q = 0; q < PPT; q++) {
+                        if (tid + q * NLS_THREADS < n) {
+                            const double b0 = cw[q][0] + x0, b1 = cw[q][1] + x1, b2 = cw[q][2] + x2;
+                            double u, v, ju[3], jv[3];
+                            fd_rows_t(K, b0, b1, b2, u, v, ju, jv);
+                            accumulate<3>(acc, ju, jv, cz[q][0] - u, cz[q][1] - v);
+                        }
+                    }
+                } else
                 for (int i = tid; i < n; i += NLS_THREADS) {
                     const int ip = J.p_sel ? J.p_sel[i] : i, iw = J.pw_sel ? J.pw_sel[i] : i;
                     const double b0 = J.pw[3 * iw] + x0, b1 = J.pw[3 * iw + 1] + x1, b2 = J.pw[3 * iw + 2] + x2;
-                    double u, v, ju[3], jv[3], uk, vk;
-                    project_cam(K, b0, b1, b2, u, v);
-                    project_cam(K, b0 + FD_STEP, b1, b2, uk, vk); ju[0] = (uk - u) / FD_STEP; jv[0] = (vk - v) / FD_STEP;
-                    project_cam(K, b0, b1 + FD_STEP, b2, uk, vk); ju[1] = (uk - u) / FD_STEP; jv[1] = (vk - v) / FD_STEP;
-                    project_cam(K, b0, b1, b2 + FD_STEP, uk, vk); ju[2] = (uk - u) / FD_STEP; jv[2] = (vk - v) / FD_STEP;
+                    double u, v, ju[3], jv[3];
+                    fd_rows_t(K, b0, b1, b2, u, v, ju, jv);
                     accumulate<3>(acc, ju, jv, (double)J.p[2 * ip] - u, (double)J.p[2 * ip + 1] - v);
                 }
                 block_sum_f64<9, NLS_WAVES>(acc, sh);
@@ -382,11 +430,8 @@ __global__ __launch_bounds__(MSV_THREADS) void k_msv1(MsvJob J)
             two_view_point(A, J.U, nf, ng, g, c);
             const double b0 = c[0] + x0, b1 = c[1] + x1, b2 = c[2] + x2;
             J.b0[3 * g] = b0; J.b0[3 * g + 1] = b1; J.b0[3 * g + 2] = b2;
-            double u, v, ju[3], jv[3], uk, vk;
-            project_cam(K, b0, b1, b2, u, v);
-            project_cam(K, b0 + FD_STEP, b1, b2, uk, vk); ju[0] = (uk - u) / FD_STEP; jv[0] = (vk - v) / FD_STEP;
-            project_cam(K, b0, b1 + FD_STEP, b2, uk, vk); ju[1] = (uk - u) / FD_STEP; jv[1] = (vk - v) / FD_STEP;
-            project_cam(K, b0, b1, b2 + FD_STEP, uk, vk); ju[2] = (uk - u) / FD_STEP; jv[2] = (vk - v) / FD_STEP;
+            double u, v, ju[3], jv[3];
+            fd_rows_t(K, b0, b1, b2, u, v, ju, jv);
             const double zu = (double)J.P[((size_t)0 * J.N0 + id) * J.nhist + (nf - 1)];
             const double zv = (double)J.P[((size_t)1 * J.N0 + id) * J.nhist + (nf - 1)];
             accumulate<3>(acc, ju, jv, zu - u, zv - v);

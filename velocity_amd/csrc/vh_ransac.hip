@@ -9,6 +9,7 @@
 #define RANSAC_THRESH2 9.0f
 #define RANSAC_CONF 0.99
 #define RANSAC_SEED 0x2545F491u
+#define RANSAC_HEAD 16  // hypotheses scored inside the compaction kernel
 
 __device__ __forceinline__ uint32_t mix32(uint32_t h)
 {
@@ -144,6 +145,39 @@ __global__ __launch_bounds__(256) void k_ransac_compact(const void* tab, size_t 
         __syncthreads();
     }
     if (tid == 0) *J.m_out = base;
+    __syncthreads();
+    // Score the first RANSAC_HEAD hypotheses here and replay the sequential rule over them: the adaptive iteration
+    // count can only shrink afterwards, so hypotheses >= *bound can never be reached and need not be scored.
+    const int m = base;
+    int bound = VH_RANSAC_ITERS;
+    if (m >= 3 && m > J.min_valid) {
+        for (int h0 = 0; h0 < RANSAC_HEAD; h0 += 4) {
+            const int hyp = h0 + wave;
+            double M[6];
+            int c = 0;
+            if (ransac_hypothesis(J.from, J.to, J.idx, m, (uint32_t)hyp, M)) {
+                for (int k = lane; k < m; k += 64) {
+                    const int i = J.idx[k];
+                    c += is_inlier(M, J.from[2 * i], J.from[2 * i + 1], J.to[2 * i], J.to[2 * i + 1]) ? 1 : 0;
+                }
+            }
+            c = vh_wave_sum_i32(c);
+            if (lane == 0) J.counts[hyp] = c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int best_count = 0, niters = VH_RANSAC_ITERS;
+            for (int it = 0; it < RANSAC_HEAD && it < niters; it++) {
+                const int c = J.counts[it];
+                if (c > max(best_count, 2)) {
+                    best_count = c;
+                    niters = ransac_update_iters(RANSAC_CONF, __ddiv_rn((double)(m - c), (double)m), niters);
+                }
+            }
+            bound = niters;
+        }
+    }
+    if (tid == 0) *J.bound = bound;
 }
 
 // ---- 2. score every hypothesis: one wavefront per hypothesis ----------------------------------------------------
@@ -153,11 +187,8 @@ __global__ __launch_bounds__(256) void k_ransac_score(const void* tab, size_t st
     const int m = *J.m_out;
     const int hyp = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (hyp >= VH_RANSAC_ITERS) return;
-    if (m < 3 || m <= J.min_valid) {
-        if (lane == 0) J.counts[hyp] = 0;
-        return;
-    }
+    if (hyp >= VH_RANSAC_ITERS || hyp < RANSAC_HEAD || hyp >= *J.bound) return;  // head already scored; tail unreachable
+    if (m < 3 || m <= J.min_valid) return;
     double M[6];
     int c = 0;
     if (ransac_hypothesis(J.from, J.to, J.idx, m, (uint32_t)hyp, M)) {

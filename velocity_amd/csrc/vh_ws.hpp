@@ -51,7 +51,7 @@ struct StreamWS {
     int roi[4];
     int dxy[2];
     unsigned long long lk_stats[3][2];  // per KLTmain stage: Newton iterations, template set-ups (profiling aid)
-    int n, m, rstatus, flags, pp, pad;
+    int n, m, rstatus, flags, pp, rbound;
 };
 
 struct vh_ctx {
