@@ -168,7 +168,8 @@ VH_API int vh_session_ptrs(vh_session* s, int slot, vh_session_view* out_host);
  * out = device float32 [batch][8 + 3*n0]: {n_cur, n_pose, frame_i, klt_flags, t[3], res | p (n0 x 2) | ids (n0, int32 bits)} */
 VH_API int vh_session_pack_state(vh_session* s, float* out, void* stream);
 
-/* test hook: 1 routes every LK window through the per-sample kernel instead of the strip kernel (both are bit-identical) */
+/* test hook: route every LK window through one implementation -- 1: per-sample kernel, 2: strip kernel, 3: LDS-staged
+ * kernel, 0: default routing per window.  All three are bit-identical. */
 VH_API void vh_debug_force_generic_lk(int on);
 
 /* ---- measurement aids (bench.py): HIP-event timing of the LK launches + Newton-iteration statistics ------------- */

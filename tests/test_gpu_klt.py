@@ -127,13 +127,31 @@ def test_strip_and_per_sample_lk_kernels_agree(seq):
     pts = np.concatenate([p0, rng.uniform(-20, 30, (60, 2)).astype(np.float32), rng.uniform([W - 30, H - 30], [W + 20, H + 20], (60, 2)).astype(np.float32)])
     for lk in (CV_COARSE, CV_FINE, dict(winSize=(9, 9), maxLevel=3, criteria=(3, 20, 0.03)), dict(winSize=(31, 31), maxLevel=1, criteria=(3, 20, 0.03))):
         a = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=0.5, **lk)
-        L.load().vh_debug_force_generic_lk(1)
-        try:
-            b = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=0.5, **lk)
-        finally:
-            L.load().vh_debug_force_generic_lk(0)
-        for x, y in zip(a, b):
-            assert np.array_equal(x, y)
+        for mode in (1, 2, 3):  # 1: per-sample kernel, 2: strip kernel, 3: LDS-staged kernel; default: routed per window
+            L.load().vh_debug_force_generic_lk(mode)
+            try:
+                b = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=0.5, **lk)
+            finally:
+                L.load().vh_debug_force_generic_lk(0)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (lk, mode)
+
+
+def test_pyr_lk_large_motion_restages_search_region():
+    """Displacements far beyond the staged search margin (coarse 6 px, fine 4 px) must still match the oracle."""
+    from velocity_amd.KLT import cv2calcOpticalFlowPyrLK
+
+    W, H = 640, 360
+    m = synth.AffineMotion(W, H, s=1.0, theta_deg=0.0, tx=9.0, ty=-7.0)
+    f0 = synth.render_frame(W, H, m, 0).numpy()
+    f1 = synth.render_frame(W, H, m, 1).numpy()
+    pts = synth.grid_tracks(300, W, H)
+    for lk, kw in ((dict(winSize=(15, 15), maxLevel=0, criteria=(3, 30, 0.01)), dict(win=15, max_level=0, max_count=30, eps=0.01)),
+                   (dict(winSize=(51, 51), maxLevel=0, criteria=(3, 30, 0.001)), dict(win=51, max_level=0, max_count=30, eps=0.001)),
+                   (dict(winSize=(15, 15), maxLevel=1, criteria=(3, 10, 0.1)), dict(win=15, max_level=1, max_count=10, eps=0.1))):
+        p2, v, err = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=2.0, **lk)
+        e2, ev, eerr = KO.lk_fb(f0, f1, pts, fbt=2.0, **kw)
+        assert np.array_equal(v, ev) and np.array_equal(p2, e2) and np.array_equal(err.ravel(), eerr)
 
 
 def test_pyr_lk_textureless_and_small_images():

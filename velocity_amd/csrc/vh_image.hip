@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(const void* pb_tab, size_t ws_
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_roi_warp(const void* job_tab, size_t tab_stride)
 {
-    const WarpJob& J = *reinterpret_cast<const WarpJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.z * tab_stride);
+    const WarpJob J = *reinterpret_cast<const WarpJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.z * tab_stride);
     if (J.mode < 0) return;
     const int rw = J.x1 - J.x0, rh = J.y1 - J.y0;
     const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;

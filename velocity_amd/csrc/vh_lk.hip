@@ -89,7 +89,7 @@ __device__ __forceinline__ int search_sample(const ImgDesc& im, int gx, int gy, 
 }
 
 // One point on one level.  All control flow is wave-uniform.
-__device__ void lk_level(const ImgDesc& I, const ImgDesc& J, int win, int level, int top_level, int max_count, double eps2,
+__device__ void lk_level(const ImgDesc I, const ImgDesc J, int win, int level, int top_level, int max_count, double eps2,
                          float p0x, float p0y, float& nxo, float& nyo, int& status, float& err, short* ldsI, int* ldsD, int lane,
                          int& n_iter, int& n_setup)
 {
@@ -304,6 +304,8 @@ __device__ __forceinline__ short2v as_s2(unsigned v) { return __builtin_bit_cast
 __device__ __forceinline__ int dot2(unsigned a, unsigned b, int c) { return __builtin_amdgcn_sdot2(as_s2(a), as_s2(b), c, false); }
 
 // NR rows x 8 bytes starting at pixel (gx, gy): lo = bytes 0..3, hi = bytes 4..7 of every row (interior fast path)
+typedef const unsigned __attribute__((address_space(1)))* gptr_u32;  // global (not flat) loads
+
 template <int NR>
 __device__ __forceinline__ void load_rows_fast(const ImgDesc& im, int gx, int gy, unsigned* lo, unsigned* hi)
 {
@@ -312,7 +314,7 @@ __device__ __forceinline__ void load_rows_fast(const ImgDesc& im, int gx, int gy
     for (int r = 0; r < NR; r++) {
         const uintptr_t a = reinterpret_cast<uintptr_t>(base + (ptrdiff_t)r * im.stride);
         const unsigned sh = (unsigned)(a & 3);
-        const unsigned* ap = reinterpret_cast<const unsigned*>(a - sh);
+        gptr_u32 ap = (gptr_u32)(a - sh);
         const unsigned d0 = ap[0], d1 = ap[1], d2 = ap[2];
         lo[r] = __builtin_amdgcn_alignbyte(d1, d0, sh);
         hi[r] = __builtin_amdgcn_alignbyte(d2, d1, sh);
@@ -404,9 +406,10 @@ __device__ __forceinline__ void strip_setup(const unsigned* lo, const unsigned* 
             for (int c = 0; c < 4; c++) {
                 const int q00 = byte_of(lo[1], hi[1], c + 1), q01 = byte_of(lo[1], hi[1], c + 2);
                 const int q10 = byte_of(lo[2], hi[2], c + 1), q11 = byte_of(lo[2], hi[2], c + 2);
-                iv[c] = vh_descale(q00 * w0.w00 + q01 * w0.w01 + q10 * w0.w10 + q11 * w0.w11, W_BITS - 5);
-                ix[c] = vh_descale(gx[0][c] * w0.w00 + gx[0][c + 1] * w0.w01 + gx[1][c] * w0.w10 + gx[1][c + 1] * w0.w11, W_BITS);
-                iy[c] = vh_descale(gy[0][c] * w0.w00 + gy[0][c + 1] * w0.w01 + gy[1][c] * w0.w10 + gy[1][c + 1] * w0.w11, W_BITS);
+                // every factor fits 24 signed bits (|pixel| <= 255, |gradient| <= 4080, weights <= 2^14): full-rate v_mad_i32_i24
+                iv[c] = vh_descale(__mul24(q00, w0.w00) + __mul24(q01, w0.w01) + __mul24(q10, w0.w10) + __mul24(q11, w0.w11), W_BITS - 5);
+                ix[c] = vh_descale(__mul24(gx[0][c], w0.w00) + __mul24(gx[0][c + 1], w0.w01) + __mul24(gx[1][c], w0.w10) + __mul24(gx[1][c + 1], w0.w11), W_BITS);
+                iy[c] = vh_descale(__mul24(gy[0][c], w0.w00) + __mul24(gy[0][c + 1], w0.w01) + __mul24(gy[1][c], w0.w10) + __mul24(gy[1][c + 1], w0.w11), W_BITS);
                 if (c >= cnt) { iv[c] = 0; ix[c] = 0; iy[c] = 0; }
             }
             const uint2 vI = make_uint2(pack16(iv[0], iv[1]), pack16(iv[2], iv[3]));
@@ -419,7 +422,7 @@ __device__ __forceinline__ void strip_setup(const unsigned* lo, const unsigned* 
 }
 
 template <int WIN_T>
-__device__ void lk_level_strip(const ImgDesc& I, const ImgDesc& J, int win_rt, int level, int top_level, int max_count, double eps2,
+__device__ void lk_level_strip(const ImgDesc I, const ImgDesc J, int win_rt, int level, int top_level, int max_count, double eps2,
                                float p0x, float p0y, float& nxo, float& nyo, int& status, float& err, uint2* tI, uint2* tX, uint2* tY,
                                int lane, int& n_iter, int& n_setup)
 {
@@ -678,6 +681,336 @@ __global__ __launch_bounds__(64) void k_lk_strip(const void* job_tab, size_t tab
     }
 }
 
+
+// =================================================================================================================
+// v3: LDS-staged kernel for the two windows the tracker uses (15x15 coarse, 51x51 fine).
+// One workgroup of NW wavefronts per track.  Per level and direction the template patch ((WIN+3)^2 pixels of the
+// previous image) and a search region ((WIN+1+2M)^2 pixels of the next image around the predicted position) are staged
+// into LDS with ONE batch of global loads (REFLECT_101 applied while staging, so the compute loops have no border
+// cases); set-up, every Newton iteration and the err pass then read LDS only.  The search region is re-staged if the
+// window drifts more than M pixels.  Strip arithmetic, exact sums and control flow are those of the kernels above
+// (bit-identical results); with NW > 1 the per-wave sums are combined through LDS.
+// =================================================================================================================
+template <int WIN, int NW, int M>
+struct LK3 {
+    static constexpr int T = 64 * NW;
+    static constexpr int SPR = (WIN + 3) >> 2;
+    static constexpr int NS = SPR * WIN;
+    static constexpr int K = (NS + T - 1) / T;
+    static constexpr int PI_ROWS = WIN + 3;                                   // template patch rows
+    static constexpr int PI_PITCH = ((4 * (SPR - 1) + 8 + 3) / 4) * 4;        // bytes read per patch row, dword multiple
+    static constexpr int RJ = WIN + 1 + 2 * M;                                // search region rows / cols
+    static constexpr int PJ_PITCH = ((((2 * M + 4 * (SPR - 1)) >> 2) * 4 + 12 + 3) / 4) * 4;
+    static constexpr int OFF_TI = 0;
+    static constexpr int OFF_TX = OFF_TI + K * T * 8;
+    static constexpr int OFF_TY = OFF_TX + K * T * 8;
+    static constexpr int OFF_PI = OFF_TY + K * T * 8;
+    static constexpr int OFF_PJ = OFF_PI + PI_ROWS * PI_PITCH;
+    static constexpr int OFF_RED = ((OFF_PJ + RJ * PJ_PITCH + 15) / 16) * 16;
+    static constexpr int LDS_BYTES = OFF_RED + 2 * NW * 4 * 8;
+};
+
+typedef const uint2 __attribute__((address_space(1)))* gptr_u32x2;
+
+// stage ROWS x PITCH bytes of image `im` starting at pixel (rx, ry) into LDS (region-aligned rows).  Compile-time
+// extents: the loop is fully unrolled and every global load of the batch is issued before the first LDS store, so a
+// staging costs one memory round trip.
+template <int T, int ROWS, int PITCH>
+__device__ __forceinline__ void stage_region(const ImgDesc& im, int rx, int ry, unsigned* dst, int tid)
+{
+    constexpr int DPR = PITCH >> 2, TOTAL = ROWS * DPR, NIT = (TOTAL + T - 1) / T;
+    const bool fast = rx >= 0 && ry >= 0 && rx + PITCH + 4 <= im.w && ry + ROWS <= im.h;
+    if (fast) {
+        unsigned d0[NIT], d1[NIT], sh[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            // unconditional loads (index clamped): a branch around a load makes hipcc wait vmcnt(0) per element
+            const int q = min(tid + it * T, TOTAL - 1);
+            const int r = q / DPR, d = q - r * DPR;
+            const uintptr_t a = reinterpret_cast<uintptr_t>(im.p + (ptrdiff_t)(ry + r) * im.stride + rx + 4 * d);
+            sh[it] = (unsigned)(a & 3);
+            gptr_u32 ap = (gptr_u32)(a - sh[it]);
+            d0[it] = ap[0]; d1[it] = ap[1];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int q = tid + it * T;
+            if (q < TOTAL) dst[q] = __builtin_amdgcn_alignbyte(d1[it], d0[it], sh[it]);
+        }
+    } else {
+        for (int q = tid; q < TOTAL; q += T) {
+            const int r = q / DPR, d = q - r * DPR;
+            unsigned v = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) v |= (unsigned)pix_r(im, rx + 4 * d + c, ry + r) << (8 * c);
+            dst[q] = v;
+        }
+    }
+}
+
+// block-wide exact sum of NV per-lane int32 partials -> int64 totals valid in every thread
+template <int NW, int NV>
+__device__ __forceinline__ void block_sum_wide(const int* part, long long* tot, long long* red, int& phase, int wave)
+{
+    long long w[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) w[k] = wave_sum_i32_wide(part[k]);
+    if (NW == 1) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) tot[k] = w[k];
+        return;
+    }
+    long long* buf = red + phase * NW * 4;  // double buffered: one barrier per reduction
+    phase ^= 1;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < NV; k++) buf[wave * 4 + k] = w[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        long long s = 0;
+#pragma unroll
+        for (int q = 0; q < NW; q++) s += buf[q * 4 + k];
+        tot[k] = s;
+    }
+}
+
+template <int WIN, int NW, int M>
+__device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_level, int max_count, double eps2, float p0x, float p0y,
+                          float& nxo, float& nyo, int& status, float& err, char* smem, int tid, int& phase, int& n_iter, int& n_setup)
+{
+    using C = LK3<WIN, NW, M>;
+    uint2* tI = reinterpret_cast<uint2*>(smem + C::OFF_TI);
+    uint2* tX = reinterpret_cast<uint2*>(smem + C::OFF_TX);
+    uint2* tY = reinterpret_cast<uint2*>(smem + C::OFF_TY);
+    unsigned* pI = reinterpret_cast<unsigned*>(smem + C::OFF_PI);
+    unsigned* pJ = reinterpret_cast<unsigned*>(smem + C::OFF_PJ);
+    long long* red = reinterpret_cast<long long*>(smem + C::OFF_RED);
+    const int wave = tid >> 6;
+
+    const float half = (float)(WIN - 1) * 0.5f;
+    const float lscale = (float)(1. / (double)(1 << level));
+    float px = __fmul_rn(p0x, lscale), py = __fmul_rn(p0y, lscale);
+    float nx, ny;
+    if (level == top_level) { nx = px; ny = py; }
+    else { nx = __fmul_rn(nxo, 2.f); ny = __fmul_rn(nyo, 2.f); }
+    nxo = nx; nyo = ny;
+
+    px = __fsub_rn(px, half); py = __fsub_rn(py, half);
+    const int ipx = vh_floor(px), ipy = vh_floor(py);
+    if (ipx < -WIN || ipx >= I.w || ipy < -WIN || ipy >= I.h) {
+        if (level == 0) { status = 0; err = 0.f; }
+        return;
+    }
+    const Win w0 = bilinear_weights(__fsub_rn(px, (float)ipx), __fsub_rn(py, (float)ipy));
+    n_setup++;
+    nx = __fsub_rn(nx, half); ny = __fsub_rn(ny, half);
+
+    // one batch of global loads: template patch + search region around the predicted position
+    int rjx = vh_floor(nx) - M, rjy = vh_floor(ny) - M;
+    __syncthreads();  // previous users of the patch buffers are done
+    stage_region<C::T, C::PI_ROWS, C::PI_PITCH>(I, ipx - 1, ipy - 1, pI, tid);
+    stage_region<C::T, C::RJ, C::PJ_PITCH>(J, rjx, rjy, pJ, tid);
+    __syncthreads();
+
+    const bool inside_I = ipx >= 1 && ipy >= 1 && ipx + WIN + 1 <= I.w - 1 && ipy + WIN + 1 <= I.h - 1;
+    int part[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < C::K; k++) {
+        const int s = tid + C::T * k;
+        if (s < C::NS) {
+            const int y = s / C::SPR, j = s - y * C::SPR, x = 4 * j, cnt = min(4, WIN - x);
+            unsigned lo[4], hi[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const unsigned* row = pI + (y + r) * (C::PI_PITCH >> 2) + j;
+                lo[r] = row[0]; hi[r] = row[1];
+            }
+            if (inside_I) strip_setup<true>(lo, hi, w0, I, ipx, ipy, x, y, cnt, tI, tX, tY, k * C::T + tid, part[0], part[1], part[2]);
+            else strip_setup<false>(lo, hi, w0, I, ipx, ipy, x, y, cnt, tI, tX, tY, k * C::T + tid, part[0], part[1], part[2]);
+        }
+    }
+    long long sA[3];
+    block_sum_wide<NW, 3>(part, sA, red, phase, wave);
+    const float A11 = __fmul_rn((float)sA[0], LK_FLT_SCALE), A12 = __fmul_rn((float)sA[1], LK_FLT_SCALE), A22 = __fmul_rn((float)sA[2], LK_FLT_SCALE);
+    float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
+    const float dA = __fsub_rn(A11, A22);
+    const float disc = __fadd_rn(__fmul_rn(dA, dA), __fmul_rn(__fmul_rn(4.f, A12), A12));
+    const float minEig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11), vh_sqrtf(disc)), (float)(2 * WIN * WIN));
+    if (minEig < 1e-4f || D < 1.1920929e-07f) {
+        if (level == 0) status = 0;
+        return;
+    }
+    D = __fdiv_rn(1.f, D);
+
+    // bilinear samples of one strip of the staged search region at window origin (inx, iny)
+    auto strip_from_region = [&](int inx, int iny, int j, int y, unsigned* lo, unsigned* hi) {
+        const int off = (inx - rjx) + 4 * j;
+        const unsigned sh = (unsigned)(off & 3);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const unsigned* row = pJ + (iny - rjy + y + r) * (C::PJ_PITCH >> 2) + (off >> 2);
+            const unsigned d0 = row[0], d1 = row[1], d2 = row[2];
+            lo[r] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+            hi[r] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        }
+    };
+    auto region_holds = [&](int inx, int iny) { return inx >= rjx && iny >= rjy && inx + WIN + 1 <= rjx + C::RJ && iny + WIN + 1 <= rjy + C::RJ; };
+    auto restage = [&](int inx, int iny) {
+        rjx = inx - M; rjy = iny - M;
+        __syncthreads();
+        stage_region<C::T, C::RJ, C::PJ_PITCH>(J, rjx, rjy, pJ, tid);
+        __syncthreads();
+    };
+
+    float pdx = 0.f, pdy = 0.f;
+    for (int it = 0; it < max_count; it++) {
+        const int inx = vh_floor(nx), iny = vh_floor(ny);
+        if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
+            if (level == 0) status = 0;
+            break;
+        }
+        if (!region_holds(inx, iny)) restage(inx, iny);
+        const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny)));
+        n_iter++;
+        int b[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < C::K; k++) {
+            const int s = tid + C::T * k;
+            if (s < C::NS) {
+                const int y = s / C::SPR, j = s - y * C::SPR;
+                unsigned lo[2], hi[2], p01, p23;
+                strip_from_region(inx, iny, j, y, lo, hi);
+                strip_bilinear(lo, hi, w, p01, p23);
+                const uint2 vI = tI[k * C::T + tid], vX = tX[k * C::T + tid], vY = tY[k * C::T + tid];
+                const unsigned d01 = __builtin_bit_cast(unsigned, as_s2(p01) - as_s2(vI.x));
+                const unsigned d23 = __builtin_bit_cast(unsigned, as_s2(p23) - as_s2(vI.y));
+                b[0] = dot2(d23, vX.y, dot2(d01, vX.x, b[0]));
+                b[1] = dot2(d23, vY.y, dot2(d01, vY.x, b[1]));
+            }
+        }
+        long long sb[2];
+        block_sum_wide<NW, 2>(b, sb, red, phase, wave);
+        const float fb1 = __fmul_rn((float)sb[0], LK_FLT_SCALE), fb2 = __fmul_rn((float)sb[1], LK_FLT_SCALE);
+        const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
+        const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
+        nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
+        nxo = __fadd_rn(nx, half); nyo = __fadd_rn(ny, half);
+        if (__dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy)) <= eps2) break;
+        if (it > 0 && fabsf(__fadd_rn(dx, pdx)) < 0.01f && fabsf(__fadd_rn(dy, pdy)) < 0.01f) {
+            nxo = __fsub_rn(nxo, __fmul_rn(dx, 0.5f));
+            nyo = __fsub_rn(nyo, __fmul_rn(dy, 0.5f));
+            break;
+        }
+        pdx = dx; pdy = dy;
+    }
+
+    if (status && level == 0) {
+        const float fx = __fsub_rn(nxo, half), fy = __fsub_rn(nyo, half);
+        const int inx = vh_floor(fx), iny = vh_floor(fy);
+        if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) { status = 0; return; }
+        if (!region_holds(inx, iny)) restage(inx, iny);
+        const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny)));
+        int se[1] = {0};
+#pragma unroll
+        for (int k = 0; k < C::K; k++) {
+            const int s = tid + C::T * k;
+            if (s < C::NS) {
+                const int y = s / C::SPR, j = s - y * C::SPR, cnt = min(4, WIN - 4 * j);
+                unsigned lo[2], hi[2], p01, p23;
+                strip_from_region(inx, iny, j, y, lo, hi);
+                strip_bilinear(lo, hi, w, p01, p23);
+                const uint2 vI = tI[k * C::T + tid];
+                const short2v d01 = as_s2(p01) - as_s2(vI.x), d23 = as_s2(p23) - as_s2(vI.y);
+                const int d[4] = {d01.x, d01.y, d23.x, d23.y};
+#pragma unroll
+                for (int c = 0; c < 4; c++) se[0] += c < cnt ? (d[c] < 0 ? -d[c] : d[c]) : 0;
+            }
+        }
+        long long sse[1];
+        block_sum_wide<NW, 1>(se, sse, red, phase, wave);
+        err = __fmul_rn((float)sse[0], __fdiv_rn(1.f, (float)(32 * WIN * WIN)));
+    }
+}
+
+template <int WIN, int NW, int M>
+__device__ void lk3_track(const PyrDesc& PI, const PyrDesc& PJ, int max_count, double eps2, float px, float py, float& ox, float& oy,
+                          int& status, float& err, char* smem, int tid, int& phase, int& n_iter, int& n_setup)
+{
+    const int nl = min(PI.nlevels, PJ.nlevels);
+    status = 1;
+    err = 0.f;
+    ox = 0.f; oy = 0.f;
+    for (int level = nl - 1; level >= 0; level--)
+        lk3_level<WIN, NW, M>(PI.lv[level], PJ.lv[level], level, nl - 1, max_count, eps2, px, py, ox, oy, status, err, smem, tid, phase, n_iter,
+                              n_setup);
+}
+
+template <int WIN, int NW, int M>
+__global__ __launch_bounds__(64 * NW) void k_lk3(const void* job_tab, size_t tab_stride)
+{
+    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
+    const int n = job.n_ptr ? *job.n_ptr : job.n;
+    const int pt = blockIdx.x;
+    if (pt >= n) return;
+    const int tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int max_count = job.max_count;
+    const double eps2 = job.eps2;
+    const float fbt = job.fbt;
+
+    const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];
+    const float px = __fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]);
+    const float py = __fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]);
+
+    float fx, fy, err;
+    int st, n_iter = 0, n_setup = 0, phase = 0;
+    lk3_track<WIN, NW, M>(job.I, job.J, max_count, eps2, px, py, fx, fy, st, err, smem, tid, phase, n_iter, n_setup);
+    float fbe = 0.f;
+    if (fbt >= 0.f) {
+        float bx, by, e2;
+        int st2;
+        lk3_track<WIN, NW, M>(job.J, job.I, max_count, eps2, fx, fy, bx, by, st2, e2, smem, tid, phase, n_iter, n_setup);
+        const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
+        fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
+        st = st && st2 && (fbe < fbt);
+    }
+    if (tid == 0) {
+        float ox, oy;
+        if (job.out_mode == VH_OUT_SCALE) {
+            ox = __fdiv_rn(fx, job.out_scale);
+            oy = __fdiv_rn(fy, job.out_scale);
+        } else {
+            const float ax = __fadd_rn(fx, job.in_off[0]), ay = __fadd_rn(fy, job.in_off[1]);
+            if (job.out_mode == VH_OUT_TRANSLATE) {
+                ox = __fadd_rn(ax, job.out_off[0]);
+                oy = __fadd_rn(ay, job.out_off[1]);
+            } else {
+                ox = __fadd_rn(__fadd_rn(__fmul_rn(ax, job.T[0]), __fmul_rn(ay, job.T[2])), job.T[4]);
+                oy = __fadd_rn(__fadd_rn(__fmul_rn(ax, job.T[1]), __fmul_rn(ay, job.T[3])), job.T[5]);
+            }
+        }
+        job.p_out[2 * pt] = ox;
+        job.p_out[2 * pt + 1] = oy;
+        job.v_out[pt] = (uint8_t)(st != 0);
+        if (job.err_out) job.err_out[pt] = err;
+        if (job.fbe_out) job.fbe_out[pt] = fbe;
+        if (job.praw_out) { job.praw_out[2 * pt] = fx; job.praw_out[2 * pt + 1] = fy; }
+        if (job.stats) {
+            atomicAdd(&job.stats[0], (unsigned long long)n_iter);
+            atomicAdd(&job.stats[1], (unsigned long long)n_setup);
+        }
+    }
+}
+
+template <int WIN, int NW, int M>
+static int launch_lk3(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
+{
+    constexpr int lds = LK3<WIN, NW, M>::LDS_BYTES;
+    hipLaunchKernelGGL((k_lk3<WIN, NW, M>), dim3(max_n, batch), dim3(64 * NW), lds, s, job_tab, tab_stride);
+    return 0;
+}
+
 template <int WIN_T>
 static int launch_strip(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s)
 {
@@ -691,13 +1024,20 @@ static int launch_strip(const void* job_tab, size_t tab_stride, int batch, int m
     return 0;
 }
 
-static int g_lk_force_generic = 0;  // test hook: route every window through the per-sample kernel
+static int g_lk_force_generic = 0;  // test hook: 1 = per-sample kernel, 2 = strip kernel, 3 = LDS-staged kernel, 0 = default routing
 void vh_lk_force_generic(int on) { g_lk_force_generic = on; }
 
 int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s)
 {
     if (max_n <= 0) return 0;
-    if (!g_lk_force_generic && win <= 63) {
+    // Default routing (measured on MI355X, profiles/): the LDS-staged 4-wave kernel for the 51x51 fine stage (equal
+    // throughput, 25% lower latency than the strip kernel), the strip kernel for the 15x15 coarse stages (the staged
+    // variant is 2.5x slower there).  Mode 3 forces the staged kernel for both windows (tests).
+    if (g_lk_force_generic == 0 || g_lk_force_generic == 3) {
+        if (win == 15 && g_lk_force_generic == 3) return launch_lk3<15, 1, 6>(job_tab, tab_stride, batch, max_n, s);
+        if (win == 51) return launch_lk3<51, 4, 4>(job_tab, tab_stride, batch, max_n, s);
+    }
+    if (g_lk_force_generic != 1 && win <= 63) {
         // int32 per-lane partial sums are exact up to 16 strips per lane (win <= 63)
         if (win == 15) return launch_strip<15>(job_tab, tab_stride, batch, max_n, win, s);
         if (win == 51) return launch_strip<51>(job_tab, tab_stride, batch, max_n, win, s);

@@ -148,7 +148,7 @@ template <int MODE, int NLS_THREADS>
 __global__ __launch_bounds__(NLS_THREADS) void k_pose(const void* tab, size_t stride)
 {
     constexpr int NLS_WAVES = NLS_THREADS / 64;
-    const PoseJob& J = pjob(tab, stride, blockIdx.x);
+    const PoseJob J = pjob(tab, stride, blockIdx.x);  // by value: pointers / counts live in SGPRs
     if (J.mode != MODE) return;
     const int n = J.n_ptr ? *J.n_ptr : J.n;
     const int tid = threadIdx.x;

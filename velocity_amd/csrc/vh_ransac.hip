@@ -123,7 +123,7 @@ __device__ void block_sum_i64(long long* v, long long* sh /* [NV * 4] */)
 // ---- 1. compaction index list of the valid pairs (order preserving) ---------------------------------------------
 __global__ __launch_bounds__(256) void k_ransac_compact(const void* tab, size_t stride)
 {
-    const RansacJob& J = rjob(tab, stride, blockIdx.x);
+    const RansacJob J = rjob(tab, stride, blockIdx.x);  // by value: fields live in SGPRs
     const int n = J.n_ptr ? *J.n_ptr : J.n;
     __shared__ int wcount[4];
     __shared__ int base;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_ransac_compact(const void* tab, size_t 
 // ---- 2. score every hypothesis: one wavefront per hypothesis ----------------------------------------------------
 __global__ __launch_bounds__(256) void k_ransac_score(const void* tab, size_t stride)
 {
-    const RansacJob& J = rjob(tab, stride, blockIdx.y);
+    const RansacJob J = rjob(tab, stride, blockIdx.y);  // by value: fields live in SGPRs
     const int m = *J.m_out;
     const int hyp = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_ransac_score(const void* tab, size_t st
 // ---- 3. sequential selection rule, inlier mask, least-squares refit ---------------------------------------------
 __global__ __launch_bounds__(256) void k_ransac_select(const void* tab, size_t stride)
 {
-    const RansacJob& J = rjob(tab, stride, blockIdx.x);
+    const RansacJob J = rjob(tab, stride, blockIdx.x);  // by value: fields live in SGPRs
     const int n = J.n_ptr ? *J.n_ptr : J.n;
     const int m = *J.m_out;
     const int tid = threadIdx.x;
