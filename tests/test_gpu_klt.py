@@ -139,6 +139,7 @@ def test_strip_and_per_sample_lk_kernels_agree(seq):
 
 def test_pyr_lk_large_motion_restages_search_region():
     """Displacements far beyond the staged search margin (coarse 6 px, fine 4 px) must still match the oracle."""
+    from velocity_amd import _lib as L
     from velocity_amd.KLT import cv2calcOpticalFlowPyrLK
 
     W, H = 640, 360
@@ -149,9 +150,14 @@ def test_pyr_lk_large_motion_restages_search_region():
     for lk, kw in ((dict(winSize=(15, 15), maxLevel=0, criteria=(3, 30, 0.01)), dict(win=15, max_level=0, max_count=30, eps=0.01)),
                    (dict(winSize=(51, 51), maxLevel=0, criteria=(3, 30, 0.001)), dict(win=51, max_level=0, max_count=30, eps=0.001)),
                    (dict(winSize=(15, 15), maxLevel=1, criteria=(3, 10, 0.1)), dict(win=15, max_level=1, max_count=10, eps=0.1))):
-        p2, v, err = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=2.0, **lk)
         e2, ev, eerr = KO.lk_fb(f0, f1, pts, fbt=2.0, **kw)
-        assert np.array_equal(v, ev) and np.array_equal(p2, e2) and np.array_equal(err.ravel(), eerr)
+        for mode in (0, 3):  # default routing and the LDS-staged kernel for both windows
+            L.load().vh_debug_force_generic_lk(mode)
+            try:
+                p2, v, err = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=2.0, **lk)
+            finally:
+                L.load().vh_debug_force_generic_lk(0)
+            assert np.array_equal(v, ev) and np.array_equal(p2, e2) and np.array_equal(err.ravel(), eerr)
 
 
 def test_pyr_lk_textureless_and_small_images():
@@ -249,3 +255,18 @@ def test_klt_main_failure_path_matches(seq):
     ep, ev, esmall, S = KO.klt_main(other, f0, None, p0[:200], stages=True)
     assert flags == S["flags"]
     assert np.array_equal(v, ev) and np.array_equal(p_all, S["p_all"])
+
+
+def test_empty_and_single_point_inputs(seq):
+    """Edge cases of the drop-in API: no points, one point."""
+    from velocity_amd import KLT
+
+    W, H, m, f0, f1, p0 = seq
+    p, v, small = KLT.KLTmain(f1, f0, None, np.zeros((0, 2), np.float32))
+    assert p.shape == (0, 2) and v.shape == (0,) and small.shape == (H // 4, W // 4)
+    p2, v2, err = KLT.cv2calcOpticalFlowPyrLK(f0, f1, np.zeros((0, 2), np.float32), **CV_COARSE)
+    assert p2.shape == (0, 2) and v2.shape == (0,) and err.shape == (0, 1)
+    one = p0[:1]
+    p2, v2, err = KLT.cv2calcOpticalFlowPyrLK(f0, f1, one, fbt=1.0, **CV_COARSE)
+    e2, ev, eerr = KO.lk_fb(f0, f1, one, fbt=1.0)
+    assert np.array_equal(p2, e2) and np.array_equal(v2, ev)
