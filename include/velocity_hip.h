@@ -172,6 +172,9 @@ VH_API int vh_session_pack_state(vh_session* s, float* out, void* stream);
  * kernel, 0: default routing per window.  All three are bit-identical. */
 VH_API void vh_debug_force_generic_lk(int on);
 
+/* test hook: 1 accumulates the reduced camera system of vh_nls_batch on the VALU instead of the f64 matrix cores */
+VH_API void vh_debug_ba_force_valu(int on);
+
 /* ---- measurement aids (bench.py): HIP-event timing of the LK launches + Newton-iteration statistics ------------- */
 VH_API int vh_profile_begin(vh_ctx* ctx, int max_launches);
 /* all outputs host arrays of 3 (KLTmain stage 0: quarter scale, 1: coarse ROI, 2: fine) */

@@ -112,3 +112,20 @@ def test_nls_batch_vs_reference_golden(golden, nt, nf, capsys):
     close(x, ex, 1e-7, 1e-9)
     close(trace[:, 0], etr[:, 0], 1e-7)  # rms residual per iteration
     close(trace[:, 1], etr[:, 1], 1e-4)  # rms(delta): the slowly decaying gauge mode amplifies rounding
+
+
+def test_nls_batch_mfma_and_valu_paths_agree(golden):
+    """The matrix-core (v_mfma_f64_16x16x4_f64) and VALU accumulations of the reduced camera system give the same BA."""
+    from velocity_amd import _lib as L
+    from velocity_amd.NLS import fcnNLS_batch
+
+    tag = "ba_50_6"
+    args = (golden["K32"], golden[f"{tag}_P"].copy(), golden[f"{tag}_pw0"], golden[f"{tag}_cw0"])
+    a = fcnNLS_batch(*args, return_info=True)
+    L.load().vh_debug_ba_force_valu(1)
+    try:
+        b = fcnNLS_batch(*args, return_info=True)
+    finally:
+        L.load().vh_debug_ba_force_valu(0)
+    close(a[2], b[2], 1e-6, 1e-9)  # fused (MFMA) vs separate multiply-add + the slow gauge mode (SURVEY App. D)
+    close(a[3][:, 0], b[3][:, 0], 1e-8)

@@ -758,6 +758,8 @@ extern "C" VH_API int vh_msv1_t(vh_ctx* c, const float* K, const float* P, const
 // bundle adjustment entry points
 // ---------------------------------------------------------------------------------------------------------------
 static int ba_parts(int nt) { int p = nt / 16; return p < 1 ? 1 : (p > 256 ? 256 : p); }
+static int g_ba_force_valu = 0;
+extern "C" VH_API void vh_debug_ba_force_valu(int on) { g_ba_force_valu = on; }
 
 extern "C" VH_API size_t vh_nls_batch_workspace(int nt, int nc) { return vh_ba_workspace_bytes(nt, nc, ba_parts(nt)); }
 
@@ -769,7 +771,7 @@ extern "C" VH_API int vh_nls_batch(vh_ctx* c, const float* K_host, const double*
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch: workspace too small");
     BaProblem P;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
-    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt);
+    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt); P.force_valu = g_ba_force_valu;
     int r = vh_ba_run(P, (hipStream_t)stream);
     if (r) return vh_fail(r, "vh_ba_run failed");
     return 0;

@@ -212,59 +212,242 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
     }
 }
 
-// Schur stage 2: reduce the partials, add the +I damping, solve S dc = rhs with Gauss-Jordan + partial pivoting
-__global__ __launch_bounds__(BA_THREADS) void k_ba_solve(BaJob J, int nparts)
+// Schur stage 1 on the matrix cores (6 nc <= 128): the reduced camera system accumulates S -= W^T Y, a genuine dense
+// contraction of shape (6nc x 3nt) . (3nt x 6nc).  One workgroup (4 wavefronts) per chunk of points; points are processed
+// in groups of 4 (12 rows of W / Y staged in LDS, zero padded to 128 columns = 8 x 8 tiles of 16 x 16); wavefront w owns
+// tile rows 2w, 2w+1 and issues v_mfma_f64_16x16x4_f64 over the three K = 4 slabs of a group (A[i][k] = W[k][16 ti + i],
+// B[k][j] = Y[k][16 tj + j]).  The per-camera diagonal blocks Jc^T Jc stay on the VALU (thread-owned entries).
+typedef double double4v __attribute__((ext_vector_type(4)));
+#define BA_NPAD 128
+
+__global__ __launch_bounds__(BA_THREADS) void k_ba_points_mfma(BaJob J)
+{
+    if (*J.done) return;
+    const int nt = J.nt, nc = J.nc, nq = 6 * nc, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sW = reinterpret_cast<double*>(smem);   // [12][128]
+    double* sY = sW + 12 * BA_NPAD;                 // [12][128]
+    double* sJc = sY + 12 * BA_NPAD;                // [4][nc][12]
+    double* sTp = sJc + 4 * 12 * nc;                // [4][12]: tp (3) + Ui (9)
+    double* sR = sTp + 48;                          // [4][128] rhs partials of the four waves
+    const int chunk = (nt + gridDim.x - 1) / gridDim.x;
+    const int i0 = blockIdx.x * chunk, i1 = min(nt, i0 + chunk);
+    const long long nent = (long long)nq * nq;
+
+    double4v acc[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc[a][t] = double4v{0.0, 0.0, 0.0, 0.0};
+    // diagonal-block entries owned by this thread: e = tid + 256 k < nc * 36
+    double accD[3] = {0.0, 0.0, 0.0};
+    double accR[2] = {0.0, 0.0};  // rhs entries q = lane, lane + 64 of the points this WAVE handled
+    for (int q = tid; q < 24 * BA_NPAD; q += BA_THREADS) sW[q] = 0.0;  // zero padding (covers sW and sY)
+
+    for (int ig = i0; ig < i1; ig += 4) {
+        __syncthreads();
+        const int i = ig + wave;  // this wave's point of the group
+        const bool live = i < i1;
+        // U_i, gp_i: lanes over cameras, wave reduction, lane 0 inverts
+        double u6[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (live)
+            for (int c = lane; c <= nc; c += 64) {
+                const size_t m = (size_t)c * nt + i;
+                const double* Jp = J.Jp + 6 * m;
+                const double ru = J.r[2 * m], rv = J.r[2 * m + 1];
+                const double a0 = Jp[0], a1 = Jp[1], a2 = Jp[2], b0 = Jp[3], b1 = Jp[4], b2 = Jp[5];
+                u6[0] += a0 * a0 + b0 * b0; u6[1] += a0 * a1 + b0 * b1; u6[2] += a0 * a2 + b0 * b2;
+                u6[3] += a1 * a1 + b1 * b1; u6[4] += a1 * a2 + b1 * b2; u6[5] += a2 * a2 + b2 * b2;
+                u6[6] += a0 * ru + b0 * rv; u6[7] += a1 * ru + b1 * rv; u6[8] += a2 * ru + b2 * rv;
+            }
+#pragma unroll
+        for (int k = 0; k < 9; k++) u6[k] = vh_wave_sum_f64(u6[k]);
+        if (lane == 0) {
+            const double U[9] = {u6[0] + 1.0, u6[1], u6[2], u6[1], u6[3] + 1.0, u6[4], u6[2], u6[4], u6[5] + 1.0};  // +I damping
+            double Ui[9];
+            inv3_sym(U, Ui);
+            double* T = sTp + 12 * wave;
+            for (int a = 0; a < 3; a++) T[a] = live ? Ui[a * 3] * u6[6] + Ui[a * 3 + 1] * u6[7] + Ui[a * 3 + 2] * u6[8] : 0.0;
+            for (int k = 0; k < 9; k++) T[3 + k] = Ui[k];
+            if (live) for (int a = 0; a < 3; a++) J.tp[3 * (size_t)i + a] = T[a];
+        }
+        for (int q = lane; q < 12 * nc; q += 64) {
+            const int c = q / 12 + 1, k = q - (c - 1) * 12;
+            sJc[wave * 12 * nc + q] = live ? J.Jc[12 * ((size_t)c * nt + i) + k] : 0.0;
+        }
+        __syncthreads();
+        // rows 3 wave .. 3 wave + 2 of the group's W and Y
+        {
+            const double* T = sTp + 12 * wave;
+            const double* Ui = T + 3;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int q = lane + 64 * h;
+                if (q < nq) {
+                    double w0 = 0, w1 = 0, w2 = 0, y0 = 0, y1 = 0, y2 = 0;
+                    if (live) {
+                        const int c = q / 6, k = q - 6 * c;
+                        const double* Jp = J.Jp + 6 * ((size_t)(c + 1) * nt + i);
+                        const double ju = sJc[wave * 12 * nc + 12 * c + k], jv = sJc[wave * 12 * nc + 12 * c + 6 + k];
+                        w0 = Jp[0] * ju + Jp[3] * jv; w1 = Jp[1] * ju + Jp[4] * jv; w2 = Jp[2] * ju + Jp[5] * jv;
+                        y0 = Ui[0] * w0 + Ui[1] * w1 + Ui[2] * w2; y1 = Ui[3] * w0 + Ui[4] * w1 + Ui[5] * w2; y2 = Ui[6] * w0 + Ui[7] * w1 + Ui[8] * w2;
+                        double* Yg = J.Y + ((size_t)i * nq + q) * 3;
+                        Yg[0] = y0; Yg[1] = y1; Yg[2] = y2;
+                        const size_t m = (size_t)(c + 1) * nt + i;
+                        accR[h] += ju * J.r[2 * m] + jv * J.r[2 * m + 1] - (w0 * T[0] + w1 * T[1] + w2 * T[2]);
+                    }
+                    sW[(3 * wave) * BA_NPAD + q] = w0; sW[(3 * wave + 1) * BA_NPAD + q] = w1; sW[(3 * wave + 2) * BA_NPAD + q] = w2;
+                    sY[(3 * wave) * BA_NPAD + q] = y0; sY[(3 * wave + 1) * BA_NPAD + q] = y1; sY[(3 * wave + 2) * BA_NPAD + q] = y2;
+                }
+            }
+        }
+        __syncthreads();
+        // diagonal blocks: sum over the 4 points of Jc^T Jc (both measurement rows)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int e = tid + BA_THREADS * k;
+            if (e < nc * 36) {
+                const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
+                double v = 0.0;
+                for (int g = 0; g < 4; g++) {
+                    const double* jc = sJc + g * 12 * nc + 12 * c;
+                    v += jc[ka] * jc[kb] + jc[6 + ka] * jc[6 + kb];
+                }
+                accD[k] += v;
+            }
+        }
+        // matrix cores: acc[ti][tj] += W^T Y over the 12 rows of the group
+#pragma unroll
+        for (int k0 = 0; k0 < 12; k0 += 4) {
+            const int kr = k0 + (lane >> 4), cc = lane & 15;
+            double bf[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) bf[t] = sY[kr * BA_NPAD + 16 * t + cc];
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const double af = sW[kr * BA_NPAD + 16 * (2 * wave + a) + cc];
+#pragma unroll
+                for (int t = 0; t < 8; t++) acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf[t], acc[a][t], 0, 0, 0);
+            }
+        }
+    }
+    // write the partials: S_part = -W^T Y (+ diagonal blocks, added after the barrier), rhs partial
+    double* Sp = J.Spart + (size_t)blockIdx.x * nent;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+                const int row = 16 * (2 * wave + a) + (lane >> 4) + 4 * rg, col = 16 * t + (lane & 15);  // f64 C/D map
+                if (row < nq && col < nq) Sp[(size_t)row * nq + col] = -acc[a][t][rg];
+            }
+    sR[wave * BA_NPAD + lane] = accR[0];
+    sR[wave * BA_NPAD + lane + 64] = accR[1];
+    __threadfence_block();
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int e = tid + BA_THREADS * k;
+        if (e < nc * 36) {
+            const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
+            Sp[(size_t)(6 * c + ka) * nq + 6 * c + kb] += accD[k];
+        }
+    }
+    if (tid < nq) J.Rpart[(size_t)blockIdx.x * nq + tid] = sR[tid] + sR[BA_NPAD + tid] + sR[2 * BA_NPAD + tid] + sR[3 * BA_NPAD + tid];
+}
+
+// Schur stage 2a: sum the per-workgroup partials into the augmented system and add +I.  A block handles 32 entries;
+// its 8 thread rows each sum a fixed slice of the partials, then the slices are combined in a fixed order (deterministic).
+__global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts)
+{
+    if (*J.done) return;
+    const int nq = 6 * J.nc, ld = nq + 1;
+    const long long nent = (long long)nq * nq, ntot = nent + nq;
+    const int lane32 = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const long long e = (long long)blockIdx.x * 32 + lane32;
+    __shared__ double sh[8][33];
+    double s = 0.0;
+    if (e < ntot) {
+        const int per = (nparts + 7) / 8, p0 = slice * per, p1 = min(nparts, p0 + per);
+        if (e < nent) for (int p = p0; p < p1; p++) s += J.Spart[(size_t)p * nent + e];
+        else for (int p = p0; p < p1; p++) s += J.Rpart[(size_t)p * nq + (e - nent)];
+    }
+    sh[slice][lane32] = s;
+    __syncthreads();
+    if (slice == 0 && e < ntot) {
+        double t = 0.0;
+        for (int k = 0; k < 8; k++) t += sh[k][lane32];
+        if (e < nent) {
+            const int a = (int)(e / nq), b = (int)(e - (long long)a * nq);
+            J.Sfull[(size_t)a * ld + b] = t + (a == b ? 1.0 : 0.0);
+        } else {
+            J.Sfull[(size_t)(e - nent) * ld + nq] = t;
+        }
+    }
+}
+
+// Schur stage 2b: solve S dc = rhs with Gauss-Jordan + partial pivoting.
+// The augmented (6nc) x (6nc+1) system lives in LDS (105 KB at nc = 19); every elimination step updates all elements
+// in parallel.  Systems that do not fit LDS fall back to a global-memory matrix.
+#define BA_SOLVE_THREADS 1024
+template <bool IN_LDS>
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaJob J, int nparts)
 {
     if (*J.done) return;
     const int nq = 6 * J.nc, tid = threadIdx.x, ld = nq + 1;
-    double* A = J.Sfull;  // [nq][nq+1] augmented
-    const long long nent = (long long)nq * nq;
-    for (long long e = tid; e < nent; e += BA_THREADS) {
-        double s = 0.0;
-        for (int p = 0; p < nparts; p++) s += J.Spart[(size_t)p * nent + e];
-        const int a = (int)(e / nq), b = (int)(e - (long long)a * nq);
-        A[(size_t)a * ld + b] = s + (a == b ? 1.0 : 0.0);
-    }
-    for (int q = tid; q < nq; q += BA_THREADS) {
-        double s = 0.0;
-        for (int p = 0; p < nparts; p++) s += J.Rpart[(size_t)p * nq + q];
-        A[(size_t)q * ld + nq] = s;
-    }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* A = IN_LDS ? reinterpret_cast<double*>(smem) : J.Sfull;  // [nq][nq+1] augmented
+    // the partials were reduced into Sfull ([nq][nq+1], +I included) by k_ba_reduce
+    if (IN_LDS)
+        for (int e = tid; e < nq * ld; e += BA_SOLVE_THREADS) A[e] = J.Sfull[e];
+    (void)nparts;
     __shared__ int s_piv;
-    __shared__ double s_inv;
+    __shared__ double s_col[256];  // column c of the current step (multipliers), nq <= 256
     __syncthreads();
+    const int rr = tid >> 5, kk = tid & 31;  // 32 x 32 arrangement of the elimination update
     for (int c = 0; c < nq; c++) {
-        if (tid == 0) {
+        if (tid < 64) {  // pivot search by the first wavefront: max |A[r][c]|, r >= c (lowest row wins ties, like LAPACK)
+            double best = -1.0;
             int piv = c;
-            double best = fabs(A[(size_t)c * ld + c]);
-            for (int r = c + 1; r < nq; r++) {
+            for (int r = c + tid; r < nq; r += 64) {
                 const double v = fabs(A[(size_t)r * ld + c]);
                 if (v > best) { best = v; piv = r; }
             }
-            s_piv = piv;
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, 64);
+                const int op = __shfl_xor(piv, o, 64);
+                if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+            }
+            if (tid == 0) s_piv = piv;
         }
         __syncthreads();
         const int piv = s_piv;
+        // swap rows c and piv, and build the multiplier column in the same pass (the swap only touches rows c, piv)
+        const double pivval = A[(size_t)piv * ld + c];
+        const double inv = 1.0 / pivval;
+        for (int r = tid; r < nq; r += BA_SOLVE_THREADS) {
+            const double v = (r == piv) ? A[(size_t)c * ld + c] : A[(size_t)r * ld + c];  // value of row r after the swap
+            s_col[r] = (r == c) ? 0.0 : v * inv;
+        }
+        __syncthreads();
         if (piv != c)
-            for (int k = tid; k <= nq; k += BA_THREADS) {
+            for (int k = tid; k <= nq; k += BA_SOLVE_THREADS) {
                 const double t = A[(size_t)c * ld + k];
                 A[(size_t)c * ld + k] = A[(size_t)piv * ld + k];
                 A[(size_t)piv * ld + k] = t;
             }
         __syncthreads();
-        if (tid == 0) s_inv = 1.0 / A[(size_t)c * ld + c];
-        __syncthreads();
-        const double inv = s_inv;
-        // eliminate column c from every other row; thread t handles rows t, t + 256, ...
-        for (int r = tid; r < nq; r += BA_THREADS) {
-            if (r == c) continue;
-            const double f = A[(size_t)r * ld + c] * inv;
-            if (f != 0.0)
-                for (int k = c; k <= nq; k++) A[(size_t)r * ld + k] -= f * A[(size_t)c * ld + k];
+        // rank-1 update of the trailing columns: A[r][k] -= f_r * A[c][k], k > c (column c itself is not needed again)
+        for (int k = c + 1 + kk; k <= nq; k += 32) {
+            const double pivrow = A[(size_t)c * ld + k];
+#pragma unroll 4
+            for (int r = rr; r < nq; r += 32)
+                if (r != c) A[(size_t)r * ld + k] -= s_col[r] * pivrow;
         }
         __syncthreads();
     }
-    for (int q = tid; q < nq; q += BA_THREADS) J.dc[q] = A[(size_t)q * ld + nq] / A[(size_t)q * ld + q];
+    for (int q = tid; q < nq; q += BA_SOLVE_THREADS) J.dc[q] = A[(size_t)q * ld + nq] / A[(size_t)q * ld + q];
 }
 
 // back-substitution dp = tp - Y dc, update x += 0.9 delta, rms(delta) and the stop flag (NLS.py:235-240)
@@ -356,16 +539,28 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     const long long nent = (long long)nq * nq;
     const int npass = (int)((nent + (long long)BA_THREADS * BA_EPT - 1) / ((long long)BA_THREADS * BA_EPT));
     const size_t lds = sizeof(double) * (size_t)(6 * nq + 12 * nc + 16);
+    const size_t lds_mfma = sizeof(double) * (size_t)(24 * BA_NPAD + 48 * nc + 48 + 4 * BA_NPAD);
+    const size_t solve_lds = sizeof(double) * (size_t)nq * (nq + 1);
+    if (solve_lds <= 160 * 1024 && solve_lds > 48 * 1024) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds);
+        if (ea != hipSuccess) return (int)ea;
+    }
     const int nmeas = nt * (nc + 1);
     const int upd_blocks = (nt + BA_THREADS - 1) / BA_THREADS;
     for (int it = 0; it < P.max_iter; it++) {
         hipLaunchKernelGGL(k_ba_cams, dim3((nc + 1 + 63) / 64), dim3(64), 0, s, J);
         hipLaunchKernelGGL(k_ba_jac, dim3((nmeas + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, s, J);
-        for (int pass = 0; pass < npass; pass++) {
-            // later passes overwrite Spart entries of their own range only
-            hipLaunchKernelGGL(k_ba_points, dim3(nparts), dim3(BA_THREADS), lds, s, J, pass);
+        if (nq <= BA_NPAD && !P.force_valu) {
+            hipLaunchKernelGGL(k_ba_points_mfma, dim3(nparts), dim3(BA_THREADS), lds_mfma, s, J);
+        } else {
+            for (int pass = 0; pass < npass; pass++) {
+                // later passes overwrite Spart entries of their own range only
+                hipLaunchKernelGGL(k_ba_points, dim3(nparts), dim3(BA_THREADS), lds, s, J, pass);
+            }
         }
-        hipLaunchKernelGGL(k_ba_solve, dim3(1), dim3(BA_THREADS), 0, s, J, nparts);
+        hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((nent + nq + 31) / 32)), dim3(BA_THREADS), 0, s, J, nparts);
+        if (solve_lds <= 160 * 1024) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(BA_SOLVE_THREADS), solve_lds, s, J, nparts);
+        else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(BA_SOLVE_THREADS), 0, s, J, nparts);
         hipLaunchKernelGGL(k_ba_update, dim3(upd_blocks), dim3(BA_THREADS), 0, s, J, it);
     }
     return (int)hipGetLastError();

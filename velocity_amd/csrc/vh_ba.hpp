@@ -32,6 +32,7 @@ struct BaProblem {
     int* info;
     void* workspace;
     int nt, nc, max_iter, nparts;
+    int force_valu;  // test hook: 1 = accumulate the reduced camera system on the VALU instead of the matrix cores
 };
 
 size_t vh_ba_workspace_bytes(int nt, int nc, int nparts);

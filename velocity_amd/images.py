@@ -24,8 +24,10 @@ def insidebbox(x, box):
     return (x[:, 0] > x0) & (x[:, 0] < x1) & (x[:, 1] > y0) & (x[:, 1] < y1)
 
 
-def intrinsic_matrix_iphone6s_video(width=3840, height=2160, halve=True):
-    """K of getCameraParams for 4K iPhone 6s video (utils/images.py:120-122,143,148-151), halved like vidExample.py:35-39."""
+def intrinsic_matrix_iphone6s_video(width=1920, height=1080, halve=True):
+    """K of getCameraParams for iPhone 6s video (utils/images.py:120-122,143,148-151): focal length of the 4K sensor crop,
+    principal point from the frame size the decoder reports (1920x1080 for the shipped clips), focal halved like
+    vidExample.py:35-39."""
     ratio = math.sqrt(4032**2 + 3024**2) / math.sqrt(3840**2 + 2160**2)
     f = 3486 * ratio
     K = np.array([[f, 0, 0], [0, f, 0], [width / 2 + 0.5, height / 2 + 0.5, 1]], np.float32)
