@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables)")
     ap.add_argument("--exchange-every", type=int, default=30)
     ap.add_argument("--no-ba", action="store_true", help="skip the BA (config 5) leg")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the track-state exchange even with one rank (smoke test of the N>1 path)")
     return ap.parse_args()
 
 
@@ -125,7 +126,8 @@ def bench_ba(nt=5000, nf=20, repeats=3):
     tr = trace.cpu().numpy()
     return dict(workload=f"C5 BA: {nf} keyframes x {nt} tracks (nx={3 * nt + 6 * nc}, nz={2 * nt * nf}), {its} LM iterations",
                 iters_per_s=round(its / best, 2), ms_per_iter=round(1e3 * best / its, 3), rms_residual_first=round(float(tr[0, 0]), 4),
-                rms_residual_last=round(float(tr[its - 1, 0]), 4), method="compact FD Jacobian + point-block Schur complement (f64)")
+                rms_residual_last=round(float(tr[its - 1, 0]), 4), method="compact FD Jacobian; point-block Schur complement with the reduced camera system on v_mfma_f64_16x16x4_f64; LDS Gauss-Jordan",
+                dense_equivalent_flop_per_iter=2.0 * (3 * nt + 6 * nc) ** 2 * (2 * nt * nf))
 
 
 def main():
@@ -140,8 +142,11 @@ def main():
     dev = torch.device("cuda", local)
     import torch.distributed as dist
 
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from velocity_amd import _lib as L
     from velocity_amd import dist as vdist
@@ -167,7 +172,7 @@ def main():
         for b in range(S):
             tables[k, b] = base_ptr + ((phase[b] + k) % a.ring) * fbytes
     tables = tables.to(dev)
-    ex = vdist.TrackStateExchange(S, N, every=a.exchange_every, device=dev) if world > 1 else None
+    ex = vdist.TrackStateExchange(S, N, every=a.exchange_every, device=dev) if use_dist else None
 
     def run(first, count):
         for i in range(first, first + count):
@@ -179,7 +184,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -196,7 +201,7 @@ def main():
     ms_sum, launches = (C.c_double * 3)(), (C.c_int * 3)()
     iters, setups = (C.c_ulonglong * 3)(), (C.c_ulonglong * 3)()
     L.check(ses.lib.vh_profile_end(ses.ws.handle, ms_sum, launches, iters, setups), "vh_profile_end")
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -239,7 +244,7 @@ def main():
                    data="synthetic",
                    config=dict(workload=cfg["name"] + f"; {S} independent streams resident per GPU, one launch sequence per step",
                                params=a.params, coarse=dict(L.LK_COARSE, **lkc), fine=dict(L.LK_FINE), streams_per_gpu=S, tracks=N,
-                               parallelism=f"streams x{world} (1 rank per GPU" + (f", RCCL all-gather of track state every {a.exchange_every} frames)" if world > 1 else ")")),
+                               parallelism=f"streams x{world} (1 rank per GPU" + (f", RCCL all-gather of track state every {a.exchange_every} frames)" if use_dist else ")")),
                    per_stream_fps=round(value / (S * world), 2), tracks_alive_frac=round(alive, 4),
                    pose_t=[round(float(x), 5) for x in st["t"]], pose_t_truth=[round(float(x), 5) for x in truth], rms_residual_px=round(st["res"], 5),
                    roofline=roof)
@@ -249,7 +254,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, K, frames, p0, p3, vp, lkc, lkf, a.cpu_seconds)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        if rank == 0 and ex is not None:
+            g = vdist.unpack_state(ex.wait()[0, 0], N)
+            assert g["n_cur"] == st["n_cur"] or g["frame_i"] <= st["frame_i"], "exchanged track state is inconsistent"
         dist.barrier()
         dist.destroy_process_group()
 

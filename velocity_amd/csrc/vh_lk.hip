@@ -91,7 +91,7 @@ __device__ __forceinline__ int search_sample(const ImgDesc& im, int gx, int gy, 
 // One point on one level.  All control flow is wave-uniform.
 __device__ void lk_level(const ImgDesc I, const ImgDesc J, int win, int level, int top_level, int max_count, double eps2,
                          float p0x, float p0y, float& nxo, float& nyo, int& status, float& err, short* ldsI, int* ldsD, int lane,
-                         int& n_iter, int& n_setup)
+                         int& n_iter, int& n_setup, bool want_err)
 {
     const float half = (float)(win - 1) * 0.5f;
     const float lscale = (float)(1. / (double)(1 << level));
@@ -186,6 +186,7 @@ __device__ void lk_level(const ImgDesc I, const ImgDesc J, int win, int level, i
         const float fx = __fsub_rn(nxo, half), fy = __fsub_rn(nyo, half);
         const int inx = vh_floor(fx), iny = vh_floor(fy);
         if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) { status = 0; return; }
+        if (!want_err) return;  // err is discarded by the caller (KLT.py:83 `pa, v, _`): only the bounds rule matters
         w = bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny));
         const bool interior = inx >= 0 && iny >= 0 && inx + win <= J.w - 1 && iny + win <= J.h - 1;
         long long se = 0;
@@ -203,14 +204,14 @@ __device__ void lk_level(const ImgDesc I, const ImgDesc J, int win, int level, i
 }
 
 __device__ void lk_track(const PyrDesc& PI, const PyrDesc& PJ, int win, int max_count, double eps2, float px, float py, float& ox,
-                         float& oy, int& status, float& err, short* ldsI, int* ldsD, int lane, int& n_iter, int& n_setup)
+                         float& oy, int& status, float& err, short* ldsI, int* ldsD, int lane, int& n_iter, int& n_setup, bool want_err)
 {
     const int nl = min(PI.nlevels, PJ.nlevels);
     status = 1;
     err = 0.f;
     ox = 0.f; oy = 0.f;
     for (int level = nl - 1; level >= 0; level--)
-        lk_level(PI.lv[level], PJ.lv[level], win, level, nl - 1, max_count, eps2, px, py, ox, oy, status, err, ldsI, ldsD, lane, n_iter, n_setup);
+        lk_level(PI.lv[level], PJ.lv[level], win, level, nl - 1, max_count, eps2, px, py, ox, oy, status, err, ldsI, ldsD, lane, n_iter, n_setup, want_err);
 }
 
 // grid = (max points, batch), block = one wavefront
@@ -232,12 +233,12 @@ __global__ __launch_bounds__(64) void k_lk(const void* job_tab, size_t tab_strid
 
     float fx, fy, err;
     int st, n_iter = 0, n_setup = 0;
-    lk_track(job.I, job.J, job.win, job.max_count, job.eps2, px, py, fx, fy, st, err, ldsI, ldsD, lane, n_iter, n_setup);
+    lk_track(job.I, job.J, job.win, job.max_count, job.eps2, px, py, fx, fy, st, err, ldsI, ldsD, lane, n_iter, n_setup, job.err_out != nullptr);
     float fbe = 0.f;
     if (job.fbt >= 0.f) {
         float bx, by, e2;
         int st2;
-        lk_track(job.J, job.I, job.win, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, ldsI, ldsD, lane, n_iter, n_setup);
+        lk_track(job.J, job.I, job.win, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, ldsI, ldsD, lane, n_iter, n_setup, false);
         const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
         fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
         st = st && st2 && (fbe < job.fbt);
@@ -424,7 +425,7 @@ __device__ __forceinline__ void strip_setup(const unsigned* lo, const unsigned* 
 template <int WIN_T>
 __device__ void lk_level_strip(const ImgDesc I, const ImgDesc J, int win_rt, int level, int top_level, int max_count, double eps2,
                                float p0x, float p0y, float& nxo, float& nyo, int& status, float& err, uint2* tI, uint2* tX, uint2* tY,
-                               int lane, int& n_iter, int& n_setup)
+                               int lane, int& n_iter, int& n_setup, bool want_err)
 {
     const int win = WIN_T ? WIN_T : win_rt;
     const int spr = (win + 3) >> 2;   // strips per window row
@@ -585,6 +586,7 @@ __device__ void lk_level_strip(const ImgDesc I, const ImgDesc J, int win_rt, int
         const float fx = __fsub_rn(nxo, half), fy = __fsub_rn(nyo, half);
         const int inx = vh_floor(fx), iny = vh_floor(fy);
         if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) { status = 0; return; }
+        if (!want_err) return;  // err is discarded by the caller (KLT.py:83 `pa, v, _`): only the bounds rule matters
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny)));
         const bool fast = inx >= 3 && iny >= 0 && inx + win + 12 <= J.w && iny + win + 1 <= J.h;
         int se = 0;
@@ -611,7 +613,7 @@ __device__ void lk_level_strip(const ImgDesc I, const ImgDesc J, int win_rt, int
 
 template <int WIN_T>
 __device__ void lk_track_strip(const PyrDesc& PI, const PyrDesc& PJ, int win, int max_count, double eps2, float px, float py, float& ox,
-                               float& oy, int& status, float& err, uint2* tI, uint2* tX, uint2* tY, int lane, int& n_iter, int& n_setup)
+                               float& oy, int& status, float& err, uint2* tI, uint2* tX, uint2* tY, int lane, int& n_iter, int& n_setup, bool want_err)
 {
     const int nl = min(PI.nlevels, PJ.nlevels);
     status = 1;
@@ -619,7 +621,7 @@ __device__ void lk_track_strip(const PyrDesc& PI, const PyrDesc& PJ, int win, in
     ox = 0.f; oy = 0.f;
     for (int level = nl - 1; level >= 0; level--)
         lk_level_strip<WIN_T>(PI.lv[level], PJ.lv[level], win, level, nl - 1, max_count, eps2, px, py, ox, oy, status, err, tI, tX, tY, lane,
-                              n_iter, n_setup);
+                              n_iter, n_setup, want_err);
 }
 
 template <int WIN_T>
@@ -643,12 +645,12 @@ __global__ __launch_bounds__(64) void k_lk_strip(const void* job_tab, size_t tab
 
     float fx, fy, err;
     int st, n_iter = 0, n_setup = 0;
-    lk_track_strip<WIN_T>(job.I, job.J, win, job.max_count, job.eps2, px, py, fx, fy, st, err, tI, tX, tY, lane, n_iter, n_setup);
+    lk_track_strip<WIN_T>(job.I, job.J, win, job.max_count, job.eps2, px, py, fx, fy, st, err, tI, tX, tY, lane, n_iter, n_setup, job.err_out != nullptr);
     float fbe = 0.f;
     if (job.fbt >= 0.f) {
         float bx, by, e2;
         int st2;
-        lk_track_strip<WIN_T>(job.J, job.I, win, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, tI, tX, tY, lane, n_iter, n_setup);
+        lk_track_strip<WIN_T>(job.J, job.I, win, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, tI, tX, tY, lane, n_iter, n_setup, false);
         const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
         fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
         st = st && st2 && (fbe < job.fbt);
@@ -777,7 +779,7 @@ __device__ __forceinline__ void block_sum_wide(const int* part, long long* tot, 
 
 template <int WIN, int NW, int M>
 __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_level, int max_count, double eps2, float p0x, float p0y,
-                          float& nxo, float& nyo, int& status, float& err, char* smem, int tid, int& phase, int& n_iter, int& n_setup)
+                          float& nxo, float& nyo, int& status, float& err, char* smem, int tid, int& phase, int& n_iter, int& n_setup, bool want_err)
 {
     using C = LK3<WIN, NW, M>;
     uint2* tI = reinterpret_cast<uint2*>(smem + C::OFF_TI);
@@ -909,6 +911,7 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
         const float fx = __fsub_rn(nxo, half), fy = __fsub_rn(nyo, half);
         const int inx = vh_floor(fx), iny = vh_floor(fy);
         if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) { status = 0; return; }
+        if (!want_err) return;  // err is discarded by the caller (KLT.py:83 `pa, v, _`): only the bounds rule matters
         if (!region_holds(inx, iny)) restage(inx, iny);
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny)));
         int se[1] = {0};
@@ -935,7 +938,7 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
 
 template <int WIN, int NW, int M>
 __device__ void lk3_track(const PyrDesc& PI, const PyrDesc& PJ, int max_count, double eps2, float px, float py, float& ox, float& oy,
-                          int& status, float& err, char* smem, int tid, int& phase, int& n_iter, int& n_setup)
+                          int& status, float& err, char* smem, int tid, int& phase, int& n_iter, int& n_setup, bool want_err)
 {
     const int nl = min(PI.nlevels, PJ.nlevels);
     status = 1;
@@ -943,7 +946,7 @@ __device__ void lk3_track(const PyrDesc& PI, const PyrDesc& PJ, int max_count, d
     ox = 0.f; oy = 0.f;
     for (int level = nl - 1; level >= 0; level--)
         lk3_level<WIN, NW, M>(PI.lv[level], PJ.lv[level], level, nl - 1, max_count, eps2, px, py, ox, oy, status, err, smem, tid, phase, n_iter,
-                              n_setup);
+                              n_setup, want_err);
 }
 
 template <int WIN, int NW, int M>
@@ -965,12 +968,12 @@ __global__ __launch_bounds__(64 * NW) void k_lk3(const void* job_tab, size_t tab
 
     float fx, fy, err;
     int st, n_iter = 0, n_setup = 0, phase = 0;
-    lk3_track<WIN, NW, M>(job.I, job.J, max_count, eps2, px, py, fx, fy, st, err, smem, tid, phase, n_iter, n_setup);
+    lk3_track<WIN, NW, M>(job.I, job.J, max_count, eps2, px, py, fx, fy, st, err, smem, tid, phase, n_iter, n_setup, job.err_out != nullptr);
     float fbe = 0.f;
     if (fbt >= 0.f) {
         float bx, by, e2;
         int st2;
-        lk3_track<WIN, NW, M>(job.J, job.I, max_count, eps2, fx, fy, bx, by, st2, e2, smem, tid, phase, n_iter, n_setup);
+        lk3_track<WIN, NW, M>(job.J, job.I, max_count, eps2, fx, fy, bx, by, st2, e2, smem, tid, phase, n_iter, n_setup, false);
         const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
         fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
         st = st && st2 && (fbe < fbt);

@@ -50,7 +50,7 @@ class TrackStateExchange:
 
     def start(self):
         """Begin the all-gather of `self.local` (non-blocking)."""
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             self.gathered[0].copy_(self.local)
             self._work = None
         else:
