@@ -114,6 +114,8 @@ VH_API int vh_pixel2uvec(vh_ctx* ctx, double cx, double cy, double f, const doub
 /* ---- triangulation (K15, K16) ---------------------------------------------------------------------------------- */
 /* fcn2vintercept(A, U), utils/MSV.py:98-142.  A [nf,3], U [3,nf,nv], out [nv,3] (all device, float64) */
 VH_API int vh_two_view_intercept(vh_ctx* ctx, const double* A, const double* U, int nf, int nv, double* out, void* stream);
+/* fcnNvintercept(A, U), utils/MSV.py:146-175: N-ray least-squares intersection.  Same layouts. */
+VH_API int vh_n_view_intercept(vh_ctx* ctx, const double* A, const double* U, int nf, int nv, double* out, void* stream);
 /* fcnMSV1_t(K, P, B, vg, ii), utils/MSV.py:8-49.  P float32 [5,N0,nhist], B float32 [nhist,14], ids = nonzero(vg)
  * (int32, ng entries).  f32_rays: K and P were float32 on the caller's side (numpy then builds the rays in float32).
  * Outputs: x_out float[3], b0 double[ng x 3], info int[2]; U_scratch double[3*(ii+1)*ng]. */

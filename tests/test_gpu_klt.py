@@ -270,3 +270,33 @@ def test_empty_and_single_point_inputs(seq):
     p2, v2, err = KLT.cv2calcOpticalFlowPyrLK(f0, f1, one, fbt=1.0, **CV_COARSE)
     e2, ev, eerr = KO.lk_fb(f0, f1, one, fbt=1.0)
     assert np.array_equal(p2, e2) and np.array_equal(v2, ev)
+
+
+@pytest.mark.parametrize("cfg", ["c2", "c3"])
+def test_klt_main_bit_exact_at_baseline_sizes(cfg):
+    """BASELINE configs 2 and 3 at full size (1080p / 2000 tracks / 3 levels, 4K / 5000 tracks / 4 levels):
+    every stage of KLTmain bit-exact against the oracle, and the tracks match the analytic motion."""
+    from velocity_amd import KLT
+
+    W, H, n, levels = (1920, 1080, 2000, 3) if cfg == "c2" else (3840, 2160, 5000, 4)
+    K = synth.K_1080P.copy()
+    if cfg == "c3":
+        K[:2, :2] *= 2
+        K[2, 0], K[2, 1] = W / 2 + 0.5, H / 2 + 0.5
+    m = synth.PlaneMotion(K, z0=3.6, traj=synth.oscillating_traj(period=60.0))
+    f0 = synth.render_frame(W, H, m, 7, device="cuda").cpu().numpy()
+    f1 = synth.render_frame(W, H, m, 8, device="cuda").cpu().numpy()
+    p0 = m.apply(7, synth.grid_tracks(n, W, H).astype(float)).astype(np.float32)
+    lkc = dict(max_level=levels - 1)
+    p, v, small, p_all, flags = KLT.KLTmain(f1, f0, None, p0, lk_coarse=lkc, return_all=True)
+    ep, ev, esmall, S = KO.klt_main(f1, f0, None, p0, lk_coarse=lkc, stages=True)
+    G = KLT.klt_stages(n)
+    for key in ("p_small", "v_small", "T_trans", "roi", "p_coarse", "v_coarse", "T23", "warped"):
+        assert np.array_equal(G[key], S[key]), key
+    assert flags == S["flags"] == 0
+    assert np.array_equal(small, esmall) and np.array_equal(v, ev) and np.array_equal(p_all, S["p_all"]) and np.array_equal(p, ep)
+    A7, A8 = m.matrix(7), m.matrix(8)
+    x0 = (p0.astype(float) - A7[:, 2]) @ np.linalg.inv(A7[:, :2]).T
+    truth = x0 @ A8[:, :2].T + A8[:, 2]
+    e = np.linalg.norm(p_all - truth, axis=1)[v]
+    assert v.mean() > 0.98 and np.median(e) < 0.03

@@ -82,9 +82,10 @@ def test_pose_random_vs_oracle():
 
 
 def test_triangulation_and_msv(golden):
-    from velocity_amd.MSV import fcn2vintercept, fcnMSV1_t
+    from velocity_amd.MSV import fcn2vintercept, fcnMSV1_t, fcnNvintercept
 
     close(fcn2vintercept(golden["tri_A"], golden["tri_U"]), golden["tri_2v"], 1e-10)
+    close(fcnNvintercept(golden["tri_A"], golden["tri_U"]), golden["tri_nv"], 1e-9)
     x, b0 = fcnMSV1_t(golden["K32"], golden["msv_P"], golden["msv_B"], golden["msv_vg"], int(golden["msv_ii"]))
     assert x.dtype == np.float32 and b0.shape == (int(golden["msv_vg"].sum()), 3)
     close(x, golden["msv_x"], 5e-6)

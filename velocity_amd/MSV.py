@@ -16,6 +16,18 @@ def fcn2vintercept(A, U):
     return out.cpu().numpy()
 
 
+def fcnNvintercept(A, U):
+    """Least-squares intersection of the nf rays of every track (utils/MSV.py:146-175).  A [nf,3], U [3,nf,nv] -> [nv,3]."""
+    torch = L.torch_cuda()
+    Ad = L.to_dev(np.asarray(A, np.float64), torch.float64).reshape(-1, 3)
+    Ud = L.to_dev(np.asarray(U, np.float64), torch.float64)
+    _, nf, nv = Ud.shape
+    out = torch.zeros((nv, 3), dtype=torch.float64, device="cuda")
+    ws = L.workspace()
+    L.check(ws.lib.vh_n_view_intercept(ws.handle, L.dptr(Ad), L.dptr(Ud), nf, nv, L.dptr(out), L.stream_ptr()), "vh_n_view_intercept")
+    return out.cpu().numpy()
+
+
 def fcnMSV1_t(K, P, B, vg, ii):
     """LM over the last camera translation with re-triangulation inside (utils/MSV.py:8-49) -> (x f32[3], b0 f64[ng,3])."""
     torch = L.torch_cuda()

@@ -58,6 +58,7 @@ _SIGS = {
     "vh_image2world": (C.c_int, [vp, f64p, vp, C.c_int, vp, vp]),
     "vh_pixel2uvec": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp, vp]),
     "vh_two_view_intercept": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "vh_n_view_intercept": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "vh_nls_batch_workspace": (C.c_size_t, [C.c_int, C.c_int]),
     "vh_nls_batch": (C.c_int, [vp, f32p, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     "vh_session_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(LKParams), C.POINTER(LKParams), C.c_int]),

@@ -740,6 +740,14 @@ extern "C" VH_API int vh_two_view_intercept(vh_ctx* c, const double* A, const do
     return 0;
 }
 
+extern "C" VH_API int vh_n_view_intercept(vh_ctx* c, const double* A, const double* U, int nf, int nv, double* out, void* stream)
+{
+    if (!c || nf < 2) return vh_fail(-1, "vh_n_view_intercept: nf must be >= 2");
+    vh_launch_n_view(A, U, nf, nv, out, (hipStream_t)stream);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" VH_API int vh_msv1_t(vh_ctx* c, const float* K, const float* P, const float* B, const int* ids, int ng, int N0, int nhist, int ii,
                                 int f32_rays, double* U_scratch, float* x_out, double* b0, int* info, void* stream)
 {

@@ -376,6 +376,30 @@ __global__ void k_two_view(const double* A, const double* U, int nf, int nv, dou
     out[3 * i] = c[0]; out[3 * i + 1] = c[1]; out[3 * i + 2] = c[2];
 }
 
+// fcnNvintercept (MSV.py:146-175): least-squares intersection of the nf rays of every track,
+//   C0 = inv(sum_f (I - u u^T)) (sum_f (I - u u^T) A_f)
+__global__ void k_n_view(const double* A, const double* U, int nf, int nv, double* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    for (int f = 0; f < nf; f++) {
+        const double u[3] = {U[(0 * nf + f) * nv + i], U[(1 * nf + f) * nv + i], U[(2 * nf + f) * nv + i]};
+        const double a[3] = {A[3 * f], A[3 * f + 1], A[3 * f + 2]};
+        for (int r = 0; r < 3; r++) {
+            double acc = 0.0;
+            for (int c = 0; c < 3; c++) {
+                const double v = (r == c ? 1.0 : 0.0) - u[r] * u[c];
+                S[r * 3 + c] += v;
+                acc += v * a[c];
+            }
+            b[r] += acc;
+        }
+    }
+    solve_dense<3>(S, b);
+    out[3 * i] = b[0]; out[3 * i + 1] = b[1]; out[3 * i + 2] = b[2];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // fcnMSV1_t (MSV.py:8-49): LM over the last camera translation; every iteration re-triangulates all points.
 // ---------------------------------------------------------------------------------------------------------------
@@ -477,5 +501,9 @@ void vh_launch_pixel2uvec(double cx, double cy, double f, const double* p, int n
 void vh_launch_two_view(const double* A, const double* U, int nf, int nv, double* out, hipStream_t s)
 {
     if (nv > 0) hipLaunchKernelGGL(k_two_view, dim3((nv + 255) / 256), dim3(256), 0, s, A, U, nf, nv, out);
+}
+void vh_launch_n_view(const double* A, const double* U, int nf, int nv, double* out, hipStream_t s)
+{
+    if (nv > 0) hipLaunchKernelGGL(k_n_view, dim3((nv + 255) / 256), dim3(256), 0, s, A, U, nf, nv, out);
 }
 void vh_launch_msv1(const MsvJob& job, hipStream_t s) { hipLaunchKernelGGL(k_msv1, dim3(1), dim3(MSV_THREADS), 0, s, job); }

@@ -42,4 +42,5 @@ void vh_launch_world2image(const double* C, const double* pw, int n, double* out
 void vh_launch_image2world(const double* Hi, const double* p, int n, double* out, hipStream_t s);
 void vh_launch_pixel2uvec(double cx, double cy, double f, const double* p, int n, double* out, hipStream_t s);
 void vh_launch_two_view(const double* A, const double* U, int nf, int nv, double* out, hipStream_t s);
+void vh_launch_n_view(const double* A, const double* U, int nf, int nv, double* out, hipStream_t s);
 void vh_launch_msv1(const MsvJob& job, hipStream_t s);
