@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("VH_BENCH_STREAMS", 32)), help="video streams resident per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VH_BENCH_STREAMS", 64)), help="video streams resident per GPU")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--params", default="baseline", choices=["baseline", "ref"],
                     help="baseline: coarse stages use the config's pyramid depth; ref: exactly utils/KLT.py:106-107 (maxLevel=4)")
@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables)")
     ap.add_argument("--exchange-every", type=int, default=30)
     ap.add_argument("--no-ba", action="store_true", help="skip the BA (config 5) leg")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("VH_BENCH_GROUPS", 1)),
+                    help="split the resident streams into this many sessions on separate HIP streams (their latency-bound stages overlap)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the track-state exchange even with one rank (smoke test of the N>1 path)")
     return ap.parse_args()
 
@@ -159,27 +161,40 @@ def main():
     K, motion, frames, p0 = make_ring(cfg, a.ring, dev, seed=0xC0FFEE + 7919 * rank)
     p3 = motion.world_points(p0)
     vp = np.ones(N, bool)  # every valid track takes part in the pose fit (the state after vidExample.py:160)
-    ses = TrackerSession(K, W, H, N, nhist=nhist, batch=S, lk_coarse=lkc, lk_fine=lkf, msv_frame=0)
+    G = max(1, min(a.groups, S))
+    assert S % G == 0, "--streams must be a multiple of --groups"
+    SG = S // G
+    sessions = [TrackerSession(K, W, H, N, nhist=nhist, batch=SG, lk_coarse=lkc, lk_fine=lkf, msv_frame=0) for _ in range(G)]
+    hip_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(G - 1)]
+    ses = sessions[0]
     # streams of one rank share the ring but run at different phases, so every launch sees S different frame pairs
     phase = [(7 * b) % a.ring for b in range(S)]
     base_ptr = frames.data_ptr()
     fbytes = W * H
     for b in range(S):
-        ses.init_stream(b, frames[phase[b]], motion.apply(phase[b], p0.astype(float)).astype(np.float32), p3 + motion.t(phase[b]), vp,
-                        np.float32([0, 0, 0]))
+        sessions[b // SG].init_stream(b % SG, frames[phase[b]], motion.apply(phase[b], p0.astype(float)).astype(np.float32),
+                                      p3 + motion.t(phase[b]), vp, np.float32([0, 0, 0]))
     tables = torch.empty((a.ring, S), dtype=torch.int64)
     for k in range(a.ring):
         for b in range(S):
             tables[k, b] = base_ptr + ((phase[b] + k) % a.ring) * fbytes
     tables = tables.to(dev)
     ex = vdist.TrackStateExchange(S, N, every=a.exchange_every, device=dev) if use_dist else None
+    torch.cuda.synchronize()
 
     def run(first, count):
         for i in range(first, first + count):
-            ses.step(frames_table=tables[i % a.ring], time_s=i / 30.0, frame_no=i)
+            row = tables[i % a.ring]
+            for g in range(G):
+                with torch.cuda.stream(hip_streams[g]):
+                    sessions[g].step(frames_table=row[g * SG:(g + 1) * SG], time_s=i / 30.0, frame_no=i)
             if ex is not None and ex.due(i):
                 ex.wait()
-                L.check(ses.lib.vh_session_pack_state(ses.handle, L.dptr(ex.local), L.stream_ptr()), "vh_session_pack_state")
+                for g in range(G):
+                    with torch.cuda.stream(hip_streams[g]):
+                        L.check(sessions[g].lib.vh_session_pack_state(sessions[g].handle, L.dptr(ex.local[g * SG:(g + 1) * SG]), L.stream_ptr()),
+                                "vh_session_pack_state")
+                torch.cuda.synchronize()
                 ex.start()
 
     def barrier():
@@ -217,7 +232,7 @@ def main():
         # dominant kernel = the fine LK launch (stage 2): algorithmic gather bytes per launch (KLT track solve row)
         wf = 51
         us_fine = 1e3 * ms_sum[2] / max(launches[2], 1)
-        bytes_fine = 2 * N * S * 1 * ((wf + 2) ** 2 + (wf + 1) ** 2)
+        bytes_fine = 2 * N * SG * 1 * ((wf + 2) ** 2 + (wf + 1) ** 2)  # per launch of session group 0 (SG streams)
         achieved = bytes_fine / (us_fine * 1e-6) / 1e9 if us_fine > 0 else 0.0
         it_f = iters[2] / max(launches[2], 1)
         su_f = setups[2] / max(launches[2], 1)
@@ -229,13 +244,13 @@ def main():
         if a.config == "c2" and os.path.exists(tpath):
             tj = json.load(open(tpath))
             k = tj["k_lk3<51, 4, 4>"]
-            traffic = int((2 * k["fetch_kib"] + k["write_kib"]) * 1024 * S / tj["streams"])
+            traffic = int((2 * k["fetch_kib"] + k["write_kib"]) * 1024 * SG / tj["streams"])
         roof = dict(bound="hbm", kernel="k_lk3<51,4,4> (fine stage: 51x51 window, level 0, fwd+bwd)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, us_per_launch=round(us_fine, 2),
                     alg_bytes_per_launch=bytes_fine,
                     valu=dict(model_gops_per_launch=round(ops_fine / 1e9, 4), achieved_tops=round(ops_fine / (us_fine * 1e-6) / 1e12, 3) if us_fine > 0 else 0,
                               peak_tops=round(VALU_PEAK_TOPS, 1), frac=round(ops_fine / (us_fine * 1e-6) / 1e12 / VALU_PEAK_TOPS, 4) if us_fine > 0 else 0,
-                              newton_iters_per_track_dir=round(it_f / (2 * N * S), 2)),
+                              newton_iters_per_track_dir=round(it_f / (2 * N * SG), 2)),
                     note="track solve is VALU/LDS bound (SURVEY §8d); the HBM figure prices its algorithmic gather bytes",
                     lk_us_per_launch=[round(1e3 * ms_sum[k] / max(launches[k], 1), 2) for k in range(3)])
         out = dict(metric="tracked frames/sec (KLT 2000 tracks + NLS pose, 1080p)" if a.config == "c2" else "tracked frames/sec (KLT 5000 tracks + NLS pose, 4K)",
@@ -244,6 +259,7 @@ def main():
                    data="synthetic",
                    config=dict(workload=cfg["name"] + f"; {S} independent streams resident per GPU, one launch sequence per step",
                                params=a.params, coarse=dict(L.LK_COARSE, **lkc), fine=dict(L.LK_FINE), streams_per_gpu=S, tracks=N,
+                               stream_groups=G,
                                parallelism=f"streams x{world} (1 rank per GPU" + (f", RCCL all-gather of track state every {a.exchange_every} frames)" if use_dist else ")")),
                    per_stream_fps=round(value / (S * world), 2), tracks_alive_frac=round(alive, 4),
                    pose_t=[round(float(x), 5) for x in st["t"]], pose_t_truth=[round(float(x), 5) for x in truth], rms_residual_px=round(st["res"], 5),

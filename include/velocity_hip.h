@@ -63,6 +63,9 @@ VH_API void vh_ctx_destroy(vh_ctx* ctx);
 /* ---- image stages (K1, K2, K8, K9) ---------------------------------------------------------------------------- */
 /* cv2.resize(im, (0,0), fx=.25, fy=.25, INTER_NEAREST), utils/KLT.py:111-113.  dst: round(h/4) x round(w/4), dense */
 VH_API int vh_resize_quarter(vh_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream);
+/* frame ingest, cv2.cvtColor(imbgr, cv2.COLOR_BGR2GRAY), vidExample.py:91.
+ * bgr: uint8 [h][w][3] with row stride stride_bytes; gray: uint8 [h][w] with row stride gray_stride */
+VH_API int vh_bgr2gray(vh_ctx* ctx, const uint8_t* bgr, int w, int h, int stride_bytes, uint8_t* gray, int gray_stride, void* stream);
 /* cv2.pyrDown as used inside cv2.calcOpticalFlowPyrLK (KLT.py:45,48).  dst: (h+1)/2 x (w+1)/2, dense */
 VH_API int vh_pyr_down(vh_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream);
 /* meshgrid + affine + cv2.remap(INTER_LINEAR), utils/KLT.py:70-73.  T: host, 3x2 row-major float32.  dst dense ROI */

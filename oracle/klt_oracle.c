@@ -756,3 +756,11 @@ KO_API void ko_klt_regional(const uint8_t *im0, const uint8_t *im, int w, int h,
 }
 
 KO_API double ko_det_log(double x) { return det_log(x); }
+
+/* cv2.cvtColor(BGR2GRAY) for 8-bit images (vidExample.py:91): OpenCV 4.x fixed point, 15 fractional bits (unpinned like the
+ * rest of the OpenCV half) */
+KO_API void ko_bgr2gray(const uint8_t *bgr, int w, int h, uint8_t *gray)
+{
+    for (size_t i = 0; i < (size_t)w * h; i++)
+        gray[i] = (uint8_t)((bgr[3 * i] * 3735u + bgr[3 * i + 1] * 19235u + bgr[3 * i + 2] * 9798u + (1u << 14)) >> 15);
+}

@@ -230,3 +230,12 @@ def klt_regional(im0, im, p0, T, lk, fbt=1.0, translate=False):
                           v.ctypes.data_as(C.POINTER(C.c_uint8)), roi, warped.ctypes.data_as(C.POINTER(C.c_uint8)))
     x0, x1, y0, y1 = roi
     return p, v.astype(bool), tuple(roi), warped.reshape(-1)[: (y1 - y0) * (x1 - x0)].reshape(y1 - y0, x1 - x0)
+
+
+def bgr2gray(imbgr):
+    """cv2.cvtColor(imbgr, cv2.COLOR_BGR2GRAY) (vidExample.py:91)."""
+    a = np.ascontiguousarray(imbgr, np.uint8)
+    h, w, _ = a.shape
+    out = np.empty((h, w), np.uint8)
+    lib().ko_bgr2gray(a.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out

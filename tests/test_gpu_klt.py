@@ -300,3 +300,12 @@ def test_klt_main_bit_exact_at_baseline_sizes(cfg):
     truth = x0 @ A8[:, :2].T + A8[:, 2]
     e = np.linalg.norm(p_all - truth, axis=1)[v]
     assert v.mean() > 0.98 and np.median(e) < 0.03
+
+
+def test_bgr2gray_bit_exact():
+    from velocity_amd.images import bgr2gray
+
+    rng = np.random.default_rng(11)
+    for (h, w) in ((1080, 1920), (37, 53), (5, 3)):
+        bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(bgr2gray(bgr), KO.bgr2gray(bgr))

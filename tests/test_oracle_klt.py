@@ -163,3 +163,11 @@ def test_klt_main_end_to_end(seq):
     T = np.array([[1, 0], [0, 1], S["T_trans"]], np.float32)
     pc, vc, roi, _ = KO.klt_regional(f0, f1, p0, T, KO.LK_COARSE, fbt=1.0, translate=True)
     assert np.array_equal(pc, S["p_coarse"]) and np.array_equal(vc, S["v_coarse"].astype(bool)) and roi == tuple(S["roi"])
+
+
+def test_bgr2gray_known_answers():
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 30]]], np.uint8)
+    g = KO.bgr2gray(px)[0]
+    assert list(g[:2]) == [255, 0]
+    assert list(g[2:5]) == [29, 150, 76]  # 0.114 / 0.587 / 0.299 of 255, rounded
+    assert g[5] == round(0.114 * 10 + 0.587 * 200 + 0.299 * 30)

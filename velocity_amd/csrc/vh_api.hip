@@ -434,6 +434,14 @@ extern "C" VH_API int vh_resize_quarter(vh_ctx* c, const uint8_t* src, int w, in
     return 0;
 }
 
+extern "C" VH_API int vh_bgr2gray(vh_ctx* c, const uint8_t* bgr, int w, int h, int stride_bytes, uint8_t* gray, int gray_stride, void* stream)
+{
+    if (!c || w < 1 || h < 1) return vh_fail(-1, "vh_bgr2gray: bad arguments");
+    vh_launch_bgr2gray(bgr, w, h, (size_t)stride_bytes, gray, (size_t)gray_stride, (hipStream_t)stream);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" VH_API int vh_pyr_down(vh_ctx* c, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream)
 {
     if (!c) return vh_fail(-1, "null ctx");

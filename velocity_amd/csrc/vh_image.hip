@@ -146,6 +146,33 @@ __global__ __launch_bounds__(256) void k_roi_warp(const void* job_tab, size_t ta
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// frame ingest: cv2.cvtColor(imbgr, COLOR_BGR2GRAY), vidExample.py:91 -- OpenCV 4.x 8-bit path:
+// gray = (B*3735 + G*19235 + R*9798 + 2^14) >> 15.  One thread = 4 pixels (12 bytes in, one packed dword out).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t* bgr, int w, int h, size_t sstride, uint8_t* gray, size_t dstride)
+{
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (y >= h || x4 >= w) return;
+    const uint8_t* s = bgr + (size_t)y * sstride + 3 * (size_t)x4;
+    uint8_t* d = gray + (size_t)y * dstride + x4;
+    const int cnt = min(4, w - x4);
+    uint32_t pack = 0;
+    for (int k = 0; k < cnt; k++) {
+        const uint32_t v = (s[3 * k] * 3735u + s[3 * k + 1] * 19235u + s[3 * k + 2] * 9798u + (1u << 14)) >> 15;
+        pack |= v << (8 * k);
+    }
+    if (cnt == 4 && ((reinterpret_cast<uintptr_t>(d) & 3) == 0)) *reinterpret_cast<uint32_t*>(d) = pack;
+    else for (int k = 0; k < cnt; k++) d[k] = (uint8_t)(pack >> (8 * k));
+}
+
+void vh_launch_bgr2gray(const uint8_t* bgr, int w, int h, size_t sstride, uint8_t* gray, size_t dstride, hipStream_t s)
+{
+    dim3 blk(64, 4), grd((w + 255) / 256, (h + 3) / 4);
+    hipLaunchKernelGGL(k_bgr2gray, grd, blk, 0, s, bgr, w, h, sstride, gray, dstride);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------------------
 void vh_launch_resize_quarter(const void* src_tab, const void* dst_tab, size_t tab_stride, int per_stream, int batch, int max_dw, int max_dh,

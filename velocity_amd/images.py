@@ -34,3 +34,16 @@ def intrinsic_matrix_iphone6s_video(width=1920, height=1080, halve=True):
     if halve:
         K[:2, :2] /= 2
     return K
+
+
+def bgr2gray(imbgr):
+    """cv2.cvtColor(imbgr, cv2.COLOR_BGR2GRAY) (vidExample.py:91): uint8 [H,W,3] -> uint8 [H,W] (numpy in -> numpy out)."""
+    torch = L.torch_cuda()
+    keep = isinstance(imbgr, torch.Tensor)
+    t = (imbgr if keep else torch.from_numpy(np.ascontiguousarray(imbgr))).cuda().contiguous()
+    assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3
+    h, w = t.shape[0], t.shape[1]
+    out = torch.empty((h, w), dtype=torch.uint8, device="cuda")
+    ws = L.workspace()
+    L.check(ws.lib.vh_bgr2gray(ws.handle, L.dptr(t), w, h, 3 * w, L.dptr(out), w, L.stream_ptr()), "vh_bgr2gray")
+    return out if keep else out.cpu().numpy()
