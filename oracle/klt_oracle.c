@@ -764,3 +764,175 @@ KO_API void ko_bgr2gray(const uint8_t *bgr, int w, int h, uint8_t *gray)
     for (size_t i = 0; i < (size_t)w * h; i++)
         gray[i] = (uint8_t)((bgr[3 * i] * 3735u + bgr[3 * i + 1] * 19235u + bgr[3 * i + 2] * 9798u + (1u << 14)) >> 15);
 }
+
+
+/* ------------------------------------------------------------------------------------------------ */
+/* frame-0 initialisation: cv2.goodFeaturesToTrack(..., useHarrisDetector) */
+/* and cv2.cornerSubPix, vidExample.py:110-115.  Restated from OpenCV 4.x's published algorithm;     */
+/* PARITY UNPINNED like the rest of the OpenCV half.  Deliberate choice: the Harris structure tensor  */
+/* is accumulated in exact integers (Sobel sums and 5x5 box sums of their products) and scaled once,  */
+/* where OpenCV accumulates scaled floats in a build-dependent order.                                  */
+/* ------------------------------------------------------------------------------------------------ */
+static inline int sobel_dx(const uint8_t *im, int w, int h, ptrdiff_t st, int x, int y)
+{
+    int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w), ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+    return (im[ym * st + xp] - im[ym * st + xm]) + 2 * (im[y * st + xp] - im[y * st + xm]) + (im[yp * st + xp] - im[yp * st + xm]);
+}
+static inline int sobel_dy(const uint8_t *im, int w, int h, ptrdiff_t st, int x, int y)
+{
+    int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w), ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+    return (im[yp * st + xm] - im[ym * st + xm]) + 2 * (im[yp * st + x] - im[ym * st + x]) + (im[yp * st + xp] - im[ym * st + xp]);
+}
+
+/* Harris response (cornerHarris, blockSize x blockSize box, Sobel aperture 3, k): float32 [h][w] */
+KO_API void ko_harris_response(const uint8_t *im, int w, int h, int stride, int block, double k, float *resp)
+{
+    int *dx = (int *)malloc(sizeof(int) * (size_t)w * h), *dy = (int *)malloc(sizeof(int) * (size_t)w * h);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            dx[(size_t)y * w + x] = sobel_dx(im, w, h, stride, x, y);
+            dy[(size_t)y * w + x] = sobel_dy(im, w, h, stride, x, y);
+        }
+    const double scale = 1.0 / (4.0 * block * 255.0); /* (1 << (aperture-1)) * block * 255 */
+    const float s2 = (float)(scale * scale), kf = (float)k;
+    const int r0 = block / 2; /* anchor = block/2: window [x - r0, x - r0 + block) */
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            long long sxx = 0, sxy = 0, syy = 0;
+            for (int j = 0; j < block; j++) {
+                int yy = reflect101(y - r0 + j, h);
+                for (int i = 0; i < block; i++) {
+                    int xx = reflect101(x - r0 + i, w);
+                    int a = dx[(size_t)yy * w + xx], b = dy[(size_t)yy * w + xx];
+                    sxx += a * a; sxy += a * b; syy += b * b;
+                }
+            }
+            float a = (float)sxx * s2, b = (float)sxy * s2, c = (float)syy * s2;
+            float tr = a + c;
+            resp[(size_t)y * w + x] = (a * c - b * b) - (kf * tr) * tr;
+        }
+    free(dx); free(dy);
+}
+
+typedef struct { float v; int idx; } cand_t;
+static int cand_cmp(const void *pa, const void *pb)
+{
+    const cand_t *a = (const cand_t *)pa, *b = (const cand_t *)pb;
+    if (a->v > b->v) return -1;
+    if (a->v < b->v) return 1;
+    return a->idx > b->idx ? -1 : (a->idx < b->idx ? 1 : 0); /* ties: higher address first (greaterThanPtr) */
+}
+
+/* goodFeaturesToTrack(image, maxCorners, quality, minDistance=0, blockSize, useHarris, k).  Returns the count; corners (x,y) float */
+KO_API int ko_good_features(const uint8_t *im, int w, int h, int stride, int max_corners, double quality, int block, double k, float *corners)
+{
+    float *eig = (float *)malloc(sizeof(float) * (size_t)w * h);
+    ko_harris_response(im, w, h, stride, block, k, eig);
+    float mx = eig[0];
+    for (size_t i = 1; i < (size_t)w * h; i++) if (eig[i] > mx) mx = eig[i];
+    const float thr = (float)((double)mx * quality);
+    /* threshold(TOZERO): keep values > thr, else 0 */
+    for (size_t i = 0; i < (size_t)w * h; i++) if (!(eig[i] > thr)) eig[i] = 0.f;
+    cand_t *c = (cand_t *)malloc(sizeof(cand_t) * (size_t)w * h);
+    int n = 0;
+    for (int y = 1; y < h - 1; y++)
+        for (int x = 1; x < w - 1; x++) {
+            float v = eig[(size_t)y * w + x];
+            if (v == 0.f) continue;
+            float m = v; /* 3x3 dilation */
+            for (int j = -1; j <= 1; j++)
+                for (int i = -1; i <= 1; i++) {
+                    float u = eig[(size_t)(y + j) * w + x + i];
+                    if (u > m) m = u;
+                }
+            if (v == m) { c[n].v = v; c[n].idx = y * w + x; n++; }
+        }
+    qsort(c, n, sizeof(cand_t), cand_cmp);
+    if (max_corners > 0 && n > max_corners) n = max_corners;
+    for (int i = 0; i < n; i++) { corners[2 * i] = (float)(c[i].idx % w); corners[2 * i + 1] = (float)(c[i].idx / w); }
+    free(c); free(eig);
+    return n;
+}
+
+/* getRectSubPix(8u -> 32f) of a pw x ph patch centred at (cx, cy), replicated border */
+static void rect_subpix(const uint8_t *im, int w, int h, ptrdiff_t st, float cx, float cy, int pw, int ph, float *dst)
+{
+    cx -= (pw - 1) * 0.5f; cy -= (ph - 1) * 0.5f;
+    int ipx = ifloor(cx), ipy = ifloor(cy);
+    float a = cx - ipx, b = cy - ipy;
+    float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
+    for (int i = 0; i < ph; i++) {
+        int y0 = ipy + i, y1 = y0 + 1;
+        y0 = y0 < 0 ? 0 : (y0 > h - 1 ? h - 1 : y0);
+        y1 = y1 < 0 ? 0 : (y1 > h - 1 ? h - 1 : y1);
+        for (int j = 0; j < pw; j++) {
+            int x0 = ipx + j, x1 = x0 + 1;
+            x0 = x0 < 0 ? 0 : (x0 > w - 1 ? w - 1 : x0);
+            x1 = x1 < 0 ? 0 : (x1 > w - 1 ? w - 1 : x1);
+            float v = (float)im[y0 * st + x0] * a11;
+            v = v + (float)im[y0 * st + x1] * a12;
+            v = v + (float)im[y1 * st + x0] * a21;
+            v = v + (float)im[y1 * st + x1] * a22;
+            dst[i * pw + j] = v;
+        }
+    }
+}
+
+/* cornerSubPix(image, corners, winSize=(win,win), zeroZone=(-1,-1), criteria=(EPS+MAX_ITER, max_iter, eps)) in place */
+KO_API void ko_corner_subpix(const uint8_t *im, int w, int h, int stride, float *pts, int n, int win, int max_iter, double eps)
+{
+    const int ww = 2 * win + 1, pw = ww + 2;
+    if (max_iter < 1) max_iter = 1;
+    if (max_iter > 100) max_iter = 100;
+    if (eps < 0) eps = 0;
+    eps *= eps;
+    float *mask = (float *)malloc(sizeof(float) * ww * ww);
+    for (int i = 0; i < ww; i++) {
+        float y = (float)(i - win) / win, vy = expf(-y * y);
+        for (int j = 0; j < ww; j++) {
+            float x = (float)(j - win) / win;
+            mask[i * ww + j] = (float)(vy * expf(-x * x));
+        }
+    }
+#pragma omp parallel
+    {
+        float *buf = (float *)malloc(sizeof(float) * pw * pw);
+#pragma omp for schedule(dynamic, 8)
+        for (int q = 0; q < n; q++) {
+            const float tx = pts[2 * q], ty = pts[2 * q + 1];
+            float cx = tx, cy = ty;
+            int iter = 0;
+            double err = 0;
+            do {
+                double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+                rect_subpix(im, w, h, stride, cx, cy, pw, pw, buf);
+                for (int i = 0; i < ww; i++) {
+                    const float *sp = buf + (i + 1) * pw + 1;
+                    const double py = i - win;
+                    for (int j = 0; j < ww; j++) {
+                        const double m = mask[i * ww + j];
+                        const double tgx = sp[j + 1] - sp[j - 1], tgy = sp[j + pw] - sp[j - pw];
+                        const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m, px = j - win;
+                        a += gxx; b += gxy; c += gyy;
+                        bb1 += gxx * px + gxy * py;
+                        bb2 += gxy * px + gyy * py;
+                    }
+                }
+                const double det = a * c - b * b;
+                if (fabs(det) <= 2.220446049250313e-16 * 2.220446049250313e-16) break;
+                const double sc = 1.0 / det;
+                const float nx = (float)(cx + c * sc * bb1 - b * sc * bb2);
+                const float ny = (float)(cy - b * sc * bb1 + a * sc * bb2);
+                err = (double)(nx - cx) * (nx - cx) + (double)(ny - cy) * (ny - cy);
+                cx = nx; cy = ny;
+                if (cx < 0 || cx >= w || cy < 0 || cy >= h) break;
+            } while (++iter < max_iter && err > eps);
+            if (fabsf(cx - tx) > win || fabsf(cy - ty) > win) { cx = tx; cy = ty; }
+            pts[2 * q] = cx; pts[2 * q + 1] = cy;
+        }
+        free(buf);
+    }
+    free(mask);
+}

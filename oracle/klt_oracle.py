@@ -239,3 +239,30 @@ def bgr2gray(imbgr):
     out = np.empty((h, w), np.uint8)
     lib().ko_bgr2gray(a.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, out.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out
+
+
+def harris_response(img, block=5, k=0.04):
+    a, pa, sa = _view(img)
+    h, w = a.shape
+    out = np.empty((h, w), np.float32)
+    lib().ko_harris_response(pa, w, h, C.c_int(sa), int(block), C.c_double(k), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def good_features(img, max_corners=1000, quality=0.01, block=5, k=0.04):
+    """cv2.goodFeaturesToTrack(img, max_corners, quality, 0, blockSize=block, useHarrisDetector=True, k=k) -> [n,2] float32 (x,y)."""
+    a, pa, sa = _view(img)
+    h, w = a.shape
+    out = np.zeros((max(max_corners, 1) if max_corners > 0 else h * w, 2), np.float32)
+    n = lib().ko_good_features(pa, w, h, C.c_int(sa), int(max_corners), C.c_double(quality), int(block), C.c_double(k),
+                               out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:n].copy()
+
+
+def corner_subpix(img, pts, win=5, max_iter=100, eps=0.001):
+    """cv2.cornerSubPix(img, pts, (win,win), (-1,-1), (EPS+MAX_ITER, max_iter, eps)) -> refined copy."""
+    a, pa, sa = _view(img)
+    h, w = a.shape
+    p = np.ascontiguousarray(pts, np.float32).copy()
+    lib().ko_corner_subpix(pa, w, h, C.c_int(sa), p.ctypes.data_as(C.POINTER(C.c_float)), p.shape[0], int(win), int(max_iter), C.c_double(eps))
+    return p

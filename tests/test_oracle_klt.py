@@ -171,3 +171,34 @@ def test_bgr2gray_known_answers():
     assert list(g[:2]) == [255, 0]
     assert list(g[2:5]) == [29, 150, 76]  # 0.114 / 0.587 / 0.299 of 255, rounded
     assert g[5] == round(0.114 * 10 + 0.587 * 200 + 0.299 * 30)
+
+
+def _checkerboard(h=240, w=320, cell=40, blur=True):
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (((yy // cell) + (xx // cell)) % 2 * 180 + 40).astype(np.float64)
+    if blur:  # soften so corners are well defined at sub-pixel level
+        k = np.array([1, 4, 6, 4, 1], float) / 16
+        img = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, img)
+        img = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 0, img)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def test_harris_corners_and_subpix_on_checkerboard():
+    img = _checkerboard()
+    cell = 40
+    pts = KO.good_features(img, max_corners=200, quality=0.01, block=5)
+    assert 20 <= len(pts) <= 200
+    # every strong corner sits on an interior checkerboard crossing (x, y multiples of the cell size, +-2 px)
+    inner = [(x, y) for x in range(cell, 320, cell) for y in range(cell, 240, cell)]
+    top = pts[: len(inner)]
+    d = np.array([min(abs(px - x) + abs(py - y) for x, y in inner) for px, py in top])
+    assert (d <= 4).all()
+    ref = KO.corner_subpix(img, top, win=5, max_iter=100, eps=0.001)
+    # the saddle points of the blurred checkerboard are at (k*cell - 0.5, l*cell - 0.5)
+    dx = np.array([min(np.hypot(px - (x - 0.5), py - (y - 0.5)) for x, y in inner) for px, py in ref])
+    assert np.median(dx) < 0.1 and (dx < 0.5).mean() > 0.9
+    # sorted by response, deterministic
+    assert np.array_equal(pts, KO.good_features(img, max_corners=200, quality=0.01, block=5))
+    r = KO.harris_response(img)
+    vals = r[top[:, 1].astype(int), top[:, 0].astype(int)]
+    assert np.all(np.diff(vals) <= 0)
