@@ -136,6 +136,15 @@ VH_API size_t vh_nls_batch_workspace(int nt, int nc);
 VH_API int vh_nls_batch(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
                         int* info, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- frame-0 initialisation ---------------------------------------------------------- */
+/* cv2.goodFeaturesToTrack(roi, maxCorners, qualityLevel, 0, blockSize=block, useHarrisDetector=True, k), vidExample.py:110.
+ * corners: device float [max_corners x 2] (x, y) sorted by response; count: device int[1] */
+VH_API int vh_good_features(vh_ctx* ctx, const uint8_t* im, int w, int h, int stride, int max_corners, double quality, int block,
+                            double k, float* corners, int* count, void* stream);
+/* cv2.cornerSubPix(im, pts, (win,win), (-1,-1), (EPS+MAX_ITER, max_iter, eps)), vidExample.py:113-115.  pts refined in place */
+VH_API int vh_corner_subpix(vh_ctx* ctx, const uint8_t* im, int w, int h, int stride, float* pts, int n, int win, int max_iter,
+                            double eps, void* stream);
+
 /* ---- tracker session: the frame loop body of vidExample.py:133-160 on the device, for ctx->batch streams ------- */
 /* device pointers into the state of one stream (read with vh_copy_to_host / torch) */
 typedef struct {

@@ -1,6 +1,7 @@
 """Config C1 (plumbing): the driver flow of vidExample.py on a rendered stand-in for IMG_4134.MOV (no decoder / cv2 here):
 real intrinsics K (images.py:120-151 halved, vidExample.py:35-39), the real hand-clicked plate corners (matlab/*.mat via the
-golden fixture), frame-0 plate pose (findR=True) -> image2world back-projection of the features (vidExample.py:118-119),
+golden fixture), Harris features + cornerSubPix in the plate ROI (vidExample.py:107-116), frame-0 plate pose (findR=True)
+-> image2world back-projection of the features (vidExample.py:118-119),
 then 12 tracked frames through the drop-in functions AND through the device-resident session; both must agree with the
 oracle loop."""
 import numpy as np
@@ -8,6 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+from oracle import klt_oracle as KO  # noqa: E402 (checker only)
 from oracle import nls_oracle as NO  # noqa: E402 (checker only)
 from oracle.session_oracle import SessionOracle  # noqa: E402
 from velocity_amd import synth  # noqa: E402
@@ -19,7 +21,7 @@ def test_c1_driver_flow_matches_oracle_and_ground_truth(golden):
     from velocity_amd import KLT, NLS
     from velocity_amd.common import addcol0, image2world, worldPointsLicensePlate
     from velocity_amd.driver import TrackerSession
-    from velocity_amd.images import boundingRect, insidebbox, intrinsic_matrix_iphone6s_video
+    from velocity_amd.images import boundingRect, cornerSubPix, goodFeaturesToTrack, insidebbox, intrinsic_matrix_iphone6s_video
 
     K = intrinsic_matrix_iphone6s_video()
     assert np.array_equal(K, golden["K32"])  # same float32 K the reference builds
@@ -30,7 +32,16 @@ def test_c1_driver_flow_matches_oracle_and_ground_truth(golden):
     np.testing.assert_allclose(residuals, golden["plate_IMG_4134_res"], rtol=1e-4)
     boxa = boundingRect(q, (H, W), border=(0, 0))
     boxb = boundingRect(q, (H, W), border=(700, 500))
-    feats = synth.grid_tracks(300, boxb[1] - boxb[0], boxb[3] - boxb[2], seed=3, frac=0.9) + np.float32([boxb[0], boxb[2]])
+    # stand-in clip rendered below; frame 0 is needed now for the feature detector (vidExample.py:109-116)
+    z0_guess = float(t[2])
+    motion = synth.PlaneMotion(K, z0=z0_guess, traj=lambda k: np.array([0.02 * k, 0.0, 0.37 * k * 0.25]))  # quarter speed keeps the ROI in frame
+    frames = [synth.render_frame(W, H, motion, k).numpy() for k in range(n)]
+    roi = frames[0][boxb[2]:boxb[3], boxb[0]:boxb[1]]
+    feats = goodFeaturesToTrack(roi, 300, 0.01, 0, blockSize=5, useHarrisDetector=True).squeeze() + np.float32([boxb[0], boxb[2]])
+    efeats = KO.good_features(roi, 300, 0.01, 5, 0.04) + np.float32([boxb[0], boxb[2]])
+    assert np.array_equal(feats, efeats)
+    feats = cornerSubPix(frames[0], feats, (5, 5), (-1, -1), (3, 100, 0.001))
+    assert np.array_equal(feats, KO.corner_subpix(frames[0], efeats, 5, 100, 0.001))
     p = np.concatenate((q, feats)).astype(np.float32)
     p3 = addcol0(image2world(K, R, t, p).astype(float)) @ R.astype(float) + t
     ep3 = NO.hom0(NO.image_to_world(K, R.astype(float), t, p).astype(float)) @ R.astype(float) + t
@@ -38,10 +49,6 @@ def test_c1_driver_flow_matches_oracle_and_ground_truth(golden):
     vp = insidebbox(p, boxa)
     assert vp[:4].sum() >= 0 and vp.sum() >= 1
 
-    # stand-in clip: the plate plane (depth = plate distance) translating at ~40 km/h: 0.37 m / frame along z, 29.97 fps
-    z0 = float(p3[:, 2].mean())
-    motion = synth.PlaneMotion(K, z0=z0, traj=lambda k: np.array([0.02 * k, 0.0, 0.37 * k * 0.25]))  # quarter speed keeps the ROI in frame
-    frames = [synth.render_frame(W, H, motion, k).numpy() for k in range(n)]
     times = [np.float32(k / 29.97) for k in range(n)]
 
     # (1) drop-in functions driven exactly like vidExample.py:133-146

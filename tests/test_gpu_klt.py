@@ -309,3 +309,21 @@ def test_bgr2gray_bit_exact():
     for (h, w) in ((1080, 1920), (37, 53), (5, 3)):
         bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         assert np.array_equal(bgr2gray(bgr), KO.bgr2gray(bgr))
+
+
+def test_frame0_features_bit_exact(seq):
+    """Row f1: Harris goodFeaturesToTrack + cornerSubPix (vidExample.py:110-115) against the oracle, on a ROI view."""
+    from velocity_amd.images import cornerSubPix, goodFeaturesToTrack
+
+    W, H, m, f0, f1, p0 = seq
+    roi = f0[40:500, 100:860]  # strided view like im[boxb[2]:boxb[3], boxb[0]:boxb[1]]
+    for img, nmax in ((roi, 1000), (f0, 300)):
+        c = goodFeaturesToTrack(img, nmax, 0.01, 0, blockSize=5, useHarrisDetector=True)
+        e = KO.good_features(img, nmax, 0.01, 5, 0.04)
+        assert c.shape == (len(e), 1, 2) and len(e) == nmax
+        assert np.array_equal(c.reshape(-1, 2), e)
+    pts = KO.good_features(roi, 1000, 0.01, 5, 0.04) + np.float32([100, 40])
+    r = cornerSubPix(f0, pts, (5, 5), (-1, -1), (3, 100, 0.001))
+    er = KO.corner_subpix(f0, pts, 5, 100, 0.001)
+    assert np.array_equal(r, er)
+    assert np.abs(r - pts).max() <= 5.0 and np.abs(r - pts).mean() > 0.01  # refined, never further than the window

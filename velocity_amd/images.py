@@ -47,3 +47,37 @@ def bgr2gray(imbgr):
     ws = L.workspace()
     L.check(ws.lib.vh_bgr2gray(ws.handle, L.dptr(t), w, h, 3 * w, L.dptr(out), w, L.stream_ptr()), "vh_bgr2gray")
     return out if keep else out.cpu().numpy()
+
+
+def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, blockSize=3, useHarrisDetector=True, k=0.04):
+    """cv2.goodFeaturesToTrack for the reference's call (vidExample.py:110: Harris, minDistance 0) -> float32 [n,1,2]."""
+    if not useHarrisDetector or minDistance:
+        raise NotImplementedError("only the Harris detector with minDistance=0 (vidExample.py:110) is implemented")
+    torch = L.torch_cuda()
+    t, h, w, st = L.img_dev(image)
+    out = torch.zeros((maxCorners, 2), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = L.workspace()
+    L.check(ws.lib.vh_good_features(ws.handle, L.dptr(t), w, h, st, int(maxCorners), float(qualityLevel), int(blockSize), float(k), L.dptr(out),
+                                    L.dptr(cnt), L.stream_ptr()), "vh_good_features")
+    n = int(cnt.item())
+    return out[:n].cpu().numpy().reshape(n, 1, 2)
+
+
+def cornerSubPix(image, corners, winSize, zeroZone, criteria):
+    """cv2.cornerSubPix(im, p, (5,5), (-1,-1), (EPS+MAX_ITER, 100, 0.001)) (vidExample.py:113-115) -> refined float32 array."""
+    if tuple(zeroZone) != (-1, -1) or winSize[0] != winSize[1]:
+        raise NotImplementedError("square windows without a zero zone only (vidExample.py:113-115)")
+    torch = L.torch_cuda()
+    typ, cnt, eps = criteria
+    if not typ & 1:
+        cnt = 100
+    if not typ & 2:
+        eps = 0.0
+    t, h, w, st = L.img_dev(image)
+    shape = np.asarray(corners).shape
+    p = L.to_dev(np.asarray(corners, np.float32).reshape(-1, 2), torch.float32).clone()
+    ws = L.workspace()
+    L.check(ws.lib.vh_corner_subpix(ws.handle, L.dptr(t), w, h, st, L.dptr(p), p.shape[0], int(winSize[0]), int(cnt), float(eps), L.stream_ptr()),
+            "vh_corner_subpix")
+    return p.cpu().numpy().reshape(shape)
