@@ -136,6 +136,14 @@ VH_API size_t vh_nls_batch_workspace(int nt, int nc);
 VH_API int vh_nls_batch(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
                         int* info, void* workspace, size_t workspace_bytes, void* stream);
 
+/* One phase of a point-sharded BA iteration (multi-GPU fcnNLS_batch): this rank owns nt of the nt_total
+ * tie points, the nc free cameras are replicated.  phase 0: init; 1: local normal equations -> [S | rhs | sums] span inside
+ * the workspace (the caller all-reduces span_doubles float64 at span_offset bytes); 2: solve + update (the caller
+ * all-reduces the span's last 4 doubles again); 3: iteration record (trace, info, stop flag).  rank0 != 0 on one rank. */
+VH_API int vh_nls_batch_phase(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int nt_total, int rank0,
+                              int phase, int it, double* trace, int* info, void* workspace, size_t workspace_bytes,
+                              size_t* span_offset, size_t* span_doubles, void* stream);
+
 /* ---- frame-0 initialisation ---------------------------------------------------------- */
 /* cv2.goodFeaturesToTrack(roi, maxCorners, qualityLevel, 0, blockSize=block, useHarrisDetector=True, k), vidExample.py:110.
  * corners: device float [max_corners x 2] (x, y) sorted by response; count: device int[1] */

@@ -75,3 +75,10 @@ def test_single_process_exchange():
     ex.start()
     st = vd.unpack_state(ex.wait()[0, 1], 16)
     assert st["n_cur"] == 14 and st["frame_i"] == 7
+
+
+def test_shard_tracks_cover_everything():
+    for nt, world in ((5000, 8), (200, 3), (8, 8)):
+        spans = [vd.shard_tracks(nt, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == nt
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

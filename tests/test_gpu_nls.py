@@ -130,3 +130,18 @@ def test_nls_batch_mfma_and_valu_paths_agree(golden):
         L.load().vh_debug_ba_force_valu(0)
     close(a[2], b[2], 1e-6, 1e-9)  # fused (MFMA) vs separate multiply-add + the slow gauge mode
     close(a[3][:, 0], b[3][:, 0], 1e-8)
+
+
+def test_nls_batch_sharded_phases_match_single_call(golden):
+    """The phase-wise (multi-GPU shardable) BA equals the single-call BA on one rank, and its trace equals the reference's."""
+    from velocity_amd.NLS import fcnNLS_batch
+    from velocity_amd.dist import fcnNLS_batch_sharded
+
+    tag = "ba_200_6"
+    args = (golden["K32"], golden[f"{tag}_P"].copy(), golden[f"{tag}_pw0"], golden[f"{tag}_cw0"])
+    cw, pw, x, tr = fcnNLS_batch(*args, return_info=True)
+    cw2, pw2, tr2 = fcnNLS_batch_sharded(*args)
+    close(cw2, cw, 1e-12, 1e-14)
+    close(pw2, pw, 1e-12, 1e-14)
+    close(tr2, tr, 1e-12)
+    close(tr2[:, 0], golden[f"{tag}_trace"][:, 0], 2e-5)

@@ -64,6 +64,8 @@ _SIGS = {
     "vh_nls_batch": (C.c_int, [vp, f32p, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     "vh_good_features": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, vp, vp, vp]),
     "vh_corner_subpix": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_double, vp]),
+    "vh_nls_batch_phase": (C.c_int, [vp, f32p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t,
+                                     C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), vp]),
     "vh_session_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(LKParams), C.POINTER(LKParams), C.c_int]),
     "vh_session_destroy": (None, [vp]),
     "vh_session_init": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, f32p, C.c_float, C.c_float, C.c_float, vp]),

@@ -788,6 +788,33 @@ extern "C" VH_API int vh_nls_batch(vh_ctx* c, const float* K_host, const double*
     BaProblem P;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt); P.force_valu = g_ba_force_valu;
+    P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0;
+    P.nx_total = 3.0 * nt + 6.0 * nc; P.nz_total = 2.0 * nt * (nc + 1);
+    int r = vh_ba_run(P, (hipStream_t)stream);
+    if (r) return vh_fail(r, "vh_ba_run failed");
+    return 0;
+}
+
+// One phase of a point-sharded BA iteration: this rank owns nt tie points, all nc cameras are replicated.
+// phase 0: init; 1: local normal equations -> [S | rhs | acc] span (the caller all-reduces it); 2: solve + update (the caller
+// all-reduces acc again); 3: iteration record.  rank0 != 0 on exactly one rank (it adds the +I damping and counts the
+// camera part of rms(delta)).  nt_total: points over all ranks.  span_offset / span_doubles (host, may be NULL) return
+// where the all-reduce span lives inside the workspace.
+extern "C" VH_API int vh_nls_batch_phase(vh_ctx* c, const float* K_host, const double* z, double* x, int nt, int nc, int nt_total, int rank0,
+                                         int phase, int it, double* trace, int* info, void* workspace, size_t workspace_bytes,
+                                         size_t* span_offset, size_t* span_doubles, void* stream)
+{
+    if (!c || !K_host || nt < 1 || nc < 1 || nt_total < nt) return vh_fail(-1, "vh_nls_batch_phase: bad arguments");
+    if (6 * nc > 256) return vh_fail(-1, "vh_nls_batch_phase: at most 42 free cameras");
+    if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch_phase: workspace too small");
+    BaProblem P;
+    for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
+    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = 1; P.nparts = ba_parts(nt);
+    P.force_valu = g_ba_force_valu;
+    P.phase = phase; P.it = it; P.add_identity = rank0 ? 1 : 0; P.count_cams = rank0 ? 1 : 0; P.defer_finalize = 1;
+    P.nx_total = 3.0 * nt_total + 6.0 * nc; P.nz_total = 2.0 * nt_total * (nc + 1);
+    if (span_offset && span_doubles) vh_ba_exchange_span(P, span_offset, span_doubles);
+    if (phase < 0 || phase > 3) return vh_fail(-1, "vh_nls_batch_phase: phase must be 0..3");
     int r = vh_ba_run(P, (hipStream_t)stream);
     if (r) return vh_fail(r, "vh_ba_run failed");
     return 0;

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts)
         for (int k = 0; k < 8; k++) t += sh[k][lane32];
         if (e < nent) {
             const int a = (int)(e / nq), b = (int)(e - (long long)a * nq);
-            J.Sfull[(size_t)a * ld + b] = t + (a == b ? 1.0 : 0.0);
+            J.Sfull[(size_t)a * ld + b] = t + ((a == b && J.add_identity) ? 1.0 : 0.0);  // sharded runs: rank 0 adds the +I
         } else {
             J.Sfull[(size_t)(e - nent) * ld + nq] = t;
         }
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
             // state layout: [points | camera positions | camera rpy] (NLS.py:203)
             const size_t idx = k < 3 ? (size_t)3 * nt + 3 * c + k : (size_t)3 * nt + 3 * nc + 3 * c + (k - 3);
             J.x[idx] += dl;
-            ss += dl * dl;
+            if (J.count_cams) ss += dl * dl;  // sharded runs: the (replicated) camera update is counted by rank 0 only
         }
     ss = vh_wave_sum_f64(ss);
     if ((tid & 63) == 0) sh[tid >> 6] = ss;
@@ -488,8 +488,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
         atomicAdd(J.acc + 1, s);
         __threadfence();
         const unsigned prev = atomicAdd(J.ticket, 1u);
-        if (prev == gridDim.x - 1) {  // last block: finish the iteration record
-            const double nz = 2.0 * nt * (nc + 1), nx = 3.0 * nt + 6.0 * nc;
+        if (prev == gridDim.x - 1 && J.defer_finalize) *J.ticket = 0u;
+        if (prev == gridDim.x - 1 && !J.defer_finalize) {  // last block: finish the iteration record
+            const double nz = J.nz_total, nx = J.nx_total;
             const double sumr = atomicAdd(J.acc, 0.0), sumd = atomicAdd(J.acc + 1, 0.0);
             const double f = sqrt(sumr / nz), xr = sqrt(sumd / nx);
             J.trace[2 * it] = f;
@@ -503,6 +504,18 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
     }
 }
 
+// iteration record from the (all-reduced) sums of a sharded run
+__global__ void k_ba_finalize(BaJob J, int it)
+{
+    if (threadIdx.x != 0 || *J.done) return;
+    const double f = sqrt(J.acc[0] / J.nz_total), xr = sqrt(J.acc[1] / J.nx_total);
+    J.trace[2 * it] = f;
+    J.trace[2 * it + 1] = xr;
+    J.info[0] = it + 1;
+    if (xr < 1e-7) { J.info[1] = 1; *J.done = 1; }
+    J.acc[0] = 0.0; J.acc[1] = 0.0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 size_t vh_ba_workspace_bytes(int nt, int nc, int nparts)
 {
@@ -510,58 +523,94 @@ size_t vh_ba_workspace_bytes(int nt, int nc, int nparts)
     size_t b = 0;
     auto add = [&](size_t n) { b += (n * sizeof(double) + 255) / 256 * 256; };
     add(36 * nf); add(2 * m); add(6 * m); add(12 * m); add(3 * (size_t)nt); add(3 * nq * nt); add(nparts * nq * nq); add(nparts * nq);
-    add(nq * (nq + 1)); add(nq); add(4); add(32);
+    add(nq * (nq + 1) + 4); add(nq); add(32);
     return b + 1024;
 }
 
+static void ba_layout(const BaProblem& P, BaJob& J, double*& flags)
+{
+    const int nt = P.nt, nc = P.nc, nq = 6 * nc, nparts = P.nparts;
+    J.nt = nt; J.nc = nc;
+    for (int k = 0; k < 9; k++) J.K[k] = P.K[k];
+    J.z = P.z; J.x = P.x; J.trace = P.trace; J.info = P.info;
+    J.add_identity = P.add_identity; J.count_cams = P.count_cams; J.defer_finalize = P.defer_finalize;
+    J.nx_total = P.nx_total; J.nz_total = P.nz_total;
+    char* w = reinterpret_cast<char*>(P.workspace);
+    auto take = [&](size_t n) { double* p = reinterpret_cast<double*>(w); w += (n * sizeof(double) + 255) / 256 * 256; return p; };
+    const size_t nf = nc + 1, m = (size_t)nt * nf;
+    J.camR = take(36 * nf); J.r = take(2 * m); J.Jp = take(6 * m); J.Jc = take(12 * m); J.tp = take(3 * (size_t)nt); J.Y = take(3 * (size_t)nq * nt);
+    J.Spart = take((size_t)nparts * nq * nq); J.Rpart = take((size_t)nparts * nq);
+    J.Sfull = take((size_t)nq * (nq + 1) + 4);     // augmented system followed by the 4 accumulators: ONE all-reduce span
+    J.acc = J.Sfull + (size_t)nq * (nq + 1);
+    J.dc = take(nq);
+    flags = take(32);
+    J.done = reinterpret_cast<int*>(flags);
+    J.ticket = reinterpret_cast<unsigned*>(flags) + 4;
+}
+
+// byte offset / length (in doubles) of the all-reduce span [Sfull | acc] inside the workspace
+void vh_ba_exchange_span(const BaProblem& P, size_t* offset_bytes, size_t* n_doubles)
+{
+    BaJob J;
+    double* flags;
+    ba_layout(P, J, flags);
+    *offset_bytes = (size_t)(reinterpret_cast<char*>(J.Sfull) - reinterpret_cast<char*>(P.workspace));
+    *n_doubles = (size_t)(6 * P.nc) * (6 * P.nc + 1) + 4;
+}
+
+// phase -1: the whole solve on one rank.  Sharded runs (velocity_amd/dist.py): 0 = init, 1 = local normal equations ->
+// [Sfull | acc] (then all-reduced by the caller), 2 = solve + update (then acc all-reduced), 3 = iteration record.
 int vh_ba_run(const BaProblem& P, hipStream_t s)
 {
     const int nt = P.nt, nc = P.nc, nq = 6 * nc;
     if (nq > BA_THREADS) return -3;  // reduced rhs ownership (one thread per entry) needs 6 nc <= 256
     const int nparts = P.nparts;
     BaJob J;
-    J.nt = nt; J.nc = nc;
-    for (int k = 0; k < 9; k++) J.K[k] = P.K[k];
-    J.z = P.z; J.x = P.x; J.trace = P.trace; J.info = P.info;
-    char* w = reinterpret_cast<char*>(P.workspace);
-    auto take = [&](size_t n) { double* p = reinterpret_cast<double*>(w); w += (n * sizeof(double) + 255) / 256 * 256; return p; };
-    const size_t nf = nc + 1, m = (size_t)nt * nf;
-    J.camR = take(36 * nf); J.r = take(2 * m); J.Jp = take(6 * m); J.Jc = take(12 * m); J.tp = take(3 * (size_t)nt); J.Y = take(3 * (size_t)nq * nt);
-    J.Spart = take((size_t)nparts * nq * nq); J.Rpart = take((size_t)nparts * nq); J.Sfull = take((size_t)nq * (nq + 1)); J.dc = take(nq);
-    J.acc = take(4);
-    double* flags = take(32);
-    J.done = reinterpret_cast<int*>(flags);
-    J.ticket = reinterpret_cast<unsigned*>(flags) + 4;
-    hipError_t e = hipMemsetAsync(J.acc, 0, 4 * sizeof(double), s);
-    if (e == hipSuccess) e = hipMemsetAsync(flags, 0, 32 * sizeof(double), s);
-    if (e == hipSuccess) e = hipMemsetAsync(P.info, 0, 2 * sizeof(int), s);
-    if (e != hipSuccess) return (int)e;
+    double* flags;
+    ba_layout(P, J, flags);
     const long long nent = (long long)nq * nq;
     const int npass = (int)((nent + (long long)BA_THREADS * BA_EPT - 1) / ((long long)BA_THREADS * BA_EPT));
     const size_t lds = sizeof(double) * (size_t)(6 * nq + 12 * nc + 16);
     const size_t lds_mfma = sizeof(double) * (size_t)(24 * BA_NPAD + 48 * nc + 48 + 4 * BA_NPAD);
     const size_t solve_lds = sizeof(double) * (size_t)nq * (nq + 1);
-    if (solve_lds <= 160 * 1024 && solve_lds > 48 * 1024) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds);
-        if (ea != hipSuccess) return (int)ea;
-    }
     const int nmeas = nt * (nc + 1);
     const int upd_blocks = (nt + BA_THREADS - 1) / BA_THREADS;
-    for (int it = 0; it < P.max_iter; it++) {
+    auto init = [&]() -> int {
+        hipError_t e = hipMemsetAsync(J.acc, 0, 4 * sizeof(double), s);
+        if (e == hipSuccess) e = hipMemsetAsync(flags, 0, 32 * sizeof(double), s);
+        if (e == hipSuccess) e = hipMemsetAsync(P.info, 0, 2 * sizeof(int), s);
+        if (e == hipSuccess && solve_lds <= 160 * 1024 && solve_lds > 48 * 1024)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds);
+        return (int)e;
+    };
+    auto normal_equations = [&]() {
         hipLaunchKernelGGL(k_ba_cams, dim3((nc + 1 + 63) / 64), dim3(64), 0, s, J);
         hipLaunchKernelGGL(k_ba_jac, dim3((nmeas + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, s, J);
         if (nq <= BA_NPAD && !P.force_valu) {
             hipLaunchKernelGGL(k_ba_points_mfma, dim3(nparts), dim3(BA_THREADS), lds_mfma, s, J);
         } else {
-            for (int pass = 0; pass < npass; pass++) {
-                // later passes overwrite Spart entries of their own range only
+            for (int pass = 0; pass < npass; pass++)  // later passes overwrite Spart entries of their own range only
                 hipLaunchKernelGGL(k_ba_points, dim3(nparts), dim3(BA_THREADS), lds, s, J, pass);
-            }
         }
         hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((nent + nq + 31) / 32)), dim3(BA_THREADS), 0, s, J, nparts);
+    };
+    auto solve_update = [&](int it) {
         if (solve_lds <= 160 * 1024) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(BA_SOLVE_THREADS), solve_lds, s, J, nparts);
         else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(BA_SOLVE_THREADS), 0, s, J, nparts);
         hipLaunchKernelGGL(k_ba_update, dim3(upd_blocks), dim3(BA_THREADS), 0, s, J, it);
+    };
+    switch (P.phase) {
+    case -1: {
+        int r = init();
+        if (r) return r;
+        for (int it = 0; it < P.max_iter; it++) { normal_equations(); solve_update(it); }
+        break;
+    }
+    case 0: { int r = init(); if (r) return r; break; }
+    case 1: normal_equations(); break;
+    case 2: solve_update(P.it); break;
+    case 3: hipLaunchKernelGGL(k_ba_finalize, dim3(1), dim3(64), 0, s, J, P.it); break;
+    default: return -4;
     }
     return (int)hipGetLastError();
 }

@@ -21,7 +21,9 @@ struct BaJob {  // passed by value to every BA kernel
     int* info;        // [2] iterations, converged
     int* done;
     unsigned* ticket;
+    double nx_total, nz_total;  // normalisation of rms(delta) / rms(residual): whole-problem sizes (sharded runs)
     int nt, nc;
+    int add_identity, count_cams, defer_finalize;
 };
 
 struct BaProblem {
@@ -32,8 +34,12 @@ struct BaProblem {
     int* info;
     void* workspace;
     int nt, nc, max_iter, nparts;
+    int phase, it;   // phase -1: whole solve; 0..3: the pieces of one sharded iteration (see vh_ba_run)
+    int add_identity, count_cams, defer_finalize;
+    double nx_total, nz_total;
     int force_valu;  // test hook: 1 = accumulate the reduced camera system on the VALU instead of the matrix cores
 };
 
 size_t vh_ba_workspace_bytes(int nt, int nc, int nparts);
 int vh_ba_run(const BaProblem& P, hipStream_t s);
+void vh_ba_exchange_span(const BaProblem& P, size_t* offset_bytes, size_t* n_doubles);

@@ -62,3 +62,85 @@ class TrackStateExchange:
             self._work.wait()
             self._work = None
         return self.gathered
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# multi-GPU bundle adjustment (BA row): tie points are sharded over ranks, the nc free cameras are
+# replicated; per LM iteration ONE all-reduce of the reduced camera system [S | rhs | sums] (6nc x (6nc+1) + 4 float64,
+# 104 KB at nc = 19) and one of 4 scalars.  No host synchronisation inside the loop.
+# ----------------------------------------------------------------------------------------------------------------
+def shard_tracks(nt, world_size, rank):
+    """Contiguous block of tie-point indices owned by `rank`."""
+    ids = shard_streams(nt, world_size, rank)
+    return ids[0] if ids else 0, (ids[-1] + 1) if ids else 0
+
+
+def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None):
+    """fcnNLS_batch (utils/NLS.py:186-250) with the tie points sharded over the ranks of `group`.
+
+    Every rank passes the FULL P / pw / cw (like the reference call) and gets the full (cw, pw) back; internally it
+    packs and solves only its own block of tracks.  Works with any world size, including an uninitialised
+    process group (single rank).  Returns (cw, pw, trace) with trace = [(rms residual, rms delta)] per iteration.
+    """
+    import ctypes as C
+
+    from . import _lib as L
+
+    tc = L.torch_cuda()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    P = np.asarray(P)
+    pw = np.asarray(pw, np.float64)
+    cw = np.asarray(cw, np.float64)
+    keep = np.isfinite(P[4]).sum(1) == P.shape[2]  # NLS.py:190
+    P, pw = P[:, keep], pw[keep]
+    _, nt_total, nf = P.shape
+    nc = nf - 1
+    lo, hi = shard_tracks(nt_total, world, rank)
+    nt = hi - lo
+    if nt < 1:
+        raise ValueError("more ranks than tie points")
+    Pl = P[:, lo:hi]
+    z = np.concatenate([Pl[0].T.reshape(-1), Pl[1].T.reshape(-1)]).astype(np.float64)  # NLS.py:198-199 on the local tracks
+    z[np.isnan(z)] = 0
+    x0 = np.concatenate((pw[lo:hi], cw[1:], np.zeros((nc, 3)))).reshape(-1)
+    K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+    zd = L.to_dev(z, tc.float64)
+    xd = L.to_dev(x0, tc.float64).clone()
+    trace = tc.zeros((max_iter, 2), dtype=tc.float64, device="cuda")
+    info = tc.zeros(2, dtype=tc.int32, device="cuda")
+    ws = L.workspace()
+    nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+    scratch = tc.empty(nbytes // 8 + 1, dtype=tc.float64, device="cuda")  # float64 so that the exchange span is a view of it
+    off, cnt = C.c_size_t(), C.c_size_t()
+
+    def phase(ph, it=0):
+        L.check(ws.lib.vh_nls_batch_phase(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, nt_total, int(rank == 0), ph, it,
+                                          L.dptr(trace), L.dptr(info), L.dptr(scratch), nbytes, C.byref(off), C.byref(cnt), L.stream_ptr()),
+                "vh_nls_batch_phase")
+
+    phase(0)
+    assert off.value % 8 == 0
+    span = scratch[off.value // 8 : off.value // 8 + cnt.value]
+    sums = span[-4:]
+    for it in range(max_iter):
+        phase(1, it)
+        if world > 1:
+            dist.all_reduce(span, group=group)
+        phase(2, it)
+        if world > 1:
+            dist.all_reduce(sums, group=group)
+        phase(3, it)
+    info_h = info.cpu().numpy()
+    x = xd.cpu().numpy()
+    # gather the point blocks (cameras are identical on every rank)
+    pw_local = tc.from_numpy(x[: 3 * nt].reshape(nt, 3)).cuda()
+    if world > 1:
+        sizes = [shard_tracks(nt_total, world, r) for r in range(world)]
+        parts = [tc.zeros((b - a, 3), dtype=tc.float64, device="cuda") for a, b in sizes]
+        dist.all_gather(parts, pw_local, group=group)
+        pw_out = tc.cat(parts).cpu().numpy()
+    else:
+        pw_out = pw_local.cpu().numpy()
+    cw_out = np.concatenate((np.zeros((1, 3)), x[3 * nt : 3 * nt + 3 * nc].reshape(nc, 3)), 0)
+    return cw_out, pw_out, trace.cpu().numpy()[: info_h[0]]
