@@ -949,7 +949,7 @@ __device__ void lk3_track(const PyrDesc& PI, const PyrDesc& PJ, int max_count, d
                               n_setup, want_err);
 }
 
-// (forcing 6 workgroups per CU through the second launch bound spills and measured 8 % slower: not used)
+// (forcing 5 or 6 workgroups per CU through the second launch bound spills and measured 3-8 % slower: not used)
 template <int WIN, int NW, int M>
 __global__ __launch_bounds__(64 * NW) void k_lk3(const void* job_tab, size_t tab_stride)
 {
