@@ -11,6 +11,14 @@
 #define W_BITS 14
 #define LK_FLT_SCALE (1.f / (1 << 20))
 
+// (float)v for |v| < 2^53 with ONE rounding: hi * 2^32 + lo is exact in float64, the final conversion rounds once --
+// identical to the int64 -> float32 conversion, in 5 instructions instead of the compiler's ~15-instruction sequence
+__device__ __forceinline__ float i64_to_f32(long long v)
+{
+    const double d = __dadd_rn(__dmul_rn((double)(int)(v >> 32), 4294967296.0), (double)(unsigned)(v & 0xffffffffll));
+    return (float)d;
+}
+
 struct Win {
     int w00, w01, w10, w11;
 };
@@ -133,7 +141,7 @@ __device__ void lk_level(const ImgDesc I, const ImgDesc J, int win, int level, i
     sA11 = vh_wave_sum_i64(sA11);
     sA12 = vh_wave_sum_i64(sA12);
     sA22 = vh_wave_sum_i64(sA22);
-    const float A11 = __fmul_rn((float)sA11, LK_FLT_SCALE), A12 = __fmul_rn((float)sA12, LK_FLT_SCALE), A22 = __fmul_rn((float)sA22, LK_FLT_SCALE);
+    const float A11 = __fmul_rn(i64_to_f32(sA11), LK_FLT_SCALE), A12 = __fmul_rn(i64_to_f32(sA12), LK_FLT_SCALE), A22 = __fmul_rn(i64_to_f32(sA22), LK_FLT_SCALE);
     float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
     const float dA = __fsub_rn(A11, A22);
     const float disc = __fadd_rn(__fmul_rn(dA, dA), __fmul_rn(__fmul_rn(4.f, A12), A12));
@@ -168,7 +176,7 @@ __device__ void lk_level(const ImgDesc I, const ImgDesc J, int win, int level, i
         }
         sb1 = vh_wave_sum_i64(sb1);
         sb2 = vh_wave_sum_i64(sb2);
-        const float b1 = __fmul_rn((float)sb1, LK_FLT_SCALE), b2 = __fmul_rn((float)sb2, LK_FLT_SCALE);
+        const float b1 = __fmul_rn(i64_to_f32(sb1), LK_FLT_SCALE), b2 = __fmul_rn(i64_to_f32(sb2), LK_FLT_SCALE);
         const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, b2), __fmul_rn(A22, b1)), D);
         const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, b1), __fmul_rn(A11, b2)), D);
         nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
@@ -298,6 +306,15 @@ __device__ __forceinline__ long long wave_sum_i32_wide(int v)
     const int hi_t = __builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) + __builtin_amdgcn_readlane(hi, 32) +
                      __builtin_amdgcn_readlane(hi, 48);
     return (long long)hi_t * 65536ll + (long long)lo_t;
+}
+
+// wave-wide sum when 16 lanes of partials provably fit int32 (one 4-sample strip per lane: 16 * 4 * 8160 * 4080 < 2^31):
+// one DPP chain per value instead of two
+__device__ __forceinline__ long long wave_sum_i32_rows(int v)
+{
+    const int r = dpp_row_sum(v);
+    return (long long)__builtin_amdgcn_readlane(r, 0) + (long long)__builtin_amdgcn_readlane(r, 16) +
+           (long long)__builtin_amdgcn_readlane(r, 32) + (long long)__builtin_amdgcn_readlane(r, 48);
 }
 
 __device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
@@ -546,8 +563,11 @@ __device__ void lk_level_strip(const ImgDesc I, const ImgDesc J, int win_rt, int
             }
         }
     }
-    const long long sA11 = wave_sum_i32_wide(a11), sA12 = wave_sum_i32_wide(a12), sA22 = wave_sum_i32_wide(a22);
-    const float A11 = __fmul_rn((float)sA11, LK_FLT_SCALE), A12 = __fmul_rn((float)sA12, LK_FLT_SCALE), A22 = __fmul_rn((float)sA22, LK_FLT_SCALE);
+    constexpr bool ROWSAFE = WIN_T != 0 && ((WIN_T + 3) >> 2) * WIN_T <= 64;  // one strip per lane
+    const long long sA11 = ROWSAFE ? wave_sum_i32_rows(a11) : wave_sum_i32_wide(a11);
+    const long long sA12 = ROWSAFE ? wave_sum_i32_rows(a12) : wave_sum_i32_wide(a12);
+    const long long sA22 = ROWSAFE ? wave_sum_i32_rows(a22) : wave_sum_i32_wide(a22);
+    const float A11 = __fmul_rn(i64_to_f32(sA11), LK_FLT_SCALE), A12 = __fmul_rn(i64_to_f32(sA12), LK_FLT_SCALE), A22 = __fmul_rn(i64_to_f32(sA22), LK_FLT_SCALE);
     float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
     const float dA = __fsub_rn(A11, A22);
     const float disc = __fadd_rn(__fmul_rn(dA, dA), __fmul_rn(__fmul_rn(4.f, A12), A12));
@@ -618,8 +638,9 @@ __device__ void lk_level_strip(const ImgDesc I, const ImgDesc J, int win_rt, int
                 if (j >= spr) { j -= spr; y++; }
             }
         }
-        const long long sb1 = wave_sum_i32_wide(b1), sb2 = wave_sum_i32_wide(b2);
-        const float fb1 = __fmul_rn((float)sb1, LK_FLT_SCALE), fb2 = __fmul_rn((float)sb2, LK_FLT_SCALE);
+        const long long sb1 = ROWSAFE ? wave_sum_i32_rows(b1) : wave_sum_i32_wide(b1);
+        const long long sb2 = ROWSAFE ? wave_sum_i32_rows(b2) : wave_sum_i32_wide(b2);
+        const float fb1 = __fmul_rn(i64_to_f32(sb1), LK_FLT_SCALE), fb2 = __fmul_rn(i64_to_f32(sb2), LK_FLT_SCALE);
         const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
         const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
         nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
@@ -657,8 +678,8 @@ __device__ void lk_level_strip(const ImgDesc I, const ImgDesc J, int win_rt, int
             j += jinc; y += yinc;
             if (j >= spr) { j -= spr; y++; }
         }
-        const long long sse = wave_sum_i32_wide(se);
-        err = __fmul_rn((float)sse, __fdiv_rn(1.f, (float)(32 * win * win)));
+        const long long sse = ROWSAFE ? wave_sum_i32_rows(se) : wave_sum_i32_wide(se);
+        err = __fmul_rn(i64_to_f32(sse), __fdiv_rn(1.f, (float)(32 * win * win)));
     }
 }
 
@@ -802,12 +823,12 @@ __device__ __forceinline__ void stage_region(const ImgDesc& im, int rx, int ry, 
 }
 
 // block-wide exact sum of NV per-lane int32 partials -> int64 totals valid in every thread
-template <int NW, int NV>
+template <int NW, int NV, bool ROWSAFE>
 __device__ __forceinline__ void block_sum_wide(const int* part, long long* tot, long long* red, int& phase, int wave)
 {
     long long w[NV];
 #pragma unroll
-    for (int k = 0; k < NV; k++) w[k] = wave_sum_i32_wide(part[k]);
+    for (int k = 0; k < NV; k++) w[k] = ROWSAFE ? wave_sum_i32_rows(part[k]) : wave_sum_i32_wide(part[k]);
     if (NW == 1) {
 #pragma unroll
         for (int k = 0; k < NV; k++) tot[k] = w[k];
@@ -884,8 +905,8 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
         }
     }
     long long sA[3];
-    block_sum_wide<NW, 3>(part, sA, red, phase, wave);
-    const float A11 = __fmul_rn((float)sA[0], LK_FLT_SCALE), A12 = __fmul_rn((float)sA[1], LK_FLT_SCALE), A22 = __fmul_rn((float)sA[2], LK_FLT_SCALE);
+    block_sum_wide<NW, 3, (C::K == 1 && C::NS <= 64)>(part, sA, red, phase, wave);
+    const float A11 = __fmul_rn(i64_to_f32(sA[0]), LK_FLT_SCALE), A12 = __fmul_rn(i64_to_f32(sA[1]), LK_FLT_SCALE), A22 = __fmul_rn(i64_to_f32(sA[2]), LK_FLT_SCALE);
     float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
     const float dA = __fsub_rn(A11, A22);
     const float disc = __fadd_rn(__fmul_rn(dA, dA), __fmul_rn(__fmul_rn(4.f, A12), A12));
@@ -943,8 +964,8 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
             }
         }
         long long sb[2];
-        block_sum_wide<NW, 2>(b, sb, red, phase, wave);
-        const float fb1 = __fmul_rn((float)sb[0], LK_FLT_SCALE), fb2 = __fmul_rn((float)sb[1], LK_FLT_SCALE);
+        block_sum_wide<NW, 2, (C::K == 1 && C::NS <= 64)>(b, sb, red, phase, wave);
+        const float fb1 = __fmul_rn(i64_to_f32(sb[0]), LK_FLT_SCALE), fb2 = __fmul_rn(i64_to_f32(sb[1]), LK_FLT_SCALE);
         const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
         const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
         nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
@@ -982,8 +1003,8 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
             }
         }
         long long sse[1];
-        block_sum_wide<NW, 1>(se, sse, red, phase, wave);
-        err = __fmul_rn((float)sse[0], __fdiv_rn(1.f, (float)(32 * WIN * WIN)));
+        block_sum_wide<NW, 1, (C::K == 1 && C::NS <= 64)>(se, sse, red, phase, wave);
+        err = __fmul_rn(i64_to_f32(sse[0]), __fdiv_rn(1.f, (float)(32 * WIN * WIN)));
     }
 }
 
