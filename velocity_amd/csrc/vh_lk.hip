@@ -1111,7 +1111,12 @@ int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, i
     // variant is 2.5x slower there).  Mode 3 forces the staged kernel for both windows (tests).
     if (g_lk_force_generic == 0 || g_lk_force_generic == 3) {
         if (win == 15 && g_lk_force_generic == 3) return launch_lk3<15, 1, 6>(job_tab, tab_stride, batch, max_n, s);
-        if (win == 51) return launch_lk3<51, 4, 4>(job_tab, tab_stride, batch, max_n, s);
+        // 4 wavefronts per track minimise latency (few tracks in flight); 2 per track halve the replicated uniform work and
+        // measured 17 % faster once the chip is full (1 per track starves occupancy: 2x slower)
+        if (win == 51) {
+            if (g_lk_force_generic == 0 && (long long)max_n * batch >= 6144) return launch_lk3<51, 2, 4>(job_tab, tab_stride, batch, max_n, s);
+            return launch_lk3<51, 4, 4>(job_tab, tab_stride, batch, max_n, s);
+        }
     }
     if (g_lk_force_generic != 1 && win <= 63) {
         // int32 per-lane partial sums are exact up to 16 strips per lane (win <= 63)
