@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-ba", action="store_true", help="skip the BA (config 5) leg")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("VH_BENCH_GROUPS", 1)),
                     help="split the resident streams into this many sessions on separate HIP streams (their latency-bound stages overlap)")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="frames start in pinned HOST memory and are uploaded every step (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the track-state exchange even with one rank (smoke test of the N>1 path)")
     return ap.parse_args()
 
@@ -169,6 +171,8 @@ def main():
     ses = sessions[0]
     # streams of one rank share the ring but run at different phases, so every launch sees S different frame pairs
     phase = [(7 * b) % a.ring for b in range(S)]
+    if a.host_frames:
+        phase = [b % a.ring for b in range(S)]  # consecutive phases: one step's batch is a contiguous slice of the extended host ring
     base_ptr = frames.data_ptr()
     fbytes = W * H
     for b in range(S):
@@ -182,7 +186,25 @@ def main():
     ex = vdist.TrackStateExchange(S, N, every=a.exchange_every, device=dev) if use_dist else None
     torch.cuda.synchronize()
 
+    feeder = None
+    if a.host_frames:
+        from velocity_amd.driver import HostFrameFeeder
+
+        assert G == 1, "--host-frames is measured with one session group"
+        feeder = HostFrameFeeder(S, H, W, depth=3)
+        reps = (S + a.ring - 1) // a.ring + 1
+        host_ring = torch.cat([frames.cpu()] * reps, 0)[: a.ring + S].contiguous().pin_memory()  # stands for the decoder's pinned output
+
+    def run_host(first, count):
+        for i in range(first, first + count):
+            k = i % a.ring
+            s_ = feeder.put(host_ring[k : k + S])  # stream b <- frame (b + i) % ring, straight from pinned memory
+            sessions[0].step(frames_table=feeder.get(s_), time_s=i / 30.0, frame_no=i)
+            feeder.after_step(s_)
+
     def run(first, count):
+        if feeder is not None:
+            return run_host(first, count)
         for i in range(first, first + count):
             row = tables[i % a.ring]
             for g in range(G):
@@ -258,7 +280,7 @@ def main():
         out = dict(metric="tracked frames/sec (KLT 2000 tracks + NLS pose, 1080p)" if a.config == "c2" else "tracked frames/sec (KLT 5000 tracks + NLS pose, 4K)",
                    value=round(value, 2), unit="frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=round(1e3 * elapsed / a.steps, 4), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="i32+f32 (KLT) / f64 (NLS)",
-                   data="synthetic",
+                   data="synthetic" + (" (frames uploaded from pinned host memory every step: PCIe-inclusive)" if a.host_frames else ""),
                    config=dict(workload=cfg["name"] + f"; {S} independent streams resident per GPU, one launch sequence per step",
                                params=a.params, coarse=dict(L.LK_COARSE, **lkc), fine=dict(L.LK_FINE), streams_per_gpu=S, tracks=N,
                                stream_groups=G,

@@ -83,3 +83,36 @@ def test_session_batch_streams_are_independent():
         assert np.array_equal(st["vg"], orcs[b].vg) and np.array_equal(st["vp"], orcs[b].vp)
         assert np.array_equal(st["p"], orcs[b].p)
         np.testing.assert_allclose(st["t"], orcs[b].t, rtol=1e-5)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_frame_feeder_gives_the_same_tracks(pinned):
+    """Frames uploaded through the pinned double-buffered feeder (side stream) == frames already resident in HBM."""
+    import torch
+
+    from velocity_amd.driver import HostFrameFeeder, TrackerSession
+
+    W, H, n0, nframes, B = 480, 270, 200, 8, 2
+    scenes = [_scene(W, H, n0, nframes, 4242 + 13 * b) for b in range(B)]
+    t0 = np.float32([1.5, 0.45, 3.6])
+    out = []
+    for mode in ("device", "host"):
+        ses = TrackerSession(scenes[0][4], W, H, n0, nhist=nframes, batch=B, msv_frame=0)
+        for b, (frames, p, p3, vp, K) in enumerate(scenes):
+            ses.init_stream(b, frames[0], p, p3, vp, t0)
+        feeder = HostFrameFeeder(B, H, W, depth=3) if mode == "host" else None
+        held = []
+        for i in range(1, nframes):
+            batch = np.stack([scenes[b][0][i] for b in range(B)])
+            if feeder is None:
+                ses.step([torch.from_numpy(batch[b]).cuda() for b in range(B)], time_s=i / 30.0, frame_no=i)
+                continue
+            src = torch.from_numpy(batch).pin_memory() if pinned else batch
+            held.append(src)
+            slot = feeder.put(src)
+            ses.step(frames_table=feeder.get(slot), time_s=i / 30.0, frame_no=i)
+            feeder.after_step(slot)
+        out.append([ses.state(b) for b in range(B)])
+    for b in range(B):
+        for key in ("vg", "vp", "p", "t", "res"):
+            assert np.array_equal(out[0][b][key], out[1][b][key]), key

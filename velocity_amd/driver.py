@@ -94,3 +94,58 @@ class TrackerSession:
                 self.handle = None
         except Exception:
             pass
+
+
+class HostFrameFeeder:
+    """Frame ingest from host memory: pinned staging buffers + a side HIP stream, double buffered,
+    so the PCIe upload of frame i+1 overlaps the tracking of frame i.  `put(frames)` starts the upload of one frame per
+    stream (numpy uint8 [H,W] arrays or a single [batch,H,W] array) and returns the slot; `get(slot)` makes the current
+    stream wait for it and returns the device table of frame pointers for TrackerSession.step(frames_table=...);
+    `after_step(slot)` hands the previous frame's buffer back.  depth >= 3 keeps the upload one frame ahead."""
+
+    def __init__(self, batch, height, width, depth=3):
+        torch = L.torch_cuda()
+        self.torch, self.batch, self.depth = torch, batch, depth
+        self.pinned = [torch.empty((batch, height, width), dtype=torch.uint8).pin_memory() for _ in range(depth)]
+        self.dev = [torch.empty((batch, height, width), dtype=torch.uint8, device="cuda") for _ in range(depth)]
+        self.tables = [torch.tensor([self.dev[k][b].data_ptr() for b in range(batch)], dtype=torch.int64, device="cuda") for k in range(depth)]
+        self.copy_stream = torch.cuda.Stream()
+        self.ready = [torch.cuda.Event() for _ in range(depth)]
+        self.free = [torch.cuda.Event() for _ in range(depth)]
+        for e in self.free + self.ready:
+            e.record()
+        self.n = 0
+        self._last = None
+
+    def put(self, frames):
+        """frames: a pinned torch uint8 tensor [batch,H,W] (uploaded in place, zero staging copies — the decoder should
+        write there), or numpy arrays, which are first staged into this feeder's pinned slot."""
+        torch = self.torch
+        slot = self.n % self.depth
+        self.n += 1
+        if isinstance(frames, torch.Tensor) and frames.is_pinned():
+            src = frames
+        else:
+            self.ready[slot].synchronize()  # the previous upload out of this staging slot must have finished
+            src = self.pinned[slot]
+            if isinstance(frames, np.ndarray) and frames.ndim == 3:
+                src.numpy()[...] = frames
+            else:
+                for b, f in enumerate(frames):
+                    src[b].numpy()[...] = f
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.free[slot])  # the tracker is done with this device buffer
+            self.dev[slot].copy_(src, non_blocking=True)
+            self.ready[slot].record(self.copy_stream)
+        return slot
+
+    def get(self, slot):
+        self.torch.cuda.current_stream().wait_event(self.ready[slot])
+        return self.tables[slot]
+
+    def after_step(self, slot):
+        """Call right after the step that consumed `slot` has been enqueued.  The frame of the PREVIOUS step was that step's
+        im0 and is free from here on (a frame is read by two steps: as im1, then as im0)."""
+        if self._last is not None:
+            self.free[self._last].record(self.torch.cuda.current_stream())
+        self._last = slot
