@@ -191,7 +191,8 @@ VH_API int vh_session_ptrs(vh_session* s, int slot, vh_session_view* out_host);
 VH_API int vh_session_pack_state(vh_session* s, float* out, void* stream);
 
 /* test hook: route every LK window through one implementation -- 1: per-sample kernel, 2: strip kernel, 3: LDS-staged
- * kernel, 0: default routing per window.  All three are bit-identical. */
+ * kernel, 4: 4-tracks-per-wavefront kernel (15x15 windows; others as in 2), 0: default routing per window and load.
+ * All are bit-identical. */
 VH_API void vh_debug_force_generic_lk(int on);
 
 /* test hook: 1 accumulates the reduced camera system of vh_nls_batch on the VALU instead of the f64 matrix cores */

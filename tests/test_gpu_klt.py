@@ -114,6 +114,15 @@ def test_pyr_lk_bit_exact(seq, lk, fbt):
     assert np.array_equal(v, ev)
     assert np.array_equal(p2, e2)
     assert np.array_equal(err.ravel(), eerr)
+    # the 4-tracks-per-wave kernel (default only for large batches) on the same border / REFLECT_101 cases
+    from velocity_amd import _lib as L
+
+    L.load().vh_debug_force_generic_lk(4)
+    try:
+        p4, v4, err4 = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=fbt, **lk)
+    finally:
+        L.load().vh_debug_force_generic_lk(0)
+    assert np.array_equal(v4, ev) and np.array_equal(p4, e2) and np.array_equal(err4.ravel(), eerr)
     assert v[: len(p0)].mean() > 0.9
 
 
@@ -127,7 +136,7 @@ def test_strip_and_per_sample_lk_kernels_agree(seq):
     pts = np.concatenate([p0, rng.uniform(-20, 30, (60, 2)).astype(np.float32), rng.uniform([W - 30, H - 30], [W + 20, H + 20], (60, 2)).astype(np.float32)])
     for lk in (CV_COARSE, CV_FINE, dict(winSize=(9, 9), maxLevel=3, criteria=(3, 20, 0.03)), dict(winSize=(31, 31), maxLevel=1, criteria=(3, 20, 0.03))):
         a = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=0.5, **lk)
-        for mode in (1, 2, 3):  # 1: per-sample kernel, 2: strip kernel, 3: LDS-staged kernel; default: routed per window
+        for mode in (1, 2, 3, 4):  # 1: per-sample, 2: strip, 3: LDS-staged, 4: 4-tracks-per-wave (15x15 only); default: routed
             L.load().vh_debug_force_generic_lk(mode)
             try:
                 b = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=0.5, **lk)
@@ -151,7 +160,7 @@ def test_pyr_lk_large_motion_restages_search_region():
                    (dict(winSize=(51, 51), maxLevel=0, criteria=(3, 30, 0.001)), dict(win=51, max_level=0, max_count=30, eps=0.001)),
                    (dict(winSize=(15, 15), maxLevel=1, criteria=(3, 10, 0.1)), dict(win=15, max_level=1, max_count=10, eps=0.1))):
         e2, ev, eerr = KO.lk_fb(f0, f1, pts, fbt=2.0, **kw)
-        for mode in (0, 3):  # default routing and the LDS-staged kernel for both windows
+        for mode in (0, 3, 4):  # default routing, the LDS-staged kernel for both windows, 4 tracks per wave for 15x15
             L.load().vh_debug_force_generic_lk(mode)
             try:
                 p2, v, err = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=2.0, **lk)

@@ -1079,6 +1079,246 @@ __global__ __launch_bounds__(64 * NW) void k_lk3(const void* job_tab, size_t tab
     }
 }
 
+// =================================================================================================================
+// v4: quarter-wave kernel for small windows (WIN <= 16, the 15x15 coarse stages).
+// One DPP row (16 lanes) per track, 4 tracks per wavefront: lane r owns window row r and its (WIN+3)/4 strips, the
+// template quads stay in registers (no LDS at all), the exact window sums are 16-lane DPP reductions, and what used to be
+// wave-uniform scalar work (weights, the 2x2 solve, the stop rules) is one vector instruction stream serving 4 tracks.
+// A one-wave-per-track kernel spends about half of its instructions of a 15x15 Newton iteration on that uniform part
+// and on the wave reduction; here it is shared 4 ways.  Rows of the search window are loaded once per lane and handed
+// to the lane above through DPP (the bilinear cell needs rows r and r+1).  Same integers, same float sequence per
+// track as the kernels above: bit-identical results.
+// =================================================================================================================
+__device__ __forceinline__ long long row16_sum_wide(int v)
+{
+    const int lo = dpp_row_sum(v & 0xffff), hi = dpp_row_sum(v >> 16);
+    return (long long)hi * 65536ll + (long long)lo;
+}
+__device__ __forceinline__ unsigned dpp_from_next_lane(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);  // row_shl:1 -> lane i reads lane i+1
+}
+
+// NW5 = number of aligned 4-byte words a lane needs from one image row, starting at pixel (gx, gy): word i = bytes 4i..4i+3
+template <int NWORDS>
+__device__ __forceinline__ void load_row_words(const ImgDesc& im, int gx, int gy, bool fast, unsigned* a)
+{
+    if (fast) {
+        const uintptr_t p = reinterpret_cast<uintptr_t>(im.p + (ptrdiff_t)gy * im.stride + gx);
+        const unsigned sh = (unsigned)(p & 3);
+        gptr_u32 ap = (gptr_u32)(p - sh);
+        unsigned d[NWORDS + 1];
+#pragma unroll
+        for (int i = 0; i <= NWORDS; i++) d[i] = ap[i];
+#pragma unroll
+        for (int i = 0; i < NWORDS; i++) a[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+    } else {
+        const uint8_t* row = im.p + (size_t)vh_reflect101(gy, im.h) * im.stride;
+#pragma unroll
+        for (int i = 0; i < NWORDS; i++) {
+            unsigned v = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) v |= (unsigned)row[vh_reflect101(gx + 4 * i + c, im.w)] << (8 * c);
+            a[i] = v;
+        }
+    }
+}
+
+template <int WIN>
+__device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int level, int top_level, int max_count, double eps2, float p0x,
+                                          float p0y, float& nxo, float& nyo, int& status, float& err, int r, int& n_iter, int& n_setup,
+                                          bool want_err)
+{
+    constexpr int NS = (WIN + 3) >> 2;  // strips per row
+    const float half = (float)(WIN - 1) * 0.5f;
+    const float lscale = (float)(1. / (double)(1 << level));
+    float px = __fmul_rn(p0x, lscale), py = __fmul_rn(p0y, lscale);
+    float nx, ny;
+    if (level == top_level) { nx = px; ny = py; }
+    else { nx = __fmul_rn(nxo, 2.f); ny = __fmul_rn(nyo, 2.f); }
+    nxo = nx; nyo = ny;
+
+    px = __fsub_rn(px, half); py = __fsub_rn(py, half);
+    const int ipx = vh_floor(px), ipy = vh_floor(py);
+    if (ipx < -WIN || ipx >= I.w || ipy < -WIN || ipy >= I.h) {
+        if (level == 0) { status = 0; err = 0.f; }
+        return;
+    }
+    const Win w0 = bilinear_weights(__fsub_rn(px, (float)ipx), __fsub_rn(py, (float)ipy));
+    n_setup++;
+
+    int a11 = 0, a12 = 0, a22 = 0;
+    uint2 tI[NS], tX[NS], tY[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) { tI[j] = make_uint2(0, 0); tX[j] = make_uint2(0, 0); tY[j] = make_uint2(0, 0); }
+    {
+        const bool fast = ipx >= 4 && ipy >= 1 && ipx + WIN + 12 <= I.w && ipy + WIN + 2 <= I.h;
+        if (r < WIN) {
+            unsigned a[4][NS + 1];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) load_row_words<NS + 1>(I, ipx - 1, ipy + r - 1 + rr, fast, a[rr]);
+#pragma unroll
+            for (int j = 0; j < NS; j++) {
+                const unsigned lo[4] = {a[0][j], a[1][j], a[2][j], a[3][j]}, hi[4] = {a[0][j + 1], a[1][j + 1], a[2][j + 1], a[3][j + 1]};
+                const int cnt = WIN - 4 * j < 4 ? WIN - 4 * j : 4;
+                if (fast) strip_setup<true>(lo, hi, w0, I, ipx, ipy, 4 * j, r, cnt, tI, tX, tY, j, a11, a12, a22);
+                else strip_setup<false>(lo, hi, w0, I, ipx, ipy, 4 * j, r, cnt, tI, tX, tY, j, a11, a12, a22);
+            }
+        }
+    }
+    const float A11 = __fmul_rn(i64_to_f32(row16_sum_wide(a11)), LK_FLT_SCALE), A12 = __fmul_rn(i64_to_f32(row16_sum_wide(a12)), LK_FLT_SCALE),
+                A22 = __fmul_rn(i64_to_f32(row16_sum_wide(a22)), LK_FLT_SCALE);
+    float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
+    const float dA = __fsub_rn(A11, A22);
+    const float disc = __fadd_rn(__fmul_rn(dA, dA), __fmul_rn(__fmul_rn(4.f, A12), A12));
+    const float minEig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11), vh_sqrtf(disc)), (float)(2 * WIN * WIN));
+    if (minEig < 1e-4f || D < 1.1920929e-07f) {
+        if (level == 0) status = 0;
+        return;
+    }
+    D = __fdiv_rn(1.f, D);
+
+    nx = __fsub_rn(nx, half); ny = __fsub_rn(ny, half);
+    float pdx = 0.f, pdy = 0.f;
+    for (int it = 0; it < max_count; it++) {
+        const int inx = vh_floor(nx), iny = vh_floor(ny);
+        if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
+            if (level == 0) status = 0;
+            break;
+        }
+        const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny)));
+        const bool fast = inx >= 3 && iny >= 0 && inx + WIN + 12 <= J.w && iny + WIN + 1 <= J.h;
+        n_iter++;
+        unsigned top[NS + 1], bot[NS + 1];
+        load_row_words<NS + 1>(J, inx, iny + r, fast, top);  // lane r = row r (lane WIN holds the last bottom row)
+#pragma unroll
+        for (int i = 0; i <= NS; i++) bot[i] = dpp_from_next_lane(top[i]);
+        int b1 = 0, b2 = 0;
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const unsigned lo[2] = {top[j], bot[j]}, hi[2] = {top[j + 1], bot[j + 1]};
+            unsigned p01, p23;
+            strip_bilinear(lo, hi, w, p01, p23);
+            const unsigned d01 = __builtin_bit_cast(unsigned, as_s2(p01) - as_s2(tI[j].x));
+            const unsigned d23 = __builtin_bit_cast(unsigned, as_s2(p23) - as_s2(tI[j].y));
+            // rows >= WIN and samples beyond the window edge carry Ix = Iy = 0, so they add nothing
+            b1 = dot2(d23, tX[j].y, dot2(d01, tX[j].x, b1));
+            b2 = dot2(d23, tY[j].y, dot2(d01, tY[j].x, b2));
+        }
+        const float fb1 = __fmul_rn(i64_to_f32(row16_sum_wide(b1)), LK_FLT_SCALE), fb2 = __fmul_rn(i64_to_f32(row16_sum_wide(b2)), LK_FLT_SCALE);
+        const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
+        const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
+        nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
+        nxo = __fadd_rn(nx, half); nyo = __fadd_rn(ny, half);
+        if (__dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy)) <= eps2) break;
+        if (it > 0 && fabsf(__fadd_rn(dx, pdx)) < 0.01f && fabsf(__fadd_rn(dy, pdy)) < 0.01f) {
+            nxo = __fsub_rn(nxo, __fmul_rn(dx, 0.5f));
+            nyo = __fsub_rn(nyo, __fmul_rn(dy, 0.5f));
+            break;
+        }
+        pdx = dx; pdy = dy;
+    }
+
+    if (status && level == 0) {
+        const float fx = __fsub_rn(nxo, half), fy = __fsub_rn(nyo, half);
+        const int inx = vh_floor(fx), iny = vh_floor(fy);
+        if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) { status = 0; return; }
+        if (!want_err) return;
+        const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny)));
+        const bool fast = inx >= 3 && iny >= 0 && inx + WIN + 12 <= J.w && iny + WIN + 1 <= J.h;
+        unsigned top[NS + 1], bot[NS + 1];
+        load_row_words<NS + 1>(J, inx, iny + r, fast, top);
+#pragma unroll
+        for (int i = 0; i <= NS; i++) bot[i] = dpp_from_next_lane(top[i]);
+        int se = 0;
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const unsigned lo[2] = {top[j], bot[j]}, hi[2] = {top[j + 1], bot[j + 1]};
+            unsigned p01, p23;
+            strip_bilinear(lo, hi, w, p01, p23);
+            const short2v d01 = as_s2(p01) - as_s2(tI[j].x), d23 = as_s2(p23) - as_s2(tI[j].y);
+            const int d[4] = {d01.x, d01.y, d23.x, d23.y};
+            const int cnt = WIN - 4 * j < 4 ? WIN - 4 * j : 4;
+#pragma unroll
+            for (int c = 0; c < 4; c++) se += (c < cnt && r < WIN) ? (d[c] < 0 ? -d[c] : d[c]) : 0;
+        }
+        err = __fmul_rn(i64_to_f32(row16_sum_wide(se)), __fdiv_rn(1.f, (float)(32 * WIN * WIN)));
+    }
+}
+
+template <int WIN>
+__device__ __forceinline__ void lkq_track(const PyrDesc& PI, const PyrDesc& PJ, int max_count, double eps2, float px, float py, float& ox,
+                                          float& oy, int& status, float& err, int r, int& n_iter, int& n_setup, bool want_err)
+{
+    const int nl = min(PI.nlevels, PJ.nlevels);
+    status = 1;
+    err = 0.f;
+    ox = 0.f; oy = 0.f;
+    for (int level = nl - 1; level >= 0; level--)
+        lkq_level<WIN>(PI.lv[level], PJ.lv[level], level, nl - 1, max_count, eps2, px, py, ox, oy, status, err, r, n_iter, n_setup, want_err);
+}
+
+template <int WIN>
+__global__ __launch_bounds__(64) void k_lk_q(const void* job_tab, size_t tab_stride)
+{
+    static_assert(WIN <= 15, "lane WIN of every 16-lane row carries the extra bottom row");
+    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
+    const int n = job.n_ptr ? *job.n_ptr : job.n;
+    const int pt = blockIdx.x * 4 + (threadIdx.x >> 4);
+    if (pt >= n) return;  // whole 16-lane rows leave together
+    const int r = threadIdx.x & 15;
+
+    const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];
+    const float px = __fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]);
+    const float py = __fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]);
+
+    float fx, fy, err;
+    int st, n_iter = 0, n_setup = 0;
+    lkq_track<WIN>(job.I, job.J, job.max_count, job.eps2, px, py, fx, fy, st, err, r, n_iter, n_setup, job.err_out != nullptr);
+    float fbe = 0.f;
+    if (job.fbt >= 0.f) {
+        float bx, by, e2;
+        int st2;
+        lkq_track<WIN>(job.J, job.I, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, r, n_iter, n_setup, false);
+        const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
+        fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
+        st = st && st2 && (fbe < job.fbt);
+    }
+    if (r == 0) {
+        float ox, oy;
+        if (job.out_mode == VH_OUT_SCALE) {
+            ox = __fdiv_rn(fx, job.out_scale);
+            oy = __fdiv_rn(fy, job.out_scale);
+        } else {
+            const float ax = __fadd_rn(fx, job.in_off[0]), ay = __fadd_rn(fy, job.in_off[1]);
+            if (job.out_mode == VH_OUT_TRANSLATE) {
+                ox = __fadd_rn(ax, job.out_off[0]);
+                oy = __fadd_rn(ay, job.out_off[1]);
+            } else {
+                ox = __fadd_rn(__fadd_rn(__fmul_rn(ax, job.T[0]), __fmul_rn(ay, job.T[2])), job.T[4]);
+                oy = __fadd_rn(__fadd_rn(__fmul_rn(ax, job.T[1]), __fmul_rn(ay, job.T[3])), job.T[5]);
+            }
+        }
+        job.p_out[2 * pt] = ox;
+        job.p_out[2 * pt + 1] = oy;
+        job.v_out[pt] = (uint8_t)(st != 0);
+        if (job.err_out) job.err_out[pt] = err;
+        if (job.fbe_out) job.fbe_out[pt] = fbe;
+        if (job.praw_out) { job.praw_out[2 * pt] = fx; job.praw_out[2 * pt + 1] = fy; }
+        if (job.stats) {
+            atomicAdd(&job.stats[0], (unsigned long long)n_iter);
+            atomicAdd(&job.stats[1], (unsigned long long)n_setup);
+        }
+    }
+}
+
+template <int WIN>
+static int launch_lkq(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lk_q<WIN>, dim3((max_n + 3) / 4, batch), dim3(64), 0, s, job_tab, tab_stride);
+    return 0;
+}
+
 template <int WIN, int NW, int M>
 static int launch_lk3(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
@@ -1100,7 +1340,7 @@ static int launch_strip(const void* job_tab, size_t tab_stride, int batch, int m
     return 0;
 }
 
-static int g_lk_force_generic = 0;  // test hook: 1 = per-sample kernel, 2 = strip kernel, 3 = LDS-staged kernel, 0 = default routing
+static int g_lk_force_generic = 0;  // test hook: 1 = per-sample kernel, 2 = strip kernel, 3 = LDS-staged kernel, 4 = 4-tracks-per-wave kernel (15x15), 0 = default routing
 void vh_lk_force_generic(int on) { g_lk_force_generic = on; }
 
 int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s)
@@ -1118,6 +1358,10 @@ int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, i
             return launch_lk3<51, 4, 4>(job_tab, tab_stride, batch, max_n, s);
         }
     }
+    // 15x15: 4 tracks per wavefront once there are enough tracks to fill the chip that way (11 % faster frame step at 64
+    // streams); below that the one-wave-per-track strip kernel has the shorter critical path.  Mode 4 forces it (tests).
+    if (win == 15 && (g_lk_force_generic == 4 || (g_lk_force_generic == 0 && (long long)max_n * batch >= 6144)))
+        return launch_lkq<15>(job_tab, tab_stride, batch, max_n, s);
     if (g_lk_force_generic != 1 && win <= 63) {
         // int32 per-lane partial sums are exact up to 16 strips per lane (win <= 63)
         if (win == 15) return launch_strip<15>(job_tab, tab_stride, batch, max_n, win, s);
