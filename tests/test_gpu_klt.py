@@ -63,6 +63,17 @@ def test_pyr_down_bit_exact_incl_views_and_odd_sizes():
     ws = L.workspace(400, 300, 1)
     L.check(ws.lib.vh_pyr_down(ws.handle, C.c_void_p(view.data_ptr()), 364, 243, 400, L.dptr(out), L.stream_ptr()))
     assert np.array_equal(out.cpu().numpy(), exp)
+    # every width residue / row alignment: the mirrored border columns come out of per-lane byte selectors, the last lane
+    # of a wave and the lanes next to the right edge fetch their own second half
+    big = rng.integers(0, 256, (80, 600), dtype=np.uint8)
+    tb = torch.from_numpy(big).cuda()
+    ws = L.workspace(600, 80, 1)
+    for w in list(range(30, 50)) + list(range(250, 266)) + [511, 512, 513, 514, 515, 516, 517, 518]:
+        for (x0, y0, h) in ((0, 0, 9), (1, 3, 34), (2, 5, 33), (3, 1, 16)):
+            exp = KO.pyr_down(big[y0:y0 + h, x0:x0 + w])
+            out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
+            L.check(ws.lib.vh_pyr_down(ws.handle, C.c_void_p(tb[y0:y0 + h, x0:x0 + w].data_ptr()), w, h, 600, L.dptr(out), L.stream_ptr()))
+            assert np.array_equal(out.cpu().numpy(), exp), (w, x0, y0, h)
 
 
 def test_remap_and_crop_shift_bit_exact():

@@ -37,17 +37,62 @@ __global__ __launch_bounds__(256) void k_resize_quarter(const void* src_tab, con
 
 // ---------------------------------------------------------------------------------------------------------------
 // pyrDown: dst = ((w+1)/2, (h+1)/2), separable [1 4 6 4 1], REFLECT_101, (sum + 128) >> 8   
-// Block = 256 threads, output tile 64 x 16.  Source tile (35 rows x 131 cols) is staged in LDS once, the
-// horizontal pass writes 35 x 64 int16 partial sums to LDS, the vertical pass produces the tile.
+// Streaming register kernel, no LDS: one thread owns 4 output columns and walks RB output rows downwards (RB = 8 when the launch fills the chip anyway, 2 for single-stream latency).  Per
+// source row it loads 16 bytes (4 dwords, re-aligned with v_alignbyte), forms the 4 horizontal sums with
+// v_dot4_u32_u8 (weights 1,4,6,4 + the fifth tap) and keeps the last five rows as packed uint16 pairs; the vertical pass
+// is packed 16-bit math (the 5x5 sum is < 2^16).  Every source row is touched (2*RB+3)/(2*RB) times, adjacent
+// lanes read adjacent 8-byte steps (coalesced, 2x overlap served by the cache).  Border threads take a byte path
+// with REFLECT_101.
 // Build tables: stream b = blockIdx.z / 2 owns two PyrBuild entries (previous / current image); level `lvl` of the
 // pyramid is read, level lvl+1 is written; disabled entries and pyramids with fewer levels exit immediately.
 // ---------------------------------------------------------------------------------------------------------------
-#define PD_TW 64
-#define PD_TH 16
-#define PD_SW (2 * PD_TW + 3)
-#define PD_SH (2 * PD_TH + 3)
-#define PD_SP 136  // padded LDS row pitch (bytes)
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+typedef const unsigned __attribute__((address_space(1)))* pd_gptr;
 
+struct PdRow { unsigned s0, s1, s2; };  // source bytes sx0 .. sx0+11 of one row
+
+// byte path (REFLECT_101 per byte): tiny levels and the two rows where the dword path could leave the allocation
+__device__ __forceinline__ PdRow pd_bytes_row(const ImgDesc& s, int sx0, int ry)
+{
+    const uint8_t* row = s.p + (size_t)ry * s.stride;
+    unsigned v[3] = {0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 11; c++) v[c >> 2] |= (unsigned)row[vh_reflect101(sx0 + c, s.w)] << (8 * (c & 3));
+    PdRow o;
+    o.s0 = v[0]; o.s1 = v[1]; o.s2 = v[2];
+    return o;
+}
+
+__device__ __forceinline__ unsigned pd_from_next_lane(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);  // wave_shl:1 -> lane i reads lane i+1
+}
+
+__device__ __forceinline__ uint2 pd_hsum(const PdRow& r)
+{
+    const unsigned wgt = 0x04060401u;  // taps 1 4 6 4 on bytes 0..3, the fifth tap (x1) is added separately
+    const unsigned h0 = __builtin_amdgcn_udot4(r.s0, wgt, r.s1 & 0xffu, false);
+    const unsigned h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(r.s1, r.s0, 2), wgt, (r.s1 >> 16) & 0xffu, false);
+    const unsigned h2 = __builtin_amdgcn_udot4(r.s1, wgt, r.s2 & 0xffu, false);
+    const unsigned h3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(r.s2, r.s1, 2), wgt, (r.s2 >> 16) & 0xffu, false);
+    return make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+}
+
+__device__ __forceinline__ unsigned pd_vert(unsigned a, unsigned b, unsigned c, unsigned d, unsigned e)
+{
+    const ushort2v va = __builtin_bit_cast(ushort2v, a), vb = __builtin_bit_cast(ushort2v, b), vc = __builtin_bit_cast(ushort2v, c),
+                   vd = __builtin_bit_cast(ushort2v, d), ve = __builtin_bit_cast(ushort2v, e);
+    const ushort2v k4 = {4, 4}, k6 = {6, 6}, k128 = {128, 128}, k8 = {8, 8};
+    const ushort2v acc = ((va + ve) + (vb + vd) * k4 + vc * k6 + k128) >> k8;  // <= 65408: no 16-bit overflow
+    return __builtin_bit_cast(unsigned, acc);
+}
+
+// Lanes of a wave read adjacent 8-byte steps of a source row, and lane i needs bytes [8i-2, 8i+8]: it loads only its own
+// 8 bytes (one dwordx2) and takes the next 8 from lane i+1 through DPP.  REFLECT_101 columns never cost a memory access:
+// a lane's 12-byte stream already holds the mirrored pixels (left edge: columns 1,2 for -1,-2; right edge: columns w-2,
+// w-3 for w, w+1), so three v_perm with per-lane selectors (identity for interior lanes) fix every row without a branch.
+// All 2*RB+3 rows are requested before the first is used.
+template <int RB>
 __global__ __launch_bounds__(256) void k_pyr_down(const void* pb_tab, size_t ws_stride, int lvl)
 {
     const PyrBuild& pb = reinterpret_cast<const PyrBuild*>(reinterpret_cast<const char*>(pb_tab) + (size_t)(blockIdx.z >> 1) * ws_stride)[blockIdx.z & 1];
@@ -56,40 +101,74 @@ __global__ __launch_bounds__(256) void k_pyr_down(const void* pb_tab, size_t ws_
     if (lvl + 1 >= P.nlevels) return;
     const ImgDesc s = P.lv[lvl];
     const ImgDesc d = P.lv[lvl + 1];
-    const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
-    if (ox0 >= d.w || oy0 >= d.h) return;
+    const int ox0 = (blockIdx.x * 64 + threadIdx.x) * 4, oy0 = (blockIdx.y * 4 + threadIdx.y) * RB;
+    if (oy0 >= d.h) return;            // wave-uniform
+    const bool live = ox0 < d.w;       // dead lanes stay for the DPP exchange, they load and store nothing
+    const int sx0 = 2 * ox0 - 2, cnt = min(4, d.w - ox0);
+    const bool wide = s.w >= 32;       // uniform per image; narrower levels go through the byte path
+    const bool left = ox0 == 0, right = sx0 + 16 > s.w;     // right: the 16-byte read passes the end of the row
+    const bool dwords = live && wide;
+    // an interior lane always loads its own 8 bytes: only such a right neighbour can provide my second half
+    const bool next_interior = threadIdx.x != 63 && ox0 + 4 < d.w && sx0 + 8 + 16 <= s.w;
+    const bool own_ext = dwords && !next_interior;
+    // per-lane byte selectors: stream position p takes position src(p) (mirror about column 0 / column w-1)
+    unsigned sel0 = 0x03020100u, sel1 = 0x07060504u, sel2 = 0x07060504u;
+    if (dwords && (left || right)) {
+        const int m = s.w - 1 - sx0;  // stream position of the last column of the row
+        unsigned sl[3] = {0, 0, 0};
+        for (int p = 0; p < 12; p++) {
+            int q = p;
+            if (left && p < 2) q = 4 - p;
+            if (q > m) q = 2 * m - q;
+            const int rel = min(max(q - (p >= 8 ? 4 : 0), 0), 7);
+            sl[p >> 2] |= (unsigned)rel << (8 * (p & 3));
+        }
+        sel0 = sl[0]; sel1 = sl[1]; sel2 = sl[2];
+    }
 
-    __shared__ uint8_t tile[PD_SH * PD_SP];
-    __shared__ uint16_t hsum[PD_SH * PD_TW];
-    const int tid = threadIdx.x;
-    const int sx0 = 2 * ox0 - 2, sy0 = 2 * oy0 - 2;
-    const bool interior = sx0 >= 0 && sy0 >= 0 && sx0 + PD_SW <= s.w && sy0 + PD_SH <= s.h;
-    if (interior) {
-        for (int i = tid; i < PD_SH * PD_SW; i += 256) {
-            int r = i / PD_SW, c = i - r * PD_SW;
-            tile[r * PD_SP + c] = s.p[(size_t)(sy0 + r) * s.stride + sx0 + c];
-        }
-    } else {
-        for (int i = tid; i < PD_SH * PD_SW; i += 256) {
-            int r = i / PD_SW, c = i - r * PD_SW;
-            int yy = vh_reflect101(sy0 + r, s.h), xx = vh_reflect101(sx0 + c, s.w);
-            tile[r * PD_SP + c] = s.p[(size_t)yy * s.stride + xx];
-        }
+    constexpr int NR = 2 * RB + 3;
+    uint2 own[NR], ext[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const int ry = vh_reflect101(2 * oy0 - 2 + k, s.h);
+        const uintptr_t a = reinterpret_cast<uintptr_t>(s.p + (size_t)ry * s.stride + sx0);
+        pd_gptr ap = (pd_gptr)(a - (a & 3));
+        // the dword reads of an edge lane touch a few bytes of the neighbouring row: not before the first / after the last row
+        const bool ok = dwords && !(left && ry == 0) && !(right && ry == s.h - 1);
+        own[k] = make_uint2(0, 0); ext[k] = make_uint2(0, 0);
+        if (ok) own[k] = make_uint2(ap[0], ap[1]);
+        if (ok && own_ext) ext[k] = make_uint2(ap[2], ap[3]);
     }
-    __syncthreads();
-    for (int i = tid; i < PD_SH * PD_TW; i += 256) {
-        int r = i >> 6, c = i & 63;
-        const uint8_t* t = &tile[r * PD_SP + 2 * c];
-        hsum[i] = (uint16_t)(t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4]);
+    uint2 h[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const int ry = vh_reflect101(2 * oy0 - 2 + k, s.h);
+        const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(s.p + (size_t)ry * s.stride + sx0) & 3);
+        const unsigned n0 = pd_from_next_lane(own[k].x), n1 = pd_from_next_lane(own[k].y);
+        const unsigned d2 = own_ext ? ext[k].x : n0, d3 = own_ext ? ext[k].y : n1;
+        const unsigned t0 = __builtin_amdgcn_alignbyte(own[k].y, own[k].x, sh), t1 = __builtin_amdgcn_alignbyte(d2, own[k].y, sh),
+                       t2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+        PdRow r;
+        r.s0 = __builtin_amdgcn_perm(t1, t0, sel0);
+        r.s1 = __builtin_amdgcn_perm(t1, t0, sel1);
+        r.s2 = __builtin_amdgcn_perm(t2, t1, sel2);
+        if (live && (!wide || (left && ry == 0) || (right && ry == s.h - 1))) r = pd_bytes_row(s, sx0, ry);
+        h[k] = pd_hsum(r);
     }
-    __syncthreads();
-    for (int i = tid; i < PD_TH * PD_TW; i += 256) {
-        int r = i >> 6, c = i & 63;
-        int ox = ox0 + c, oy = oy0 + r;
-        if (ox < d.w && oy < d.h) {
-            const uint16_t* hcol = &hsum[(2 * r) * PD_TW + c];
-            int acc = hcol[0] + 4 * hcol[PD_TW] + 6 * hcol[2 * PD_TW] + 4 * hcol[3 * PD_TW] + hcol[4 * PD_TW];
-            const_cast<uint8_t*>(d.p)[(size_t)oy * d.stride + ox] = (uint8_t)((acc + 128) >> 8);
+    if (!live) return;
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+        const int oy = oy0 + r;
+        const unsigned o01 = pd_vert(h[2 * r].x, h[2 * r + 1].x, h[2 * r + 2].x, h[2 * r + 3].x, h[2 * r + 4].x);
+        const unsigned o23 = pd_vert(h[2 * r].y, h[2 * r + 1].y, h[2 * r + 2].y, h[2 * r + 3].y, h[2 * r + 4].y);
+        const unsigned pack = __builtin_amdgcn_perm(o23, o01, 0x06040200u);
+        if (oy < d.h) {
+            uint8_t* dp = const_cast<uint8_t*>(d.p) + (size_t)oy * d.stride + ox0;
+            if (cnt == 4 && (reinterpret_cast<uintptr_t>(dp) & 3) == 0) {
+                *reinterpret_cast<uint32_t*>(dp) = pack;
+            } else {
+                for (int k = 0; k < cnt; k++) dp[k] = (uint8_t)(pack >> (8 * k));
+            }
         }
     }
 }
@@ -187,8 +266,15 @@ void vh_launch_pyr_down_ws(const void* pb_tab, size_t ws_stride, int batch, int 
     // dims of level lvl+1 when level 0 is max_w0 x max_h0
     int w = max_w0, h = max_h0;
     for (int l = 0; l <= lvl; l++) { w = (w + 1) / 2; h = (h + 1) / 2; }
-    dim3 grd((w + PD_TW - 1) / PD_TW, (h + PD_TH - 1) / PD_TH, batch * 2);
-    hipLaunchKernelGGL(k_pyr_down, grd, dim3(256), 0, s, pb_tab, ws_stride, lvl);
+    dim3 blk(64, 4);
+    // 4 output rows per thread (11 source rows in flight) once the launch fills the chip; 2 for single-stream latency
+    if ((long long)w * h * batch >= (1ll << 20)) {
+        dim3 grd((w + 255) / 256, (h + 15) / 16, batch * 2);
+        hipLaunchKernelGGL(k_pyr_down<4>, grd, blk, 0, s, pb_tab, ws_stride, lvl);
+    } else {
+        dim3 grd((w + 255) / 256, (h + 7) / 8, batch * 2);
+        hipLaunchKernelGGL(k_pyr_down<2>, grd, blk, 0, s, pb_tab, ws_stride, lvl);
+    }
 }
 
 void vh_launch_roi_warp(const void* job_tab, size_t tab_stride, int batch, int max_w, int max_h, hipStream_t s)
