@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("VH_BENCH_STREAMS", 64)), help="video streams resident per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("VH_BENCH_STREAMS", 128)), help="video streams resident per GPU")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--params", default="baseline", choices=["baseline", "ref"],
                     help="baseline: coarse stages use the config's pyramid depth; ref: exactly utils/KLT.py:106-107 (maxLevel=4)")
@@ -54,8 +54,8 @@ def parse():
     return ap.parse_args()
 
 
-def make_ring(cfg, ring, device, seed):
-    """`ring` frames of a periodic plane motion + the tracks / world points of frame 0."""
+def make_ring(cfg, ring, device, seed, nsets=1):
+    """nsets x `ring` frames of a periodic plane motion (one texture per set) + the tracks / world points of frame 0."""
     from velocity_amd import synth
 
     W, H = cfg["w"], cfg["h"]
@@ -64,7 +64,7 @@ def make_ring(cfg, ring, device, seed):
         K[:2, :2] *= W / 1920.0
         K[2, 0], K[2, 1] = W / 2 + 0.5, H / 2 + 0.5
     m = synth.PlaneMotion(K, z0=3.6, traj=synth.oscillating_traj(period=float(ring)))
-    frames = torch.stack([synth.render_frame(W, H, m, k, seed=seed, device=device) for k in range(ring)])
+    frames = torch.stack([synth.render_frame(W, H, m, k, seed=seed + 104729 * t, device=device) for t in range(nsets) for k in range(ring)])
     p0 = synth.grid_tracks(cfg["n"], W, H, seed=(seed & 0xFF) + 1)
     return K, m, frames, p0
 
@@ -160,7 +160,9 @@ def main():
     lvl = cfg["levels"] - 1 if a.params == "baseline" else 4
     lkc, lkf = dict(max_level=lvl), dict()
     nhist = a.warmup + a.steps + 3
-    K, motion, frames, p0 = make_ring(cfg, a.ring, dev, seed=0xC0FFEE + 7919 * rank)
+    # one texture set per `ring` streams, so no two resident streams ever work on the same pixels
+    nsets = 1 if a.host_frames else (S + a.ring - 1) // a.ring
+    K, motion, frames, p0 = make_ring(cfg, a.ring, dev, seed=0xC0FFEE + 7919 * rank, nsets=nsets)
     p3 = motion.world_points(p0)
     vp = np.ones(N, bool)  # every valid track takes part in the pose fit (the state after vidExample.py:160)
     G = max(1, min(a.groups, S))
@@ -169,19 +171,20 @@ def main():
     sessions = [TrackerSession(K, W, H, N, nhist=nhist, batch=SG, lk_coarse=lkc, lk_fine=lkf, msv_frame=0) for _ in range(G)]
     hip_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(G - 1)]
     ses = sessions[0]
-    # streams of one rank share the ring but run at different phases, so every launch sees S different frame pairs
+    # streams of one texture set share its ring but run at different phases, so every launch sees S different frame pairs
     phase = [(7 * b) % a.ring for b in range(S)]
+    fset = [0 if a.host_frames else b // a.ring for b in range(S)]
     if a.host_frames:
         phase = [b % a.ring for b in range(S)]  # consecutive phases: one step's batch is a contiguous slice of the extended host ring
     base_ptr = frames.data_ptr()
     fbytes = W * H
     for b in range(S):
-        sessions[b // SG].init_stream(b % SG, frames[phase[b]], motion.apply(phase[b], p0.astype(float)).astype(np.float32),
+        sessions[b // SG].init_stream(b % SG, frames[fset[b] * a.ring + phase[b]], motion.apply(phase[b], p0.astype(float)).astype(np.float32),
                                       p3 + motion.t(phase[b]), vp, np.float32([0, 0, 0]))
     tables = torch.empty((a.ring, S), dtype=torch.int64)
     for k in range(a.ring):
         for b in range(S):
-            tables[k, b] = base_ptr + ((phase[b] + k) % a.ring) * fbytes
+            tables[k, b] = base_ptr + (fset[b] * a.ring + (phase[b] + k) % a.ring) * fbytes
     tables = tables.to(dev)
     ex = vdist.TrackStateExchange(S, N, every=a.exchange_every, device=dev) if use_dist else None
     torch.cuda.synchronize()
@@ -193,7 +196,7 @@ def main():
         assert G == 1, "--host-frames is measured with one session group"
         feeder = HostFrameFeeder(S, H, W, depth=3)
         reps = (S + a.ring - 1) // a.ring + 1
-        host_ring = torch.cat([frames.cpu()] * reps, 0)[: a.ring + S].contiguous().pin_memory()  # stands for the decoder's pinned output
+        host_ring = torch.cat([frames[: a.ring].cpu()] * reps, 0)[: a.ring + S].contiguous().pin_memory()  # stands for the decoder's pinned output
 
     def run_host(first, count):
         for i in range(first, first + count):
@@ -259,15 +262,17 @@ def main():
         it_f = iters[2] / max(launches[2], 1)
         su_f = setups[2] / max(launches[2], 1)
         ops_fine = wf * wf * (47.0 * su_f + 12.0 * it_f)  # SURVEY §8d op model: 47 op/px set-up, 12 op/px per Newton iteration
-        # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (collected at 8 streams, scales
+        # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (collected at the stream count stored in the file, scales
         # linearly with the stream count); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
         traffic = None
+        fine_kernel = "k_lk3<51, 2, 4>" if N * SG >= 6144 else "k_lk3<51, 4, 4>"  # routing of vh_launch_lk (wavefronts per track)
         tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         if a.config == "c2" and os.path.exists(tpath):
             tj = json.load(open(tpath))
-            k = tj["k_lk3<51, 4, 4>"]
-            traffic = int((2 * k["fetch_kib"] + k["write_kib"]) * 1024 * SG / tj["streams"])
-        roof = dict(bound="hbm", kernel="k_lk3<51,4,4> (fine stage: 51x51 window, level 0, fwd+bwd)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+            k = tj.get(fine_kernel)
+            if k is not None:
+                traffic = int((2 * k["fetch_kib"] + k["write_kib"]) * 1024 * SG / tj["streams"])
+        roof = dict(bound="hbm", kernel=fine_kernel + " (fine stage: 51x51 window, level 0, fwd+bwd)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, us_per_launch=round(us_fine, 2),
                     alg_bytes_per_launch=bytes_fine,
                     valu=dict(model_gops_per_launch=round(ops_fine / 1e9, 4), achieved_tops=round(ops_fine / (us_fine * 1e-6) / 1e12, 3) if us_fine > 0 else 0,
@@ -291,7 +296,7 @@ def main():
         if not a.no_ba:
             out["ba"] = bench_ba()
         if a.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(cfg, K, frames, p0, p3, vp, lkc, lkf, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cfg, K, frames[: a.ring], p0, p3, vp, lkc, lkf, a.cpu_seconds)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
     if use_dist:

@@ -200,21 +200,50 @@ __global__ __launch_bounds__(256) void k_roi_warp(const void* job_tab, size_t ta
         }
     } else {
         const float y = (float)(J.y0 + ry);
-        for (int k = 0; k < cnt; k++) {
+        const float yx = __fmul_rn(y, J.T[2]), yy = __fmul_rn(y, J.T[3]);
+        int fx[4], fy[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
             const float x = (float)(J.x0 + x4 + k);
             // float32, one rounding per operation, no fma (numpy: x*T00 + y*T10 + T20)
-            const float mx = __fadd_rn(__fadd_rn(__fmul_rn(x, J.T[0]), __fmul_rn(y, J.T[2])), J.T[4]);
-            const float my = __fadd_rn(__fadd_rn(__fmul_rn(x, J.T[1]), __fmul_rn(y, J.T[3])), J.T[5]);
-            const int fx = vh_round(__fmul_rn(mx, 32.f)), fy = vh_round(__fmul_rn(my, 32.f));
-            const int sx = fx >> 5, sy = fy >> 5, ax = fx & 31, ay = fy & 31;
-            const bool x0in = sx >= 0 && sx < s.w, x1in = sx + 1 >= 0 && sx + 1 < s.w;
-            const bool y0in = sy >= 0 && sy < s.h, y1in = sy + 1 >= 0 && sy + 1 < s.h;
-            const uint8_t* r0 = s.p + (ptrdiff_t)sy * s.stride + sx;
-            const int s00 = (y0in && x0in) ? r0[0] : 0, s01 = (y0in && x1in) ? r0[1] : 0;
-            const int s10 = (y1in && x0in) ? r0[s.stride] : 0, s11 = (y1in && x1in) ? r0[s.stride + 1] : 0;
-            const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
-            const uint32_t v = (uint32_t)((s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11 + (1 << 14)) >> 15);
-            pack |= v << (8 * k);
+            const float mx = __fadd_rn(__fadd_rn(__fmul_rn(x, J.T[0]), yx), J.T[4]);
+            const float my = __fadd_rn(__fadd_rn(__fmul_rn(x, J.T[1]), yy), J.T[5]);
+            fx[k] = vh_round(__fmul_rn(mx, 32.f));
+            fy[k] = vh_round(__fmul_rn(my, 32.f));
+        }
+        const int sx0 = fx[0] >> 5, sy0 = fy[0] >> 5;
+        // near-identity maps (the tracker's case): the 4 pixels sample one source row pair at consecutive columns, so the
+        // 2 x 5 source bytes come from two aligned dword pairs instead of 16 byte gathers
+        const bool run = cnt == 4 && (fx[1] >> 5) == sx0 + 1 && (fx[2] >> 5) == sx0 + 2 && (fx[3] >> 5) == sx0 + 3 && (fy[1] >> 5) == sy0 &&
+                         (fy[2] >> 5) == sy0 && (fy[3] >> 5) == sy0 && sx0 >= 3 && sx0 + 8 <= s.w && sy0 >= 0 && sy0 + 1 < s.h;
+        if (run) {
+            const uintptr_t a0 = reinterpret_cast<uintptr_t>(s.p + (ptrdiff_t)sy0 * s.stride + sx0), a1 = a0 + s.stride;
+            const unsigned sh0 = (unsigned)(a0 & 3), sh1 = (unsigned)(a1 & 3);
+            pd_gptr p0 = (pd_gptr)(a0 - sh0), p1 = (pd_gptr)(a1 - sh1);
+            const unsigned t0 = p0[0], t1 = p0[1], b0 = p1[0], b1 = p1[1];
+            const unsigned tl = __builtin_amdgcn_alignbyte(t1, t0, sh0), th = (t1 >> (8 * sh0)) & 0xffu;
+            const unsigned bl = __builtin_amdgcn_alignbyte(b1, b0, sh1), bh = (b1 >> (8 * sh1)) & 0xffu;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ax = fx[k] & 31, ay = fy[k] & 31;
+                const int s00 = (tl >> (8 * k)) & 0xff, s01 = k < 3 ? (int)((tl >> (8 * k + 8)) & 0xff) : (int)th;
+                const int s10 = (bl >> (8 * k)) & 0xff, s11 = k < 3 ? (int)((bl >> (8 * k + 8)) & 0xff) : (int)bh;
+                const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+                const uint32_t v = (uint32_t)((s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11 + (1 << 14)) >> 15);
+                pack |= v << (8 * k);
+            }
+        } else {
+            for (int k = 0; k < cnt; k++) {
+                const int sx = fx[k] >> 5, sy = fy[k] >> 5, ax = fx[k] & 31, ay = fy[k] & 31;
+                const bool x0in = sx >= 0 && sx < s.w, x1in = sx + 1 >= 0 && sx + 1 < s.w;
+                const bool y0in = sy >= 0 && sy < s.h, y1in = sy + 1 >= 0 && sy + 1 < s.h;
+                const uint8_t* r0 = s.p + (ptrdiff_t)sy * s.stride + sx;
+                const int s00 = (y0in && x0in) ? r0[0] : 0, s01 = (y0in && x1in) ? r0[1] : 0;
+                const int s10 = (y1in && x0in) ? r0[s.stride] : 0, s11 = (y1in && x1in) ? r0[s.stride + 1] : 0;
+                const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+                const uint32_t v = (uint32_t)((s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11 + (1 << 14)) >> 15);
+                pack |= v << (8 * k);
+            }
         }
     }
     if (cnt == 4 && ((reinterpret_cast<uintptr_t>(drow + x4) & 3) == 0)) {
