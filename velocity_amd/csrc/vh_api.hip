@@ -89,6 +89,7 @@ extern "C" VH_API int vh_ctx_create(vh_ctx** out, int batch, int max_w, int max_
             B.v_all = (uint8_t*)(base + carve(max_pts));
             B.inl = (uint8_t*)(base + carve(max_pts));
             B.idx = (int*)(base + carve(sizeof(int) * max_pts));
+            B.pairs = (float4*)(base + carve(sizeof(float4) * max_pts));
             B.counts = (int*)(base + carve(sizeof(int) * VH_RANSAC_ITERS));
         }
     }
@@ -185,7 +186,7 @@ __global__ void k_klt_setup(StreamWS* ws_all)
     RansacJob& R = ws.ransac;
     R.from = io.p0; R.to = B.p_small; R.valid = B.v_small; R.n_ptr = nullptr; R.n = n;
     R.min_valid = 0; R.gate_valid = 1;
-    R.idx = B.idx; R.counts = B.counts; R.m_out = &ws.m; R.bound = &ws.rbound; R.M = ws.M; R.inl = B.inl; R.status = &ws.rstatus;
+    R.idx = B.idx; R.pairs = B.pairs; R.counts = B.counts; R.m_out = &ws.m; R.bound = &ws.rbound; R.M = ws.M; R.inl = B.inl; R.status = &ws.rstatus;
 }
 
 // ---- stage 1 -> 2: mean translation, ROI, shifted crop, job B (KLT.py:121-124, 55-68) ---------------------------
@@ -577,7 +578,7 @@ extern "C" VH_API int vh_ransac_affine(vh_ctx* c, const float* from, const float
     RansacJob R;
     memset(&R, 0, sizeof(R));
     R.from = from; R.to = to; R.valid = const_cast<uint8_t*>(valid ? valid : B.v_all); R.n = n; R.min_valid = 0; R.gate_valid = 0;
-    R.idx = B.idx; R.counts = B.counts; R.m_out = &c->d_ws[0].m; R.bound = &c->d_ws[0].rbound; R.M = M; R.inl = inl; R.status = status;
+    R.idx = B.idx; R.pairs = B.pairs; R.counts = B.counts; R.m_out = &c->d_ws[0].m; R.bound = &c->d_ws[0].rbound; R.M = M; R.inl = inl; R.status = status;
     VH_CHECK(vh_store(&c->d_ws[0].ransac, R, s));
     vh_launch_ransac(&c->d_ws[0].ransac, sizeof(StreamWS), 1, n, s);
     VH_LAUNCH_CHECK();

@@ -24,6 +24,7 @@ struct RansacJob {
     int min_valid;        // run only when more than this many valid pairs (KLT.py:126: v.sum() > 10 -> 10)
     int gate_valid;       // 1: write the inlier mask back into `valid` (KLT.py:117)
     int* idx;             // scratch n    : compacted index list
+    float4* pairs;        // scratch n    : compacted pairs (from.x, from.y, to.x, to.y): one coalesced 16-byte load per pair when scoring
     int* counts;          // scratch VH_RANSAC_ITERS : inliers per hypothesis
     int* m_out;           // scratch 1    : number of valid pairs
     int* bound;           // scratch 1    : upper bound of the hypotheses the sequential rule can still reach

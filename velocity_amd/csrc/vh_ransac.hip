@@ -120,49 +120,65 @@ __device__ void block_sum_i64(long long* v, long long* sh /* [NV * 4] */)
     for (int k = 0; k < NV; k++) v[k] = sh[k * 4] + sh[k * 4 + 1] + sh[k * 4 + 2] + sh[k * 4 + 3];
 }
 
-// ---- 1. compaction index list of the valid pairs (order preserving) ---------------------------------------------
-__global__ __launch_bounds__(256) void k_ransac_compact(const void* tab, size_t stride)
+// inliers of model M among the m compacted pairs, counted by one wavefront (one 16-byte load per pair)
+__device__ __forceinline__ int score_pairs(const float4* pairs, int m, const double* M, int lane)
+{
+    int c = 0;
+    for (int k = lane; k < m; k += 64) {
+        const float4 q = pairs[k];
+        c += is_inlier(M, q.x, q.y, q.z, q.w) ? 1 : 0;
+    }
+    return vh_wave_sum_i32(c);
+}
+
+// ---- 1. compaction of the valid pairs (order preserving) + the first RANSAC_HEAD hypotheses ---------------------
+// One 1024-thread block per stream: the whole head (16 hypotheses) is scored in one round, one wavefront each.
+__global__ __launch_bounds__(1024) void k_ransac_compact(const void* tab, size_t stride)
 {
     const RansacJob J = rjob(tab, stride, blockIdx.x);  // by value: fields live in SGPRs
     const int n = J.n_ptr ? *J.n_ptr : J.n;
-    __shared__ int wcount[4];
+    __shared__ int wcount[16];
     __shared__ int base;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) base = 0;
     __syncthreads();
-    for (int c = 0; c < n; c += 256) {
+    for (int c = 0; c < n; c += 1024) {
         const int i = c + tid;
         const bool f = i < n && J.valid[i] != 0;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f) {
+            const float2 a = reinterpret_cast<const float2*>(J.from)[i], b = reinterpret_cast<const float2*>(J.to)[i];
+            q = make_float4(a.x, a.y, b.x, b.y);
+        }
         const unsigned long long bal = __ballot(f);
         const int pre = __popcll(bal & ((1ull << lane) - 1ull));
         if (lane == 0) wcount[wave] = __popcll(bal);
         __syncthreads();
-        int off = base;
-        for (int q = 0; q < wave; q++) off += wcount[q];
-        if (f) J.idx[off + pre] = i;
+        int off = base, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const int cw = wcount[w];
+            off += w < wave ? cw : 0;
+            tot += cw;
+        }
+        if (f) { J.idx[off + pre] = i; J.pairs[off + pre] = q; }
         __syncthreads();
-        if (tid == 0) base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        if (tid == 0) base += tot;
         __syncthreads();
     }
     if (tid == 0) *J.m_out = base;
-    __syncthreads();
+    __syncthreads();  // also makes this block's J.idx / J.pairs stores visible to all of its waves
     // Score the first RANSAC_HEAD hypotheses here and replay the sequential rule over them: the adaptive iteration
     // count can only shrink afterwards, so hypotheses >= *bound can never be reached and need not be scored.
     const int m = base;
     int bound = VH_RANSAC_ITERS;
     if (m >= 3 && m > J.min_valid) {
-        for (int h0 = 0; h0 < RANSAC_HEAD; h0 += 4) {
-            const int hyp = h0 + wave;
+        static_assert(RANSAC_HEAD == 16, "one wavefront per head hypothesis");
+        {
             double M[6];
             int c = 0;
-            if (ransac_hypothesis(J.from, J.to, J.idx, m, (uint32_t)hyp, M)) {
-                for (int k = lane; k < m; k += 64) {
-                    const int i = J.idx[k];
-                    c += is_inlier(M, J.from[2 * i], J.from[2 * i + 1], J.to[2 * i], J.to[2 * i + 1]) ? 1 : 0;
-                }
-            }
-            c = vh_wave_sum_i32(c);
-            if (lane == 0) J.counts[hyp] = c;
+            if (ransac_hypothesis(J.from, J.to, J.idx, m, (uint32_t)wave, M)) c = score_pairs(J.pairs, m, M, lane);
+            if (lane == 0) J.counts[wave] = c;
         }
         __syncthreads();
         if (tid == 0) {
@@ -191,13 +207,7 @@ __global__ __launch_bounds__(256) void k_ransac_score(const void* tab, size_t st
     if (m < 3 || m <= J.min_valid) return;
     double M[6];
     int c = 0;
-    if (ransac_hypothesis(J.from, J.to, J.idx, m, (uint32_t)hyp, M)) {
-        for (int k = lane; k < m; k += 64) {
-            const int i = J.idx[k];
-            c += is_inlier(M, J.from[2 * i], J.from[2 * i + 1], J.to[2 * i], J.to[2 * i + 1]) ? 1 : 0;
-        }
-    }
-    c = vh_wave_sum_i32(c);
+    if (ransac_hypothesis(J.from, J.to, J.idx, m, (uint32_t)hyp, M)) c = score_pairs(J.pairs, m, M, lane);
     if (lane == 0) J.counts[hyp] = c;
 }
 
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(256) void k_ransac_select(const void* tab, size_t s
 void vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
     (void)max_n;
-    hipLaunchKernelGGL(k_ransac_compact, dim3(batch), dim3(256), 0, s, job_tab, tab_stride);
+    hipLaunchKernelGGL(k_ransac_compact, dim3(batch), dim3(1024), 0, s, job_tab, tab_stride);
     hipLaunchKernelGGL(k_ransac_score, dim3((VH_RANSAC_ITERS + 3) / 4, batch), dim3(256), 0, s, job_tab, tab_stride);
     hipLaunchKernelGGL(k_ransac_select, dim3(batch), dim3(256), 0, s, job_tab, tab_stride);
 }

@@ -19,6 +19,7 @@ struct StreamBufs {  // fixed after vh_ctx_create
     uint8_t* v_all;                        // all-ones mask for the stateless RANSAC entry
     uint8_t* inl;
     int* idx;
+    float4* pairs;
     int* counts;
 };
 
