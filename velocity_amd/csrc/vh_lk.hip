@@ -368,26 +368,30 @@ __device__ __forceinline__ StripWeights strip_weights(const Win& w)
     return s;
 }
 
-// bilinear x32 samples of the 4 strip positions from 2 rows (lo,hi): returns packed pairs (v0,v1), (v2,v3)
-__device__ __forceinline__ void strip_bilinear(const unsigned* lo, const unsigned* hi, const StripWeights& w, unsigned& p01, unsigned& p23)
+// packed horizontal neighbours (b_c, b_{c+1}), c = 0..3, of one row (lo = bytes 0..3, hi = byte 4..)
+__device__ __forceinline__ void strip_row_pairs(unsigned lo, unsigned hi, unsigned* t)
+{
+    t[0] = __builtin_amdgcn_perm(0u, lo, 0x0c010c00u);
+    t[1] = __builtin_amdgcn_perm(0u, lo, 0x0c020c01u);
+    t[2] = __builtin_amdgcn_perm(0u, lo, 0x0c030c02u);
+    t[3] = __builtin_amdgcn_perm(hi, lo, 0x0c040c03u);
+}
+// bilinear x32 samples of the 4 strip positions from the packed pairs of the top and bottom row
+__device__ __forceinline__ void strip_bilinear_pairs(const unsigned* t, const unsigned* b, const StripWeights& w, unsigned& p01, unsigned& p23)
 {
     int v[4];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        // packed horizontal neighbours (b_c, b_{c+1}) of both rows
-        unsigned t, b;
-        if (c < 3) {
-            const unsigned sel = 0x0c000c00u + (unsigned)c + ((unsigned)(c + 1) << 16);
-            t = __builtin_amdgcn_perm(0u, lo[0], sel);
-            b = __builtin_amdgcn_perm(0u, lo[1], sel);
-        } else {
-            t = __builtin_amdgcn_perm(hi[0], lo[0], 0x0c040c03u);
-            b = __builtin_amdgcn_perm(hi[1], lo[1], 0x0c040c03u);
-        }
-        v[c] = dot2(b, w.wb, dot2(t, w.wt, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-    }
+    for (int c = 0; c < 4; c++) v[c] = dot2(b[c], w.wb, dot2(t[c], w.wt, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
     p01 = pack16(v[0], v[1]);
     p23 = pack16(v[2], v[3]);
+}
+// bilinear x32 samples of the 4 strip positions from 2 rows (lo,hi): returns packed pairs (v0,v1), (v2,v3)
+__device__ __forceinline__ void strip_bilinear(const unsigned* lo, const unsigned* hi, const StripWeights& w, unsigned& p01, unsigned& p23)
+{
+    unsigned t[4], b[4];
+    strip_row_pairs(lo[0], hi[0], t);
+    strip_row_pairs(lo[1], hi[1], b);
+    strip_bilinear_pairs(t, b, w, p01, p23);
 }
 
 
@@ -396,35 +400,36 @@ __device__ __forceinline__ void strip_bilinear(const unsigned* lo, const unsigne
 //   sum_k w_k * Scharr(P)[pos + k]  ==  Scharr(V)[pos]   with   V[pos] = sum_k w_k * P[pos + k]   (no rounding before the descale)
 // V is needed on a 3 x 6 block for the 4 samples of a strip (18 x 2 v_dot2 on packed byte pairs); the template sample itself
 // is descale(V, 9).  Exactly the same integers as interpolating the gradient image, at ~55 % of the instructions.
-__device__ __forceinline__ void strip_setup_linear(const unsigned* lo, const unsigned* hi, const Win& w0, int cnt, uint2* tI, uint2* tX,
-                                                   uint2* tY, int slot, int& a11, int& a12, int& a22)
+// the six packed byte pairs (c, c+1), c = 0..5, of one 8-byte patch row
+__device__ __forceinline__ void setup_row_pairs(unsigned lo, unsigned hi, unsigned* pr)
 {
-    const unsigned wt = pack16(w0.w00, w0.w01), wb = pack16(w0.w10, w0.w11);
-    unsigned pr[4][6];  // pr[r][c] = (byte c, byte c+1) of row r as a packed int16 pair
+    pr[0] = __builtin_amdgcn_perm(0u, lo, 0x0c010c00u);
+    pr[1] = __builtin_amdgcn_perm(0u, lo, 0x0c020c01u);
+    pr[2] = __builtin_amdgcn_perm(0u, lo, 0x0c030c02u);
+    pr[3] = __builtin_amdgcn_perm(hi, lo, 0x0c040c03u);
+    pr[4] = __builtin_amdgcn_perm(0u, hi, 0x0c010c00u);
+    pr[5] = __builtin_amdgcn_perm(0u, hi, 0x0c020c01u);
+}
+// one row of V from the pairs of two consecutive patch rows
+__device__ __forceinline__ void setup_v_row(const unsigned* top, const unsigned* bot, unsigned wt, unsigned wb, int* V)
+{
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        pr[r][0] = __builtin_amdgcn_perm(0u, lo[r], 0x0c010c00u);
-        pr[r][1] = __builtin_amdgcn_perm(0u, lo[r], 0x0c020c01u);
-        pr[r][2] = __builtin_amdgcn_perm(0u, lo[r], 0x0c030c02u);
-        pr[r][3] = __builtin_amdgcn_perm(hi[r], lo[r], 0x0c040c03u);
-        pr[r][4] = __builtin_amdgcn_perm(0u, hi[r], 0x0c010c00u);
-        pr[r][5] = __builtin_amdgcn_perm(0u, hi[r], 0x0c020c01u);
-    }
-    int V[3][6];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 6; c++) V[r][c] = dot2(pr[r + 1][c], wb, dot2(pr[r][c], wt, 0));
+    for (int c = 0; c < 6; c++) V[c] = dot2(bot[c], wb, dot2(top[c], wt, 0));
+}
+// template samples, gradients and structure-tensor partials of one strip from its three V rows
+__device__ __forceinline__ void setup_from_v(const int* V0, const int* V1, const int* V2, int cnt, uint2* tI, uint2* tX, uint2* tY, int slot,
+                                             int& a11, int& a12, int& a22)
+{
     int S[6], D[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) {
-        S[c] = __mul24(V[0][c] + V[2][c], 3) + __mul24(V[1][c], 10);  // every V fits 23 bits
-        D[c] = V[2][c] - V[0][c];
+        S[c] = __mul24(V0[c] + V2[c], 3) + __mul24(V1[c], 10);  // every V fits 23 bits
+        D[c] = V2[c] - V0[c];
     }
     int iv[4], ix[4], iy[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        iv[c] = vh_descale(V[1][c + 1], W_BITS - 5);
+        iv[c] = vh_descale(V1[c + 1], W_BITS - 5);
         ix[c] = vh_descale(S[c + 2] - S[c], W_BITS);
         iy[c] = vh_descale((D[c] + D[c + 2]) * 3 + D[c + 1] * 10, W_BITS);
     }
@@ -437,6 +442,19 @@ __device__ __forceinline__ void strip_setup_linear(const unsigned* lo, const uns
     a11 = dot2(vX.y, vX.y, dot2(vX.x, vX.x, a11));
     a12 = dot2(vX.y, vY.y, dot2(vX.x, vY.x, a12));
     a22 = dot2(vY.y, vY.y, dot2(vY.x, vY.x, a22));
+}
+
+__device__ __forceinline__ void strip_setup_linear(const unsigned* lo, const unsigned* hi, const Win& w0, int cnt, uint2* tI, uint2* tX,
+                                                   uint2* tY, int slot, int& a11, int& a12, int& a22)
+{
+    const unsigned wt = pack16(w0.w00, w0.w01), wb = pack16(w0.w10, w0.w11);
+    unsigned pr[4][6];  // pr[r][c] = (byte c, byte c+1) of row r as a packed int16 pair
+#pragma unroll
+    for (int r = 0; r < 4; r++) setup_row_pairs(lo[r], hi[r], pr[r]);
+    int V[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; r++) setup_v_row(pr[r], pr[r + 1], wt, wb, V[r]);
+    setup_from_v(V[0], V[1], V[2], cnt, tI, tX, tY, slot, a11, a12, a22);
 }
 
 template <bool FAST>
@@ -770,7 +788,11 @@ struct LK3 {
     static constexpr int T = 64 * NW;
     static constexpr int SPR = (WIN + 3) >> 2;
     static constexpr int NS = SPR * WIN;
-    static constexpr int K = (NS + T - 1) / T;
+    // lane -> (strip column j, run q): every lane owns K vertically consecutive strips of one column, so consecutive
+    // strips share patch rows, byte pairs and V rows in registers (a strip's set-up needs 1 new V row instead of 3, a
+    // Newton iteration 1 new search row instead of 2)
+    static constexpr int RUNS = T / SPR;
+    static constexpr int K = (WIN + RUNS - 1) / RUNS;
     static constexpr int PI_ROWS = WIN + 3;                                   // template patch rows
     static constexpr int PI_PITCH = ((4 * (SPR - 1) + 8 + 3) / 4) * 4;        // bytes read per patch row, dword multiple
     static constexpr int RJ = WIN + 1 + 2 * M;                                // search region rows / cols
@@ -888,24 +910,57 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
     __syncthreads();
 
     const bool inside_I = ipx >= 1 && ipy >= 1 && ipx + WIN + 1 <= I.w - 1 && ipy + WIN + 1 <= I.h - 1;
+    // this lane's strips: column j, window rows y0 .. y0+K-1
+    const int run = tid / C::SPR, j = tid - run * C::SPR, y0 = run * C::K;
+    const bool lane_on = run < C::RUNS;
+    const int cnt = min(4, WIN - 4 * j);
     int part[3] = {0, 0, 0};
+    if (lane_on && inside_I) {
+        // interior: rolling V rows (see strip_setup_linear): patch rows y .. y+3 feed strip y; one new row per strip
+        const unsigned wt = pack16(w0.w00, w0.w01), wb = pack16(w0.w10, w0.w11);
+        const unsigned* col = pI + j;
+        unsigned prA[6], prB[6];
+        int V0[6], V1[6];
+        {
+            unsigned pr0[6];
+            const unsigned* r0 = col + y0 * (C::PI_PITCH >> 2);
+            setup_row_pairs(r0[0], r0[1], pr0);
+            setup_row_pairs(r0[C::PI_PITCH >> 2], r0[(C::PI_PITCH >> 2) + 1], prA);
+            setup_row_pairs(r0[2 * (C::PI_PITCH >> 2)], r0[2 * (C::PI_PITCH >> 2) + 1], prB);
+            setup_v_row(pr0, prA, wt, wb, V0);
+            setup_v_row(prA, prB, wt, wb, V1);
+        }
 #pragma unroll
-    for (int k = 0; k < C::K; k++) {
-        const int s = tid + C::T * k;
-        if (s < C::NS) {
-            const int y = s / C::SPR, j = s - y * C::SPR, x = 4 * j, cnt = min(4, WIN - x);
-            unsigned lo[4], hi[4];
+        for (int k = 0; k < C::K; k++) {
+            const int y = y0 + k;
+            if (y < WIN) {
+                const unsigned* rn = col + (y + 3) * (C::PI_PITCH >> 2);
+                unsigned prN[6];
+                int V2[6];
+                setup_row_pairs(rn[0], rn[1], prN);
+                setup_v_row(prB, prN, wt, wb, V2);
+                setup_from_v(V0, V1, V2, cnt, tI, tX, tY, k * C::T + tid, part[0], part[1], part[2]);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const unsigned* row = pI + (y + r) * (C::PI_PITCH >> 2) + j;
-                lo[r] = row[0]; hi[r] = row[1];
+                for (int c = 0; c < 6; c++) { V0[c] = V1[c]; V1[c] = V2[c]; prB[c] = prN[c]; }
             }
-            if (inside_I) strip_setup<true>(lo, hi, w0, I, ipx, ipy, x, y, cnt, tI, tX, tY, k * C::T + tid, part[0], part[1], part[2]);
-            else strip_setup<false>(lo, hi, w0, I, ipx, ipy, x, y, cnt, tI, tX, tY, k * C::T + tid, part[0], part[1], part[2]);
+        }
+    } else if (lane_on) {
+#pragma unroll
+        for (int k = 0; k < C::K; k++) {
+            const int y = y0 + k;
+            if (y < WIN) {
+                unsigned lo[4], hi[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const unsigned* row = pI + (y + r) * (C::PI_PITCH >> 2) + j;
+                    lo[r] = row[0]; hi[r] = row[1];
+                }
+                strip_setup<false>(lo, hi, w0, I, ipx, ipy, 4 * j, y, cnt, tI, tX, tY, k * C::T + tid, part[0], part[1], part[2]);
+            }
         }
     }
     long long sA[3];
-    block_sum_wide<NW, 3, (C::K == 1 && C::NS <= 64)>(part, sA, red, phase, wave);
+    block_sum_wide<NW, 3, (C::K == 1 && C::T == 64)>(part, sA, red, phase, wave);
     const float A11 = __fmul_rn(i64_to_f32(sA[0]), LK_FLT_SCALE), A12 = __fmul_rn(i64_to_f32(sA[1]), LK_FLT_SCALE), A22 = __fmul_rn(i64_to_f32(sA[2]), LK_FLT_SCALE);
     float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
     const float dA = __fsub_rn(A11, A22);
@@ -917,17 +972,13 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
     }
     D = __fdiv_rn(1.f, D);
 
-    // bilinear samples of one strip of the staged search region at window origin (inx, iny)
-    auto strip_from_region = [&](int inx, int iny, int j, int y, unsigned* lo, unsigned* hi) {
+    // packed byte pairs of window row y (strip column j) of the staged search region at window origin (inx, iny)
+    auto region_row_pairs = [&](int inx, int iny, int y, unsigned* t) {
         const int off = (inx - rjx) + 4 * j;
         const unsigned sh = (unsigned)(off & 3);
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const unsigned* row = pJ + (iny - rjy + y + r) * (C::PJ_PITCH >> 2) + (off >> 2);
-            const unsigned d0 = row[0], d1 = row[1], d2 = row[2];
-            lo[r] = __builtin_amdgcn_alignbyte(d1, d0, sh);
-            hi[r] = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        }
+        const unsigned* row = pJ + (iny - rjy + y) * (C::PJ_PITCH >> 2) + (off >> 2);
+        const unsigned d0 = row[0], d1 = row[1], d2 = row[2];
+        strip_row_pairs(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh), t);
     };
     auto region_holds = [&](int inx, int iny) { return inx >= rjx && iny >= rjy && inx + WIN + 1 <= rjx + C::RJ && iny + WIN + 1 <= rjy + C::RJ; };
     auto restage = [&](int inx, int iny) {
@@ -948,23 +999,28 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny)));
         n_iter++;
         int b[2] = {0, 0};
+        if (lane_on) {
+            unsigned top[4];
+            region_row_pairs(inx, iny, y0, top);
 #pragma unroll
-        for (int k = 0; k < C::K; k++) {
-            const int s = tid + C::T * k;
-            if (s < C::NS) {
-                const int y = s / C::SPR, j = s - y * C::SPR;
-                unsigned lo[2], hi[2], p01, p23;
-                strip_from_region(inx, iny, j, y, lo, hi);
-                strip_bilinear(lo, hi, w, p01, p23);
-                const uint2 vI = tI[k * C::T + tid], vX = tX[k * C::T + tid], vY = tY[k * C::T + tid];
-                const unsigned d01 = __builtin_bit_cast(unsigned, as_s2(p01) - as_s2(vI.x));
-                const unsigned d23 = __builtin_bit_cast(unsigned, as_s2(p23) - as_s2(vI.y));
-                b[0] = dot2(d23, vX.y, dot2(d01, vX.x, b[0]));
-                b[1] = dot2(d23, vY.y, dot2(d01, vY.x, b[1]));
+            for (int k = 0; k < C::K; k++) {
+                const int y = y0 + k;
+                if (y < WIN) {
+                    unsigned bot[4], p01, p23;
+                    region_row_pairs(inx, iny, y + 1, bot);  // the bottom row of strip y is the top row of strip y+1
+                    strip_bilinear_pairs(top, bot, w, p01, p23);
+                    const uint2 vI = tI[k * C::T + tid], vX = tX[k * C::T + tid], vY = tY[k * C::T + tid];
+                    const unsigned d01 = __builtin_bit_cast(unsigned, as_s2(p01) - as_s2(vI.x));
+                    const unsigned d23 = __builtin_bit_cast(unsigned, as_s2(p23) - as_s2(vI.y));
+                    b[0] = dot2(d23, vX.y, dot2(d01, vX.x, b[0]));
+                    b[1] = dot2(d23, vY.y, dot2(d01, vY.x, b[1]));
+#pragma unroll
+                    for (int c = 0; c < 4; c++) top[c] = bot[c];
+                }
             }
         }
         long long sb[2];
-        block_sum_wide<NW, 2, (C::K == 1 && C::NS <= 64)>(b, sb, red, phase, wave);
+        block_sum_wide<NW, 2, (C::K == 1 && C::T == 64)>(b, sb, red, phase, wave);
         const float fb1 = __fmul_rn(i64_to_f32(sb[0]), LK_FLT_SCALE), fb2 = __fmul_rn(i64_to_f32(sb[1]), LK_FLT_SCALE);
         const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
         const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
@@ -987,23 +1043,28 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
         if (!region_holds(inx, iny)) restage(inx, iny);
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny)));
         int se[1] = {0};
+        if (lane_on) {
+            unsigned top[4];
+            region_row_pairs(inx, iny, y0, top);
 #pragma unroll
-        for (int k = 0; k < C::K; k++) {
-            const int s = tid + C::T * k;
-            if (s < C::NS) {
-                const int y = s / C::SPR, j = s - y * C::SPR, cnt = min(4, WIN - 4 * j);
-                unsigned lo[2], hi[2], p01, p23;
-                strip_from_region(inx, iny, j, y, lo, hi);
-                strip_bilinear(lo, hi, w, p01, p23);
-                const uint2 vI = tI[k * C::T + tid];
-                const short2v d01 = as_s2(p01) - as_s2(vI.x), d23 = as_s2(p23) - as_s2(vI.y);
-                const int d[4] = {d01.x, d01.y, d23.x, d23.y};
+            for (int k = 0; k < C::K; k++) {
+                const int y = y0 + k;
+                if (y < WIN) {
+                    unsigned bot[4], p01, p23;
+                    region_row_pairs(inx, iny, y + 1, bot);
+                    strip_bilinear_pairs(top, bot, w, p01, p23);
+                    const uint2 vI = tI[k * C::T + tid];
+                    const short2v d01 = as_s2(p01) - as_s2(vI.x), d23 = as_s2(p23) - as_s2(vI.y);
+                    const int d[4] = {d01.x, d01.y, d23.x, d23.y};
 #pragma unroll
-                for (int c = 0; c < 4; c++) se[0] += c < cnt ? (d[c] < 0 ? -d[c] : d[c]) : 0;
+                    for (int c = 0; c < 4; c++) se[0] += c < cnt ? (d[c] < 0 ? -d[c] : d[c]) : 0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) top[c] = bot[c];
+                }
             }
         }
         long long sse[1];
-        block_sum_wide<NW, 1, (C::K == 1 && C::NS <= 64)>(se, sse, red, phase, wave);
+        block_sum_wide<NW, 1, (C::K == 1 && C::T == 64)>(se, sse, red, phase, wave);
         err = __fmul_rn(i64_to_f32(sse[0]), __fdiv_rn(1.f, (float)(32 * WIN * WIN)));
     }
 }
