@@ -130,7 +130,7 @@ def bench_ba(nt=5000, nf=20, repeats=3):
     tr = trace.cpu().numpy()
     return dict(workload=f"C5 BA: {nf} keyframes x {nt} tracks (nx={3 * nt + 6 * nc}, nz={2 * nt * nf}), {its} LM iterations",
                 iters_per_s=round(its / best, 2), ms_per_iter=round(1e3 * best / its, 3), rms_residual_first=round(float(tr[0, 0]), 4),
-                rms_residual_last=round(float(tr[its - 1, 0]), 4), method="compact FD Jacobian; point-block Schur complement with the reduced camera system on v_mfma_f64_16x16x4_f64; LDS Gauss-Jordan",
+                rms_residual_last=round(float(tr[its - 1, 0]), 4), method="compact FD Jacobian; point-block Schur complement with the reduced camera system on v_mfma_f64_16x16x4_f64; register-resident Gauss-Jordan (SPD, pivot-free)",
                 dense_equivalent_flop_per_iter=2.0 * (3 * nt + 6 * nc) ** 2 * (2 * nt * nf))
 
 

@@ -145,3 +145,29 @@ def test_nls_batch_sharded_phases_match_single_call(golden):
     close(pw2, pw, 1e-12, 1e-14)
     close(tr2, tr, 1e-12)
     close(tr2[:, 0], golden[f"{tag}_trace"][:, 0], 2e-5)
+
+
+@pytest.mark.parametrize("nt,nf", [(40, 12), (30, 26), (24, 36)])
+def test_nls_batch_many_cameras_vs_oracle(golden, nt, nf):
+    """6(nf-1) = 66 / 150 / 210 reduced unknowns: the three register tilings of the Gauss-Jordan solve (<=127, <=192, <=256)."""
+    from oracle import nls_oracle as O
+    from velocity_amd.NLS import fcnNLS_batch
+
+    K = golden["K32"].astype(np.float64)
+    r = np.random.default_rng(77 + nf)
+    X = np.stack([r.uniform(-3, 3, nt), r.uniform(-1.5, 1.5, nt), r.uniform(9, 14, nt)], 1)
+    cams = np.stack([[0.05 * k, 0.01 * np.sin(k), 0.2 * k] for k in range(nf)])
+    P = np.full((5, nt, nf), np.nan, np.float32)
+    for k in range(nf):
+        q = (X + cams[k]) @ K
+        P[0:2, :, k] = (q[:, :2] / q[:, 2:3] + r.normal(0, 0.1, (nt, 2))).T.astype(np.float32)
+        P[4, :, k] = k
+    pw0 = X + r.normal(0, 0.05, X.shape)
+    cw0 = cams + r.normal(0, 0.02, cams.shape)
+    cw0[0] = 0
+    cw, pw, x, tr = fcnNLS_batch(golden["K32"], P.copy(), pw0, cw0, return_info=True)
+    ecw, epw, ex, etr = O.nls_batch(golden["K32"], P.copy(), pw0, cw0, return_info=True)
+    assert len(tr) == len(etr)
+    close(tr[:, 0], etr[:, 0], 1e-6)       # rms residual per iteration
+    close(cw, ecw, 1e-4, 1e-6)
+    close(pw, epw, 1e-4, 1e-6)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): bench line, stream sweep, rocprofv3 kernel stats and the two HBM-traffic PMC passes.
 # Usage: bash tools/collect_profiles.sh <streams> ; results under gpurun_out/prof/
-S=${1:-64}
+S=${1:-128}
 R=/root/repo
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
@@ -11,7 +11,9 @@ for s in 1 2 4 8 16 32 64 128 256; do
   python $R/bench.py --streams $s --steps 60 --warmup 10 --cpu-seconds 0 --no-ba 2>/dev/null | tail -1 > $OUT/sweep_$s.json
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --streams $S --steps 40 --warmup 5 --cpu-seconds 0 --no-ba > $OUT/stats.log 2>&1
+find $OUT/stats -name "*kernel_trace.csv" -delete   # tens of MB; the per-kernel summary is what is kept
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_q|k_lk_strip|k_pyr_down|k_roi_warp' --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --streams $S --steps 6 --warmup 2 --cpu-seconds 0 --no-ba > $OUT/pmc_$c.log 2>&1
+  find $OUT/pmc_$c -name "*kernel_trace.csv" -delete
 done
-ls -R $OUT | head -40
+du -sh $OUT; tail -2 $OUT/bench_default.err; ls -R $OUT | head -40

@@ -387,67 +387,105 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts)
     }
 }
 
-// Schur stage 2b: solve S dc = rhs with Gauss-Jordan + partial pivoting.
-// The augmented (6nc) x (6nc+1) system lives in LDS (105 KB at nc = 19); every elimination step updates all elements
-// in parallel.  Systems that do not fit LDS fall back to a global-memory matrix.
-#define BA_SOLVE_THREADS 1024
-template <bool IN_LDS>
-__global__ __launch_bounds__(BA_SOLVE_THREADS) void k_ba_solve(BaJob J, int nparts)
+// Schur stage 2b: solve S dc = rhs  (the reference: inv(JtJ + I) @ Jt r, NLS.py:235).
+// S = V + I - W^T (U + I)^-1 W is the Schur complement of the symmetric positive definite JtJ + I, hence itself SPD:
+// Gaussian elimination needs no pivoting there (it is backward stable for SPD systems), so the result equals LAPACK's
+// partially pivoted inverse to rounding -- and without the pivot search a Gauss-Jordan step needs ONE barrier.
+// The augmented (6nc) x (6nc+1) system is REGISTER resident: thread (rr, kk) of a G x G arrangement owns rows rr + G m
+// (m < RM) and columns kk + G j (j < CM).  Step c: the owners of row c and of column c have published them (double
+// buffered LDS vectors); every thread scales its multipliers, updates its own elements with FMAs, and the owners of row /
+// column c+1 publish those right away.  The single workgroup runs on one CU and is bound by the dependent-latency chain
+// of a step (barrier, LDS round trip, reciprocal, FMA), not by bandwidth: the LDS-resident version this replaces streamed
+// the whole matrix through LDS every step and took 200-250 us at nc = 19; this one takes ~1/4 of that.
+template <int RM, int CM, int G>
+__global__ __launch_bounds__(G * G) void k_ba_solve(BaJob J, int nparts)
 {
-    if (*J.done) return;
-    const int nq = 6 * J.nc, tid = threadIdx.x, ld = nq + 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* A = IN_LDS ? reinterpret_cast<double*>(smem) : J.Sfull;  // [nq][nq+1] augmented
-    // the partials were reduced into Sfull ([nq][nq+1], +I included) by k_ba_reduce
-    if (IN_LDS)
-        for (int e = tid; e < nq * ld; e += BA_SOLVE_THREADS) A[e] = J.Sfull[e];
     (void)nparts;
-    __shared__ int s_piv;
-    __shared__ double s_col[256];  // column c of the current step (multipliers), nq <= 256
-    __syncthreads();
-    const int rr = tid >> 5, kk = tid & 31;  // 32 x 32 arrangement of the elimination update
-    for (int c = 0; c < nq; c++) {
-        if (tid < 64) {  // pivot search by the first wavefront: max |A[r][c]|, r >= c (lowest row wins ties, like LAPACK)
-            double best = -1.0;
-            int piv = c;
-            for (int r = c + tid; r < nq; r += 64) {
-                const double v = fabs(A[(size_t)r * ld + c]);
-                if (v > best) { best = v; piv = r; }
-            }
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(best, o, 64);
-                const int op = __shfl_xor(piv, o, 64);
-                if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
-            }
-            if (tid == 0) s_piv = piv;
+    if (*J.done) return;
+    constexpr int NTH = G * G;
+    const int nq = 6 * J.nc, tid = threadIdx.x, ld = nq + 1;
+    const int rr = tid / G, kk = tid % G;
+    __shared__ double s_row[2][G * CM];   // row c, columns >= c
+    __shared__ double s_colv[2][G * RM];  // column c of every row
+    __shared__ double s_diag[G * RM];     // pivots
+    // the partials were reduced into Sfull ([nq][nq+1], +I included) by k_ba_reduce
+    double a[RM][CM];
+#pragma unroll
+    for (int m = 0; m < RM; m++)
+#pragma unroll
+        for (int j = 0; j < CM; j++) {
+            const int r = rr + G * m, k = kk + G * j;
+            a[m][j] = (r < nq && k <= nq) ? J.Sfull[(size_t)r * ld + k] : 0.0;
         }
-        __syncthreads();
-        const int piv = s_piv;
-        // swap rows c and piv, and build the multiplier column in the same pass (the swap only touches rows c, piv)
-        const double pivval = A[(size_t)piv * ld + c];
-        const double inv = 1.0 / pivval;
-        for (int r = tid; r < nq; r += BA_SOLVE_THREADS) {
-            const double v = (r == piv) ? A[(size_t)c * ld + c] : A[(size_t)r * ld + c];  // value of row r after the swap
-            s_col[r] = (r == c) ? 0.0 : v * inv;
-        }
-        __syncthreads();
-        if (piv != c)
-            for (int k = tid; k <= nq; k += BA_SOLVE_THREADS) {
-                const double t = A[(size_t)c * ld + k];
-                A[(size_t)c * ld + k] = A[(size_t)piv * ld + k];
-                A[(size_t)piv * ld + k] = t;
-            }
-        __syncthreads();
-        // rank-1 update of the trailing columns: A[r][k] -= f_r * A[c][k], k > c (column c itself is not needed again)
-        for (int k = c + 1 + kk; k <= nq; k += 32) {
-            const double pivrow = A[(size_t)c * ld + k];
-#pragma unroll 4
-            for (int r = rr; r < nq; r += 32)
-                if (r != c) A[(size_t)r * ld + k] -= s_col[r] * pivrow;
-        }
-        __syncthreads();
+    if (rr == 0) {
+#pragma unroll
+        for (int j = 0; j < CM; j++) s_row[0][kk + G * j] = a[0][j];
     }
-    for (int q = tid; q < nq; q += BA_SOLVE_THREADS) J.dc[q] = A[(size_t)q * ld + nq] / A[(size_t)q * ld + q];
+    if (kk == 0) {
+#pragma unroll
+        for (int m = 0; m < RM; m++) s_colv[0][rr + G * m] = a[m][0];
+    }
+    __syncthreads();
+    // the column-group index of the pivot is a compile-time constant inside the unrolled outer loop: no dynamic register
+    // indexing, finished column groups drop out of the update statically
+#pragma unroll
+    for (int cj = 0; cj < CM; cj++) {
+        for (int ck = 0; ck < G; ck++) {
+            const int c = G * cj + ck;
+            if (c >= nq) break;
+            const int buf = c & 1;
+            const double pivval = s_colv[buf][c];
+            const double inv = 1.0 / pivval;
+            if (tid == 0) s_diag[c] = pivval;
+            double f[RM];
+#pragma unroll
+            for (int m = 0; m < RM; m++) f[m] = (rr + G * m == c) ? 0.0 : s_colv[buf][rr + G * m] * inv;  // row c itself stays
+#pragma unroll
+            for (int j = cj; j < CM; j++) {
+                // column group cj: only the columns behind c; later groups: all (columns past nq hold zeros)
+                if (j > cj || kk > ck) {
+                    const double pivrow = s_row[buf][kk + G * j];
+#pragma unroll
+                    for (int m = 0; m < RM; m++) a[m][j] = __builtin_fma(-f[m], pivrow, a[m][j]);
+                }
+            }
+            // publish row c+1 and column c+1 for the next step (the other buffer: slow wavefronts may still read this one)
+            const int c1 = c + 1;
+            if (c1 < nq) {
+                if (ck + 1 < G) {
+                    if (rr == ck + 1) {
+#pragma unroll
+                        for (int j = cj; j < CM; j++) s_row[buf ^ 1][kk + G * j] = a[cj < RM ? cj : 0][j];
+                    }
+                    if (kk == ck + 1) {
+#pragma unroll
+                        for (int m = 0; m < RM; m++) s_colv[buf ^ 1][rr + G * m] = a[m][cj];
+                    }
+                } else if (cj + 1 < CM) {
+                    if (rr == 0) {
+#pragma unroll
+                        for (int j = cj + 1; j < CM; j++) s_row[buf ^ 1][kk + G * j] = a[cj + 1 < RM ? cj + 1 : 0][j];
+                    }
+                    if (kk == 0) {
+#pragma unroll
+                        for (int m = 0; m < RM; m++) s_colv[buf ^ 1][rr + G * m] = a[m][cj + 1 < CM ? cj + 1 : cj];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // dc[c] = rhs[c] / pivot of c
+    if (kk == (nq % G)) {
+#pragma unroll
+        for (int j = 0; j < CM; j++)
+            if (j == (nq / G)) {
+#pragma unroll
+                for (int m = 0; m < RM; m++) s_colv[0][rr + G * m] = a[m][j];
+            }
+    }
+    __syncthreads();
+    for (int q = tid; q < nq; q += NTH) J.dc[q] = s_colv[0][q] / s_diag[q];
 }
 
 // back-substitution dp = tp - Y dc, update x += 0.9 delta, rms(delta) and the stop flag (NLS.py:235-240)
@@ -572,15 +610,12 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     const int npass = (int)((nent + (long long)BA_THREADS * BA_EPT - 1) / ((long long)BA_THREADS * BA_EPT));
     const size_t lds = sizeof(double) * (size_t)(6 * nq + 12 * nc + 16);
     const size_t lds_mfma = sizeof(double) * (size_t)(24 * BA_NPAD + 48 * nc + 48 + 4 * BA_NPAD);
-    const size_t solve_lds = sizeof(double) * (size_t)nq * (nq + 1);
     const int nmeas = nt * (nc + 1);
     const int upd_blocks = (nt + BA_THREADS - 1) / BA_THREADS;
     auto init = [&]() -> int {
         hipError_t e = hipMemsetAsync(J.acc, 0, 4 * sizeof(double), s);
         if (e == hipSuccess) e = hipMemsetAsync(flags, 0, 32 * sizeof(double), s);
         if (e == hipSuccess) e = hipMemsetAsync(P.info, 0, 2 * sizeof(int), s);
-        if (e == hipSuccess && solve_lds <= 160 * 1024 && solve_lds > 48 * 1024)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds);
         return (int)e;
     };
     auto normal_equations = [&]() {
@@ -595,8 +630,10 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((nent + nq + 31) / 32)), dim3(BA_THREADS), 0, s, J, nparts);
     };
     auto solve_update = [&](int it) {
-        if (solve_lds <= 160 * 1024) hipLaunchKernelGGL(k_ba_solve<true>, dim3(1), dim3(BA_SOLVE_THREADS), solve_lds, s, J, nparts);
-        else hipLaunchKernelGGL(k_ba_solve<false>, dim3(1), dim3(BA_SOLVE_THREADS), 0, s, J, nparts);
+        // up to 127 unknowns: 256 threads x 64 doubles (same speed as 1024 x 16: the step is a latency chain, not work)
+        if (nq + 1 <= 128) hipLaunchKernelGGL((k_ba_solve<8, 8, 16>), dim3(1), dim3(256), 0, s, J, nparts);
+        else if (nq <= 192) hipLaunchKernelGGL((k_ba_solve<6, 7, 32>), dim3(1), dim3(1024), 0, s, J, nparts);
+        else hipLaunchKernelGGL((k_ba_solve<8, 9, 32>), dim3(1), dim3(1024), 0, s, J, nparts);
         hipLaunchKernelGGL(k_ba_update, dim3(upd_blocks), dim3(BA_THREADS), 0, s, J, it);
     };
     switch (P.phase) {
