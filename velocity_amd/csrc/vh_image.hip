@@ -228,8 +228,10 @@ __global__ __launch_bounds__(256) void k_roi_warp(const void* job_tab, size_t ta
                 const int ax = fx[k] & 31, ay = fy[k] & 31;
                 const int s00 = (tl >> (8 * k)) & 0xff, s01 = k < 3 ? (int)((tl >> (8 * k + 8)) & 0xff) : (int)th;
                 const int s10 = (bl >> (8 * k)) & 0xff, s11 = k < 3 ? (int)((bl >> (8 * k + 8)) & 0xff) : (int)bh;
-                const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
-                const uint32_t v = (uint32_t)((s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11 + (1 << 14)) >> 15);
+                // OpenCV's 15-bit weights w = 32 (32-ax | ax)(32-ay | ay) factor exactly: sum s w = 32 [32 t + ay (b - t)] with
+                // t = 32 s00 + ax (s01 - s00), b likewise -> (sum + 2^14) >> 15 == (32 t + ay (b - t) + 2^9) >> 10
+                const int t = 32 * s00 + ax * (s01 - s00), b = 32 * s10 + ax * (s11 - s10);
+                const uint32_t v = (uint32_t)((32 * t + ay * (b - t) + (1 << 9)) >> 10);
                 pack |= v << (8 * k);
             }
         } else {
@@ -240,8 +242,10 @@ __global__ __launch_bounds__(256) void k_roi_warp(const void* job_tab, size_t ta
                 const uint8_t* r0 = s.p + (ptrdiff_t)sy * s.stride + sx;
                 const int s00 = (y0in && x0in) ? r0[0] : 0, s01 = (y0in && x1in) ? r0[1] : 0;
                 const int s10 = (y1in && x0in) ? r0[s.stride] : 0, s11 = (y1in && x1in) ? r0[s.stride + 1] : 0;
-                const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
-                const uint32_t v = (uint32_t)((s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11 + (1 << 14)) >> 15);
+                // OpenCV's 15-bit weights w = 32 (32-ax | ax)(32-ay | ay) factor exactly: sum s w = 32 [32 t + ay (b - t)] with
+                // t = 32 s00 + ax (s01 - s00), b likewise -> (sum + 2^14) >> 15 == (32 t + ay (b - t) + 2^9) >> 10
+                const int t = 32 * s00 + ax * (s01 - s00), b = 32 * s10 + ax * (s11 - s10);
+                const uint32_t v = (uint32_t)((32 * t + ay * (b - t) + (1 << 9)) >> 10);
                 pack |= v << (8 * k);
             }
         }
