@@ -178,82 +178,109 @@ __global__ __launch_bounds__(256) void k_pyr_down(const void* pb_tab, size_t ws_
 // (translateFlag branch, SURVEY App. B intent); mode 1: float32 affine map + remap(INTER_LINEAR) with 5-bit
 // fixed-point coordinates and 15-bit weights, constant-0 border.  One thread = 4 consecutive ROI pixels.
 // ---------------------------------------------------------------------------------------------------------------
+#define RW_ROWS 4  // ROI rows per thread: their source loads are all in flight together (one memory round trip per 16 pixels)
+
+__device__ __forceinline__ void roi_store4(uint8_t* drow, int x4, int cnt, uint32_t pack)
+{
+    if (cnt == 4 && ((reinterpret_cast<uintptr_t>(drow + x4) & 3) == 0)) {
+        *reinterpret_cast<uint32_t*>(drow + x4) = pack;
+    } else {
+        for (int k = 0; k < cnt; k++) drow[x4 + k] = (uint8_t)(pack >> (8 * k));
+    }
+}
+
+// OpenCV's 15-bit weights w = 32 (32-ax | ax)(32-ay | ay) factor exactly: sum s w = 32 [32 t + ay (b - t)] with
+// t = 32 s00 + ax (s01 - s00), b likewise -> (sum + 2^14) >> 15 == (32 t + ay (b - t) + 2^9) >> 10
+__device__ __forceinline__ uint32_t remap_blend(int s00, int s01, int s10, int s11, int ax, int ay)
+{
+    const int t = 32 * s00 + ax * (s01 - s00), b = 32 * s10 + ax * (s11 - s10);
+    return (uint32_t)((32 * t + ay * (b - t) + (1 << 9)) >> 10);
+}
+
 __global__ __launch_bounds__(256) void k_roi_warp(const void* job_tab, size_t tab_stride)
 {
     const WarpJob J = *reinterpret_cast<const WarpJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.z * tab_stride);
     if (J.mode < 0) return;
     const int rw = J.x1 - J.x0, rh = J.y1 - J.y0;
     const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int ry = blockIdx.y * blockDim.y + threadIdx.y;
-    if (ry >= rh || x4 >= rw) return;
+    const int ry0 = (blockIdx.y * blockDim.y + threadIdx.y) * RW_ROWS;
+    if (ry0 >= rh || x4 >= rw) return;
     const ImgDesc s = J.src;
-    uint8_t* drow = J.dst + (size_t)ry * J.dst_stride;
     const int cnt = min(4, rw - x4);
-    uint32_t pack = 0;
     if (J.mode == 0) {
-        const int sy = J.y0 + ry + J.dy;
-        const bool yin = sy >= 0 && sy < s.h;
-        for (int k = 0; k < cnt; k++) {
-            int sx = J.x0 + x4 + k + J.dx;
-            uint32_t v = (yin && sx >= 0 && sx < s.w) ? s.p[(size_t)sy * s.stride + sx] : 0u;
-            pack |= v << (8 * k);
+        for (int r = 0; r < RW_ROWS && ry0 + r < rh; r++) {
+            const int sy = J.y0 + ry0 + r + J.dy;
+            const bool yin = sy >= 0 && sy < s.h;
+            uint32_t pack = 0;
+            for (int k = 0; k < cnt; k++) {
+                int sx = J.x0 + x4 + k + J.dx;
+                uint32_t v = (yin && sx >= 0 && sx < s.w) ? s.p[(size_t)sy * s.stride + sx] : 0u;
+                pack |= v << (8 * k);
+            }
+            roi_store4(J.dst + (size_t)(ry0 + r) * J.dst_stride, x4, cnt, pack);
         }
-    } else {
-        const float y = (float)(J.y0 + ry);
+        return;
+    }
+    // affine remap: coordinates of RW_ROWS x 4 pixels, then every row's source loads, then the blends
+    float xa[4], xb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float x = (float)(J.x0 + x4 + k);
+        xa[k] = __fmul_rn(x, J.T[0]);
+        xb[k] = __fmul_rn(x, J.T[1]);
+    }
+    int fx[RW_ROWS][4], fy[RW_ROWS][4];
+    bool run[RW_ROWS];
+    unsigned t0[RW_ROWS], t1[RW_ROWS], b0[RW_ROWS], b1[RW_ROWS], sh0[RW_ROWS], sh1[RW_ROWS];
+#pragma unroll
+    for (int r = 0; r < RW_ROWS; r++) {
+        const float y = (float)(J.y0 + ry0 + r);
         const float yx = __fmul_rn(y, J.T[2]), yy = __fmul_rn(y, J.T[3]);
-        int fx[4], fy[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float x = (float)(J.x0 + x4 + k);
             // float32, one rounding per operation, no fma (numpy: x*T00 + y*T10 + T20)
-            const float mx = __fadd_rn(__fadd_rn(__fmul_rn(x, J.T[0]), yx), J.T[4]);
-            const float my = __fadd_rn(__fadd_rn(__fmul_rn(x, J.T[1]), yy), J.T[5]);
-            fx[k] = vh_round(__fmul_rn(mx, 32.f));
-            fy[k] = vh_round(__fmul_rn(my, 32.f));
+            const float mx = __fadd_rn(__fadd_rn(xa[k], yx), J.T[4]);
+            const float my = __fadd_rn(__fadd_rn(xb[k], yy), J.T[5]);
+            fx[r][k] = vh_round(__fmul_rn(mx, 32.f));
+            fy[r][k] = vh_round(__fmul_rn(my, 32.f));
         }
-        const int sx0 = fx[0] >> 5, sy0 = fy[0] >> 5;
+        const int sx0 = fx[r][0] >> 5, sy0 = fy[r][0] >> 5;
         // near-identity maps (the tracker's case): the 4 pixels sample one source row pair at consecutive columns, so the
         // 2 x 5 source bytes come from two aligned dword pairs instead of 16 byte gathers
-        const bool run = cnt == 4 && (fx[1] >> 5) == sx0 + 1 && (fx[2] >> 5) == sx0 + 2 && (fx[3] >> 5) == sx0 + 3 && (fy[1] >> 5) == sy0 &&
-                         (fy[2] >> 5) == sy0 && (fy[3] >> 5) == sy0 && sx0 >= 3 && sx0 + 8 <= s.w && sy0 >= 0 && sy0 + 1 < s.h;
-        if (run) {
-            const uintptr_t a0 = reinterpret_cast<uintptr_t>(s.p + (ptrdiff_t)sy0 * s.stride + sx0), a1 = a0 + s.stride;
-            const unsigned sh0 = (unsigned)(a0 & 3), sh1 = (unsigned)(a1 & 3);
-            pd_gptr p0 = (pd_gptr)(a0 - sh0), p1 = (pd_gptr)(a1 - sh1);
-            const unsigned t0 = p0[0], t1 = p0[1], b0 = p1[0], b1 = p1[1];
-            const unsigned tl = __builtin_amdgcn_alignbyte(t1, t0, sh0), th = (t1 >> (8 * sh0)) & 0xffu;
-            const unsigned bl = __builtin_amdgcn_alignbyte(b1, b0, sh1), bh = (b1 >> (8 * sh1)) & 0xffu;
+        run[r] = cnt == 4 && ry0 + r < rh && (fx[r][1] >> 5) == sx0 + 1 && (fx[r][2] >> 5) == sx0 + 2 && (fx[r][3] >> 5) == sx0 + 3 &&
+                 (fy[r][1] >> 5) == sy0 && (fy[r][2] >> 5) == sy0 && (fy[r][3] >> 5) == sy0 && sx0 >= 3 && sx0 + 8 <= s.w && sy0 >= 0 &&
+                 sy0 + 1 < s.h;
+        // unconditional loads (a branch around a load makes the compiler wait per row): rows that do not qualify read a safe address
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(s.p + (run[r] ? (ptrdiff_t)sy0 * s.stride + sx0 : 0)), a1 = a0 + (run[r] ? s.stride : 0);
+        sh0[r] = (unsigned)(a0 & 3); sh1[r] = (unsigned)(a1 & 3);
+        pd_gptr p0 = (pd_gptr)(a0 - sh0[r]), p1 = (pd_gptr)(a1 - sh1[r]);
+        t0[r] = p0[0]; t1[r] = p0[1]; b0[r] = p1[0]; b1[r] = p1[1];
+    }
+#pragma unroll
+    for (int r = 0; r < RW_ROWS; r++) {
+        if (ry0 + r >= rh) break;
+        uint32_t pack = 0;
+        if (run[r]) {
+            const unsigned tl = __builtin_amdgcn_alignbyte(t1[r], t0[r], sh0[r]), th = (t1[r] >> (8 * sh0[r])) & 0xffu;
+            const unsigned bl = __builtin_amdgcn_alignbyte(b1[r], b0[r], sh1[r]), bh = (b1[r] >> (8 * sh1[r])) & 0xffu;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int ax = fx[k] & 31, ay = fy[k] & 31;
                 const int s00 = (tl >> (8 * k)) & 0xff, s01 = k < 3 ? (int)((tl >> (8 * k + 8)) & 0xff) : (int)th;
                 const int s10 = (bl >> (8 * k)) & 0xff, s11 = k < 3 ? (int)((bl >> (8 * k + 8)) & 0xff) : (int)bh;
-                // OpenCV's 15-bit weights w = 32 (32-ax | ax)(32-ay | ay) factor exactly: sum s w = 32 [32 t + ay (b - t)] with
-                // t = 32 s00 + ax (s01 - s00), b likewise -> (sum + 2^14) >> 15 == (32 t + ay (b - t) + 2^9) >> 10
-                const int t = 32 * s00 + ax * (s01 - s00), b = 32 * s10 + ax * (s11 - s10);
-                const uint32_t v = (uint32_t)((32 * t + ay * (b - t) + (1 << 9)) >> 10);
-                pack |= v << (8 * k);
+                pack |= remap_blend(s00, s01, s10, s11, fx[r][k] & 31, fy[r][k] & 31) << (8 * k);
             }
         } else {
             for (int k = 0; k < cnt; k++) {
-                const int sx = fx[k] >> 5, sy = fy[k] >> 5, ax = fx[k] & 31, ay = fy[k] & 31;
+                const int sx = fx[r][k] >> 5, sy = fy[r][k] >> 5;
                 const bool x0in = sx >= 0 && sx < s.w, x1in = sx + 1 >= 0 && sx + 1 < s.w;
                 const bool y0in = sy >= 0 && sy < s.h, y1in = sy + 1 >= 0 && sy + 1 < s.h;
                 const uint8_t* r0 = s.p + (ptrdiff_t)sy * s.stride + sx;
                 const int s00 = (y0in && x0in) ? r0[0] : 0, s01 = (y0in && x1in) ? r0[1] : 0;
                 const int s10 = (y1in && x0in) ? r0[s.stride] : 0, s11 = (y1in && x1in) ? r0[s.stride + 1] : 0;
-                // OpenCV's 15-bit weights w = 32 (32-ax | ax)(32-ay | ay) factor exactly: sum s w = 32 [32 t + ay (b - t)] with
-                // t = 32 s00 + ax (s01 - s00), b likewise -> (sum + 2^14) >> 15 == (32 t + ay (b - t) + 2^9) >> 10
-                const int t = 32 * s00 + ax * (s01 - s00), b = 32 * s10 + ax * (s11 - s10);
-                const uint32_t v = (uint32_t)((32 * t + ay * (b - t) + (1 << 9)) >> 10);
-                pack |= v << (8 * k);
+                pack |= remap_blend(s00, s01, s10, s11, fx[r][k] & 31, fy[r][k] & 31) << (8 * k);
             }
         }
-    }
-    if (cnt == 4 && ((reinterpret_cast<uintptr_t>(drow + x4) & 3) == 0)) {
-        *reinterpret_cast<uint32_t*>(drow + x4) = pack;
-    } else {
-        for (int k = 0; k < cnt; k++) drow[x4 + k] = (uint8_t)(pack >> (8 * k));
+        roi_store4(J.dst + (size_t)(ry0 + r) * J.dst_stride, x4, cnt, pack);
     }
 }
 
@@ -312,6 +339,6 @@ void vh_launch_pyr_down_ws(const void* pb_tab, size_t ws_stride, int batch, int 
 
 void vh_launch_roi_warp(const void* job_tab, size_t tab_stride, int batch, int max_w, int max_h, hipStream_t s)
 {
-    dim3 blk(64, 4), grd((max_w + 255) / 256, (max_h + 3) / 4, batch);
+    dim3 blk(64, 4), grd((max_w + 255) / 256, (max_h + 4 * RW_ROWS - 1) / (4 * RW_ROWS), batch);
     hipLaunchKernelGGL(k_roi_warp, grd, blk, 0, s, job_tab, tab_stride);
 }
