@@ -136,6 +136,14 @@ VH_API size_t vh_nls_batch_workspace(int nt, int nc);
 VH_API int vh_nls_batch(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
                         int* info, void* workspace, size_t workspace_bytes, void* stream);
 
+/* fcnNLS_batch2(K, P, pw, cw), utils/NLS.py:253-328: the constrained sibling -- tie points, ONE joint rotation applied to the
+ * points and a straight-line camera trajectory (elevation, azimuth, one range per camera 1..nc; camera 0 at the origin).
+ * Same z packing, damping (+I), step (0.9) and stop rule (rms(delta) < 1e-7); the reference runs at most 20 iterations.
+ *   x [3 nt + 5 + nc] float64 = points | joint rpy (3) | el, az | ranges (nc)   (NLS.py:274), updated in place.
+ * trace / info / workspace as vh_nls_batch (the same workspace size serves both). */
+VH_API int vh_nls_batch2(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
+                         int* info, void* workspace, size_t workspace_bytes, void* stream);
+
 /* One phase of a point-sharded BA iteration (multi-GPU fcnNLS_batch): this rank owns nt of the nt_total
  * tie points, the nc free cameras are replicated.  phase 0: init; 1: local normal equations -> [S | rhs | sums] span inside
  * the workspace (the caller all-reduces span_doubles float64 at span_offset bytes); 2: solve + update (the caller

@@ -311,3 +311,72 @@ def bookkeeping_step(vg, vp, v):
     vg[vg] = v
     vp = vp & vg
     return vg, vp, vp[vg]
+
+
+def _sc2cc_rows(sc):
+    """common.py:106-111 (row branch): [range, el, az] -> ned"""
+    r = sc[:, 0]
+    a = r * np.cos(sc[:, 1])
+    return np.stack([a * np.cos(sc[:, 2]), a * np.sin(sc[:, 2]), -r * np.sin(sc[:, 1])], 1)
+
+
+def ba2_predict(x, K, nc, nt):
+    """fzKautograd_batch of fcnNLS_batch2 (NLS.py:276-291)."""
+    C = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], float)
+    j = nt * 3
+    R = rpy_to_dcm(x[j : j + 3])
+    pc = x[:j].reshape(nt, 3) @ R
+    sc = np.zeros((nc, 3))
+    sc[:, 0] = x[j + 5 : j + 5 + nc]
+    sc[:, 1] = x[j + 3]
+    sc[:, 2] = x[j + 4]
+    off = _sc2cc_rows(sc) @ C
+    phat = np.concatenate([pc] + [pc + off[i] for i in range(nc)], 0)
+    q = phat @ K
+    return (q[:, :2] / q[:, 2:3]).ravel("F")
+
+
+def nls_batch2(K, P, pw, cw, max_iter=20, return_info=False):
+    """fcnNLS_batch2 (NLS.py:253-328) restated: dense forward-difference J, inv(JtJ + I), x += 0.9 delta, stop rms(delta) < 1e-7."""
+    P = np.asarray(P)
+    pw = np.asarray(pw, float)
+    cw = np.asarray(cw, float)
+    v = np.isfinite(P[4]).sum(1) == P.shape[2]
+    P, pw = P[:, v], pw[v]
+    _, nt, nc = P.shape
+    nc -= 1
+    nx = nt * 3 + nc + 5
+    K = np.asarray(K).astype(float)
+    C = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], float)
+    z = P[:2].ravel("F")
+    z = np.concatenate((z[::2], z[1::2])).astype(float)
+    nanz = np.isnan(z)
+    z[nanz] = 0
+    d = C @ (cw[1] - cw[0])
+    r = np.linalg.norm(d)
+    x = np.concatenate((pw.ravel(), np.zeros(3), [np.arcsin(-d[2] / r), np.arctan2(d[1], d[0])], np.arange(1, nc + 1) * r))
+    dx = 1e-6
+    mdm = np.eye(nx)
+    trace = []
+    for i in range(max_iter):
+        zhat = ba2_predict(x, K, nc, nt)
+        zhat[nanz] = 0
+        JT = np.zeros((nx, z.size))
+        for j in range(nx):
+            x1 = x.copy()
+            x1[j] += dx
+            JT[j] = ba2_predict(x1, K, nc, nt)
+        JT = (JT - zhat) / dx
+        delta = np.linalg.inv(JT @ JT.T + mdm) @ JT @ (z - zhat) * 0.9
+        x = x + delta
+        trace.append((rms(z - zhat), rms(delta)))
+        if rms(delta) < 1e-7:
+            break
+    j = nt * 3
+    sc = np.zeros((nc, 3))
+    sc[:, 0], sc[:, 1], sc[:, 2] = x[j + 5 : j + 5 + nc], x[j + 3], x[j + 4]
+    cw_out = np.concatenate((np.zeros((1, 3)), _sc2cc_rows(sc) @ C), 0)
+    pw_out = x[:j].reshape(nt, 3)
+    if return_info:
+        return cw_out, pw_out, x, np.array(trace)
+    return cw_out, pw_out

@@ -169,6 +169,20 @@ for nt, nf in ((20, 4), (50, 6), (200, 6)):
             tr.append((f, x))
     out[f"{tag}_trace"] = np.array(tr)
 
+# ---- constrained BA (fcnNLS_batch2, NLS.py:253-328): joint rotation + straight-line trajectory ---
+# (nf - 1 != 3: with exactly 3 fitted cameras the reference's sc2cc takes its column branch, common.py:100)
+for nt, nf in ((20, 5), (40, 7)):
+    P, pw0, cw0 = ba_scene(nt, nf, 2000 + nt)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        cw, pw = RN.fcnNLS_batch2(K32, P.copy(), pw0.copy(), cw0.copy())
+    tag = f"ba2_{nt}_{nf}"
+    out[f"{tag}_P"], out[f"{tag}_pw0"], out[f"{tag}_cw0"] = P, pw0, cw0
+    out[f"{tag}_cw"], out[f"{tag}_pw"] = cw, pw
+    last = [l for l in buf.getvalue().splitlines() if l.startswith("fcnNLS_batch2 done")][-1]
+    out[f"{tag}_steps"] = np.int64(float(last.split("done in ")[1].split(" steps")[0]))
+    out[f"{tag}_f"] = np.float64(float(last.split("f=")[1]))
+
 # ---- bookkeeping simulation (vidExample.py:125-129,135-136,139,151-153) --------------------------
 vg = np.ones(10, bool)
 vp = np.array([1, 1, 1, 1, 0, 1, 0, 1, 1, 0], bool)

@@ -171,3 +171,46 @@ def test_nls_batch_many_cameras_vs_oracle(golden, nt, nf):
     close(tr[:, 0], etr[:, 0], 1e-6)       # rms residual per iteration
     close(cw, ecw, 1e-4, 1e-6)
     close(pw, epw, 1e-4, 1e-6)
+
+
+@pytest.mark.parametrize("nt,nf", [(20, 5), (40, 7)])
+def test_nls_batch2_vs_reference_golden(golden, nt, nf, capsys):
+    """fcnNLS_batch2 (joint rotation + straight-line trajectory): vs the reference's own run and vs the oracle's trace."""
+    from oracle import nls_oracle as O
+    from velocity_amd.NLS import fcnNLS_batch2
+
+    tag = f"ba2_{nt}_{nf}"
+    args = (golden["K32"], golden[f"{tag}_P"].copy(), golden[f"{tag}_pw0"], golden[f"{tag}_cw0"])
+    cw, pw, x, tr = fcnNLS_batch2(*args, return_info=True)
+    out = capsys.readouterr().out
+    assert f"fcnNLS_batch2 done in {int(golden[f'{tag}_steps'])} steps" in out
+    assert pw.shape == (nt, 3) and cw.shape == (nf, 3) and np.all(cw[0] == 0)
+    close(cw, golden[f"{tag}_cw"], 1e-5, 1e-7)
+    close(pw, golden[f"{tag}_pw"], 1e-5, 1e-7)
+    close(tr[-1, 0], golden[f"{tag}_f"], 2e-6)
+    ecw, epw, ex, etr = O.nls_batch2(*args, return_info=True)
+    assert len(tr) == len(etr)
+    close(tr[:, 0], etr[:, 0], 1e-7)
+    close(x, ex, 1e-5, 1e-7)  # the joint rpy entries are ~1e-5 rad: absolute floor
+
+
+def test_nls_batch2_recovers_a_straight_line_trajectory(golden):
+    """Noise-free synthetic case: the fitted trajectory direction and spacing match the truth (up to the BA gauge = scale)."""
+    from velocity_amd.NLS import fcnNLS_batch2
+
+    K = golden["K32"].astype(np.float64)
+    r = np.random.default_rng(5)
+    nt, nf = 60, 9
+    X = np.stack([r.uniform(-3, 3, nt), r.uniform(-1.5, 1.5, nt), r.uniform(9, 14, nt)], 1)
+    step = np.array([0.06, -0.01, 0.3])
+    cams = np.arange(nf)[:, None] * step
+    P = np.full((5, nt, nf), np.nan, np.float32)
+    for k in range(nf):
+        q = (X + cams[k]) @ K
+        P[0:2, :, k] = (q[:, :2] / q[:, 2:3]).T.astype(np.float32)
+        P[4, :, k] = k
+    cw, pw = fcnNLS_batch2(golden["K32"], P, X + r.normal(0, 0.03, X.shape), cams + r.normal(0, 0.01, cams.shape))
+    d = np.diff(cw, axis=0)
+    dirs = d / np.linalg.norm(d, axis=1, keepdims=True)
+    assert np.allclose(dirs, dirs[0], atol=1e-9)                       # one straight line by construction of the model
+    assert np.dot(dirs[0], step / np.linalg.norm(step)) > 0.999        # pointing along the true motion

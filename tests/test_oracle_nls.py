@@ -99,3 +99,14 @@ def test_bookkeeping(golden):
     assert np.array_equal(vg, golden["bk_vg"]) and np.array_equal(vp, golden["bk_vp"]) and np.array_equal(sel, golden["bk_sel"])
     assert np.array_equal(np.nonzero(vg)[0], [0, 3, 4, 5, 6, 8, 9])
     assert np.array_equal(np.nonzero(vg)[0][sel], np.nonzero(vp)[0])
+
+
+@pytest.mark.parametrize("nt,nf", [(20, 5), (40, 7)])
+def test_nls_batch2_against_reference(golden, nt, nf):
+    """fcnNLS_batch2 (NLS.py:253-328): final cameras / points, the step count and the residual the reference prints."""
+    tag = f"ba2_{nt}_{nf}"
+    cw, pw, x, trace = O.nls_batch2(golden["K32"], golden[f"{tag}_P"].copy(), golden[f"{tag}_pw0"], golden[f"{tag}_cw0"], return_info=True)
+    close(cw, golden[f"{tag}_cw"], 1e-9, 1e-12)
+    close(pw, golden[f"{tag}_pw"], 1e-9, 1e-12)
+    assert len(trace) - 1 == int(golden[f"{tag}_steps"])
+    close(trace[-1, 0], golden[f"{tag}_f"], 2e-6)  # printed with %g

@@ -103,3 +103,58 @@ def fcnNLS_batch(K, P, pw, cw, max_iter=10, return_info=False):
     if return_info:
         return cw_out, pw_out, x, tr
     return cw_out, pw_out
+
+
+def _cam2ned():  # common.py:159-164
+    return np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], np.float64)
+
+
+def fcnNLS_batch2(K, P, pw, cw, max_iter=20, return_info=False):
+    """Constrained bundle adjustment (utils/NLS.py:253-328): tie points, one joint rotation and a straight-line camera
+    trajectory [el, az, ranges] -> (cw [nc+1,3], pw [nt,3]).
+
+    Host side = the reference's filtering, packing and initial state (NLS.py:257-274); the LM iterations run on the
+    device (vh_nls_batch2).  Reference defect resolved by intent: `sc2cc` switches to its column branch when exactly 3
+    cameras are fitted (shape ambiguity, common.py:100); here the ranges / el / az are always read row-wise.
+    """
+    torch = L.torch_cuda()
+    P = np.asarray(P)
+    pw = np.asarray(pw, np.float64)
+    cw = np.asarray(cw, np.float64)
+    keep = np.isfinite(P[4]).sum(1) == P.shape[2]  # NLS.py:257
+    P, pw = P[:, keep], pw[keep]
+    _, nt, nf = P.shape
+    nc = nf - 1
+    z = np.concatenate([P[0].T.reshape(-1), P[1].T.reshape(-1)]).astype(np.float64)  # NLS.py:266-267
+    z[np.isnan(z)] = 0
+    C = _cam2ned()
+    d = C @ (cw[1] - cw[0])  # cam -> ned (NLS.py:272), then cc2sc (common.py:81-94)
+    r = np.linalg.norm(d)
+    el, az = np.arcsin(-d[2] / r), np.arctan2(d[1], d[0])
+    ranges = np.arange(1, nc + 1) * r
+    x0 = np.concatenate((pw.ravel(), np.zeros(3), [el, az], ranges))  # NLS.py:274
+    K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+    zd = L.to_dev(z, torch.float64)
+    xd = L.to_dev(x0, torch.float64).clone()
+    trace = torch.zeros((max_iter, 2), dtype=torch.float64, device="cuda")
+    info = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ws = L.workspace()
+    nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    L.check(ws.lib.vh_nls_batch2(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, int(max_iter), L.dptr(trace), L.dptr(info),
+                                 L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch2")
+    info = info.cpu().numpy()
+    x = xd.cpu().numpy()
+    tr = trace.cpu().numpy()[: info[0]]
+    if not info[1]:
+        print("WARNING: fcnNLS_batch() reaching max iterations!")  # NLS.py:314 (sic)
+    print(f"fcnNLS_batch2 done in {info[0] - 1:g} steps, f={tr[-1, 0]:g}")  # NLS.py:315 (without the wall-time column)
+    j = nt * 3
+    rg, el, az = x[j + 5 : j + 5 + nc], x[j + 3], x[j + 4]
+    a = rg * np.cos(el)
+    ned = np.stack([a * np.cos(az), a * np.sin(az), -rg * np.sin(el)], 1)  # sc2cc, row-wise (common.py:106-111)
+    cw_out = np.concatenate((np.zeros((1, 3)), ned @ C), 0)
+    pw_out = x[:j].reshape(nt, 3)
+    if return_info:
+        return cw_out, pw_out, x, tr
+    return cw_out, pw_out

@@ -789,8 +789,25 @@ extern "C" VH_API int vh_nls_batch(vh_ctx* c, const float* K_host, const double*
     BaProblem P;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt); P.force_valu = g_ba_force_valu;
-    P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0;
+    P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 0;
     P.nx_total = 3.0 * nt + 6.0 * nc; P.nz_total = 2.0 * nt * (nc + 1);
+    int r = vh_ba_run(P, (hipStream_t)stream);
+    if (r) return vh_fail(r, "vh_ba_run failed");
+    return 0;
+}
+
+// fcnNLS_batch2 (NLS.py:253-328): tie points + ONE joint rotation + a straight-line camera trajectory (el, az, one range per camera)
+extern "C" VH_API int vh_nls_batch2(vh_ctx* c, const float* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
+                                    int* info, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!c || !K_host || nt < 1 || nc < 1 || max_iter < 1) return vh_fail(-1, "vh_nls_batch2: bad arguments");
+    if (6 * nc > 256) return vh_fail(-1, "vh_nls_batch2: at most 42 free cameras");
+    if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch2: workspace too small");
+    BaProblem P;
+    for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
+    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt); P.force_valu = 1;
+    P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 1;
+    P.nx_total = 3.0 * nt + nc + 5.0; P.nz_total = 2.0 * nt * (nc + 1);
     int r = vh_ba_run(P, (hipStream_t)stream);
     if (r) return vh_fail(r, "vh_ba_run failed");
     return 0;
@@ -812,7 +829,7 @@ extern "C" VH_API int vh_nls_batch_phase(vh_ctx* c, const float* K_host, const d
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = 1; P.nparts = ba_parts(nt);
     P.force_valu = g_ba_force_valu;
-    P.phase = phase; P.it = it; P.add_identity = rank0 ? 1 : 0; P.count_cams = rank0 ? 1 : 0; P.defer_finalize = 1;
+    P.phase = phase; P.it = it; P.add_identity = rank0 ? 1 : 0; P.count_cams = rank0 ? 1 : 0; P.defer_finalize = 1; P.model = 0;
     P.nx_total = 3.0 * nt_total + 6.0 * nc; P.nz_total = 2.0 * nt_total * (nc + 1);
     if (span_offset && span_doubles) vh_ba_exchange_span(P, span_offset, span_doubles);
     if (phase < 0 || phase > 3) return vh_fail(-1, "vh_nls_batch_phase: phase must be 0..3");

@@ -35,11 +35,41 @@ __device__ __forceinline__ void ba_project(const double* K, const double* R, con
 }
 
 // camera rotation matrices: R(rpy) and the three forward-difference neighbours R(rpy + dx e_k)  (NLS.py:206-216,228-233)
+// model 1 (fcnNLS_batch2, NLS.py:278-291): one joint rotation applied to the points; camera c sits at
+// sc2cc([range_c, el, az]) @ cam2ned() on a straight line; camera 0 is the origin
+__device__ void ba2_offset(double range, double el, double az, double* o)
+{
+    // sc2cc (common.py:97-112): ned = [r cos(el) cos(az), r cos(el) sin(az), -r sin(el)];  ned @ [[0,0,1],[1,0,0],[0,1,0]] = [n1, n2, n0]
+    const double a = range * cos(el);
+    const double n0 = a * cos(az), n1 = a * sin(az), n2 = -range * sin(el);
+    o[0] = n1; o[1] = n2; o[2] = n0;
+}
+
 __global__ void k_ba_cams(BaJob J)
 {
     if (*J.done) return;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;  // camera index 0..nc (0 = fixed identity camera)
     if (c > J.nc) return;
+    if (J.model == 1) {
+        const double* g = J.x + 3 * J.nt;  // rpy(3), el, az, ranges(nc)
+        if (c == 0) {
+            ba_rpy2dcm(g, J.camR);
+            for (int k = 0; k < 3; k++) {
+                double a[3] = {g[0], g[1], g[2]};
+                a[k] += BA_FD;
+                ba_rpy2dcm(a, J.camR + 9 * (k + 1));
+            }
+            for (int k = 0; k < 12; k++) J.camR[36 + k] = 0.0;
+            return;
+        }
+        double* o = J.camR + 36 + 12 * (size_t)c;
+        const double rg = g[5 + (c - 1)], el = g[3], az = g[4];
+        ba2_offset(rg, el, az, o);
+        ba2_offset(rg, el + BA_FD, az, o + 3);
+        ba2_offset(rg, el, az + BA_FD, o + 6);
+        ba2_offset(rg + BA_FD, el, az, o + 9);
+        return;
+    }
     double* out = J.camR + (size_t)c * 36;
     if (c == 0) {
         for (int q = 0; q < 4; q++)
@@ -66,8 +96,42 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
         const int c = m / nt, i = m - c * nt;
         double K[9];
         for (int k = 0; k < 9; k++) K[k] = J.K[k];
-        const double* R = J.camR + (size_t)c * 36;
         double w[3] = {J.x[3 * i], J.x[3 * i + 1], J.x[3 * i + 2]};
+        if (J.model == 1) {
+            // zhat = pscale((pw @ R + offset_c) @ K); columns of the compact Jacobian: point (3) | rpy (3), el, az, range_c
+            const double* R0 = J.camR;
+            const double* off = J.camR + 36 + 12 * (size_t)c;
+            double u, v, uk, vk;
+            ba_project(K, R0, w, off, u, v);
+            const double ru = J.z[m] - u, rv = J.z[(size_t)nt * nf + m] - v;
+            J.r[2 * (size_t)m] = ru;
+            J.r[2 * (size_t)m + 1] = rv;
+            ss = ru * ru + rv * rv;
+            double* Jp = J.Jp + 6 * (size_t)m;
+            for (int k = 0; k < 3; k++) {
+                double wk[3] = {w[0], w[1], w[2]};
+                wk[k] += BA_FD;
+                ba_project(K, R0, wk, off, uk, vk);
+                Jp[k] = (uk - u) / BA_FD;
+                Jp[3 + k] = (vk - v) / BA_FD;
+            }
+            double* Jc = J.Jc + 12 * (size_t)m;
+            for (int k = 0; k < 3; k++) {  // joint roll / pitch / yaw
+                ba_project(K, R0 + 9 * (k + 1), w, off, uk, vk);
+                Jc[k] = (uk - u) / BA_FD;
+                Jc[6 + k] = (vk - v) / BA_FD;
+            }
+            for (int k = 0; k < 3; k++) {  // el, az, range of this camera (camera 0 is fixed: exact zeros, as the reference's FD gives)
+                if (c > 0) {
+                    ba_project(K, R0, w, off + 3 * (k + 1), uk, vk);
+                    Jc[3 + k] = (uk - u) / BA_FD;
+                    Jc[9 + k] = (vk - v) / BA_FD;
+                } else {
+                    Jc[3 + k] = 0.0; Jc[9 + k] = 0.0;
+                }
+            }
+        } else {
+        const double* R = J.camR + (size_t)c * 36;
         double t[3] = {0, 0, 0};
         if (c > 0) for (int k = 0; k < 3; k++) t[k] = J.x[3 * nt + 3 * (c - 1) + k];
         double u, v, uk, vk;
@@ -101,6 +165,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
         } else {
             for (int k = 0; k < 12; k++) Jc[k] = 0.0;
         }
+        }
     }
     // sum of squared residuals of this iteration (trace only)
     ss = vh_wave_sum_f64(ss);
@@ -123,12 +188,12 @@ __device__ void inv3_sym(const double* U, double* Ui)
 __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
 {
     if (*J.done) return;
-    const int nt = J.nt, nc = J.nc, nq = 6 * nc, tid = threadIdx.x;
+    const int nt = J.nt, nc = J.nc, nq = J.nq, tid = threadIdx.x;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sW = reinterpret_cast<double*>(smem);  // [3][nq]
     double* sY = sW + 3 * nq;                      // [3][nq]
-    double* sJc = sY + 3 * nq;                     // [nc][12]
-    double* sTp = sJc + 12 * nc;                   // [3] tp_i, [3..] scratch
+    double* sJc = sY + 3 * nq;                     // [nc + 1][12]
+    double* sTp = sJc + 12 * (nc + 1);             // [3] tp_i, [3..] scratch
     const int chunk = (nt + gridDim.x - 1) / gridDim.x;
     const int i0 = blockIdx.x * chunk, i1 = min(nt, i0 + chunk);
     const long long nent = (long long)nq * nq;
@@ -160,18 +225,40 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
                 for (int a = 0; a < 3; a++) J.tp[3 * (size_t)i + a] = sTp[a];
             }
         }
-        // stage the camera Jacobians of this point
-        for (int q = tid; q < 12 * nc; q += BA_THREADS) {
-            const int c = q / 12 + 1, k = q - (c - 1) * 12;
-            sJc[q] = J.Jc[12 * ((size_t)c * nt + i) + k];
+        // stage the camera Jacobians of this point (model 0: cameras 1..nc at sJc[12 (c-1)]; model 1: cameras 0..nc at sJc[12 c])
+        if (J.model == 1) {
+            for (int q = tid; q < 12 * (nc + 1); q += BA_THREADS) {
+                const int c = q / 12, k = q - c * 12;
+                sJc[q] = J.Jc[12 * ((size_t)c * nt + i) + k];
+            }
+        } else {
+            for (int q = tid; q < 12 * nc; q += BA_THREADS) {
+                const int c = q / 12 + 1, k = q - (c - 1) * 12;
+                sJc[q] = J.Jc[12 * ((size_t)c * nt + i) + k];
+            }
         }
         __syncthreads();
         // W_i [3][nq] and Y_i = U_i^-1 W_i
         for (int q = tid; q < nq; q += BA_THREADS) {
-            const int c = q / 6, k = q - 6 * c;  // camera c+1, parameter k (0..2 pos, 3..5 rpy)
-            const double* Jp = J.Jp + 6 * ((size_t)(c + 1) * nt + i);
-            const double ju = sJc[12 * c + k], jv = sJc[12 * c + 6 + k];
-            const double w0 = Jp[0] * ju + Jp[3] * jv, w1 = Jp[1] * ju + Jp[4] * jv, w2 = Jp[2] * ju + Jp[5] * jv;
+            double w0 = 0.0, w1 = 0.0, w2 = 0.0, gq = 0.0;
+            if (J.model == 1) {
+                // column q < 5 (joint rpy, el, az) collects every camera, column q >= 5 is the range of camera q - 4
+                const int c_lo = q < 5 ? 0 : q - 4, c_hi = q < 5 ? nc : q - 4, k = q < 5 ? q : 5;
+                for (int c = c_lo; c <= c_hi; c++) {
+                    const size_t m = (size_t)c * nt + i;
+                    const double* Jp = J.Jp + 6 * m;
+                    const double ju = sJc[12 * c + k], jv = sJc[12 * c + 6 + k];
+                    w0 += Jp[0] * ju + Jp[3] * jv; w1 += Jp[1] * ju + Jp[4] * jv; w2 += Jp[2] * ju + Jp[5] * jv;
+                    gq += ju * J.r[2 * m] + jv * J.r[2 * m + 1];
+                }
+            } else {
+                const int c = q / 6, k = q - 6 * c;  // camera c+1, parameter k (0..2 pos, 3..5 rpy)
+                const size_t m = (size_t)(c + 1) * nt + i;
+                const double* Jp = J.Jp + 6 * m;
+                const double ju = sJc[12 * c + k], jv = sJc[12 * c + 6 + k];
+                w0 = Jp[0] * ju + Jp[3] * jv; w1 = Jp[1] * ju + Jp[4] * jv; w2 = Jp[2] * ju + Jp[5] * jv;
+                gq = ju * J.r[2 * m] + jv * J.r[2 * m + 1];
+            }
             sW[q] = w0; sW[nq + q] = w1; sW[2 * nq + q] = w2;
             const double* Ui = sTp + 3;
             const double y0 = Ui[0] * w0 + Ui[1] * w1 + Ui[2] * w2, y1 = Ui[3] * w0 + Ui[4] * w1 + Ui[5] * w2, y2 = Ui[6] * w0 + Ui[7] * w1 + Ui[8] * w2;
@@ -180,8 +267,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
                 double* Yg = J.Y + ((size_t)i * nq + q) * 3;
                 Yg[0] = y0; Yg[1] = y1; Yg[2] = y2;
                 // reduced rhs: gc - W^T tp
-                const size_t m = (size_t)(c + 1) * nt + i;
-                accR += ju * J.r[2 * m] + jv * J.r[2 * m + 1] - (w0 * sTp[0] + w1 * sTp[1] + w2 * sTp[2]);
+                accR += gq - (w0 * sTp[0] + w1 * sTp[1] + w2 * sTp[2]);
             }
         }
         __syncthreads();
@@ -192,6 +278,16 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
             if (ent < nent) {
                 const int a = (int)(ent / nq), b = (int)(ent - (long long)a * nq);
                 double v = -(sW[a] * sY[b] + sW[nq + a] * sY[nq + b] + sW[2 * nq + a] * sY[2 * nq + b]);
+                if (J.model == 1) {
+                    // V[a][b] over the cameras that carry both columns (shared columns: all; a range column: its camera)
+                    const int ka = a < 5 ? a : 5, kb = b < 5 ? b : 5;
+                    int c_lo = 0, c_hi = nc;
+                    if (a >= 5) { c_lo = a - 4; c_hi = a - 4; }
+                    if (b >= 5) { c_lo = max(c_lo, b - 4); c_hi = min(c_hi, b - 4); }
+                    for (int c = c_lo; c <= c_hi; c++) v += sJc[12 * c + ka] * sJc[12 * c + kb] + sJc[12 * c + 6 + ka] * sJc[12 * c + 6 + kb];
+                    accS[e] += v;
+                    continue;
+                }
                 const int ca = a / 6, cb = b / 6;
                 if (ca == cb) {
                     const int ka = a - 6 * ca, kb = b - 6 * cb;
@@ -364,7 +460,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points_mfma(BaJob J)
 __global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts)
 {
     if (*J.done) return;
-    const int nq = 6 * J.nc, ld = nq + 1;
+    const int nq = J.nq, ld = nq + 1;
     const long long nent = (long long)nq * nq, ntot = nent + nq;
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const long long e = (long long)blockIdx.x * 64 + lane;
@@ -415,7 +511,7 @@ __global__ __launch_bounds__(G * G) void k_ba_solve(BaJob J, int nparts)
     (void)nparts;
     if (*J.done) return;
     constexpr int NTH = G * G;
-    const int nq = 6 * J.nc, tid = threadIdx.x, ld = nq + 1;
+    const int nq = J.nq, tid = threadIdx.x, ld = nq + 1;
     const int rr = tid / G, kk = tid % G;
     __shared__ double s_row[2][G * CM];   // row c, columns >= c
     __shared__ double s_colv[2][G * RM];  // column c of every row
@@ -504,7 +600,7 @@ __global__ __launch_bounds__(G * G) void k_ba_solve(BaJob J, int nparts)
 __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
 {
     if (*J.done) return;
-    const int nt = J.nt, nc = J.nc, nq = 6 * nc, tid = threadIdx.x;
+    const int nt = J.nt, nc = J.nc, nq = J.nq, tid = threadIdx.x;
     __shared__ double sh[BA_THREADS / 64];
     double ss = 0.0;
     // one wavefront per point: the lanes split the 6nc columns of the point's 3 x 6nc block of Y (consecutive lanes read
@@ -531,8 +627,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
         for (int q = tid; q < nq; q += BA_THREADS) {
             const int c = q / 6, k = q - 6 * c;
             const double dl = J.dc[q] * 0.9;
-            // state layout: [points | camera positions | camera rpy] (NLS.py:203)
-            const size_t idx = k < 3 ? (size_t)3 * nt + 3 * c + k : (size_t)3 * nt + 3 * nc + 3 * c + (k - 3);
+            // state layout: [points | camera positions | camera rpy] (NLS.py:203); model 1: [points | rpy, el, az, ranges] in reduced order
+            const size_t idx = J.model == 1 ? (size_t)3 * nt + q
+                                            : (k < 3 ? (size_t)3 * nt + 3 * c + k : (size_t)3 * nt + 3 * nc + 3 * c + (k - 3));
             J.x[idx] += dl;
             if (J.count_cams) ss += dl * dl;  // sharded runs: the (replicated) camera update is counted by rank 0 only
         }
@@ -588,6 +685,7 @@ static void ba_layout(const BaProblem& P, BaJob& J, double*& flags)
 {
     const int nt = P.nt, nc = P.nc, nq = 6 * nc, nparts = P.nparts;
     J.nt = nt; J.nc = nc;
+    J.model = P.model; J.nq = P.model == 1 ? nc + 5 : 6 * nc;  // buffers are sized for 6 nc >= nc + 5
     for (int k = 0; k < 9; k++) J.K[k] = P.K[k];
     J.z = P.z; J.x = P.x; J.trace = P.trace; J.info = P.info;
     J.add_identity = P.add_identity; J.count_cams = P.count_cams; J.defer_finalize = P.defer_finalize;
@@ -619,15 +717,15 @@ void vh_ba_exchange_span(const BaProblem& P, size_t* offset_bytes, size_t* n_dou
 // [Sfull | acc] (then all-reduced by the caller), 2 = solve + update (then acc all-reduced), 3 = iteration record.
 int vh_ba_run(const BaProblem& P, hipStream_t s)
 {
-    const int nt = P.nt, nc = P.nc, nq = 6 * nc;
-    if (nq > BA_THREADS) return -3;  // reduced rhs ownership (one thread per entry) needs 6 nc <= 256
+    const int nt = P.nt, nc = P.nc, nq = P.model == 1 ? nc + 5 : 6 * nc;
+    if (6 * nc > BA_THREADS) return -3;  // reduced rhs ownership (one thread per entry) needs 6 nc <= 256
     const int nparts = P.nparts;
     BaJob J;
     double* flags;
     ba_layout(P, J, flags);
     const long long nent = (long long)nq * nq;
     const int npass = (int)((nent + (long long)BA_THREADS * BA_EPT - 1) / ((long long)BA_THREADS * BA_EPT));
-    const size_t lds = sizeof(double) * (size_t)(6 * nq + 12 * nc + 16);
+    const size_t lds = sizeof(double) * (size_t)(6 * nq + 12 * (nc + 1) + 16);
     const size_t lds_mfma = sizeof(double) * (size_t)(24 * BA_NPAD + 48 * nc + 48 + 4 * BA_NPAD);
     const int nmeas = nt * (nc + 1);
     // one wavefront per point, grid-strided: every block ends with an atomic on one address, so keep the block count low
@@ -641,7 +739,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     auto normal_equations = [&]() {
         hipLaunchKernelGGL(k_ba_cams, dim3((nc + 1 + 63) / 64), dim3(64), 0, s, J);
         hipLaunchKernelGGL(k_ba_jac, dim3((nmeas + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, s, J);
-        if (nq <= BA_NPAD && !P.force_valu) {
+        if (nq <= BA_NPAD && !P.force_valu && P.model == 0) {  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
             hipLaunchKernelGGL(k_ba_points_mfma, dim3(nparts), dim3(BA_THREADS), lds_mfma, s, J);
         } else {
             for (int pass = 0; pass < npass; pass++)  // later passes overwrite Spart entries of their own range only

@@ -5,8 +5,10 @@
 struct BaJob {  // passed by value to every BA kernel
     double K[9];
     const double* z;  // [2 * nt * (nc+1)] measurements, [all u | all v], camera-major / track-minor (NLS.py:198-199)
-    double* x;        // [3 nt + 6 nc] state: points | camera positions | camera rpy (NLS.py:203)
-    double* camR;     // [(nc+1)][4][9] R(rpy) and its three forward-difference neighbours
+    double* x;        // model 0: [3 nt + 6 nc] points | camera positions | camera rpy (NLS.py:203)
+                      // model 1: [3 nt + 3 + 2 + nc] points | joint rpy | el, az | camera ranges (NLS.py:274)
+    double* camR;     // model 0: [(nc+1)][4][9] R(rpy) and its three forward-difference neighbours
+                      // model 1: [4][9] joint R and neighbours, then [(nc+1)][4][3] camera offsets: base, +d el, +d az, +d range
     double* r;        // [m][2] residuals z - zhat
     double* Jp;       // [m][2][3] d(u,v)/d(point)
     double* Jc;       // [m][2][6] d(u,v)/d(camera pos, rpy)
@@ -23,6 +25,8 @@ struct BaJob {  // passed by value to every BA kernel
     unsigned* ticket;
     double nx_total, nz_total;  // normalisation of rms(delta) / rms(residual): whole-problem sizes (sharded runs)
     int nt, nc;
+    int nq;     // reduced unknowns: 6 nc (model 0) or nc + 5 (model 1)
+    int model;  // 0: fcnNLS_batch (free cameras, NLS.py:186-250); 1: fcnNLS_batch2 (joint rotation + straight-line trajectory, NLS.py:253-328)
     int add_identity, count_cams, defer_finalize;
 };
 
@@ -37,6 +41,7 @@ struct BaProblem {
     int phase, it;   // phase -1: whole solve; 0..3: the pieces of one sharded iteration (see vh_ba_run)
     int add_identity, count_cams, defer_finalize;
     double nx_total, nz_total;
+    int model;       // see BaJob::model
     int force_valu;  // test hook: 1 = accumulate the reduced camera system on the VALU instead of the matrix cores
 };
 
