@@ -1,11 +1,14 @@
-// Pyramidal Lucas-Kanade track solve (K3+K4+K5): one wavefront per track.
+// Pyramidal Lucas-Kanade track solve (K3+K4+K5).
 //
 // Replaces cv2calcOpticalFlowPyrLK (utils/KLT.py:37-51): forward LK over all pyramid levels, optional backward LK from
 // the result, forward-backward gate, and the map-back of KLTregional (KLT.py:86-89) / the 1/4-scale stage (KLT.py:115).
-// Arithmetic follows SURVEY Appendix A: Scharr derivatives (never materialised: computed on the fly from the 4x4
-// neighbourhood of every window sample), 14-bit fixed-point bilinear weights, int16 template / gradient windows kept
-// in LDS (lane-private columns, conflict free), exact int64 window sums reduced over the wavefront with a butterfly so
-// every lane holds the same sums and the Newton step / stop rules are wave-uniform.
+// Arithmetic follows SURVEY Appendix A: Scharr derivatives (never materialised), 14-bit fixed-point bilinear weights,
+// int16 template / gradient windows, exact integer window sums converted once to float32, so every implementation in this
+// file returns the same bits.  Four implementations, routed by vh_launch_lk (window size and number of tracks in flight):
+//   k_lk            per-sample reference kernel, one wavefront per track (any window; fallback for windows > 63 px)
+//   k_lk_strip<W>   strips of 4 samples per lane on packed 16-bit dot products, one wavefront per track, loads from L1/L2
+//   k_lk3<W,NW,M>   LDS-staged patch + search region, NW wavefronts per track, vertical strip runs (the 51x51 fine stage)
+//   k_lk_q<W>       4 tracks per wavefront, one 16-lane DPP row per track, template in registers (the 15x15 coarse stages)
 #include "vh_kernels.hpp"
 
 #define W_BITS 14
