@@ -167,9 +167,17 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
         }
         }
     }
-    // sum of squared residuals of this iteration (trace only)
+    // sum of squared residuals of this iteration (trace only): one atomic per block, spread over 16 addresses -- thousands of
+    // same-address atomics would serialise in L2 and dominate the kernel
+    __shared__ double s_ss[BA_THREADS / 64];
     ss = vh_wave_sum_f64(ss);
-    if ((threadIdx.x & 63) == 0 && ss != 0.0) atomicAdd(J.acc, ss);
+    if ((threadIdx.x & 63) == 0) s_ss[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < BA_THREADS / 64; k++) t += s_ss[k];
+        if (t != 0.0) atomicAdd(J.rslot + (blockIdx.x & 15), t);
+    }
 }
 
 __device__ void inv3_sym(const double* U, double* Ui)
@@ -482,6 +490,11 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts)
         for (; p < p1; p++) s += src[(size_t)p * step];
     }
     sh[slice][lane] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // fold the residual partials of k_ba_jac (previous launch) into acc[0]
+        double t = 0.0;
+        for (int k = 0; k < 16; k++) { t += J.rslot[k]; J.rslot[k] = 0.0; }
+        J.acc[0] += t;
+    }
     __syncthreads();
     if (slice == 0 && e < ntot) {
         double t = 0.0;
@@ -701,6 +714,7 @@ static void ba_layout(const BaProblem& P, BaJob& J, double*& flags)
     flags = take(32);
     J.done = reinterpret_cast<int*>(flags);
     J.ticket = reinterpret_cast<unsigned*>(flags) + 4;
+    J.rslot = flags + 8;  // doubles 8..23 of the 32-double flag block
 }
 
 // byte offset / length (in doubles) of the all-reduce span [Sfull | acc] inside the workspace

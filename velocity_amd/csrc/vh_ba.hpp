@@ -19,6 +19,7 @@ struct BaJob {  // passed by value to every BA kernel
     double* Sfull;    // [6 nc][6 nc + 1]
     double* dc;       // [6 nc]
     double* acc;      // [2] sum r^2, sum delta^2
+    double* rslot;    // [16] partial sums of r^2 (k_ba_jac spreads its atomics, k_ba_reduce folds them into acc[0])
     double* trace;    // [max_iter][2] rms(z - zhat), rms(delta) (what NLS.py:238 prints)
     int* info;        // [2] iterations, converged
     int* done;
