@@ -447,6 +447,37 @@ __device__ __forceinline__ void setup_from_v(const int* V0, const int* V1, const
     a22 = dot2(vY.y, vY.y, dot2(vY.x, vY.x, a22));
 }
 
+// Rolling form for a vertical run of strips: per V row keep its horizontal differences H[c] = V[c+2] - V[c] and its
+// horizontally smoothed values G[c] = 3 (V[c] + V[c+2]) + 10 V[c+1], c = 0..3.  Then (exact integer identities)
+//   Scharr_x = 3 (H0 + H2) + 10 H1,   Scharr_y = G2 - G0,   so a new strip costs one H row and one G row, not a 3 x 6 block of S / D
+__device__ __forceinline__ void setup_hg_row(const int* V, int* H, int* G)
+{
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        H[c] = V[c + 2] - V[c];
+        G[c] = __mul24(V[c] + V[c + 2], 3) + __mul24(V[c + 1], 10);  // every V fits 22 bits
+    }
+}
+__device__ __forceinline__ void setup_from_hg(const int* H0, const int* H1, const int* H2, const int* G0, const int* G2, const int* Vmid, int cnt,
+                                              uint2* tI, uint2* tX, uint2* tY, int slot, int& a11, int& a12, int& a22)
+{
+    int iv[4], ix[4], iy[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        iv[c] = vh_descale(Vmid[c], W_BITS - 5);
+        ix[c] = vh_descale(__mul24(H0[c] + H2[c], 3) + __mul24(H1[c], 10), W_BITS);
+        iy[c] = vh_descale(G2[c] - G0[c], W_BITS);
+    }
+    const unsigned m01 = cnt >= 2 ? 0xffffffffu : 0x0000ffffu, m23 = cnt >= 4 ? 0xffffffffu : (cnt == 3 ? 0x0000ffffu : 0u);
+    const uint2 vI = make_uint2(pack16(iv[0], iv[1]) & m01, pack16(iv[2], iv[3]) & m23);
+    const uint2 vX = make_uint2(pack16(ix[0], ix[1]) & m01, pack16(ix[2], ix[3]) & m23);
+    const uint2 vY = make_uint2(pack16(iy[0], iy[1]) & m01, pack16(iy[2], iy[3]) & m23);
+    tI[slot] = vI; tX[slot] = vX; tY[slot] = vY;
+    a11 = dot2(vX.y, vX.y, dot2(vX.x, vX.x, a11));
+    a12 = dot2(vX.y, vY.y, dot2(vX.x, vY.x, a12));
+    a22 = dot2(vY.y, vY.y, dot2(vY.x, vY.x, a22));
+}
+
 __device__ __forceinline__ void strip_setup_linear(const unsigned* lo, const unsigned* hi, const Win& w0, int cnt, uint2* tI, uint2* tX,
                                                    uint2* tY, int slot, int& a11, int& a12, int& a22)
 {
@@ -922,16 +953,21 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
         // interior: rolling V rows (see strip_setup_linear): patch rows y .. y+3 feed strip y; one new row per strip
         const unsigned wt = pack16(w0.w00, w0.w01), wb = pack16(w0.w10, w0.w11);
         const unsigned* col = pI + j;
-        unsigned prA[6], prB[6];
-        int V0[6], V1[6];
+        unsigned prB[6];
+        int H0[4], H1[4], G0[4], G1[4], Vm[4];  // of V rows y, y+1 (Vm = the middle row's sample columns, for the template value)
         {
-            unsigned pr0[6];
+            unsigned pr0[6], prA[6];
+            int V0[6], V1[6];
             const unsigned* r0 = col + y0 * (C::PI_PITCH >> 2);
             setup_row_pairs(r0[0], r0[1], pr0);
             setup_row_pairs(r0[C::PI_PITCH >> 2], r0[(C::PI_PITCH >> 2) + 1], prA);
             setup_row_pairs(r0[2 * (C::PI_PITCH >> 2)], r0[2 * (C::PI_PITCH >> 2) + 1], prB);
             setup_v_row(pr0, prA, wt, wb, V0);
             setup_v_row(prA, prB, wt, wb, V1);
+            setup_hg_row(V0, H0, G0);
+            setup_hg_row(V1, H1, G1);
+#pragma unroll
+            for (int c = 0; c < 4; c++) Vm[c] = V1[c + 1];
         }
 #pragma unroll
         for (int k = 0; k < C::K; k++) {
@@ -939,12 +975,15 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
             if (y < WIN) {
                 const unsigned* rn = col + (y + 3) * (C::PI_PITCH >> 2);
                 unsigned prN[6];
-                int V2[6];
+                int V2[6], H2[4], G2[4];
                 setup_row_pairs(rn[0], rn[1], prN);
                 setup_v_row(prB, prN, wt, wb, V2);
-                setup_from_v(V0, V1, V2, cnt, tI, tX, tY, k * C::T + tid, part[0], part[1], part[2]);
+                setup_hg_row(V2, H2, G2);
+                setup_from_hg(H0, H1, H2, G0, G2, Vm, cnt, tI, tX, tY, k * C::T + tid, part[0], part[1], part[2]);
 #pragma unroll
-                for (int c = 0; c < 6; c++) { V0[c] = V1[c]; V1[c] = V2[c]; prB[c] = prN[c]; }
+                for (int c = 0; c < 4; c++) { H0[c] = H1[c]; H1[c] = H2[c]; G0[c] = G1[c]; G1[c] = G2[c]; Vm[c] = V2[c + 1]; }
+#pragma unroll
+                for (int c = 0; c < 6; c++) prB[c] = prN[c];
             }
         }
     } else if (lane_on) {
