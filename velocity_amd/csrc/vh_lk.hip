@@ -832,9 +832,15 @@ struct LK3 {
     static constexpr int RJ = WIN + 1 + 2 * M;                                // search region rows / cols
     static constexpr int PJ_PITCH = ((((2 * M + 4 * (SPR - 1)) >> 2) * 4 + 12 + 3) / 4) * 4;
     static constexpr int OFF_TI = 0;
-    static constexpr int OFF_TX = OFF_TI + K * T * 8;
-    static constexpr int OFF_TY = OFF_TX + K * T * 8;
-    static constexpr int OFF_PI = OFF_TY + K * T * 8;
+    // template slots: exactly one per strip.  Full runs (K rows) first, k-major over their lanes; the last run (LAST_ROWS
+    // rows) behind them.  slot(k, tid) = slot_base + k * slot_stride, both per lane.
+    static constexpr int FULL_RUNS = WIN / K;                    // runs that own K rows
+    static constexpr int LAST_ROWS = WIN - FULL_RUNS * K;        // rows of the partial run (0: none)
+    static constexpr int FULL_LANES = FULL_RUNS * SPR;
+    static constexpr int SLOTS = NS;
+    static constexpr int OFF_TX = OFF_TI + SLOTS * 8;
+    static constexpr int OFF_TY = OFF_TX + SLOTS * 8;
+    static constexpr int OFF_PI = OFF_TY + SLOTS * 8;
     static constexpr int OFF_PJ = OFF_PI + PI_ROWS * PI_PITCH;
     static constexpr int OFF_RED = ((OFF_PJ + RJ * PJ_PITCH + 15) / 16) * 16;
     static constexpr int LDS_BYTES = OFF_RED + 2 * NW * 4 * 8;
@@ -948,6 +954,8 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
     const int run = tid / C::SPR, j = tid - run * C::SPR, y0 = run * C::K;
     const bool lane_on = run < C::RUNS;
     const int cnt = min(4, WIN - 4 * j);
+    const int slot_base = tid < C::FULL_LANES ? tid : C::FULL_LANES * C::K + (tid - C::FULL_LANES);
+    const int slot_stride = tid < C::FULL_LANES ? C::FULL_LANES : C::SPR;
     int part[3] = {0, 0, 0};
     if (lane_on && inside_I) {
         // interior: rolling V rows (see strip_setup_linear): patch rows y .. y+3 feed strip y; one new row per strip
@@ -979,7 +987,7 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
                 setup_row_pairs(rn[0], rn[1], prN);
                 setup_v_row(prB, prN, wt, wb, V2);
                 setup_hg_row(V2, H2, G2);
-                setup_from_hg(H0, H1, H2, G0, G2, Vm, cnt, tI, tX, tY, k * C::T + tid, part[0], part[1], part[2]);
+                setup_from_hg(H0, H1, H2, G0, G2, Vm, cnt, tI, tX, tY, slot_base + k * slot_stride, part[0], part[1], part[2]);
 #pragma unroll
                 for (int c = 0; c < 4; c++) { H0[c] = H1[c]; H1[c] = H2[c]; G0[c] = G1[c]; G1[c] = G2[c]; Vm[c] = V2[c + 1]; }
 #pragma unroll
@@ -997,7 +1005,7 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
                     const unsigned* row = pI + (y + r) * (C::PI_PITCH >> 2) + j;
                     lo[r] = row[0]; hi[r] = row[1];
                 }
-                strip_setup<false>(lo, hi, w0, I, ipx, ipy, 4 * j, y, cnt, tI, tX, tY, k * C::T + tid, part[0], part[1], part[2]);
+                strip_setup<false>(lo, hi, w0, I, ipx, ipy, 4 * j, y, cnt, tI, tX, tY, slot_base + k * slot_stride, part[0], part[1], part[2]);
             }
         }
     }
@@ -1051,7 +1059,8 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
                     unsigned bot[4], p01, p23;
                     region_row_pairs(inx, iny, y + 1, bot);  // the bottom row of strip y is the top row of strip y+1
                     strip_bilinear_pairs(top, bot, w, p01, p23);
-                    const uint2 vI = tI[k * C::T + tid], vX = tX[k * C::T + tid], vY = tY[k * C::T + tid];
+                    const int slot = slot_base + k * slot_stride;
+                    const uint2 vI = tI[slot], vX = tX[slot], vY = tY[slot];
                     const unsigned d01 = __builtin_bit_cast(unsigned, as_s2(p01) - as_s2(vI.x));
                     const unsigned d23 = __builtin_bit_cast(unsigned, as_s2(p23) - as_s2(vI.y));
                     b[0] = dot2(d23, vX.y, dot2(d01, vX.x, b[0]));
@@ -1095,7 +1104,7 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
                     unsigned bot[4], p01, p23;
                     region_row_pairs(inx, iny, y + 1, bot);
                     strip_bilinear_pairs(top, bot, w, p01, p23);
-                    const uint2 vI = tI[k * C::T + tid];
+                    const uint2 vI = tI[slot_base + k * slot_stride];
                     const short2v d01 = as_s2(p01) - as_s2(vI.x), d23 = as_s2(p23) - as_s2(vI.y);
                     const int d[4] = {d01.x, d01.y, d23.x, d23.y};
 #pragma unroll
@@ -1124,7 +1133,8 @@ __device__ void lk3_track(const PyrDesc& PI, const PyrDesc& PJ, int max_count, d
                               n_setup, want_err);
 }
 
-// (forcing 5 or 6 workgroups per CU through the second launch bound spills and measured 3-8 % slower: not used)
+// (forcing 5 or 6 workgroups per CU through the second launch bound spills and measured 3-8 % slower; a 128-VGPR cap
+// + a 3-pixel search margin to fit 7 workgroups of the 2-wave variant per CU: 11 spilled registers, 5 % slower: not used)
 template <int WIN, int NW, int M>
 __global__ __launch_bounds__(64 * NW) void k_lk3(const void* job_tab, size_t tab_stride)
 {
