@@ -21,12 +21,32 @@ def build(native=False, force=False):
     name = "libklt_oracle_native.so" if native else "libklt_oracle.so"
     path = os.path.join(_HERE, "_build", name)
     src = os.path.join(_HERE, "klt_oracle.c")
+    stamp = path + ".host"
+    if native:
+        # -march=native code must not travel to another machine (the build tree is copied to the GPU box as it is)
+        host = _host_signature()
+        if not os.path.exists(stamp) or open(stamp).read() != host:
+            force = True
     if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
         cmd = ["make", "-C", _HERE, "-s"] + (["NATIVE=1"] if native else [])
         if force:
             cmd.insert(3, "-B")
         subprocess.run(cmd, check=True)
+        if native:
+            with open(stamp, "w") as f:
+                f.write(_host_signature())
     return path
+
+
+def _host_signature():
+    import hashlib
+
+    try:
+        txt = open("/proc/cpuinfo").read()
+        keep = [l for l in txt.splitlines() if l.startswith(("model name", "flags"))][:2]
+        return hashlib.sha1("\n".join(keep).encode()).hexdigest()
+    except OSError:
+        return "unknown"
 
 
 def lib(native=False):
