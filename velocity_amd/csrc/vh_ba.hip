@@ -45,13 +45,11 @@ __device__ void ba2_offset(double range, double el, double az, double* o)
     o[0] = n1; o[1] = n2; o[2] = n0;
 }
 
-__global__ void k_ba_cams(BaJob J)
+// par = the camera-side part of the state (J.x + 3 nt, or a copy of it): model 0 [positions (3 nc) | rpy (3 nc)], model 1 [rpy, el, az, ranges]
+__device__ void ba_cam_tables(const BaJob& J, int c, const double* par)  // camera index 0..nc (0 = fixed identity camera)
 {
-    if (*J.done) return;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;  // camera index 0..nc (0 = fixed identity camera)
-    if (c > J.nc) return;
     if (J.model == 1) {
-        const double* g = J.x + 3 * J.nt;  // rpy(3), el, az, ranges(nc)
+        const double* g = par;  // rpy(3), el, az, ranges(nc)
         if (c == 0) {
             ba_rpy2dcm(g, J.camR);
             for (int k = 0; k < 3; k++) {
@@ -76,13 +74,21 @@ __global__ void k_ba_cams(BaJob J)
             for (int k = 0; k < 9; k++) out[q * 9 + k] = (k % 4 == 0) ? 1.0 : 0.0;
         return;
     }
-    const double* rpy = J.x + 3 * J.nt + 3 * J.nc + 3 * (c - 1);
+    const double* rpy = par + 3 * J.nc + 3 * (c - 1);
     ba_rpy2dcm(rpy, out);
     for (int k = 0; k < 3; k++) {
         double a[3] = {rpy[0], rpy[1], rpy[2]};
         a[k] += BA_FD;
         ba_rpy2dcm(a, out + 9 * (k + 1));
     }
+}
+
+// first iteration only: later iterations get their tables from block 0 of k_ba_update, right after it moved the cameras
+__global__ void k_ba_cams(BaJob J)
+{
+    if (*J.done) return;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c <= J.nc) ba_cam_tables(J, c, J.x + 3 * J.nt);
 }
 
 // residual and compact forward-difference Jacobian of every measurement pair (camera c, track i)
@@ -615,6 +621,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
     if (*J.done) return;
     const int nt = J.nt, nc = J.nc, nq = J.nq, tid = threadIdx.x;
     __shared__ double sh[BA_THREADS / 64];
+    __shared__ double s_par[256];  // new camera-side parameters (block 0)
     double ss = 0.0;
     // one wavefront per point: the lanes split the 6nc columns of the point's 3 x 6nc block of Y (consecutive lanes read
     // consecutive 24-byte column triples -> coalesced; a thread-per-point walk of the 2.7 KB rows ran at 0.3 TB/s)
@@ -643,9 +650,17 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
             // state layout: [points | camera positions | camera rpy] (NLS.py:203); model 1: [points | rpy, el, az, ranges] in reduced order
             const size_t idx = J.model == 1 ? (size_t)3 * nt + q
                                             : (k < 3 ? (size_t)3 * nt + 3 * c + k : (size_t)3 * nt + 3 * nc + 3 * c + (k - 3));
-            J.x[idx] += dl;
+            const double nv = J.x[idx] + dl;
+            J.x[idx] = nv;
+            s_par[idx - (size_t)3 * nt] = nv;
             if (J.count_cams) ss += dl * dl;  // sharded runs: the (replicated) camera update is counted by rank 0 only
         }
+    if (blockIdx.x == 0) {
+        // the cameras of the next iteration are final now: build their rotation / offset tables here, from the LDS copy of the
+        // new parameters (saves a launch per iteration)
+        __syncthreads();
+        for (int c = tid; c <= nc; c += BA_THREADS) ba_cam_tables(J, c, s_par);
+    }
     ss = vh_wave_sum_f64(ss);
     if ((tid & 63) == 0) sh[tid >> 6] = ss;
     __syncthreads();
@@ -750,8 +765,8 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         if (e == hipSuccess) e = hipMemsetAsync(P.info, 0, 2 * sizeof(int), s);
         return (int)e;
     };
-    auto normal_equations = [&]() {
-        hipLaunchKernelGGL(k_ba_cams, dim3((nc + 1 + 63) / 64), dim3(64), 0, s, J);
+    auto normal_equations = [&](int it) {
+        if (it == 0) hipLaunchKernelGGL(k_ba_cams, dim3((nc + 1 + 63) / 64), dim3(64), 0, s, J);
         hipLaunchKernelGGL(k_ba_jac, dim3((nmeas + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, s, J);
         if (nq <= BA_NPAD && !P.force_valu && P.model == 0) {  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
             hipLaunchKernelGGL(k_ba_points_mfma, dim3(nparts), dim3(BA_THREADS), lds_mfma, s, J);
@@ -772,11 +787,11 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     case -1: {
         int r = init();
         if (r) return r;
-        for (int it = 0; it < P.max_iter; it++) { normal_equations(); solve_update(it); }
+        for (int it = 0; it < P.max_iter; it++) { normal_equations(it); solve_update(it); }
         break;
     }
     case 0: { int r = init(); if (r) return r; break; }
-    case 1: normal_equations(); break;
+    case 1: normal_equations(P.it); break;
     case 2: solve_update(P.it); break;
     case 3: hipLaunchKernelGGL(k_ba_finalize, dim3(1), dim3(64), 0, s, J, P.it); break;
     default: return -4;
