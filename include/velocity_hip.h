@@ -63,6 +63,10 @@ VH_API void vh_ctx_destroy(vh_ctx* ctx);
 /* ---- image stages (K1, K2, K8, K9) ---------------------------------------------------------------------------- */
 /* cv2.resize(im, (0,0), fx=.25, fy=.25, INTER_NEAREST), utils/KLT.py:111-113.  dst: round(h/4) x round(w/4), dense */
 VH_API int vh_resize_quarter(vh_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream);
+/* frame ingest, optional rescale: cv2.resize(im, (0,0), fx=scale, fy=scale, interpolation=INTER_NEAREST), vidExample.py:99-102.
+ * dst: round(h fy) x round(w fx) with row stride dst_stride */
+VH_API int vh_resize_nearest(vh_ctx* ctx, const uint8_t* src, int w, int h, int stride, double fx, double fy, uint8_t* dst, int dst_stride,
+                             void* stream);
 /* frame ingest, cv2.cvtColor(imbgr, cv2.COLOR_BGR2GRAY), vidExample.py:91.
  * bgr: uint8 [h][w][3] with row stride stride_bytes; gray: uint8 [h][w] with row stride gray_stride */
 VH_API int vh_bgr2gray(vh_ctx* ctx, const uint8_t* bgr, int w, int h, int stride_bytes, uint8_t* gray, int gray_stride, void* stream);

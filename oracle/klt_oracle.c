@@ -123,6 +123,29 @@ KO_API void ko_resize_quarter(const uint8_t *src, int w, int h, int sstride, uin
     }
 }
 
+/* cv2.resize(im, (0,0), fx, fy, INTER_NEAREST) (vidExample.py:99-102, the `scale != 1` ingest branch): dsize = round(w fx) x round(h fy),
+ * sx = min(floor(x / fx), w - 1) (OpenCV resizeNN: x_ofs = cvFloor(x * (1/fx))) */
+KO_API void ko_resize_nearest_dims(int w, int h, double fx, double fy, int *dw, int *dh)
+{
+    *dw = (int)lrint(w * fx);
+    *dh = (int)lrint(h * fy);
+}
+KO_API void ko_resize_nearest(const uint8_t *src, int w, int h, int sstride, double fx, double fy, uint8_t *dst)
+{
+    int dw, dh;
+    ko_resize_nearest_dims(w, h, fx, fy, &dw, &dh);
+    const double ifx = 1.0 / fx, ify = 1.0 / fy;
+    for (int y = 0; y < dh; y++) {
+        int sy = (int)floor(y * ify);
+        if (sy > h - 1) sy = h - 1;
+        for (int x = 0; x < dw; x++) {
+            int sx = (int)floor(x * ifx);
+            if (sx > w - 1) sx = w - 1;
+            dst[(size_t)y * dw + x] = src[(ptrdiff_t)sy * sstride + sx];
+        }
+    }
+}
+
 /* Scharr derivative of the un-padded image with REFLECT_101 support, zero in the padding */
 static void level_make_deriv(level_t *L)
 {

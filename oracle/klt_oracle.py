@@ -101,6 +101,19 @@ def resize_quarter(img, L=None):
     return out
 
 
+def resize_nearest(img, fx, fy=None, L=None):
+    """cv2.resize(img, (0, 0), fx=fx, fy=fy, interpolation=cv2.INTER_NEAREST)"""
+    L = L or lib()
+    fy = fx if fy is None else fy
+    a, p, st = _view(img)
+    h, w = a.shape
+    dw, dh = C.c_int(), C.c_int()
+    L.ko_resize_nearest_dims(w, h, C.c_double(fx), C.c_double(fy), C.byref(dw), C.byref(dh))
+    out = np.empty((dh.value, dw.value), np.uint8)
+    L.ko_resize_nearest(p, w, h, C.c_int(st), C.c_double(fx), C.c_double(fy), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
 def pyramid_levels(w, h, win, max_level):
     return lib().ko_pyramid_levels(w, h, win, max_level)
 

@@ -340,6 +340,19 @@ def test_klt_main_bit_exact_at_baseline_sizes(cfg):
     assert v.mean() > 0.98 and np.median(e) < 0.03
 
 
+def test_resize_nearest_bit_exact():
+    """ingest rescale (vidExample.py:99-102, INTER_NEAREST) at several factors, incl. the driver's 0.5 and non-integer ratios"""
+    from velocity_amd.images import resize_nearest
+
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (271, 483), dtype=np.uint8)
+    for fx, fy in ((0.5, 0.5), (0.25, 0.25), (2.0, 2.0), (0.37, 0.61), (1.7, 0.9), (1.0, 1.0)):
+        got = resize_nearest(img, fx, fy)
+        exp = KO.resize_nearest(img, fx, fy)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (fx, fy)
+    assert np.array_equal(resize_nearest(img, 0.25), KO.resize_quarter(img))  # the tracker's own 1/4 stage is the same rule
+
+
 def test_bgr2gray_bit_exact():
     from velocity_amd.images import bgr2gray
 

@@ -435,6 +435,17 @@ extern "C" VH_API int vh_resize_quarter(vh_ctx* c, const uint8_t* src, int w, in
     return 0;
 }
 
+extern "C" VH_API int vh_resize_nearest(vh_ctx* c, const uint8_t* src, int w, int h, int stride, double fx, double fy, uint8_t* dst, int dst_stride,
+                                        void* stream)
+{
+    if (!c || w < 1 || h < 1 || !(fx > 0) || !(fy > 0)) return vh_fail(-1, "vh_resize_nearest: bad arguments");
+    const int dw = (int)lrint(w * fx), dh = (int)lrint(h * fy);
+    if (dw < 1 || dh < 1 || dst_stride < dw) return vh_fail(-1, "vh_resize_nearest: bad output size");
+    vh_launch_resize_nearest(src, w, h, (size_t)stride, dst, dw, dh, (size_t)dst_stride, 1.0 / fx, 1.0 / fy, (hipStream_t)stream);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" VH_API int vh_bgr2gray(vh_ctx* c, const uint8_t* bgr, int w, int h, int stride_bytes, uint8_t* gray, int gray_stride, void* stream)
 {
     if (!c || w < 1 || h < 1) return vh_fail(-1, "vh_bgr2gray: bad arguments");

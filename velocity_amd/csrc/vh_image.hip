@@ -312,6 +312,33 @@ void vh_launch_bgr2gray(const uint8_t* bgr, int w, int h, size_t sstride, uint8_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// frame ingest, optional rescale: cv2.resize(im, (0,0), fx=scale, fy=scale, INTER_NEAREST) (vidExample.py:99-102).
+// dst[y][x] = src[min(floor(y / fy), h-1)][min(floor(x / fx), w-1)], one thread = 4 output pixels
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize_nearest(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, int dw, int dh, size_t dstride,
+                                                        double ifx, double ify)
+{
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (y >= dh || x4 >= dw) return;
+    const int sy = min((int)floor(y * ify), h - 1);
+    const uint8_t* srow = src + (size_t)sy * sstride;
+    uint8_t* d = dst + (size_t)y * dstride + x4;
+    const int cnt = min(4, dw - x4);
+    uint32_t pack = 0;
+    for (int k = 0; k < cnt; k++) pack |= (uint32_t)srow[min((int)floor((x4 + k) * ifx), w - 1)] << (8 * k);
+    if (cnt == 4 && ((reinterpret_cast<uintptr_t>(d) & 3) == 0)) *reinterpret_cast<uint32_t*>(d) = pack;
+    else for (int k = 0; k < cnt; k++) d[k] = (uint8_t)(pack >> (8 * k));
+}
+
+void vh_launch_resize_nearest(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, int dw, int dh, size_t dstride, double ifx, double ify,
+                              hipStream_t s)
+{
+    dim3 blk(64, 4), grd((dw + 255) / 256, (dh + 3) / 4);
+    hipLaunchKernelGGL(k_resize_nearest, grd, blk, 0, s, src, w, h, sstride, dst, dw, dh, dstride, ifx, ify);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------------------
 void vh_launch_resize_quarter(const void* src_tab, const void* dst_tab, size_t tab_stride, int per_stream, int batch, int max_dw, int max_dh,

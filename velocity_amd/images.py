@@ -49,6 +49,20 @@ def bgr2gray(imbgr):
     return out if keep else out.cpu().numpy()
 
 
+def resize_nearest(im, fx, fy=None):
+    """cv2.resize(im, (0, 0), fx=fx, fy=fy, interpolation=cv2.INTER_NEAREST) -- the `scale != 1` branch of the frame ingest
+    (vidExample.py:99-102).  uint8 [H,W] -> uint8 [round(H fy), round(W fx)] (numpy in -> numpy out, tensor in -> tensor out)."""
+    torch = L.torch_cuda()
+    fy = fx if fy is None else fy
+    keep = isinstance(im, torch.Tensor)
+    t, h, w, st = L.img_dev(im)
+    dw, dh = int(np.rint(w * fx)), int(np.rint(h * fy))
+    out = torch.empty((dh, dw), dtype=torch.uint8, device="cuda")
+    ws = L.workspace()
+    L.check(ws.lib.vh_resize_nearest(ws.handle, L.dptr(t), w, h, st, float(fx), float(fy), L.dptr(out), dw, L.stream_ptr()), "vh_resize_nearest")
+    return out if keep else out.cpu().numpy()
+
+
 def goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, blockSize=3, useHarrisDetector=True, k=0.04):
     """cv2.goodFeaturesToTrack for the reference's call (vidExample.py:110: Harris, minDistance 0) -> float32 [n,1,2]."""
     if not useHarrisDetector or minDistance:
