@@ -410,3 +410,31 @@ def test_pyr_lk_fuzz_all_kernels_vs_oracle():
             assert np.array_equal(got[1], exp[1]), ctx
             assert np.array_equal(got[0], exp[0]), ctx
             assert np.array_equal(got[2].ravel(), exp[2]), ctx
+
+
+def test_klt_main_fuzz_vs_oracle():
+    """KLTmain on random frame sizes / motions / track sets (clustered ROIs, points outside the frame, strong and weak motion):
+    final tracks, status mask, quarter-scale image and failure flag bit-exact against the oracle.  Fixed seed."""
+    from velocity_amd import KLT
+
+    rng = np.random.default_rng(77)
+    for case in range(10):
+        W, H = int(rng.integers(320, 1000)), int(rng.integers(240, 640))
+        m = synth.AffineMotion(W, H, s=float(rng.uniform(0.985, 1.015)), theta_deg=float(rng.uniform(-0.6, 0.6)),
+                               tx=float(rng.uniform(-14, 14)), ty=float(rng.uniform(-10, 10)))
+        f0 = synth.render_frame(W, H, m, 0, seed=500 + case).numpy()
+        f1 = synth.render_frame(W, H, m, 1, seed=500 + case).numpy()
+        n = int(rng.integers(12, 700))
+        cx, cy = rng.uniform(0.3, 0.7) * W, rng.uniform(0.3, 0.7) * H
+        sx, sy = rng.uniform(0.1, 0.5) * W, rng.uniform(0.1, 0.5) * H
+        pts = np.stack([rng.normal(cx, sx, n), rng.normal(cy, sy, n)], 1).astype(np.float32)  # some land outside the frame
+        lvl = int(rng.integers(1, 5))
+        lkc = dict(max_level=lvl)
+        p, v, small, p_all, flags = KLT.KLTmain(f1, f0, None, pts, lk_coarse=lkc, return_all=True)
+        ep, ev, esmall, S = KO.klt_main(f1, f0, None, pts, lk_coarse=lkc, stages=True)
+        ctx = (case, W, H, n, lvl)
+        assert flags == S["flags"], ctx
+        assert np.array_equal(small, esmall), ctx
+        assert np.array_equal(v, ev), ctx
+        assert np.array_equal(p_all, S["p_all"]), ctx
+        assert np.array_equal(p, ep), ctx
