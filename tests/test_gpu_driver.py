@@ -77,3 +77,24 @@ def test_c1_driver_flow_matches_oracle_and_ground_truth(golden):
     # ground truth here (that is checked on consistent scenes in test_gpu_session.py / bench.py); it must be steady though.
     sp = st["S"][2:5, 8]
     assert np.all(sp > 0) and sp.std() / sp.mean() < 0.05
+
+
+def test_bench_distributed_path_one_rank():
+    """bench.py with the RCCL process group initialised (one rank): init, async all-gather of the packed track state, barrier and
+    the MAX all-reduce of the timing -- the code path of `torch.distributed.run --nproc-per-node N bench.py --gpus N`."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29622", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--streams", "4", "--steps", "35", "--warmup", "2",
+                        "--cpu-seconds", "0", "--no-ba", "--exchange-every", "10"], env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 35 and d["value"] > 0 and d["tracks_alive_frac"] > 0.9
+    assert "RCCL" in d["config"]["parallelism"]
+    for key in ("metric", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "roofline"):
+        assert key in d

@@ -214,3 +214,33 @@ def test_nls_batch2_recovers_a_straight_line_trajectory(golden):
     dirs = d / np.linalg.norm(d, axis=1, keepdims=True)
     assert np.allclose(dirs, dirs[0], atol=1e-9)                       # one straight line by construction of the model
     assert np.dot(dirs[0], step / np.linalg.norm(step)) > 0.999        # pointing along the true motion
+
+
+def test_nls_batch_sharded_through_rccl_one_rank(golden, tmp_path):
+    """The sharded BA with an initialised NCCL (= RCCL) process group of one rank: the all-reduces / all-gather go through RCCL
+    on its own stream, ordered against the library's kernels by the current-stream events -- the code path of a multi-GPU run."""
+    import os
+    import subprocess
+    import sys
+
+    script = tmp_path / "ba_rccl.py"
+    script.write_text(
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, os.environ['VH_REPO'])\n"
+        "from velocity_amd.NLS import fcnNLS_batch\n"
+        "from velocity_amd.dist import fcnNLS_batch_sharded\n"
+        "g = np.load(os.path.join(os.environ['VH_REPO'], 'tests', 'golden', 'nls_golden.npz'))\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "args = (g['K32'], g['ba_200_6_P'].copy(), g['ba_200_6_pw0'], g['ba_200_6_cw0'])\n"
+        "cw, pw, x, tr = fcnNLS_batch(*args, return_info=True)\n"
+        "cw2, pw2, tr2 = fcnNLS_batch_sharded(*args)\n"
+        "np.testing.assert_allclose(cw2, cw, rtol=1e-12, atol=1e-14)\n"
+        "np.testing.assert_allclose(pw2, pw, rtol=1e-12, atol=1e-14)\n"
+        "np.testing.assert_allclose(tr2, tr, rtol=1e-12)\n"
+        "dist.destroy_process_group()\n"
+        "print('RCCL_BA_OK')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", VH_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert "RCCL_BA_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -89,6 +89,7 @@ def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None):
     tc = L.torch_cuda()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    collective = dist.is_initialized()  # also with one rank: the same stream-ordered RCCL calls as a multi-GPU run
     P = np.asarray(P)
     pw = np.asarray(pw, np.float64)
     cw = np.asarray(cw, np.float64)
@@ -125,17 +126,17 @@ def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None):
     sums = span[-4:]
     for it in range(max_iter):
         phase(1, it)
-        if world > 1:
+        if collective:
             dist.all_reduce(span, group=group)
         phase(2, it)
-        if world > 1:
+        if collective:
             dist.all_reduce(sums, group=group)
         phase(3, it)
     info_h = info.cpu().numpy()
     x = xd.cpu().numpy()
     # gather the point blocks (cameras are identical on every rank)
     pw_local = tc.from_numpy(x[: 3 * nt].reshape(nt, 3)).cuda()
-    if world > 1:
+    if collective:
         sizes = [shard_tracks(nt_total, world, r) for r in range(world)]
         parts = [tc.zeros((b - a, 3), dtype=tc.float64, device="cuda") for a, b in sizes]
         dist.all_gather(parts, pw_local, group=group)
