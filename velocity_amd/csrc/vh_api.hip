@@ -717,7 +717,7 @@ extern "C" VH_API int vh_pose(vh_ctx* c, const float* K, const float* p, const d
     static_assert(sizeof(PoseJob) <= sizeof(LKJob), "PoseJob must fit in the LKJob slot");
     PoseJob* d = reinterpret_cast<PoseJob*>(&c->d_ws[0].lk);
     VH_CHECK(vh_store(d, J, s));
-    vh_launch_pose(d, sizeof(PoseJob), 1, J.mode, s);
+    vh_launch_pose(d, sizeof(PoseJob), 1, J.mode, n, s);
     VH_LAUNCH_CHECK();
     return 0;
 }

@@ -37,7 +37,7 @@ struct MsvJob {
     int* info_out;        // out 2
 };
 
-void vh_launch_pose(const void* tab, size_t stride, int batch, int mode, hipStream_t s);
+void vh_launch_pose(const void* tab, size_t stride, int batch, int mode, int max_n, hipStream_t s);
 void vh_launch_world2image(const double* C, const double* pw, int n, double* out, hipStream_t s);
 void vh_launch_image2world(const double* Hi, const double* p, int n, double* out, hipStream_t s);
 void vh_launch_pixel2uvec(double cx, double cy, double f, const double* p, int n, double* out, hipStream_t s);

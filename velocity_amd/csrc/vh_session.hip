@@ -325,7 +325,7 @@ extern "C" VH_API int vh_session_step(vh_session* s, const uint8_t* const* frame
     int r = vh_run_klt_main(c, 0, nb, st, s->coarse, s->fine);
     if (r) return r;
     hipLaunchKernelGGL(k_sess_book_a, dim3(nb), dim3(256), 0, st, s->d_ss);
-    vh_launch_pose(&s->d_ss[0].pose, sizeof(SessStream), nb, 0, st);
+    vh_launch_pose(&s->d_ss[0].pose, sizeof(SessStream), nb, 0, s->N0, st);
     hipLaunchKernelGGL(k_sess_book_b, dim3(nb), dim3(256), 0, st, s->d_ss, frames_dev, time_s, frame_no);
     s->steps++;
     if (s->steps == s->msv_frame && s->msv_frame >= 1 && s->msv_frame + 1 <= 16 && s->msv_frame < s->nhist) {
