@@ -29,7 +29,9 @@ CONFIGS = {
     "c2": dict(w=1920, h=1080, n=2000, levels=3, name="C2 synthetic 1080p@30fps, 2000 KLT tracks, 3 pyramid levels"),
     "c3": dict(w=3840, h=2160, n=5000, levels=4, name="C3 synthetic 4K@30fps, 5000 KLT tracks, 4 pyramid levels"),
 }
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s (int32/f32 VALU)
+# integer / packed-16 VALU issue peak: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3 T lane-instructions/s.  (The 32-lane rate of the
+# guide is the fp32 FMA class; the SQ counters of these kernels show 4 cycles per wave64 instruction, profiles/r01_lk_sq_pmc.md.)
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -272,12 +274,16 @@ def main():
             k = tj.get(fine_kernel)
             if k is not None:
                 traffic = int((2 * k["fetch_kib"] + k["write_kib"]) * 1024 * SG / tj["streams"])
+        sq_util = None  # measured VALU issue utilisation of that kernel (SQ_ACTIVE_INST_VALU / available quad-cycles), from profiles/
+        if a.config == "c2" and os.path.exists(tpath):
+            sq_util = json.load(open(tpath)).get("sq_valu_issue_utilisation", {}).get(fine_kernel)
         roof = dict(bound="hbm", kernel=fine_kernel + " (fine stage: 51x51 window, level 0, fwd+bwd)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, us_per_launch=round(us_fine, 2),
                     alg_bytes_per_launch=bytes_fine,
                     valu=dict(model_gops_per_launch=round(ops_fine / 1e9, 4), achieved_tops=round(ops_fine / (us_fine * 1e-6) / 1e12, 3) if us_fine > 0 else 0,
                               peak_tops=round(VALU_PEAK_TOPS, 1), frac=round(ops_fine / (us_fine * 1e-6) / 1e12 / VALU_PEAK_TOPS, 4) if us_fine > 0 else 0,
-                              newton_iters_per_track_dir=round(it_f / (2 * N * SG), 2)),
+                              newton_iters_per_track_dir=round(it_f / (2 * N * SG), 2),
+                              sq_valu_issue_utilisation=sq_util),
                     note="track solve is VALU/LDS bound (SURVEY §8d); the HBM figure prices its algorithmic gather bytes",
                     lk_us_per_launch=[round(1e3 * ms_sum[k] / max(launches[k], 1), 2) for k in range(3)],
                     lk_newton_iters_per_setup=[round(iters[k] / max(setups[k], 1), 2) for k in range(3)],

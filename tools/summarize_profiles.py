@@ -63,6 +63,10 @@ for cname, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
         v = v[n // 4:]  # drop the warm-up quarter
         traffic.setdefault(k, {})[key] = round(sum(v) / len(v), 1)
         traffic[k]["launches"] = len(v)
+# VALU issue utilisation from the SQ passes (tools/pmc_lk.sh, profiles/rNN_lk_sq_pmc.md): kept across regenerations
+sq_path = os.path.join(DST, f"{tag}_lk_sq_util.json")
+if os.path.exists(sq_path):
+    traffic["sq_valu_issue_utilisation"] = json.load(open(sq_path))
 json.dump(traffic, open(os.path.join(DST, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 
 # BA per-kernel stats + the bench line of the profiled run
@@ -113,7 +117,7 @@ o.append(f"Dominant kernel `{kname}` (fine LK stage): {float(k['AverageNs']) / 1
 o.append(f"HBM traffic of that kernel (`profiles/{tag}_hbm_traffic.json`, separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes at {traffic['streams']} streams, "
          f"FETCH_SIZE doubled per MI355X_MICROARCH.md): {(2 * kk['fetch_kib'] + kk['write_kib']) * 1024 / traffic['streams'] / 1e6:.1f} MB per stream and launch vs "
          f"22.05 MB algorithmic gather bytes; `roofline.achieved` = {rf['achieved']} GB/s of gather bytes ({100 * rf['frac']:.1f} % of 8 TB/s) - the kernel is VALU "
-         f"bound: {100 * rf['valu']['frac']:.0f} % of the 78.6 T lane-op/s VALU peak by the SURVEY op model.\n")
+         f"bound: {100 * rf['valu']['frac']:.0f} % of the 39.3 T lane-instruction/s integer VALU peak by the SURVEY op model, {100 * (rf['valu'].get('sq_valu_issue_utilisation') or 0):.0f} % VALU issue utilisation by the SQ counters (`profiles/{tag}_lk_sq_pmc.md`).\n")
 o.append(f"Throughput vs resident streams (`profiles/{tag}_stream_sweep.json`, 60 steps each): "
          + ", ".join(f"{s_} -> {v['frames_per_s'] / 1e3:.2f} k" for s_, v in sweep.items()) + " frames/s.\n")
 if host:
