@@ -458,6 +458,7 @@ __device__ __forceinline__ void setup_hg_row(const int* V, int* H, int* G)
         G[c] = __mul24(V[c] + V[c + 2], 3) + __mul24(V[c + 1], 10);  // every V fits 22 bits
     }
 }
+template <bool FULL01>  // FULL01: every strip holds at least 2 samples (window width % 4 != 1): the first pair needs no mask
 __device__ __forceinline__ void setup_from_hg(const int* H0, const int* H1, const int* H2, const int* G0, const int* G2, const int* Vmid, int cnt,
                                               uint2* tI, uint2* tX, uint2* tY, int slot, int& a11, int& a12, int& a22)
 {
@@ -468,10 +469,10 @@ __device__ __forceinline__ void setup_from_hg(const int* H0, const int* H1, cons
         ix[c] = vh_descale(__mul24(H0[c] + H2[c], 3) + __mul24(H1[c], 10), W_BITS);
         iy[c] = vh_descale(G2[c] - G0[c], W_BITS);
     }
-    const unsigned m01 = cnt >= 2 ? 0xffffffffu : 0x0000ffffu, m23 = cnt >= 4 ? 0xffffffffu : (cnt == 3 ? 0x0000ffffu : 0u);
-    const uint2 vI = make_uint2(pack16(iv[0], iv[1]) & m01, pack16(iv[2], iv[3]) & m23);
-    const uint2 vX = make_uint2(pack16(ix[0], ix[1]) & m01, pack16(ix[2], ix[3]) & m23);
-    const uint2 vY = make_uint2(pack16(iy[0], iy[1]) & m01, pack16(iy[2], iy[3]) & m23);
+    const unsigned m01 = (FULL01 || cnt >= 2) ? 0xffffffffu : 0x0000ffffu, m23 = cnt >= 4 ? 0xffffffffu : (cnt == 3 ? 0x0000ffffu : 0u);
+    const uint2 vI = make_uint2(FULL01 ? pack16(iv[0], iv[1]) : (pack16(iv[0], iv[1]) & m01), pack16(iv[2], iv[3]) & m23);
+    const uint2 vX = make_uint2(FULL01 ? pack16(ix[0], ix[1]) : (pack16(ix[0], ix[1]) & m01), pack16(ix[2], ix[3]) & m23);
+    const uint2 vY = make_uint2(FULL01 ? pack16(iy[0], iy[1]) : (pack16(iy[0], iy[1]) & m01), pack16(iy[2], iy[3]) & m23);
     tI[slot] = vI; tX[slot] = vX; tY[slot] = vY;
     a11 = dot2(vX.y, vX.y, dot2(vX.x, vX.x, a11));
     a12 = dot2(vX.y, vY.y, dot2(vX.x, vY.x, a12));
@@ -987,7 +988,7 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
                 setup_row_pairs(rn[0], rn[1], prN);
                 setup_v_row(prB, prN, wt, wb, V2);
                 setup_hg_row(V2, H2, G2);
-                setup_from_hg(H0, H1, H2, G0, G2, Vm, cnt, tI, tX, tY, slot_base + k * slot_stride, part[0], part[1], part[2]);
+                setup_from_hg<(WIN % 4) != 1>(H0, H1, H2, G0, G2, Vm, cnt, tI, tX, tY, slot_base + k * slot_stride, part[0], part[1], part[2]);
 #pragma unroll
                 for (int c = 0; c < 4; c++) { H0[c] = H1[c]; H1[c] = H2[c]; G0[c] = G1[c]; G1[c] = G2[c]; Vm[c] = V2[c + 1]; }
 #pragma unroll
