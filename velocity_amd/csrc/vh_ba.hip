@@ -516,25 +516,43 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts)
 
 // Schur stage 2b: solve S dc = rhs  (the reference: inv(JtJ + I) @ Jt r, NLS.py:235).
 // S = V + I - W^T (U + I)^-1 W is the Schur complement of the symmetric positive definite JtJ + I, hence itself SPD:
-// Gaussian elimination needs no pivoting there (it is backward stable for SPD systems), so the result equals LAPACK's
-// partially pivoted inverse to rounding -- and without the pivot search a Gauss-Jordan step needs ONE barrier.
+// Gaussian elimination needs no pivoting there (it is backward stable for SPD systems; every leading diagonal block is
+// SPD too), so the result equals LAPACK's partially pivoted inverse to rounding.
 // The augmented (6nc) x (6nc+1) system is REGISTER resident: thread (rr, kk) of a G x G arrangement owns rows rr + G m
-// (m < RM) and columns kk + G j (j < CM).  Step c: the owners of row c and of column c have published them (double
-// buffered LDS vectors); every thread scales its multipliers, updates its own elements with FMAs, and the owners of row /
-// column c+1 publish those right away.  The single workgroup runs on one CU and is bound by the dependent-latency chain
-// of a step (barrier, LDS round trip, reciprocal, FMA), not by bandwidth: the LDS-resident version this replaces streamed
-// the whole matrix through LDS every step and took 200-250 us at nc = 19; this one takes ~1/4 of that.
+// (m < RM) and columns kk + G j (j < CM).  The single workgroup runs on one CU and is bound by the dependent-latency chain
+// of an elimination round (barrier, LDS round trip, reciprocal, FMAs), not by work -- so a round eliminates a 2 x 2 pivot
+// block: the owners of rows / columns c, c+1 have published them (double-buffered LDS vectors), every thread forms its
+// multipliers F = [A(r,c) A(r,c+1)] P^-1, applies the rank-2 update to its own elements and the owners of the next block
+// publish right away.  One barrier per TWO unknowns; a last scalar round handles an odd count.  (History: LDS-resident
+// pivoted Gauss-Jordan 200-250 us at nc = 19 -> register-resident scalar rounds 80 us -> this.)
+template <int RM, int CM, int G>
+__device__ __forceinline__ void ba_publish(const double (&a)[RM][CM], double* row_slot, double* col_slot, int rr, int kk, int jn, int pos)
+{
+    // row / column with position `pos` inside group jn (rows and columns use the same group width, so the row group is jn too).
+    // jn is a constant after the caller's outer loop is unrolled: the register indices below are static.
+    if (rr == pos) {
+#pragma unroll
+        for (int j = 0; j < CM; j++)
+            if (j >= jn) row_slot[kk + G * j] = a[jn < RM ? jn : 0][j];
+    }
+    if (kk == pos) {
+#pragma unroll
+        for (int m = 0; m < RM; m++) col_slot[rr + G * m] = a[m][jn < CM ? jn : 0];
+    }
+}
+
 template <int RM, int CM, int G>
 __global__ __launch_bounds__(G * G) void k_ba_solve(BaJob J, int nparts)
 {
     (void)nparts;
     if (*J.done) return;
+    static_assert(G % 2 == 0, "a pivot pair never straddles a group");
     constexpr int NTH = G * G;
     const int nq = J.nq, tid = threadIdx.x, ld = nq + 1;
     const int rr = tid / G, kk = tid % G;
-    __shared__ double s_row[2][G * CM];   // row c, columns >= c
-    __shared__ double s_colv[2][G * RM];  // column c of every row
-    __shared__ double s_diag[G * RM];     // pivots
+    __shared__ double s_row[2][2][G * CM];   // [buffer][row of the pair][column]
+    __shared__ double s_colv[2][2][G * RM];  // [buffer][column of the pair][row]
+    __shared__ double s_pinv[G * RM / 2 + 1][4];  // inverse pivot blocks (a scalar round stores {1/pivot, 0, 0, 0})
     // the partials were reduced into Sfull ([nq][nq+1], +I included) by k_ba_reduce
     double a[RM][CM];
 #pragma unroll
@@ -544,75 +562,78 @@ __global__ __launch_bounds__(G * G) void k_ba_solve(BaJob J, int nparts)
             const int r = rr + G * m, k = kk + G * j;
             a[m][j] = (r < nq && k <= nq) ? J.Sfull[(size_t)r * ld + k] : 0.0;
         }
-    if (rr == 0) {
-#pragma unroll
-        for (int j = 0; j < CM; j++) s_row[0][kk + G * j] = a[0][j];
-    }
-    if (kk == 0) {
-#pragma unroll
-        for (int m = 0; m < RM; m++) s_colv[0][rr + G * m] = a[m][0];
-    }
+    ba_publish<RM, CM, G>(a, s_row[0][0], s_colv[0][0], rr, kk, 0, 0);
+    ba_publish<RM, CM, G>(a, s_row[0][1], s_colv[0][1], rr, kk, 0, 1);
     __syncthreads();
-    // the column-group index of the pivot is a compile-time constant inside the unrolled outer loop: no dynamic register
+    // the column-group index of the pivots is a compile-time constant inside the unrolled outer loop: no dynamic register
     // indexing, finished column groups drop out of the update statically
 #pragma unroll
     for (int cj = 0; cj < CM; cj++) {
-        for (int ck = 0; ck < G; ck++) {
+        for (int ck = 0; ck < G; ck += 2) {
             const int c = G * cj + ck;
             if (c >= nq) break;
-            const int buf = c & 1;
-            const double pivval = s_colv[buf][c];
-            const double inv = 1.0 / pivval;
-            if (tid == 0) s_diag[c] = pivval;
-            double f[RM];
+            const int buf = (c >> 1) & 1;
+            const bool pair = c + 1 < nq;
+            double f0[RM], f1[RM];
+            if (pair) {
+                const double p00 = s_colv[buf][0][c], p01 = s_colv[buf][1][c], p10 = s_colv[buf][0][c + 1], p11 = s_colv[buf][1][c + 1];
+                const double inv = 1.0 / (p00 * p11 - p01 * p10);
+                const double i00 = p11 * inv, i01 = -p01 * inv, i10 = -p10 * inv, i11 = p00 * inv;
+                if (tid == 0) { s_pinv[c >> 1][0] = i00; s_pinv[c >> 1][1] = i01; s_pinv[c >> 1][2] = i10; s_pinv[c >> 1][3] = i11; }
 #pragma unroll
-            for (int m = 0; m < RM; m++) f[m] = (rr + G * m == c) ? 0.0 : s_colv[buf][rr + G * m] * inv;  // row c itself stays
+                for (int m = 0; m < RM; m++) {
+                    const int r = rr + G * m;
+                    const double v0 = s_colv[buf][0][r], v1 = s_colv[buf][1][r];
+                    const bool piv = (r == c) || (r == c + 1);  // the pivot rows stay
+                    f0[m] = piv ? 0.0 : v0 * i00 + v1 * i10;
+                    f1[m] = piv ? 0.0 : v0 * i01 + v1 * i11;
+                }
+            } else {  // last unknown of an odd system: scalar round
+                const double inv = 1.0 / s_colv[buf][0][c];
+                if (tid == 0) { s_pinv[c >> 1][0] = inv; s_pinv[c >> 1][1] = 0.0; s_pinv[c >> 1][2] = 0.0; s_pinv[c >> 1][3] = 0.0; }
 #pragma unroll
-            for (int j = cj; j < CM; j++) {
-                // column group cj: only the columns behind c; later groups: all (columns past nq hold zeros)
-                if (j > cj || kk > ck) {
-                    const double pivrow = s_row[buf][kk + G * j];
-#pragma unroll
-                    for (int m = 0; m < RM; m++) a[m][j] = __builtin_fma(-f[m], pivrow, a[m][j]);
+                for (int m = 0; m < RM; m++) {
+                    f0[m] = (rr + G * m == c) ? 0.0 : s_colv[buf][0][rr + G * m] * inv;
+                    f1[m] = 0.0;
                 }
             }
-            // publish row c+1 and column c+1 for the next step (the other buffer: slow wavefronts may still read this one)
-            const int c1 = c + 1;
-            if (c1 < nq) {
-                if (ck + 1 < G) {
-                    if (rr == ck + 1) {
 #pragma unroll
-                        for (int j = cj; j < CM; j++) s_row[buf ^ 1][kk + G * j] = a[cj < RM ? cj : 0][j];
-                    }
-                    if (kk == ck + 1) {
+            for (int j = cj; j < CM; j++) {
+                // column group cj: only the columns behind the pair; later groups: all (columns past nq hold zeros)
+                if (j > cj || kk > ck + (pair ? 1 : 0)) {
+                    const double r0 = s_row[buf][0][kk + G * j], r1 = pair ? s_row[buf][1][kk + G * j] : 0.0;
 #pragma unroll
-                        for (int m = 0; m < RM; m++) s_colv[buf ^ 1][rr + G * m] = a[m][cj];
-                    }
+                    for (int m = 0; m < RM; m++) a[m][j] = __builtin_fma(-f1[m], r1, __builtin_fma(-f0[m], r0, a[m][j]));
+                }
+            }
+            // publish the next pair (the other buffer: slow wavefronts may still read this one)
+            if (c + 2 < nq) {
+                if (ck + 2 < G) {
+                    ba_publish<RM, CM, G>(a, s_row[buf ^ 1][0], s_colv[buf ^ 1][0], rr, kk, cj, ck + 2);
+                    if (c + 3 < nq) ba_publish<RM, CM, G>(a, s_row[buf ^ 1][1], s_colv[buf ^ 1][1], rr, kk, cj, ck + 3);
                 } else if (cj + 1 < CM) {
-                    if (rr == 0) {
-#pragma unroll
-                        for (int j = cj + 1; j < CM; j++) s_row[buf ^ 1][kk + G * j] = a[cj + 1 < RM ? cj + 1 : 0][j];
-                    }
-                    if (kk == 0) {
-#pragma unroll
-                        for (int m = 0; m < RM; m++) s_colv[buf ^ 1][rr + G * m] = a[m][cj + 1 < CM ? cj + 1 : cj];
-                    }
+                    ba_publish<RM, CM, G>(a, s_row[buf ^ 1][0], s_colv[buf ^ 1][0], rr, kk, cj + 1, 0);
+                    if (c + 3 < nq) ba_publish<RM, CM, G>(a, s_row[buf ^ 1][1], s_colv[buf ^ 1][1], rr, kk, cj + 1, 1);
                 }
             }
             __syncthreads();
         }
     }
-    // dc[c] = rhs[c] / pivot of c
+    // dc = P^-1 rhs per pivot block
     if (kk == (nq % G)) {
 #pragma unroll
         for (int j = 0; j < CM; j++)
             if (j == (nq / G)) {
 #pragma unroll
-                for (int m = 0; m < RM; m++) s_colv[0][rr + G * m] = a[m][j];
+                for (int m = 0; m < RM; m++) s_colv[0][0][rr + G * m] = a[m][j];
             }
     }
     __syncthreads();
-    for (int q = tid; q < nq; q += NTH) J.dc[q] = s_colv[0][q] / s_diag[q];
+    for (int q = tid; q < nq; q += NTH) {
+        const int b = q >> 1, q0 = 2 * b;
+        const double r0 = s_colv[0][0][q0], r1 = (q0 + 1 < nq) ? s_colv[0][0][q0 + 1] : 0.0;
+        J.dc[q] = (q & 1) ? s_pinv[b][2] * r0 + s_pinv[b][3] * r1 : s_pinv[b][0] * r0 + s_pinv[b][1] * r1;
+    }
 }
 
 // back-substitution dp = tp - Y dc, update x += 0.9 delta, rms(delta) and the stop flag (NLS.py:235-240)
