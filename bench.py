@@ -53,7 +53,32 @@ def parse():
     ap.add_argument("--host-frames", action="store_true",
                     help="frames start in pinned HOST memory and are uploaded every step (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the track-state exchange even with one rank (smoke test of the N>1 path)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for tests)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="TEST ONLY: allow more ranks than visible GPUs (ranks share devices round-robin; needs --backend gloo, RCCL refuses duplicate devices)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (one per visible GPU) through
+    torch.distributed.run, exactly as the driver would, and hand back its exit code.  Fewer visible GPUs than ranks is an error."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < a.gpus and not a.oversubscribe:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} needs {a.gpus} visible MI355X, this node shows {have} "
+                         "(refusing to print a 1-GPU number labelled as a multi-GPU run)")
+    if a.oversubscribe and a.backend != "gloo":
+        raise SystemExit("bench.py: --oversubscribe needs --backend gloo (RCCL refuses two ranks on one device)")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def make_ring(cfg, ring, device, seed, nsets=1):
@@ -142,8 +167,16 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no MI355X visible (velocity_amd has no CPU path)")
+    if local >= ndev and not a.oversubscribe:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local} but only {ndev} are visible")
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -152,7 +185,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from velocity_amd import _lib as L
     from velocity_amd import dist as vdist

@@ -151,7 +151,7 @@ VH_API int vh_nls_batch2(vh_ctx* ctx, const float* K_host, const double* z, doub
 /* One phase of a point-sharded BA iteration (multi-GPU fcnNLS_batch): this rank owns nt of the nt_total
  * tie points, the nc free cameras are replicated.  phase 0: init; 1: local normal equations -> [S | rhs | sums] span inside
  * the workspace (the caller all-reduces span_doubles float64 at span_offset bytes); 2: solve + update (the caller
- * all-reduces the span's last 4 doubles again); 3: iteration record (trace, info, stop flag).  rank0 != 0 on one rank. */
+ * then all-reduces ONLY sum delta^2 = the span's third-from-last double; sum r^2 was final after phase 1); 3: iteration record (trace, info, stop flag).  rank0 != 0 on one rank. */
 VH_API int vh_nls_batch_phase(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int nt_total, int rank0,
                               int phase, int it, double* trace, int* info, void* workspace, size_t workspace_bytes,
                               size_t* span_offset, size_t* span_doubles, void* stream);
@@ -197,6 +197,11 @@ VH_API int vh_session_init(vh_session* s, int slot, const uint8_t* frame0, int s
                            const uint8_t* vp, const float* t0_host, float time0, float frame_no, float res0, void* stream);
 /* one frame for every stream: frames_dev = device array of ctx->batch frame pointers (dense, w x h) */
 VH_API int vh_session_step(vh_session* s, const uint8_t* const* frames_dev, float time_s, float frame_no, void* stream);
+/* the same with one timestamp / frame number PER STREAM (device float[batch] each): independent videos with their own
+ * CAP_PROP_POS_MSEC / frame counters (vidExample.py:142: B[i,12:14]).  The frames of step i must stay alive until step i+1 has
+ * run (they are that step's im0). */
+VH_API int vh_session_step_v(vh_session* s, const uint8_t* const* frames_dev, const float* time_s_dev, const float* frame_no_dev,
+                             void* stream);
 VH_API int vh_session_ptrs(vh_session* s, int slot, vh_session_view* out_host);
 /* Packed track state of every stream for the cross-GPU exchange (RCCL all-gather, DESIGN.md "multi-GPU"):
  * out = device float32 [batch][8 + 3*n0]: {n_cur, n_pose, frame_i, klt_flags, t[3], res | p (n0 x 2) | ids (n0, int32 bits)} */

@@ -380,3 +380,96 @@ def nls_batch2(K, P, pw, cw, max_iter=20, return_info=False):
     if return_info:
         return cw_out, pw_out, x, np.array(trace)
     return cw_out, pw_out
+
+
+# ----------------------------------------------------------------------------------------------------
+# structured bundle adjustment: the SAME damped step as nls_batch(), through the point-block Schur complement
+# ----------------------------------------------------------------------------------------------------
+def _ba_project_all(K, pw, R, t):
+    """uv [nf, nt, 2] of every (camera, track) pair: b = pw @ R_c + t_c ; uv = pscale(b @ K)  (NLS.py:206-216)."""
+    b = np.einsum("ik,ckj->cij", pw, R) + t[:, None, :]
+    q = b @ K
+    return q[..., 0:2] / q[..., 2:3]
+
+
+def ba_compact_jacobian(x, K, nc, nt):
+    """Forward-difference Jacobian of fcnNLS_batch kept COMPACT: J has 9 structural non-zeros per measurement row (3 for the tie
+    point, 6 for the camera).  Every entry is (f(x + dx e_j) - f(x)) / dx with the reference's dx and re-projection (NLS.py:228-233),
+    i.e. exactly the non-zero entries of ba_jacobian_fd(); the structural zeros are exact zeros there too (f does not move).
+    Returns uv [nf,nt,2], Jp [nf,nt,2,3], Jc [nf,nt,2,6] (camera 0 is fixed: Jc[0] = 0)."""
+    nf = nc + 1
+    pw = x[: 3 * nt].reshape(nt, 3)
+    pos = np.concatenate([np.zeros((1, 3)), x[3 * nt : 3 * nt + 3 * nc].reshape(nc, 3)])
+    rpy = np.concatenate([np.zeros((1, 3)), x[3 * nt + 3 * nc :].reshape(nc, 3)])
+    R = np.stack([np.eye(3)] + [rpy_to_dcm(rpy[c]) for c in range(1, nf)])
+    uv = _ba_project_all(K, pw, R, pos)
+    Jp = np.zeros((nf, nt, 2, 3))
+    Jc = np.zeros((nf, nt, 2, 6))
+    for k in range(3):
+        pk = pw.copy()
+        pk[:, k] += FD_STEP
+        Jp[..., k] = (_ba_project_all(K, pk, R, pos) - uv) / FD_STEP
+        tk = pos.copy()
+        tk[:, k] += FD_STEP
+        Jc[..., k] = (_ba_project_all(K, pw, R, tk) - uv) / FD_STEP
+        Rk = np.stack([np.eye(3)] + [rpy_to_dcm(rpy[c] + FD_STEP * np.eye(3)[k]) for c in range(1, nf)])
+        Jc[..., 3 + k] = (_ba_project_all(K, pw, Rk, pos) - uv) / FD_STEP
+    Jc[0] = 0.0
+    return uv, Jp, Jc
+
+
+def ba_schur_step(x, z, K, nc, nt, gain=0.9):
+    """One LM step of fcnNLS_batch: delta = inv(J^T J + I) J^T (z - zhat) * gain (NLS.py:235), computed through
+        H = [[U W],[W^T V]] + I,  S = V + I - W^T (U+I)^-1 W,  S dc = gc - W^T (U+I)^-1 gp,  dp = (U+I)^-1 (gp - W dc)
+    with 3x3 point blocks U_i and 6x6 camera blocks V_c -- algebraically the dense inverse.  Returns (delta, rms residual)."""
+    nf, nq = nc + 1, 6 * nc
+    uv, Jp, Jc = ba_compact_jacobian(x, K, nc, nt)
+    zu = z[: nf * nt].reshape(nf, nt)
+    zv = z[nf * nt :].reshape(nf, nt)
+    r = np.stack([zu - uv[..., 0], zv - uv[..., 1]], -1)  # [nf, nt, 2]
+    U = np.einsum("cima,cimb->iab", Jp, Jp) + np.eye(3)
+    gp = np.einsum("cima,cim->ia", Jp, r)
+    Ui = np.linalg.inv(U)
+    W = np.einsum("cima,cimk->iack", Jp[1:], Jc[1:]).reshape(nt, 3, nq)
+    V = np.einsum("cimk,ciml->ckl", Jc[1:], Jc[1:])
+    gc = np.einsum("cimk,cim->ck", Jc[1:], r[1:]).reshape(nq)
+    Y = Ui @ W  # [nt, 3, nq]
+    tp = np.einsum("iab,ib->ia", Ui, gp)
+    S = np.eye(nq) - np.einsum("iak,ial->kl", W, Y)
+    for c in range(nc):
+        S[6 * c : 6 * c + 6, 6 * c : 6 * c + 6] += V[c]
+    rhs = gc - np.einsum("iak,ia->k", W, tp)
+    dc = np.linalg.solve(S, rhs)
+    dp = tp - Y @ dc
+    dcm = dc.reshape(nc, 6)
+    delta = np.concatenate([dp.reshape(-1), dcm[:, :3].reshape(-1), dcm[:, 3:].reshape(-1)]) * gain  # state order: points | positions | rpy
+    return delta, math.sqrt((r * r).sum() / z.size)
+
+
+def nls_batch_schur(K, P, pw, cw, max_iter=10, return_info=False):
+    """fcnNLS_batch (NLS.py:186-250) with the structured solve: same packing, damping, step and stop rule as nls_batch(), feasible at
+    BASELINE config 5 (20 keyframes x 5000 tracks), where the dense J^T alone would be 24 GB.  Pinned to nls_batch() (which is pinned
+    to the reference's own run) in tests/test_oracle_nls.py."""
+    K = np.asarray(K).astype(float)
+    z, bad, x, nt, nc = ba_pack(K, np.asarray(P), np.asarray(pw, float), np.asarray(cw, float))
+    assert not bad.any(), "full-length tracks only (NLS.py:190); NaN measurements are the dense oracle's business"
+    x, trace = ba_schur_solve(K, z, x, nt, nc, max_iter)
+    j = nt * 3
+    pw_out = x[:j].reshape(nt, 3)
+    cw_out = np.concatenate((np.zeros((1, 3)), x[j : j + nc * 3].reshape(nc, 3)), 0)
+    if return_info:
+        return cw_out, pw_out, x, trace
+    return cw_out, pw_out
+
+
+def ba_schur_solve(K, z, x, nt, nc, max_iter=10):
+    """LM loop on an already packed problem (z, x as vh_nls_batch takes them).  Returns (x, trace [(rms residual, rms delta)])."""
+    x = np.asarray(x, float).copy()
+    trace = []
+    for _ in range(max_iter):
+        delta, f = ba_schur_step(x, z, K, nc, nt)
+        x = x + delta
+        trace.append((f, rms(delta)))
+        if rms(delta) < 1e-7:
+            break
+    return x, np.array(trace)

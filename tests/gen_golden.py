@@ -169,6 +169,20 @@ for nt, nf in ((20, 4), (50, 6), (200, 6)):
             tr.append((f, x))
     out[f"{tag}_trace"] = np.array(tr)
 
+# ---- dense BA at (1000, 10): nx = 3054, nz = 20000 -- the largest size the reference's dense path finishes in about a minute; pins the
+# structured (Schur) restatement, which is the C5-sized oracle, to the reference itself (last paragraph)
+P, pw0, cw0 = ba_scene(1000, 10, 3000)
+buf = io.StringIO()
+with contextlib.redirect_stdout(buf):
+    cw, pw = RN.fcnNLS_batch(K32, P.copy(), pw0.copy(), cw0.copy())
+out["ba_1000_10_P"], out["ba_1000_10_pw0"], out["ba_1000_10_cw0"] = P, pw0, cw0
+out["ba_1000_10_cw"], out["ba_1000_10_pw"] = cw, pw
+tr = []
+for line in buf.getvalue().splitlines():
+    if ": " in line and "f=" in line and "x=" in line and not line.startswith("fcnNLS"):
+        tr.append((float(line.split("f=")[1].split(",")[0]), float(line.split("x=")[1])))
+out["ba_1000_10_trace"] = np.array(tr)
+
 # ---- constrained BA (fcnNLS_batch2, NLS.py:253-328): joint rotation + straight-line trajectory ---
 # (nf - 1 != 3: with exactly 3 fitted cameras the reference's sc2cc takes its column branch, common.py:100)
 for nt, nf in ((20, 5), (40, 7)):

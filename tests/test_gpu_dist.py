@@ -1,0 +1,123 @@
+"""N > 1 on ONE MI355X: two ranks share cuda:0 and talk over gloo (which stages device tensors through the host), so every
+multi-rank code path -- the point-sharded BA with its two all-reduces per iteration and the ragged point gather, the
+track-state all-gather of real tracker sessions, and bench.py's own rank launcher -- executes before an 8-GPU node ever
+sees it.  RCCL itself refuses two ranks on one device; its one-rank path is covered in test_gpu_nls.py / test_gpu_driver.py."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_COMMON = (
+    "import os, sys, json, numpy as np, torch, torch.distributed as dist\n"
+    "sys.path.insert(0, os.environ['VH_REPO'])\n"
+    "rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+    "torch.cuda.set_device(0)\n"
+    "dist.init_process_group('gloo', rank=rank, world_size=world)\n"
+)
+
+
+def _run_ranks(tmp_path, body, world=2, timeout=600, extra_env=None):
+    script = tmp_path / "ranks.py"
+    script.write_text(_COMMON + body + "dist.barrier()\ndist.destroy_process_group()\nprint(f'RANK{rank}_OK', flush=True)\n")
+    env = dict(os.environ, VH_REPO=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    out = r.stdout + r.stderr
+    for k in range(world):
+        assert f"RANK{k}_OK" in out, out[-4000:]
+    return out
+
+
+@pytest.mark.parametrize("tag,world", [("ba_200_6", 2), ("ba_50_6", 3)])
+def test_sharded_ba_world_n_equals_single_call(tmp_path, tag, world):
+    """fcnNLS_batch_sharded over 2 (even shards) and 3 (ragged shards: 17/17/16 points) ranks == the single-call BA: trace (rms residual
+    AND rms delta per iteration: the residual sum must be all-reduced exactly once) and final state to 1e-10."""
+    body = (
+        "from velocity_amd.NLS import fcnNLS_batch\n"
+        "from velocity_amd.dist import fcnNLS_batch_sharded\n"
+        "g = np.load(os.path.join(os.environ['VH_REPO'], 'tests', 'golden', 'nls_golden.npz'))\n"
+        f"tag = '{tag}'\n"
+        "args = (g['K32'], g[tag + '_P'].copy(), g[tag + '_pw0'], g[tag + '_cw0'])\n"
+        "cw2, pw2, tr2 = fcnNLS_batch_sharded(*args)\n"
+        "import io, contextlib\n"
+        "with contextlib.redirect_stdout(io.StringIO()):\n"
+        "    cw, pw, x, tr = fcnNLS_batch(*args, return_info=True)\n"
+        "assert len(tr2) == len(tr) == 10, (len(tr2), len(tr))\n"
+        "np.testing.assert_allclose(tr2[:, 0], tr[:, 0], rtol=1e-10)\n"
+        "np.testing.assert_allclose(tr2[:, 1], tr[:, 1], rtol=1e-7)\n"
+        "np.testing.assert_allclose(cw2, cw, rtol=1e-10, atol=1e-12)\n"
+        "np.testing.assert_allclose(pw2, pw, rtol=1e-10, atol=1e-12)\n"
+        "np.testing.assert_allclose(tr2[:, 0], g[tag + '_trace'][:, 0], rtol=2e-5)\n"
+    )
+    _run_ranks(tmp_path, body, world=world)
+
+
+def test_track_state_exchange_world2_real_sessions(tmp_path):
+    """Two ranks, each tracking its own stream (different motion) with a real TrackerSession on the shared device; the packed states
+    are all-gathered and every rank must see BOTH streams' state exactly as the owners hold it."""
+    body = (
+        "from velocity_amd import synth, _lib as L, dist as vd\n"
+        "from velocity_amd.driver import TrackerSession\n"
+        "W, H, n = 640, 360, 300\n"
+        "K = synth.K_1080P\n"
+        "def run(r):\n"
+        "    m = synth.AffineMotion(W, H, tx=2.0 + 1.5 * r, ty=-0.5 * r)\n"
+        "    fr = [synth.render_frame(W, H, m, k, seed=11 + r).cuda() for k in range(4)]\n"
+        "    p0 = synth.grid_tracks(n, W, H, seed=3 + r)\n"
+        "    ses = TrackerSession(K, W, H, n, nhist=8, batch=1, msv_frame=0)\n"
+        "    ses.init_stream(0, fr[0], p0, synth.plane_pose_scene(p0, K), np.ones(n, bool), np.float32([0, 0, 3.6]))\n"
+        "    for k in range(1, 4):\n"
+        "        ses.step([fr[k]], time_s=k / 30.0, frame_no=k)\n"
+        "    return ses, fr\n"
+        "ses, keep = run(rank)\n"
+        "ex = vd.TrackStateExchange(1, n, every=3, device='cuda')\n"
+        "L.check(ses.lib.vh_session_pack_state(ses.handle, L.dptr(ex.local), L.stream_ptr()), 'pack')\n"
+        "torch.cuda.synchronize()\n"
+        "ex.start()\n"
+        "g = ex.wait()\n"
+        "assert g.shape[0] == world\n"
+        "mine = vd.unpack_state(g[rank, 0], n)\n"
+        "st = ses.state(0)\n"
+        "assert mine['n_cur'] == st['n_cur'] and np.array_equal(mine['p'], st['p']) and np.array_equal(mine['ids'], st['ids'])\n"
+        "other_ses, keep2 = run(1 - rank)   # recompute the peer's stream locally: the gathered record must equal it bit for bit\n"
+        "peer = vd.unpack_state(g[1 - rank, 0], n)\n"
+        "so = other_ses.state(0)\n"
+        "assert peer['n_cur'] == so['n_cur'] and np.array_equal(peer['p'], so['p']) and np.array_equal(peer['ids'], so['ids'])\n"
+        "assert np.array_equal(peer['t'], so['t']) and peer['frame_i'] == 3\n"
+        "assert not np.array_equal(peer['p'], mine['p'])\n"
+    )
+    _run_ranks(tmp_path, body)
+
+
+def test_bench_self_launches_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` without a torchrun environment starts its own two ranks and reports n_gpus = 2 (here: both on
+    cuda:0 over gloo); the whole-job value counts the frames of both ranks."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--oversubscribe", "--streams", "2", "--steps", "6",
+           "--warmup", "2", "--no-ba", "--cpu-seconds", "0", "--exchange-every", "3", "--min-seconds", "0", "--no-extras"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["streams_per_gpu"] == 2 and out["scaling"] == "weak"
+    assert out["tracks_alive_frac"] > 0.9
+    assert abs(out["value"] - 2 * 2 * out["steps"] / (out["ms_per_step"] * out["steps"] / 1e3)) < 1e-6 * out["value"] + 1.0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """On a node with fewer GPUs than --gpus the bench exits non-zero with a clear message instead of printing n_gpus: 1."""
+    import torch
+
+    want = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "visible MI355X" in (r.stdout + r.stderr) and "n_gpus" not in r.stdout

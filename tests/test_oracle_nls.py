@@ -110,3 +110,43 @@ def test_nls_batch2_against_reference(golden, nt, nf):
     close(pw, golden[f"{tag}_pw"], 1e-9, 1e-12)
     assert len(trace) - 1 == int(golden[f"{tag}_steps"])
     close(trace[-1, 0], golden[f"{tag}_f"], 2e-6)  # printed with %g
+
+
+@pytest.mark.parametrize("tag", ["ba_20_4", "ba_50_6", "ba_200_6"])
+def test_structured_ba_equals_dense_and_reference(golden, tag):
+    """The point-block Schur restatement (feasible at C5) takes the same LM steps as the dense restatement and as the reference's run."""
+    args = (golden["K32"], golden[f"{tag}_P"].copy(), golden[f"{tag}_pw0"], golden[f"{tag}_cw0"])
+    cw, pw, x, tr = O.nls_batch_schur(*args, return_info=True)
+    dcw, dpw, dx, dtr = O.nls_batch(*args, return_info=True)
+    assert len(tr) == len(dtr) == 10
+    np.testing.assert_allclose(tr[:, 0], dtr[:, 0], rtol=1e-7)
+    np.testing.assert_allclose(tr[:, 1], dtr[:, 1], rtol=1e-4)  # the slow gauge mode amplifies rounding (SURVEY App. D)
+    np.testing.assert_allclose(x, dx, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(tr[:, 0], golden[f"{tag}_trace"][:, 0], rtol=2e-5)  # the reference prints %g
+    np.testing.assert_allclose(cw, golden[f"{tag}_cw"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pw, golden[f"{tag}_pw"], rtol=1e-5, atol=1e-6)
+
+
+def test_structured_ba_equals_dense_at_1000x10(golden):
+    """(nt, nf) = (1000, 10): nx = 3054, nz = 20000 -- the largest size the dense restatement finishes in seconds (2 iterations)."""
+    from velocity_amd import synth
+
+    P, pw0, cw0 = synth.ba_scene(1000, 10, seed=3)
+    a = O.nls_batch(golden["K32"], P.copy(), pw0, cw0, max_iter=2, return_info=True)
+    b = O.nls_batch_schur(golden["K32"], P.copy(), pw0, cw0, max_iter=2, return_info=True)
+    np.testing.assert_allclose(b[3][:, 0], a[3][:, 0], rtol=1e-8)
+    np.testing.assert_allclose(b[3][:, 1], a[3][:, 1], rtol=1e-6)
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-6, atol=1e-6)
+
+
+def test_structured_ba_vs_reference_run_at_1000x10(golden):
+    """The reference's OWN fcnNLS_batch run at (nt, nf) = (1000, 10) (nx = 3054; tests/gen_golden.py) pins the structured restatement
+    beyond the sizes the dense restatement is run at: per-iteration trace (the reference prints %g) and the final cameras / points."""
+    tag = "ba_1000_10"
+    cw, pw, x, tr = O.nls_batch_schur(golden["K32"], golden[f"{tag}_P"].copy(), golden[f"{tag}_pw0"], golden[f"{tag}_cw0"], return_info=True)
+    ref = golden[f"{tag}_trace"]
+    assert len(tr) == len(ref) == 10 and pw.shape == (1000, 3)
+    np.testing.assert_allclose(tr[:, 0], ref[:, 0], rtol=2e-5)
+    np.testing.assert_allclose(tr[:, 1], ref[:, 1], rtol=1e-4)
+    np.testing.assert_allclose(cw, golden[f"{tag}_cw"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pw, golden[f"{tag}_pw"], rtol=1e-5, atol=1e-6)

@@ -72,6 +72,7 @@ _SIGS = {
     "vh_session_destroy": (None, [vp]),
     "vh_session_init": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, f32p, C.c_float, C.c_float, C.c_float, vp]),
     "vh_session_step": (C.c_int, [vp, vp, C.c_float, C.c_float, vp]),
+    "vh_session_step_v": (C.c_int, [vp, vp, vp, vp, vp]),
     "vh_session_ptrs": (C.c_int, [vp, C.c_int, C.POINTER(SessionView)]),
     "vh_session_pack_state": (C.c_int, [vp, vp, vp]),
     "vh_debug_force_generic_lk": (None, [C.c_int]),

@@ -46,7 +46,8 @@ struct vh_session {
     char* arena;
     SessStream* d_ss;
     SessStream* h_ss;  // host mirror of the pointer fields
-    int steps;
+    int* h_frame;      // per stream: frames stepped since its vh_session_init (host mirror of SessStream::frame_i; the
+                       // reference fires fcnMSV1_t at `i == msvFrame` of EACH video, vidExample.py:155)
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -146,8 +147,11 @@ __global__ __launch_bounds__(256) void k_sess_book_a(SessStream* ss_all)
 }
 
 // results records B, S and history P (vidExample.py:142-146, 151-153, 164); then advance the frame state
-__global__ __launch_bounds__(256) void k_sess_book_b(SessStream* ss_all, const uint8_t* const* frames, float time_s, float frame_no)
+__global__ __launch_bounds__(256) void k_sess_book_b(SessStream* ss_all, const uint8_t* const* frames, float time_s, float frame_no,
+                                                     const float* times, const float* frame_nos)
 {
+    if (times) time_s = times[blockIdx.x];          // independent videos: per-stream timestamp (B[i,12] = CAP_PROP_POS_MSEC / 1000)
+    if (frame_nos) frame_no = frame_nos[blockIdx.x];
     SessStream& S = ss_all[blockIdx.x];
     const int tid = threadIdx.x, i = S.frame_i + 1, nh = S.nhist, N0 = S.N0;
     if (i < nh) {
@@ -193,9 +197,10 @@ __global__ __launch_bounds__(256) void k_sess_book_b(SessStream* ss_all, const u
 }
 
 // p3[vg] = p3hat - t ; vp = vg   (vidExample.py:159-160)
-__global__ __launch_bounds__(256) void k_sess_after_msv(SessStream* ss_all)
+__global__ __launch_bounds__(256) void k_sess_after_msv(SessStream* ss_all, int msv_frame)
 {
     SessStream& S = ss_all[blockIdx.x];
+    if (S.frame_i != msv_frame) return;  // only the streams whose own frame counter is at the MSV frame
     for (int k = threadIdx.x; k < S.n_cur; k += 256) {
         const int g = S.ids[k];
         for (int c = 0; c < 3; c++) S.p3[3 * g + c] = S.msv_b0[3 * k + c] - (double)S.t[c];
@@ -246,16 +251,17 @@ extern "C" VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, i
     vh_session* s = new (std::nothrow) vh_session();
     if (!s) return vh_fail(-1, "out of host memory");
     s->ctx = ctx; s->batch = ctx->batch; s->N0 = n0; s->nhist = nhist; s->w = w; s->h = h; s->msv_frame = msv_frame;
-    s->coarse = *coarse; s->fine = *fine; s->steps = 0;
+    s->coarse = *coarse; s->fine = *fine;
     const int dw = (int)lrint(w * 0.25), dh = (int)lrint(h * 0.25);
     s->h_ss = new SessStream[s->batch];
     memset(s->h_ss, 0, sizeof(SessStream) * s->batch);
+    s->h_frame = new int[s->batch]();
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     for (int pass = 0; pass < 2; pass++) {
         if (pass == 1) {
             hipError_t e = hipMalloc((void**)&s->arena, off);
-            if (e != hipSuccess) { delete[] s->h_ss; delete s; vh_set_error("hipMalloc(session)", e, __FILE__, __LINE__); return (int)e; }
+            if (e != hipSuccess) { delete[] s->h_ss; delete[] s->h_frame; delete s; vh_set_error("hipMalloc(session)", e, __FILE__, __LINE__); return (int)e; }
             (void)hipMemset(s->arena, 0, off);
             off = 0;
         }
@@ -287,7 +293,7 @@ extern "C" VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, i
         J.t_out = d->t; J.R_out = nullptr; J.res_out = &d->res; J.p_proj = S.p_proj; J.info_out = d->pose_info;
     }
     hipError_t e = hipMemcpy(s->d_ss, s->h_ss, sizeof(SessStream) * s->batch, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(s->arena); delete[] s->h_ss; delete s; vh_set_error("hipMemcpy(session)", e, __FILE__, __LINE__); return (int)e; }
+    if (e != hipSuccess) { (void)hipFree(s->arena); delete[] s->h_ss; delete[] s->h_frame; delete s; vh_set_error("hipMemcpy(session)", e, __FILE__, __LINE__); return (int)e; }
     *out = s;
     return 0;
 }
@@ -297,6 +303,7 @@ extern "C" VH_API void vh_session_destroy(vh_session* s)
     if (!s) return;
     (void)hipFree(s->arena);
     delete[] s->h_ss;
+    delete[] s->h_frame;
     delete s;
 }
 
@@ -311,11 +318,13 @@ extern "C" VH_API int vh_session_init(vh_session* s, int slot, const uint8_t* fr
     // quarter-scale copy of frame 0 = im0_small of the first step (pp starts at 0 -> previous index 1)
     int r = vh_resize_quarter(s->ctx, frame0, s->w, s->h, stride, s->h_ss[slot].small[1], stream);
     if (r) return r;
+    s->h_frame[slot] = 0;  // a (re-)initialised slot starts a new clip: its MSV frame counts from here
     SESS_CHECK();
     return 0;
 }
 
-extern "C" VH_API int vh_session_step(vh_session* s, const uint8_t* const* frames_dev, float time_s, float frame_no, void* stream)
+static int session_step(vh_session* s, const uint8_t* const* frames_dev, float time_s, float frame_no, const float* times_dev,
+                        const float* frame_nos_dev, void* stream)
 {
     if (!s || !frames_dev) return vh_fail(-1, "vh_session_step: bad arguments");
     hipStream_t st = (hipStream_t)stream;
@@ -326,23 +335,38 @@ extern "C" VH_API int vh_session_step(vh_session* s, const uint8_t* const* frame
     if (r) return r;
     hipLaunchKernelGGL(k_sess_book_a, dim3(nb), dim3(256), 0, st, s->d_ss);
     vh_launch_pose(&s->d_ss[0].pose, sizeof(SessStream), nb, 0, s->N0, st);
-    hipLaunchKernelGGL(k_sess_book_b, dim3(nb), dim3(256), 0, st, s->d_ss, frames_dev, time_s, frame_no);
-    s->steps++;
-    if (s->steps == s->msv_frame && s->msv_frame >= 1 && s->msv_frame + 1 <= 16 && s->msv_frame < s->nhist) {
-        for (int b = 0; b < nb; b++) {
-            const SessStream& H = s->h_ss[b];
-            MsvJob J;
-            memset(&J, 0, sizeof(J));
-            for (int k = 0; k < 9; k++) J.K[k] = H.K[k];
-            J.P = H.P; J.B = H.B; J.ids = H.ids; J.ng_ptr = &s->d_ss[b].n_cur; J.ng = 0; J.N0 = s->N0; J.nhist = s->nhist;
-            J.nf = s->msv_frame + 1; J.max_iter = 1000; J.f32_rays = 1;
-            J.U = H.msv_U; J.b0 = H.msv_b0; J.x_out = s->d_ss[b].msv_x; J.info_out = s->d_ss[b].msv_info;
-            vh_launch_msv1(J, st);
-        }
-        hipLaunchKernelGGL(k_sess_after_msv, dim3(nb), dim3(256), 0, st, s->d_ss);
+    hipLaunchKernelGGL(k_sess_book_b, dim3(nb), dim3(256), 0, st, s->d_ss, frames_dev, time_s, frame_no, times_dev, frame_nos_dev);
+    // fcnMSV1_t fires when a stream reaches ITS frame msv_frame (vidExample.py:155), whenever that stream was initialised
+    const bool msv_ok = s->msv_frame >= 1 && s->msv_frame + 1 <= 16 && s->msv_frame < s->nhist;
+    bool any = false;
+    for (int b = 0; b < nb; b++) {
+        const int fi = ++s->h_frame[b];
+        if (!msv_ok || fi != s->msv_frame) continue;
+        any = true;
+        const SessStream& H = s->h_ss[b];
+        MsvJob J;
+        memset(&J, 0, sizeof(J));
+        for (int k = 0; k < 9; k++) J.K[k] = H.K[k];
+        J.P = H.P; J.B = H.B; J.ids = H.ids; J.ng_ptr = &s->d_ss[b].n_cur; J.ng = 0; J.N0 = s->N0; J.nhist = s->nhist;
+        J.nf = s->msv_frame + 1; J.max_iter = 1000; J.f32_rays = 1;
+        J.U = H.msv_U; J.b0 = H.msv_b0; J.x_out = s->d_ss[b].msv_x; J.info_out = s->d_ss[b].msv_info;
+        vh_launch_msv1(J, st);
     }
+    if (any) hipLaunchKernelGGL(k_sess_after_msv, dim3(nb), dim3(256), 0, st, s->d_ss, s->msv_frame);
     SESS_CHECK();
     return 0;
+}
+
+extern "C" VH_API int vh_session_step(vh_session* s, const uint8_t* const* frames_dev, float time_s, float frame_no, void* stream)
+{
+    return session_step(s, frames_dev, time_s, frame_no, nullptr, nullptr, stream);
+}
+
+extern "C" VH_API int vh_session_step_v(vh_session* s, const uint8_t* const* frames_dev, const float* time_s_dev, const float* frame_no_dev,
+                                        void* stream)
+{
+    if (!time_s_dev || !frame_no_dev) return vh_fail(-1, "vh_session_step_v: bad arguments");
+    return session_step(s, frames_dev, 0.f, 0.f, time_s_dev, frame_no_dev, stream);
 }
 
 // packed track state of every stream for the cross-GPU exchange (K20): per stream a record of 8 + 3*N0 float32 words

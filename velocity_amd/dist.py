@@ -44,6 +44,11 @@ class TrackStateExchange:
         self.gathered = torch.zeros((self.world, streams_per_rank, record_words(n0)), dtype=torch.float32, device=dev)
         self._work = None
         self.count = 0
+        # gloo (tests only) has no device all-gather: stage through host buffers there; RCCL gathers device to device
+        self._host = dist.is_initialized() and dist.get_backend(group) == "gloo" and self.local.is_cuda
+        if self._host:
+            self._h_local = torch.zeros_like(self.local, device="cpu")
+            self._h_gathered = torch.zeros_like(self.gathered, device="cpu")
 
     def due(self, frame_index):
         return self.every > 0 and frame_index % self.every == 0
@@ -53,6 +58,9 @@ class TrackStateExchange:
         if self.world == 1 and not dist.is_initialized():
             self.gathered[0].copy_(self.local)
             self._work = None
+        elif self._host:
+            self._h_local.copy_(self.local)
+            self._work = dist.all_gather_into_tensor(self._h_gathered.view(-1), self._h_local.view(-1), group=self.group, async_op=True)
         else:
             self._work = dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group, async_op=True)
         self.count += 1
@@ -61,6 +69,8 @@ class TrackStateExchange:
         if self._work is not None:
             self._work.wait()
             self._work = None
+            if self._host:
+                self.gathered.copy_(self._h_gathered)
         return self.gathered
 
 
@@ -123,25 +133,30 @@ def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None):
     phase(0)
     assert off.value % 8 == 0
     span = scratch[off.value // 8 : off.value // 8 + cnt.value]
-    sums = span[-4:]
+    # the span ends with the 4 accumulators [sum r^2, sum delta^2, -, -]: sum r^2 travels with the first all-reduce (it is final
+    # after phase 1), so the second one carries ONLY sum delta^2 -- reducing the whole tail again would count sum r^2 world times
+    sum_delta = span[-3:-2]
     for it in range(max_iter):
         phase(1, it)
         if collective:
             dist.all_reduce(span, group=group)
         phase(2, it)
         if collective:
-            dist.all_reduce(sums, group=group)
+            dist.all_reduce(sum_delta, group=group)
         phase(3, it)
     info_h = info.cpu().numpy()
     x = xd.cpu().numpy()
     # gather the point blocks (cameras are identical on every rank)
-    pw_local = tc.from_numpy(x[: 3 * nt].reshape(nt, 3)).cuda()
     if collective:
+        # equal-sized padded blocks: gloo (CPU tests, one-device GPU tests) cannot gather ragged lists
         sizes = [shard_tracks(nt_total, world, r) for r in range(world)]
-        parts = [tc.zeros((b - a, 3), dtype=tc.float64, device="cuda") for a, b in sizes]
-        dist.all_gather(parts, pw_local, group=group)
-        pw_out = tc.cat(parts).cpu().numpy()
+        pad = max(b - a for a, b in sizes)
+        mine = tc.zeros((pad, 3), dtype=tc.float64, device="cuda")
+        mine[:nt] = xd[: 3 * nt].view(nt, 3)
+        parts = [tc.zeros((pad, 3), dtype=tc.float64, device="cuda") for _ in sizes]
+        dist.all_gather(parts, mine, group=group)
+        pw_out = tc.cat([q[: b - a] for q, (a, b) in zip(parts, sizes)]).cpu().numpy()
     else:
-        pw_out = pw_local.cpu().numpy()
+        pw_out = x[: 3 * nt].reshape(nt, 3).copy()
     cw_out = np.concatenate((np.zeros((1, 3)), x[3 * nt : 3 * nt + 3 * nc].reshape(nc, 3)), 0)
     return cw_out, pw_out, trace.cpu().numpy()[: info_h[0]]

@@ -54,11 +54,23 @@ class TrackerSession:
         self._frames.copy_(torch.tensor(ptrs, dtype=torch.int64), non_blocking=False)
 
     def step(self, frames=None, time_s=0.0, frame_no=0.0, frames_table=None):
-        """One frame for every stream.  Either `frames` (list of tensors) or `frames_table` (int64 CUDA tensor of pointers)."""
+        """One frame for every stream.  Either `frames` (list of tensors) or `frames_table` (int64 CUDA tensor of pointers).
+
+        time_s / frame_no: scalars (every stream shares the clock) or sequences / tensors of `batch` values (independent videos,
+        each with its own CAP_PROP_POS_MSEC and frame counter).  With `frames_table` the caller owns the frame buffers: the
+        frames of step i are read again by step i+1 (as im0) and must stay alive until that step has run."""
         if frames is not None:
             self.set_frames(frames)
         tab = self._frames if frames_table is None else frames_table
-        L.check(self.lib.vh_session_step(self.handle, L.dptr(tab), float(time_s), float(frame_no), L.stream_ptr()), "vh_session_step")
+        if np.ndim(time_s) == 0 and np.ndim(frame_no) == 0 and not hasattr(time_s, "is_cuda"):
+            L.check(self.lib.vh_session_step(self.handle, L.dptr(tab), float(time_s), float(frame_no), L.stream_ptr()), "vh_session_step")
+            return
+        torch = self.torch
+        tv = L.to_dev(time_s if hasattr(time_s, "is_cuda") else np.broadcast_to(np.asarray(time_s, np.float32), (self.batch,)), torch.float32)
+        fv = L.to_dev(frame_no if hasattr(frame_no, "is_cuda") else np.broadcast_to(np.asarray(frame_no, np.float32), (self.batch,)), torch.float32)
+        assert tv.numel() == self.batch and fv.numel() == self.batch
+        self._clock_keep = (tv, fv)
+        L.check(self.lib.vh_session_step_v(self.handle, L.dptr(tab), L.dptr(tv), L.dptr(fv), L.stream_ptr()), "vh_session_step_v")
 
     def view(self, slot=0):
         v = L.SessionView()

@@ -142,3 +142,33 @@ def plane_pose_scene(p_pixels, K=K_1080P, depth=3.6):
     x = (p_pixels[:, 0].astype(float) - K[2, 0]) / K[0, 0] * depth
     y = (p_pixels[:, 1].astype(float) - K[2, 1]) / K[1, 1] * depth
     return np.stack([x, y, np.zeros_like(x)], 1)
+
+
+def ba_scene(nt, nf, seed=5, K=K_1080P, noise_px=0.1, sigma_pts=0.05, sigma_cams=0.02):
+    """Sliding-window BA input: nt tie points seen in all nf keyframes of a camera moving (0.05, 0, 0.37) m per
+    frame, pixel noise N(0, noise_px^2), initial state = truth + N(0, sigma^2).  Returns the reference-shaped arguments of
+    fcnNLS_batch(K, P, pw, cw): history P float32 [5, nt, nf] (rows 0,1 = u,v ; row 4 = frame index), pw0 [nt,3], cw0 [nf,3]."""
+    Kd = np.asarray(K, float)
+    r = np.random.default_rng(seed)
+    X = np.stack([r.uniform(-3, 3, nt), r.uniform(-1.5, 1.5, nt), r.uniform(9, 14, nt)], 1)
+    cams = np.stack([[0.05 * k, 0.0, 0.37 * k] for k in range(nf)])
+    P = np.full((5, nt, nf), np.nan, np.float32)
+    for k in range(nf):
+        q = (X + cams[k]) @ Kd
+        P[0:2, :, k] = (q[:, :2] / q[:, 2:3] + r.normal(0, noise_px, (nt, 2))).T.astype(np.float32)
+        P[4, :, k] = k
+    pw0 = X + r.normal(0, sigma_pts, X.shape)
+    cw0 = cams + r.normal(0, sigma_cams, cams.shape)
+    cw0[0] = 0
+    return P, pw0, cw0
+
+
+def ba_pack(P, pw, cw):
+    """(z, x0, nt, nc) exactly as fcnNLS_batch packs them (utils/NLS.py:190-203): z = [all u | all v] camera-major / track-minor,
+    x = [points | camera positions 1..nc | camera rpy = 0]."""
+    keep = np.isfinite(P[4]).sum(1) == P.shape[2]
+    P, pw = P[:, keep], np.asarray(pw, float)[keep]
+    _, nt, nf = P.shape
+    z = np.concatenate([P[0].T.reshape(-1), P[1].T.reshape(-1)]).astype(np.float64)
+    x0 = np.concatenate((pw, np.asarray(cw, float)[1:], np.zeros((nf - 1, 3)))).reshape(-1)
+    return z, x0, nt, nf - 1
