@@ -5,15 +5,22 @@ One "step" = one tracked frame for every resident stream: KLTmain (3-stage pyram
 warp) + estimateWorldCameraPose(findR=False) + the track-state bookkeeping, all device resident (vh_session_step),
 frames already in HBM when the timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--config c2|c3] [--params baseline|ref]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--config c2|c3] [--params baseline|ref] [--scene plane|roll]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): every rank tracks its own S
-streams (weak scaling, no data-path collective) and all-gathers the packed track state every 30 frames (config C4).
-Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU over RCCL, launched either by the driver through torch.distributed.run or -- when no torchrun
+environment is present -- by bench.py itself (self_launch); every rank tracks its own S streams (weak scaling, no
+data-path collective) and all-gathers the packed track state every 30 frames (config C4).  Rank 0 prints ONE JSON line.
+
+The line carries, next to the contract's fields: `roofline` (dominant kernel, measured live with HIP events inside the
+library), `cpu_baseline` (the CPU port on all host cores AND on one core), `ba` (config 5: LM iterations/s of one window
+and of 8 / 64 batched windows, with its own structured-CPU baseline), and at N = 1 the `extras` legs: one stream alone
+(the literal C2 workload: latency), the reference's own LK parameters (utils/KLT.py:106-107), config C3 (4K / 5000
+tracks) and the camera-roll scene that drives the affine remap through its gather path.
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -29,10 +36,24 @@ CONFIGS = {
     "c2": dict(w=1920, h=1080, n=2000, levels=3, name="C2 synthetic 1080p@30fps, 2000 KLT tracks, 3 pyramid levels"),
     "c3": dict(w=3840, h=2160, n=5000, levels=4, name="C3 synthetic 4K@30fps, 5000 KLT tracks, 4 pyramid levels"),
 }
-# integer / packed-16 VALU issue peak: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3 T lane-instructions/s.  (The 32-lane rate of the
-# guide is the fp32 FMA class; the SQ counters of these kernels show 4 cycles per wave64 instruction, profiles/r01_lk_sq_pmc.md.)
-VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+CLOCK_GHZ = 2.4
+N_SIMD = 256 * 4
+
+
+def valu_peak():
+    """VALU issue peak in T lane-instructions/s for the integer / packed-16 instruction mix of the LK kernels, from the committed
+    micro-benchmark (tools/ubench/valu_rate.hip -> profiles/r02_valu_rate.json: lanes per clock per SIMD of v_dot2_i32_i16, v_perm_b32,
+    v_add_u32, v_mad_i32_i24 at 1-8 waves per SIMD).  Falls back to the 16 lanes/clk the round-1 SQ counters showed."""
+    path = os.path.join(ROOT, "profiles", "r02_valu_rate.json")
+    lanes, src = 16.0, "assumed 16 lanes/clk/SIMD (profiles/r01_lk_sq_pmc.md); micro-benchmark file missing"
+    try:
+        j = json.load(open(path))
+        lanes = float(j["summary"]["int_valu_lanes_per_clk_per_simd"])
+        src = "profiles/r02_valu_rate.json (tools/ubench/valu_rate.hip)"
+    except Exception:
+        pass
+    return N_SIMD * lanes * CLOCK_GHZ * 1e9 / 1e12, lanes, src
 
 
 def parse():
@@ -44,10 +65,17 @@ def parse():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--params", default="baseline", choices=["baseline", "ref"],
                     help="baseline: coarse stages use the config's pyramid depth; ref: exactly utils/KLT.py:106-107 (maxLevel=4)")
+    ap.add_argument("--scene", default="plane", choices=["plane", "roll"],
+                    help="plane: translation + zoom (the reference's plate-plane model); roll: + camera roll <= 0.05 deg/frame (SURVEY §8d's "
+                         "rotation: the affine remap takes its gather path)")
     ap.add_argument("--ring", type=int, default=60, help="distinct synthetic frames kept in HBM (one motion period)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables)")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="keep timing further blocks of --steps steps until the timed region is at least this long (an external sampler can "
+                         "then corroborate the run); 0 = exactly --steps steps")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each cpu_baseline leg (0 disables)")
     ap.add_argument("--exchange-every", type=int, default=30)
     ap.add_argument("--no-ba", action="store_true", help="skip the BA (config 5) leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (single stream, reference parameters, C3, roll scene)")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("VH_BENCH_GROUPS", 1)),
                     help="split the resident streams into this many sessions on separate HIP streams (their latency-bound stages overlap)")
     ap.add_argument("--host-frames", action="store_true",
@@ -81,7 +109,7 @@ def self_launch(a):
     return subprocess.call(cmd, env=env)
 
 
-def make_ring(cfg, ring, device, seed, nsets=1):
+def make_ring(cfg, ring, device, seed, nsets=1, scene="plane"):
     """nsets x `ring` frames of a periodic plane motion (one texture per set) + the tracks / world points of frame 0."""
     from velocity_amd import synth
 
@@ -90,75 +118,352 @@ def make_ring(cfg, ring, device, seed, nsets=1):
     if W != 1920:
         K[:2, :2] *= W / 1920.0
         K[2, 0], K[2, 1] = W / 2 + 0.5, H / 2 + 0.5
-    m = synth.PlaneMotion(K, z0=3.6, traj=synth.oscillating_traj(period=float(ring)))
+    roll = synth.oscillating_roll(period=float(ring)) if scene == "roll" else None
+    m = synth.PlaneMotion(K, z0=3.6, traj=synth.oscillating_traj(period=float(ring)), roll=roll)
     frames = torch.stack([synth.render_frame(W, H, m, k, seed=seed + 104729 * t, device=device) for t in range(nsets) for k in range(ring)])
     p0 = synth.grid_tracks(cfg["n"], W, H, seed=(seed & 0xFF) + 1)
     return K, m, frames, p0
 
 
-def cpu_baseline(cfg, K, frames, p0, p3, vp, lkc, lkf, budget_s):
-    """The oracle's frame loop (C restatement, OpenMP over points, all host cores) on the first frames of stream 0."""
+def cpu_baseline(cfg, K, frames, p0, p3, vp, lkc, lkf, budget_s, threads):
+    """The oracle's frame loop (C restatement, OpenMP over points, + NumPy NLS) on the first frames of stream 0, on `threads` host cores."""
     from oracle import klt_oracle
     from oracle.session_oracle import SessionOracle
 
     klt_oracle.build(native=True)
     host = [frames[k].cpu().numpy() for k in range(len(frames))]  # the periodic ring; the CPU loop walks it cyclically
     max_frames = 2000
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:  # pragma: no cover
+        threadpool_limits = None
+    import contextlib
+
     orc = SessionOracle(K, host[0], p0, p3, vp, np.float32([0, 0, 3.6]), nhist=max_frames + 2, lk_coarse=lkc, lk_fine=lkf, msv_frame=0, native=True)
-    orc.step(host[1], np.float32(1 / 30), 1)  # warm-up (page faults, thread pool)
-    t0, done = time.perf_counter(), 0
-    for k in range(2, max_frames):
-        orc.step(host[k % len(host)], np.float32(k / 30), k)
-        done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return dict(value=done / dt, unit="tracked frames/s", cores=os.cpu_count(), kind="port",
+    used = klt_oracle.set_threads(orc.lib, threads)
+    with contextlib.ExitStack() as stack:
+        if threadpool_limits is not None and threads == 1:
+            stack.enter_context(threadpool_limits(limits=1))  # NumPy's BLAS pool (the NLS half) down to one core too
+        orc.step(host[1], np.float32(1 / 30), 1)  # warm-up (page faults, thread pool)
+        t0, done = time.perf_counter(), 0
+        for k in range(2, max_frames):
+            orc.step(host[k % len(host)], np.float32(k / 30), k)
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        dt = time.perf_counter() - t0
+    klt_oracle.set_threads(orc.lib, 0)
+    return dict(value=round(done / dt, 3), unit="tracked frames/s", cores=used, kind="port",
                 sample=f"{done} frames of stream 0 ({cfg['w']}x{cfg['h']}, {cfg['n']} tracks), oracle C/OpenMP KLT + NumPy NLS, {dt:.1f} s")
 
 
-def bench_ba(nt=5000, nf=20, repeats=3):
-    """BASELINE config 5: sliding-window BA, 20 keyframes x 5000 full-length tracks, 10 LM iterations (fcnNLS_batch)."""
+# ----------------------------------------------------------------------------------------------------------------------------------
+# config 5: bundle adjustment
+# ----------------------------------------------------------------------------------------------------------------------------------
+def bench_ba(nt=5000, nf=20, repeats=3, cpu_seconds=12.0, windows=(1, 8, 64)):
+    """BASELINE config 5: sliding-window BA, 20 keyframes x 5000 full-length tracks, 10 LM iterations (fcnNLS_batch): one window, and
+    `windows` independent windows batched into the same launches (vh_nls_batch_multi) -- the mode that fills the chip."""
     from velocity_amd import _lib as L
     from velocity_amd import synth
 
-    rng = np.random.default_rng(5)
     K = synth.K_1080P
-    X = np.stack([rng.uniform(-3, 3, nt), rng.uniform(-1.5, 1.5, nt), rng.uniform(9, 14, nt)], 1)
-    cams = np.stack([[0.05 * k, 0.0, 0.37 * k] for k in range(nf)])
-    Kd = K.astype(float)
-    z_u, z_v = [], []
-    for k in range(nf):
-        q = (X + cams[k]) @ Kd
-        uv = q[:, :2] / q[:, 2:3] + rng.normal(0, 0.1, (nt, 2))
-        z_u.append(uv[:, 0].astype(np.float32))
-        z_v.append(uv[:, 1].astype(np.float32))
-    z = np.concatenate([np.concatenate(z_u), np.concatenate(z_v)]).astype(np.float64)
-    nc = nf - 1
-    x0 = np.concatenate([(X + rng.normal(0, 0.05, X.shape)).ravel(), (cams[1:] + rng.normal(0, 0.02, (nc, 3))).ravel(), np.zeros(3 * nc)])
     ws = L.workspace()
-    zd = L.to_dev(z, torch.float64)
-    nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    trace = torch.zeros((10, 2), dtype=torch.float64, device="cuda")
-    info = torch.zeros(2, dtype=torch.int32, device="cuda")
     K32 = np.ascontiguousarray(K.reshape(9))
-    best = None
-    for _ in range(repeats + 1):
-        xd = L.to_dev(x0, torch.float64).clone()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        L.check(ws.lib.vh_nls_batch(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, 10, L.dptr(trace), L.dptr(info),
-                                    L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch")
-        torch.cuda.synchronize()
+    nc = nf - 1
+    nx, nz = 3 * nt + 6 * nc, 2 * nt * nf
+    out = dict(workload=f"C5 BA: {nf} keyframes x {nt} tracks (nx={nx}, nz={nz}), 10 LM iterations per window",
+               method="compact FD Jacobian; point-block Schur complement with the reduced camera system on v_mfma_f64_16x16x4_f64; "
+                      "register-resident Gauss-Jordan (SPD, pivot-free)",
+               dense_equivalent_flop_per_iter=2.0 * nx ** 2 * nz, by_windows={})
+    first = None
+    for nw in windows:
+        if not hasattr(ws.lib, "vh_nls_batch_multi") and nw > 1:
+            continue
+        zs, xs = [], []
+        for w in range(nw):
+            P, pw0, cw0 = synth.ba_scene(nt, nf, seed=5 + w)
+            z, x0, _, _ = synth.ba_pack(P, pw0, cw0)
+            zs.append(z)
+            xs.append(x0)
+            if w == 0 and first is None:
+                first = (P, pw0, cw0)
+        zd = L.to_dev(np.stack(zs), torch.float64)
+        x0d = L.to_dev(np.stack(xs), torch.float64)
+        nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+        scratch = torch.empty((nw, nbytes), dtype=torch.uint8, device="cuda")
+        trace = torch.zeros((nw, 10, 2), dtype=torch.float64, device="cuda")
+        info = torch.zeros((nw, 2), dtype=torch.int32, device="cuda")
+        best = None
+        for _ in range(repeats + 1):
+            xd = x0d.clone()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if nw == 1:
+                L.check(ws.lib.vh_nls_batch(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, 10, L.dptr(trace), L.dptr(info),
+                                            L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch")
+            else:
+                L.check(ws.lib.vh_nls_batch_multi(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, nw, 10, L.dptr(trace),
+                                                  L.dptr(info), L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        its = int(info.cpu()[:, 0].sum())
+        tr = trace.cpu().numpy()
+        out["by_windows"][str(nw)] = dict(iters_per_s=round(its / best, 1), ms_per_window_iter=round(1e3 * best / its, 4),
+                                          rms_residual_first=round(float(tr[0, 0, 0]), 4), rms_residual_last=round(float(tr[0, -1, 0]), 4))
+        del scratch, zd, x0d
+    one = out["by_windows"]["1"]
+    out.update(iters_per_s=one["iters_per_s"], ms_per_iter=one["ms_per_window_iter"], rms_residual_first=one["rms_residual_first"],
+               rms_residual_last=one["rms_residual_last"])
+    if cpu_seconds > 0 and first is not None:
+        # the structured CPU restatement (oracle/nls_oracle.py::ba_schur_step: NumPy einsum / LAPACK on the host's cores): the dense
+        # reference path itself is infeasible at C5 (J^T alone 24 GB, ~10 min / iteration; BASELINE.md section 2)
+        from oracle import nls_oracle as NO
+
+        z, x0, _, _ = synth.ba_pack(*first)
+        Kd = K.astype(float)
+        NO.ba_schur_step(x0, z, Kd, nc, nt)  # warm-up (BLAS thread pool)
+        x, done, t0 = x0.copy(), 0, time.perf_counter()
+        while done < 10 and time.perf_counter() - t0 < cpu_seconds:
+            delta, f = NO.ba_schur_step(x, z, Kd, nc, nt)
+            x = x + delta
+            done += 1
         dt = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=round(done / dt, 3), unit="LM iterations/s", cores=os.cpu_count(), kind="port",
+                                   sample=f"{done} LM iterations of the same C5 window, structured (Schur) NumPy restatement, {dt:.1f} s; the dense "
+                                          "reference path (utils/NLS.py:228-235) is infeasible at this size")
+        out["gpu_over_cpu"] = round(one["iters_per_s"] / out["cpu_baseline"]["value"], 1)
+    return out
+
+
+def bench_ba_multi_gpu(rank, world, barrier, reduce_max, nt=5000, nf=20, windows_per_gpu=8):
+    """Config 5 on N GPUs, both ways: (a) replicas -- every rank solves its own `windows_per_gpu` independent
+    windows, no collective (the mode that scales: a sliding-window tracker has one window per stream); (b) ONE window with its tie
+    points sharded over the ranks and two all-reduces per LM iteration (Amdahl-limited by the replicated 114 x 114 solve)."""
+    from velocity_amd import _lib as L
+    from velocity_amd import dist as vdist
+    from velocity_amd import synth
+
+    K = synth.K_1080P
+    ws = L.workspace()
+    K32 = np.ascontiguousarray(K.reshape(9))
+    nc, nw = nf - 1, windows_per_gpu
+    packs = [synth.ba_pack(*synth.ba_scene(nt, nf, seed=5 + rank * nw + w)) for w in range(nw)]
+    zd = L.to_dev(np.stack([p[0] for p in packs]), torch.float64)
+    x0d = L.to_dev(np.stack([p[1] for p in packs]), torch.float64)
+    nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+    scratch = torch.empty((nw, nbytes), dtype=torch.uint8, device="cuda")
+    trace = torch.zeros((nw, 10, 2), dtype=torch.float64, device="cuda")
+    info = torch.zeros((nw, 2), dtype=torch.int32, device="cuda")
+    best = None
+    for _ in range(3):
+        xd = x0d.clone()
+        barrier()
+        t0 = time.perf_counter()
+        L.check(ws.lib.vh_nls_batch_multi(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, nw, 10, L.dptr(trace), L.dptr(info),
+                                          L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
+        barrier()
+        dt = reduce_max(time.perf_counter() - t0)
         best = dt if best is None else min(best, dt)
-    its = int(info.cpu()[0])
-    tr = trace.cpu().numpy()
-    return dict(workload=f"C5 BA: {nf} keyframes x {nt} tracks (nx={3 * nt + 6 * nc}, nz={2 * nt * nf}), {its} LM iterations",
-                iters_per_s=round(its / best, 2), ms_per_iter=round(1e3 * best / its, 3), rms_residual_first=round(float(tr[0, 0]), 4),
-                rms_residual_last=round(float(tr[its - 1, 0]), 4), method="compact FD Jacobian; point-block Schur complement with the reduced camera system on v_mfma_f64_16x16x4_f64; register-resident Gauss-Jordan (SPD, pivot-free)",
-                dense_equivalent_flop_per_iter=2.0 * (3 * nt + 6 * nc) ** 2 * (2 * nt * nf))
+    out = dict(workload=f"C5 BA: {nf} keyframes x {nt} tracks, 10 LM iterations per window",
+               replicas=dict(windows_per_gpu=nw, n_gpus=world, iters_per_s=round(world * nw * 10 / best, 1), collective="none"))
+    P, pw0, cw0 = synth.ba_scene(nt, nf, seed=5)
+    best = None
+    for _ in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        _cw, _pw, tr = vdist.fcnNLS_batch_sharded(K, P, pw0, cw0)
+        barrier()
+        dt = reduce_max(time.perf_counter() - t0)
+        best = dt if best is None else min(best, dt)
+    out["point_sharded"] = dict(n_gpus=world, iters_per_s=round(len(tr) / best, 1), ms_per_iter=round(1e3 * best / len(tr), 4),
+                                collective="2 all-reduces per LM iteration (104 KB + 8 B)", rms_residual_last=round(float(tr[-1, 0]), 4),
+                                note="includes the host-side packing of fcnNLS_batch_sharded; Amdahl-limited by the replicated reduced-system solve")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# the tracker workload
+# ----------------------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """`streams` resident video streams of one config on this rank's GPU: sessions, frame rings, the step loop."""
+
+    def __init__(self, a, cfg, params, scene, streams, steps, warmup, dev, rank, groups=1, host_frames=False):
+        from velocity_amd.driver import TrackerSession
+
+        self.a, self.cfg, self.S, self.N, self.W, self.H = a, cfg, streams, cfg["n"], cfg["w"], cfg["h"]
+        S, N, W, H = self.S, self.N, self.W, self.H
+        lvl = cfg["levels"] - 1 if params == "baseline" else 4
+        self.lkc, self.lkf = dict(max_level=lvl), dict()
+        self.params, self.scene, self.ring = params, scene, a.ring
+        nhist = min(warmup + steps + 3, 512)
+        # one texture set per `ring` streams, so no two resident streams ever work on the same pixels
+        nsets = 1 if host_frames else (S + a.ring - 1) // a.ring
+        self.K, self.motion, self.frames, self.p0 = make_ring(cfg, a.ring, dev, seed=0xC0FFEE + 7919 * rank, nsets=nsets, scene=scene)
+        self.p3 = self.motion.world_points(self.p0)
+        self.vp = np.ones(N, bool)  # every valid track takes part in the pose fit (the state after vidExample.py:160)
+        G = max(1, min(groups, S))
+        assert S % G == 0, "--streams must be a multiple of --groups"
+        self.G, self.SG = G, S // G
+        SG = self.SG
+        self.sessions = [TrackerSession(self.K, W, H, N, nhist=nhist, batch=SG, lk_coarse=self.lkc, lk_fine=self.lkf, msv_frame=0) for _ in range(G)]
+        self.hip_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(G - 1)]
+        # streams of one texture set share its ring but run at different phases, so every launch sees S different frame pairs
+        self.phase = [(7 * b) % a.ring for b in range(S)]
+        fset = [0 if host_frames else b // a.ring for b in range(S)]
+        if host_frames:
+            self.phase = [b % a.ring for b in range(S)]  # consecutive phases: one step's batch is a contiguous slice of the extended host ring
+        base_ptr, fbytes = self.frames.data_ptr(), W * H
+        for b in range(S):
+            self.sessions[b // SG].init_stream(b % SG, self.frames[fset[b] * a.ring + self.phase[b]],
+                                               self.motion.apply(self.phase[b], self.p0.astype(float)).astype(np.float32),
+                                               self.p3 + self.motion.t(self.phase[b]), self.vp, np.float32([0, 0, 0]))
+        tables = torch.empty((a.ring, S), dtype=torch.int64)
+        for k in range(a.ring):
+            for b in range(S):
+                tables[k, b] = base_ptr + (fset[b] * a.ring + (self.phase[b] + k) % a.ring) * fbytes
+        self.tables = tables.to(dev)
+        self.feeder = None
+        if host_frames:
+            from velocity_amd.driver import HostFrameFeeder
+
+            assert G == 1, "--host-frames is measured with one session group"
+            self.feeder = HostFrameFeeder(S, H, W, depth=3)
+            reps = (S + a.ring - 1) // a.ring + 1
+            self.host_ring = torch.cat([self.frames[: a.ring].cpu()] * reps, 0)[: a.ring + S].contiguous().pin_memory()  # the decoder's pinned output
+        torch.cuda.synchronize()
+
+    def run(self, first, count, ex=None):
+        from velocity_amd import _lib as L
+
+        a, G, SG = self.a, self.G, self.SG
+        for i in range(first, first + count):
+            if self.feeder is not None:
+                k = i % a.ring
+                s_ = self.feeder.put(self.host_ring[k : k + self.S])  # stream b <- frame (b + i) % ring, straight from pinned memory
+                self.sessions[0].step(frames_table=self.feeder.get(s_), time_s=i / 30.0, frame_no=i)
+                self.feeder.after_step(s_)
+                continue
+            row = self.tables[i % a.ring]
+            for g in range(G):
+                with torch.cuda.stream(self.hip_streams[g]):
+                    self.sessions[g].step(frames_table=row[g * SG:(g + 1) * SG], time_s=i / 30.0, frame_no=i)
+            if ex is not None and ex.due(i):
+                ex.wait()
+                for g in range(G):
+                    with torch.cuda.stream(self.hip_streams[g]):
+                        L.check(self.sessions[g].lib.vh_session_pack_state(self.sessions[g].handle, L.dptr(ex.local[g * SG:(g + 1) * SG]), L.stream_ptr()),
+                                "vh_session_pack_state")
+                torch.cuda.synchronize()
+                ex.start()
+
+    def measure(self, steps, warmup, min_seconds, barrier, reduce_max, ex=None):
+        """W warm-up steps, then EXACTLY `steps` timed steps between barrier + synchronize; if that took less than min_seconds, further
+        blocks of `steps` steps are timed the same way (all ranks agree on the count) and `value` is computed over all timed steps."""
+        from velocity_amd import _lib as L
+
+        ses = self.sessions[0]
+        self.run(1, warmup, ex)
+        barrier()
+        L.check(ses.lib.vh_profile_begin(ses.ws.handle, 3 * steps + 8), "vh_profile_begin")
+        barrier()
+        t0 = time.perf_counter()
+        self.run(1 + warmup, steps, ex)
+        if ex is not None:
+            ex.wait()
+        barrier()
+        elapsed = reduce_max(time.perf_counter() - t0)
+        prof = dict(ms_sum=(C.c_double * 3)(), launches=(C.c_int * 3)(), iters=(C.c_ulonglong * 3)(), setups=(C.c_ulonglong * 3)())
+        L.check(ses.lib.vh_profile_end(ses.ws.handle, prof["ms_sum"], prof["launches"], prof["iters"], prof["setups"]), "vh_profile_end")
+        timed, blocks = steps, 1
+        if min_seconds > 0 and elapsed < min_seconds:
+            more = int(math.ceil((min_seconds - elapsed) / max(elapsed, 1e-6)))
+            barrier()
+            t0 = time.perf_counter()
+            self.run(1 + warmup + steps, more * steps, ex)
+            if ex is not None:
+                ex.wait()
+            barrier()
+            elapsed += reduce_max(time.perf_counter() - t0)
+            timed += more * steps
+            blocks += more
+        st = ses.state(0)
+        done = warmup + timed
+        truth = self.motion.t((self.phase[0] + done) % self.ring) - self.motion.t(self.phase[0])
+        return dict(elapsed=elapsed, timed_steps=timed, blocks=blocks, prof=prof, st=st, alive=st["n_cur"] / self.N, truth=truth)
+
+    def close(self):
+        torch.cuda.synchronize()
+        self.sessions, self.frames, self.tables, self.feeder = [], None, None, None
+        torch.cuda.empty_cache()
+
+
+def roofline_of(wl, m, world):
+    """roofline object of the dominant kernel (the fine-stage LK launch) from the in-library HIP-event timing of the first timed block."""
+    N, SG = wl.N, wl.SG
+    prof = m["prof"]
+    ms_sum, launches, iters, setups = prof["ms_sum"], prof["launches"], prof["iters"], prof["setups"]
+    wf = 51
+    us_fine = 1e3 * ms_sum[2] / max(launches[2], 1)
+    # algorithmic gather bytes per launch of session group 0 (SG streams): SURVEY §8d, KLT track solve row: 2 N L [(w+2)^2 + (w+1)^2], L = 1
+    bytes_fine = 2 * N * SG * 1 * ((wf + 2) ** 2 + (wf + 1) ** 2)
+    achieved = bytes_fine / (us_fine * 1e-6) / 1e9 if us_fine > 0 else 0.0
+    it_f = iters[2] / max(launches[2], 1)
+    su_f = setups[2] / max(launches[2], 1)
+    ops_fine = wf * wf * (47.0 * su_f + 12.0 * it_f)  # SURVEY §8d op model: 47 op/px set-up, 12 op/px per Newton iteration
+    fine_kernel = "k_lk3<51, 2, 4>" if N * SG >= 6144 else "k_lk3<51, 4, 4>"  # routing of vh_launch_lk (wavefronts per track)
+    # HBM bytes and SQ issue utilisation of that kernel are NOT measured by this run: they come from the PMC passes committed under
+    # profiles/ (collected at the stream count stored in the file, scaled linearly); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    traffic, sq_util, tsrc = None, None, None
+    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if wl.cfg is CONFIGS["c2"] and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            k = tj.get(fine_kernel)
+            if k is not None:
+                traffic = int((2 * k["fetch_kib"] + k["write_kib"]) * 1024 * SG / tj["streams"])
+            sq_util = tj.get("sq_valu_issue_utilisation", {}).get(fine_kernel)
+            tsrc = f"profiles/{name} (rocprofv3 --pmc pass of an earlier run, scaled to {SG} streams; not measured in this run)"
+            break
+    peak_tops, lanes, peak_src = valu_peak()
+    ach_tops = ops_fine / (us_fine * 1e-6) / 1e12 if us_fine > 0 else 0.0
+    return dict(bound="hbm", kernel=fine_kernel + " (fine stage: 51x51 window, level 0, fwd+bwd)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+                unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=tsrc, us_per_launch=round(us_fine, 2),
+                alg_bytes_per_launch=bytes_fine,
+                valu=dict(model_gops_per_launch=round(ops_fine / 1e9, 4), achieved_tops=round(ach_tops, 3), peak_tops=round(peak_tops, 1),
+                          peak_lanes_per_clk_per_simd=lanes, peak_source=peak_src, frac=round(ach_tops / peak_tops, 4),
+                          newton_iters_per_track_dir=round(it_f / (2 * N * SG), 2), sq_valu_issue_utilisation=sq_util,
+                          sq_valu_issue_utilisation_source=tsrc),
+                note="track solve is VALU/LDS bound (SURVEY §8d); the HBM figure prices its algorithmic gather bytes",
+                lk_us_per_launch=[round(1e3 * ms_sum[k] / max(launches[k], 1), 2) for k in range(3)],
+                lk_newton_iters_per_setup=[round(iters[k] / max(setups[k], 1), 2) for k in range(3)],
+                lk_setups_per_track=[round(setups[k] / max(launches[k], 1) / (N * SG), 2) for k in range(3)])
+
+
+def headline_hbm(cfg, fps):
+    """SURVEY §8d 'Headline KLT number': (B_img + 21 N) bytes per tracked frame x frames/s against the HBM peak."""
+    L_ = cfg["levels"]
+    b_img = cfg["w"] * cfg["h"] * (1.0 + 2.0 * sum(4.0 ** -l for l in range(1, L_)))
+    per_frame = b_img + 21.0 * cfg["n"]
+    gbs = per_frame * fps / 1e9
+    return dict(bytes_per_frame=int(per_frame), achieved_gbs=round(gbs, 2), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 5),
+                note="image-stage algorithmic bytes only: the step is VALU / latency bound, nowhere near HBM bound (as SURVEY §8d predicted)")
+
+
+def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev):
+    """One more single-GPU workload next to the headline one; returns its summary (None when it does not fit / fails)."""
+    try:
+        wl = Workload(a, CONFIGS[cfg_key], params, scene, streams, steps, warmup, dev, rank=0)
+        m = wl.measure(steps, warmup, 1.0, torch.cuda.synchronize, lambda t: t)
+        fps = wl.S * m["timed_steps"] / m["elapsed"]
+        out = dict(workload=f"{cfg_key} / params {params} / scene {scene}", streams=streams, value=round(fps, 2), unit="frames/s",
+                   ms_per_step=round(1e3 * m["elapsed"] / m["timed_steps"], 4), timed_steps=m["timed_steps"], tracks_alive_frac=round(m["alive"], 4),
+                   rms_residual_px=round(m["st"]["res"], 5),
+                   lk_us_per_launch=[round(1e3 * m["prof"]["ms_sum"][k] / max(m["prof"]["launches"][k], 1), 2) for k in range(3)])
+        wl.close()
+        return out
+    except Exception as e:  # an extra leg must never take the headline number down with it
+        return dict(workload=f"{cfg_key} / params {params} / scene {scene}", error=f"{type(e).__name__}: {e}"[:300])
 
 
 def main():
@@ -192,73 +497,10 @@ def main():
 
     from velocity_amd import _lib as L
     from velocity_amd import dist as vdist
-    from velocity_amd.driver import TrackerSession
 
-    S, N, W, H = a.streams, cfg["n"], cfg["w"], cfg["h"]
-    lvl = cfg["levels"] - 1 if a.params == "baseline" else 4
-    lkc, lkf = dict(max_level=lvl), dict()
-    nhist = a.warmup + a.steps + 3
-    # one texture set per `ring` streams, so no two resident streams ever work on the same pixels
-    nsets = 1 if a.host_frames else (S + a.ring - 1) // a.ring
-    K, motion, frames, p0 = make_ring(cfg, a.ring, dev, seed=0xC0FFEE + 7919 * rank, nsets=nsets)
-    p3 = motion.world_points(p0)
-    vp = np.ones(N, bool)  # every valid track takes part in the pose fit (the state after vidExample.py:160)
-    G = max(1, min(a.groups, S))
-    assert S % G == 0, "--streams must be a multiple of --groups"
-    SG = S // G
-    sessions = [TrackerSession(K, W, H, N, nhist=nhist, batch=SG, lk_coarse=lkc, lk_fine=lkf, msv_frame=0) for _ in range(G)]
-    hip_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(G - 1)]
-    ses = sessions[0]
-    # streams of one texture set share its ring but run at different phases, so every launch sees S different frame pairs
-    phase = [(7 * b) % a.ring for b in range(S)]
-    fset = [0 if a.host_frames else b // a.ring for b in range(S)]
-    if a.host_frames:
-        phase = [b % a.ring for b in range(S)]  # consecutive phases: one step's batch is a contiguous slice of the extended host ring
-    base_ptr = frames.data_ptr()
-    fbytes = W * H
-    for b in range(S):
-        sessions[b // SG].init_stream(b % SG, frames[fset[b] * a.ring + phase[b]], motion.apply(phase[b], p0.astype(float)).astype(np.float32),
-                                      p3 + motion.t(phase[b]), vp, np.float32([0, 0, 0]))
-    tables = torch.empty((a.ring, S), dtype=torch.int64)
-    for k in range(a.ring):
-        for b in range(S):
-            tables[k, b] = base_ptr + (fset[b] * a.ring + (phase[b] + k) % a.ring) * fbytes
-    tables = tables.to(dev)
+    S, N = a.streams, cfg["n"]
+    wl = Workload(a, cfg, a.params, a.scene, S, a.steps, a.warmup, dev, rank, groups=a.groups, host_frames=a.host_frames)
     ex = vdist.TrackStateExchange(S, N, every=a.exchange_every, device=dev) if use_dist else None
-    torch.cuda.synchronize()
-
-    feeder = None
-    if a.host_frames:
-        from velocity_amd.driver import HostFrameFeeder
-
-        assert G == 1, "--host-frames is measured with one session group"
-        feeder = HostFrameFeeder(S, H, W, depth=3)
-        reps = (S + a.ring - 1) // a.ring + 1
-        host_ring = torch.cat([frames[: a.ring].cpu()] * reps, 0)[: a.ring + S].contiguous().pin_memory()  # stands for the decoder's pinned output
-
-    def run_host(first, count):
-        for i in range(first, first + count):
-            k = i % a.ring
-            s_ = feeder.put(host_ring[k : k + S])  # stream b <- frame (b + i) % ring, straight from pinned memory
-            sessions[0].step(frames_table=feeder.get(s_), time_s=i / 30.0, frame_no=i)
-            feeder.after_step(s_)
-
-    def run(first, count):
-        if feeder is not None:
-            return run_host(first, count)
-        for i in range(first, first + count):
-            row = tables[i % a.ring]
-            for g in range(G):
-                with torch.cuda.stream(hip_streams[g]):
-                    sessions[g].step(frames_table=row[g * SG:(g + 1) * SG], time_s=i / 30.0, frame_no=i)
-            if ex is not None and ex.due(i):
-                ex.wait()
-                for g in range(G):
-                    with torch.cuda.stream(hip_streams[g]):
-                        L.check(sessions[g].lib.vh_session_pack_state(sessions[g].handle, L.dptr(ex.local[g * SG:(g + 1) * SG]), L.stream_ptr()),
-                                "vh_session_pack_state")
-                torch.cuda.synchronize()
-                ex.start()
 
     def barrier():
         torch.cuda.synchronize()
@@ -266,85 +508,60 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run(1, a.warmup)
-    barrier()
-    L.check(ses.lib.vh_profile_begin(ses.ws.handle, 3 * a.steps + 8), "vh_profile_begin")
-    barrier()
-    t0 = time.perf_counter()
-    run(1 + a.warmup, a.steps)
-    if ex is not None:
-        ex.wait()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ms_sum, launches = (C.c_double * 3)(), (C.c_int * 3)()
-    iters, setups = (C.c_ulonglong * 3)(), (C.c_ulonglong * 3)()
-    L.check(ses.lib.vh_profile_end(ses.ws.handle, ms_sum, launches, iters, setups), "vh_profile_end")
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def reduce_max(t):
+        if not use_dist:
+            return t
+        tmax = torch.tensor([t], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        return float(tmax.item())
 
-    # health of the tracked state (a bench that lost its tracks would be measuring nothing)
-    st = ses.state(0)
-    alive = st["n_cur"] / N
-    truth = motion.t((phase[0] + a.warmup + a.steps) % a.ring) - motion.t(phase[0])
+    m = wl.measure(a.steps, a.warmup, a.min_seconds, barrier, reduce_max, ex)
+    st = m["st"]
 
     if rank == 0:
-        total_frames = S * world * a.steps
-        value = total_frames / elapsed
-        # dominant kernel = the fine LK launch (stage 2): algorithmic gather bytes per launch (KLT track solve row)
-        wf = 51
-        us_fine = 1e3 * ms_sum[2] / max(launches[2], 1)
-        bytes_fine = 2 * N * SG * 1 * ((wf + 2) ** 2 + (wf + 1) ** 2)  # per launch of session group 0 (SG streams)
-        achieved = bytes_fine / (us_fine * 1e-6) / 1e9 if us_fine > 0 else 0.0
-        it_f = iters[2] / max(launches[2], 1)
-        su_f = setups[2] / max(launches[2], 1)
-        ops_fine = wf * wf * (47.0 * su_f + 12.0 * it_f)  # SURVEY §8d op model: 47 op/px set-up, 12 op/px per Newton iteration
-        # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (collected at the stream count stored in the file, scales
-        # linearly with the stream count); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
-        traffic = None
-        fine_kernel = "k_lk3<51, 2, 4>" if N * SG >= 6144 else "k_lk3<51, 4, 4>"  # routing of vh_launch_lk (wavefronts per track)
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if a.config == "c2" and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            k = tj.get(fine_kernel)
-            if k is not None:
-                traffic = int((2 * k["fetch_kib"] + k["write_kib"]) * 1024 * SG / tj["streams"])
-        sq_util = None  # measured VALU issue utilisation of that kernel (SQ_ACTIVE_INST_VALU / available quad-cycles), from profiles/
-        if a.config == "c2" and os.path.exists(tpath):
-            sq_util = json.load(open(tpath)).get("sq_valu_issue_utilisation", {}).get(fine_kernel)
-        roof = dict(bound="hbm", kernel=fine_kernel + " (fine stage: 51x51 window, level 0, fwd+bwd)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, us_per_launch=round(us_fine, 2),
-                    alg_bytes_per_launch=bytes_fine,
-                    valu=dict(model_gops_per_launch=round(ops_fine / 1e9, 4), achieved_tops=round(ops_fine / (us_fine * 1e-6) / 1e12, 3) if us_fine > 0 else 0,
-                              peak_tops=round(VALU_PEAK_TOPS, 1), frac=round(ops_fine / (us_fine * 1e-6) / 1e12 / VALU_PEAK_TOPS, 4) if us_fine > 0 else 0,
-                              newton_iters_per_track_dir=round(it_f / (2 * N * SG), 2),
-                              sq_valu_issue_utilisation=sq_util),
-                    note="track solve is VALU/LDS bound (SURVEY §8d); the HBM figure prices its algorithmic gather bytes",
-                    lk_us_per_launch=[round(1e3 * ms_sum[k] / max(launches[k], 1), 2) for k in range(3)],
-                    lk_newton_iters_per_setup=[round(iters[k] / max(setups[k], 1), 2) for k in range(3)],
-                    lk_setups_per_track=[round(setups[k] / max(launches[k], 1) / (N * SG), 2) for k in range(3)])
+        elapsed, timed = m["elapsed"], m["timed_steps"]
+        value = S * world * timed / elapsed
         out = dict(metric="tracked frames/sec (KLT 2000 tracks + NLS pose, 1080p)" if a.config == "c2" else "tracked frames/sec (KLT 5000 tracks + NLS pose, 4K)",
                    value=round(value, 2), unit="frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
-                   ms_per_step=round(1e3 * elapsed / a.steps, 4), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="i32+f32 (KLT) / f64 (NLS)",
+                   ms_per_step=round(1e3 * elapsed / timed, 4), timed_steps=timed, timed_seconds=round(elapsed, 3),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="i32+f32 (KLT) / f64 (NLS)",
                    data="synthetic" + (" (frames uploaded from pinned host memory every step: PCIe-inclusive)" if a.host_frames else ""),
                    config=dict(workload=cfg["name"] + f"; {S} independent streams resident per GPU, one launch sequence per step",
-                               params=a.params, coarse=dict(L.LK_COARSE, **lkc), fine=dict(L.LK_FINE), streams_per_gpu=S, tracks=N,
-                               stream_groups=G,
-                               parallelism=f"streams x{world} (1 rank per GPU" + (f", RCCL all-gather of track state every {a.exchange_every} frames)" if use_dist else ")")),
-                   per_stream_fps=round(value / (S * world), 2), tracks_alive_frac=round(alive, 4),
-                   pose_t=[round(float(x), 5) for x in st["t"]], pose_t_truth=[round(float(x), 5) for x in truth], rms_residual_px=round(st["res"], 5),
-                   roofline=roof)
-        if not a.no_ba:
-            out["ba"] = bench_ba()
-        if a.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(cfg, K, frames[: a.ring], p0, p3, vp, lkc, lkf, a.cpu_seconds)
-            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+                               params=a.params, scene=a.scene, coarse=dict(L.LK_COARSE, **wl.lkc), fine=dict(L.LK_FINE), streams_per_gpu=S, tracks=N,
+                               stream_groups=wl.G,
+                               parallelism=f"streams x{world} (1 rank per GPU" + (f", {'RCCL' if a.backend == 'nccl' else a.backend} all-gather of track state every {a.exchange_every} frames)" if use_dist else ")")),
+                   per_stream_fps=round(value / (S * world), 2), tracks_alive_frac=round(m["alive"], 4),
+                   pose_t=[round(float(x), 5) for x in st["t"]], pose_t_truth=[round(float(x), 5) for x in m["truth"]], rms_residual_px=round(st["res"], 5),
+                   roofline=roofline_of(wl, m, world), headline_hbm=headline_hbm(cfg, value / world))
+        cpu_args = (cfg, wl.K, wl.frames[: a.ring], wl.p0, wl.p3, wl.vp, wl.lkc, wl.lkf)
+    if use_dist and rank == 0 and ex is not None:
+        g = vdist.unpack_state(ex.wait()[0, 0], N)
+        assert g["n_cur"] == st["n_cur"] or g["frame_i"] <= st["frame_i"], "exchanged track state is inconsistent"
+
+    if rank == 0:
+        if a.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(*cpu_args, a.cpu_seconds, 0)
+            out["cpu_baseline_1core"] = cpu_baseline(*cpu_args, a.cpu_seconds, 1)
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    wl.close()
+    if rank == 0:
+        if not a.no_extras and world == 1 and not a.host_frames:
+            c2 = a.config == "c2"
+            legs = dict(single_stream=extra_leg(a, a.config, a.params, a.scene, 1, 200, 20, dev))
+            legs["single_stream"]["latency_ms"] = legs["single_stream"].get("ms_per_step")
+            legs["ref_params"] = extra_leg(a, a.config, "ref" if a.params == "baseline" else "baseline", a.scene, S, 60, 10, dev)
+            legs["other_config"] = extra_leg(a, "c3" if c2 else "c2", a.params, a.scene, 32 if c2 else 128, 30 if c2 else 60, 6, dev)
+            legs["roll_scene"] = extra_leg(a, a.config, a.params, "roll" if a.scene == "plane" else "plane", S, 60, 10, dev)
+            out["extras"] = legs
+        if not a.no_ba and world == 1:
+            out["ba"] = bench_ba(cpu_seconds=a.cpu_seconds)
+    if not a.no_ba and world > 1:
+        ba = bench_ba_multi_gpu(rank, world, barrier, reduce_max)
+        if rank == 0:
+            out["ba"] = ba
+    if rank == 0:
         print(json.dumps(out))
     if use_dist:
-        if rank == 0 and ex is not None:
-            g = vdist.unpack_state(ex.wait()[0, 0], N)
-            assert g["n_cur"] == st["n_cur"] or g["frame_i"] <= st["frame_i"], "exchanged track state is inconsistent"
         dist.barrier()
         dist.destroy_process_group()
 

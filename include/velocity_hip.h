@@ -140,6 +140,13 @@ VH_API size_t vh_nls_batch_workspace(int nt, int nc);
 VH_API int vh_nls_batch(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
                         int* info, void* workspace, size_t workspace_bytes, void* stream);
 
+/* nwin independent fcnNLS_batch problems of the same shape (one sliding window per video stream) solved by ONE launch sequence
+ * (grid.y = window): z [nwin][2 nt (nc+1)], x [nwin][3 nt + 6 nc], trace [nwin][max_iter][2], info [nwin][2]; workspace = nwin blocks
+ * of workspace_bytes_per_window >= vh_nls_batch_workspace(nt, nc) bytes (a multiple of 256).  Every window takes exactly the steps
+ * vh_nls_batch would take on it (its own stop flag included). */
+VH_API int vh_nls_batch_multi(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int nwin, int max_iter,
+                              double* trace, int* info, void* workspace, size_t workspace_bytes_per_window, void* stream);
+
 /* fcnNLS_batch2(K, P, pw, cw), utils/NLS.py:253-328: the constrained sibling -- tie points, ONE joint rotation applied to the
  * points and a straight-line camera trajectory (elevation, azimuth, one range per camera 1..nc; camera 0 at the origin).
  * Same z packing, damping (+I), step (0.9) and stop rule (rms(delta) < 1e-7); the reference runs at most 20 iterations.

@@ -30,7 +30,24 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #define KO_API __attribute__((visibility("default")))
+
+/* worker threads of every parallel loop below (bench.py's cpu_baseline: all host cores / one core).  n <= 0: all cores. */
+KO_API int ko_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n <= 0) n = omp_get_num_procs();
+    omp_set_num_threads(n);
+    return n;
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------------ */
 /* small helpers                                                                                     */

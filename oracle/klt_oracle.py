@@ -62,6 +62,12 @@ def lib(native=False):
     return _LIB
 
 
+def set_threads(L, n):
+    """OpenMP worker threads of library handle L (0 = all cores); returns the count in use."""
+    L.ko_set_threads.restype = C.c_int
+    return int(L.ko_set_threads(C.c_int(int(n))))
+
+
 def _u8(a):
     a = np.ascontiguousarray(a, np.uint8)
     return a, a.ctypes.data_as(C.POINTER(C.c_uint8))

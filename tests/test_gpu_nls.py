@@ -262,3 +262,28 @@ def test_nls_batch_at_full_c5_vs_structured_oracle(golden):
     close(x, ex, 1e-6, 1e-6)                # final state (points ~10 m, cameras ~7 m, rpy ~1e-3 rad)
     close(cw, ecw, 1e-6, 1e-7)
     assert tr[-1, 0] < 0.11 and tr[0, 0] > 5  # converged to the 0.1 px measurement noise from a ~7 px start
+
+
+def test_nls_batch_windows_equal_single_calls(golden, capsys):
+    """Batched windows (vh_nls_batch_multi, grid.y = window) take exactly the steps the single-window call takes on each of them."""
+    from velocity_amd import synth
+    from velocity_amd.NLS import fcnNLS_batch, fcnNLS_batch_windows
+
+    K32 = golden["K32"]
+    # small windows: same number of partial systems as the single call -> the same arithmetic, bit for bit
+    scenes = [synth.ba_scene(50, 6, seed=100 + w) for w in range(5)]
+    multi = fcnNLS_batch_windows(K32, [s[0] for s in scenes], [s[1] for s in scenes], [s[2] for s in scenes], return_info=True)
+    for (P, pw0, cw0), (cw, pw, x, tr) in zip(scenes, multi):
+        scw, spw, sx, strace = fcnNLS_batch(K32, P.copy(), pw0, cw0, return_info=True)
+        assert np.array_equal(x, sx) and np.array_equal(tr, strace)
+    # larger windows: fewer partial systems per window than the single call (different summation order of the partials)
+    scenes = [synth.ba_scene(1500, 8, seed=200 + w) for w in range(20)]
+    multi = fcnNLS_batch_windows(K32, [s[0] for s in scenes], [s[1] for s in scenes], [s[2] for s in scenes], return_info=True)
+    for w in (0, 7, 19):
+        P, pw0, cw0 = scenes[w]
+        scw, spw, sx, strace = fcnNLS_batch(K32, P.copy(), pw0, cw0, return_info=True)
+        close(multi[w][3][:, 0], strace[:, 0], 1e-10)
+        close(multi[w][2], sx, 1e-7, 1e-9)
+    capsys.readouterr()
+    with pytest.raises(ValueError):
+        fcnNLS_batch_windows(K32, [scenes[0][0], synth.ba_scene(40, 8)[0]], [scenes[0][1], synth.ba_scene(40, 8)[1]], [scenes[0][2], synth.ba_scene(40, 8)[2]])

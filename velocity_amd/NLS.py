@@ -105,6 +105,49 @@ def fcnNLS_batch(K, P, pw, cw, max_iter=10, return_info=False):
     return cw_out, pw_out
 
 
+def fcnNLS_batch_windows(K, Ps, pws, cws, max_iter=10, return_info=False):
+    """fcnNLS_batch (utils/NLS.py:186-250) for several independent windows of the SAME shape (one sliding window per video stream)
+    in one launch sequence (vh_nls_batch_multi, grid.y = window).  Ps / pws / cws: sequences of the reference's P, pw, cw arguments;
+    every window must keep the same number of full-length tracks and frames.  Returns [(cw, pw), ...] (with return_info: also x, trace)."""
+    torch = L.torch_cuda()
+    zs, xs, shape = [], [], None
+    for P, pw, cw in zip(Ps, pws, cws):
+        P, pw, cw = np.asarray(P), np.asarray(pw, np.float64), np.asarray(cw, np.float64)
+        keep = np.isfinite(P[4]).sum(1) == P.shape[2]  # NLS.py:190
+        P, pw = P[:, keep], pw[keep]
+        _, nt, nf = P.shape
+        if shape is None:
+            shape = (nt, nf)
+        elif shape != (nt, nf):
+            raise ValueError(f"fcnNLS_batch_windows: window shapes differ ({shape} vs {(nt, nf)})")
+        z = np.concatenate([P[0].T.reshape(-1), P[1].T.reshape(-1)]).astype(np.float64)  # NLS.py:198-199
+        z[np.isnan(z)] = 0
+        zs.append(z)
+        xs.append(np.concatenate((pw, cw[1:], np.zeros((nf - 1, 3)))).reshape(-1))  # NLS.py:202-203
+    nt, nf = shape
+    nc, nw = nf - 1, len(zs)
+    K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+    zd = L.to_dev(np.stack(zs), torch.float64)
+    xd = L.to_dev(np.stack(xs), torch.float64).clone()
+    trace = torch.zeros((nw, max_iter, 2), dtype=torch.float64, device="cuda")
+    info = torch.zeros((nw, 2), dtype=torch.int32, device="cuda")
+    ws = L.workspace()
+    nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+    scratch = torch.empty((nw, nbytes), dtype=torch.uint8, device="cuda")
+    L.check(ws.lib.vh_nls_batch_multi(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, nw, int(max_iter), L.dptr(trace),
+                                      L.dptr(info), L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
+    info, x, tr = info.cpu().numpy(), xd.cpu().numpy(), trace.cpu().numpy()
+    out = []
+    for w in range(nw):
+        if not info[w, 1]:
+            print("WARNING: fcnNLS_batch() reaching max iterations!")  # NLS.py:242
+        j = nt * 3
+        pw_out = x[w, :j].reshape(nt, 3)
+        cw_out = np.concatenate((np.zeros((1, 3)), x[w, j : j + nc * 3].reshape(nc, 3)), 0)
+        out.append((cw_out, pw_out, x[w], tr[w, : info[w, 0]]) if return_info else (cw_out, pw_out))
+    return out
+
+
 def _cam2ned():  # common.py:159-164
     return np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], np.float64)
 

@@ -63,6 +63,7 @@ _SIGS = {
     "vh_n_view_intercept": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "vh_nls_batch_workspace": (C.c_size_t, [C.c_int, C.c_int]),
     "vh_nls_batch": (C.c_int, [vp, f32p, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
+    "vh_nls_batch_multi": (C.c_int, [vp, f32p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     "vh_nls_batch2": (C.c_int, [vp, f32p, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     "vh_good_features": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, vp, vp, vp]),
     "vh_corner_subpix": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_double, vp]),

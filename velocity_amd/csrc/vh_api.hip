@@ -26,7 +26,7 @@ int vh_fail(int code, const char* msg)
 }
 #define VH_LAUNCH_CHECK() VH_CHECK(hipGetLastError())
 
-extern "C" VH_API int vh_version(void) { return 101; }
+extern "C" VH_API int vh_version(void) { return 102; }
 void vh_lk_force_generic(int on);
 extern "C" VH_API void vh_debug_force_generic_lk(int on) { vh_lk_force_generic(on); }
 extern "C" VH_API int vh_copy_to_host(void* dst_host, const void* src_dev, size_t bytes, void* stream)
@@ -802,7 +802,32 @@ extern "C" VH_API int vh_nls_batch(vh_ctx* c, const float* K_host, const double*
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt); P.force_valu = g_ba_force_valu;
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 0;
+    P.nwin = 1; P.ws_stride = P.z_stride = P.x_stride = P.trace_stride = P.info_stride = 0;
     P.nx_total = 3.0 * nt + 6.0 * nc; P.nz_total = 2.0 * nt * (nc + 1);
+    int r = vh_ba_run(P, (hipStream_t)stream);
+    if (r) return vh_fail(r, "vh_ba_run failed");
+    return 0;
+}
+
+// nwin independent windows of the same shape through ONE launch sequence (grid.y = window): a sliding-window tracker has one window per
+// video stream, and a single C5 window leaves the chip idle (its solve is one workgroup, its MFMA contraction is latency bound)
+extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const float* K_host, const double* z, double* x, int nt, int nc, int nwin, int max_iter,
+                                         double* trace, int* info, void* workspace, size_t workspace_bytes_per_window, void* stream)
+{
+    if (!c || !K_host || nt < 1 || nc < 1 || max_iter < 1 || nwin < 1 || nwin > 65535) return vh_fail(-1, "vh_nls_batch_multi: bad arguments");
+    if (6 * nc > 256) return vh_fail(-1, "vh_nls_batch_multi: at most 42 free cameras");
+    if (workspace_bytes_per_window < vh_ba_workspace_bytes(nt, nc, ba_parts(nt)) || workspace_bytes_per_window % 256)
+        return vh_fail(-1, "vh_nls_batch_multi: per-window workspace too small or not a multiple of 256 bytes");
+    BaProblem P;
+    for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
+    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.force_valu = g_ba_force_valu;
+    // fewer partial systems per window when many windows fill the chip anyway (the partials are reduced through HBM)
+    int parts = ba_parts(nt), cap = 512 / nwin < 32 ? 32 : 512 / nwin;
+    P.nparts = nwin > 1 && parts > cap ? cap : parts;
+    P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 0;
+    P.nx_total = 3.0 * nt + 6.0 * nc; P.nz_total = 2.0 * nt * (nc + 1);
+    P.nwin = nwin; P.ws_stride = workspace_bytes_per_window; P.z_stride = (size_t)2 * nt * (nc + 1); P.x_stride = (size_t)3 * nt + 6 * (size_t)nc;
+    P.trace_stride = (size_t)2 * max_iter; P.info_stride = 2;
     int r = vh_ba_run(P, (hipStream_t)stream);
     if (r) return vh_fail(r, "vh_ba_run failed");
     return 0;
@@ -819,6 +844,7 @@ extern "C" VH_API int vh_nls_batch2(vh_ctx* c, const float* K_host, const double
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt); P.force_valu = 1;
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 1;
+    P.nwin = 1; P.ws_stride = P.z_stride = P.x_stride = P.trace_stride = P.info_stride = 0;
     P.nx_total = 3.0 * nt + nc + 5.0; P.nz_total = 2.0 * nt * (nc + 1);
     int r = vh_ba_run(P, (hipStream_t)stream);
     if (r) return vh_fail(r, "vh_ba_run failed");
@@ -842,6 +868,7 @@ extern "C" VH_API int vh_nls_batch_phase(vh_ctx* c, const float* K_host, const d
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = 1; P.nparts = ba_parts(nt);
     P.force_valu = g_ba_force_valu;
     P.phase = phase; P.it = it; P.add_identity = rank0 ? 1 : 0; P.count_cams = rank0 ? 1 : 0; P.defer_finalize = 1; P.model = 0;
+    P.nwin = 1; P.ws_stride = P.z_stride = P.x_stride = P.trace_stride = P.info_stride = 0;
     P.nx_total = 3.0 * nt_total + 6.0 * nc; P.nz_total = 2.0 * nt_total * (nc + 1);
     if (span_offset && span_doubles) vh_ba_exchange_span(P, span_offset, span_doubles);
     if (phase < 0 || phase > 3) return vh_fail(-1, "vh_nls_batch_phase: phase must be 0..3");

@@ -14,6 +14,17 @@
 #define BA_THREADS 256
 #define BA_EPT 64  // Schur entries owned by one thread per pass
 
+// batched windows: shift every pointer of the job to window w (the job travels by value, so this edits the kernel's own copy)
+__device__ __forceinline__ void ba_select_window(BaJob& J, int w)
+{
+    if (w == 0) return;
+    const size_t d = (size_t)w * (J.ws_stride / sizeof(double));
+    J.camR += d; J.r += d; J.Jp += d; J.Jc += d; J.tp += d; J.Y += d; J.Spart += d; J.Rpart += d; J.Sfull += d; J.dc += d; J.acc += d; J.rslot += d;
+    J.done = reinterpret_cast<int*>(reinterpret_cast<char*>(J.done) + (size_t)w * J.ws_stride);
+    J.ticket = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(J.ticket) + (size_t)w * J.ws_stride);
+    J.z += (size_t)w * J.z_stride; J.x += (size_t)w * J.x_stride; J.trace += (size_t)w * J.trace_stride; J.info += (size_t)w * J.info_stride;
+}
+
 __device__ void ba_rpy2dcm(const double* rpy, double* C)
 {
     const double sr = sin(rpy[0]), cr = cos(rpy[0]), sp = sin(rpy[1]), cp = cos(rpy[1]), sy = sin(rpy[2]), cy = cos(rpy[2]);
@@ -86,6 +97,7 @@ __device__ void ba_cam_tables(const BaJob& J, int c, const double* par)  // came
 // first iteration only: later iterations get their tables from block 0 of k_ba_update, right after it moved the cameras
 __global__ void k_ba_cams(BaJob J)
 {
+    ba_select_window(J, blockIdx.y);
     if (*J.done) return;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c <= J.nc) ba_cam_tables(J, c, J.x + 3 * J.nt);
@@ -94,6 +106,7 @@ __global__ void k_ba_cams(BaJob J)
 // residual and compact forward-difference Jacobian of every measurement pair (camera c, track i)
 __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
 {
+    ba_select_window(J, blockIdx.y);
     if (*J.done) return;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     const int nt = J.nt, nf = J.nc + 1;
@@ -201,6 +214,7 @@ __device__ void inv3_sym(const double* U, double* Ui)
 // the workgroup's partial of S (thread-owned entries, registers) and of the reduced right-hand side go to global memory.
 __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
 {
+    ba_select_window(J, blockIdx.y);
     if (*J.done) return;
     const int nt = J.nt, nc = J.nc, nq = J.nq, tid = threadIdx.x;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -333,6 +347,7 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(BA_THREADS) void k_ba_points_mfma(BaJob J)
 {
+    ba_select_window(J, blockIdx.y);
     if (*J.done) return;
     const int nt = J.nt, nc = J.nc, nq = 6 * nc, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -473,6 +488,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points_mfma(BaJob J)
 // slices are combined in a fixed order (deterministic).
 __global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts)
 {
+    ba_select_window(J, blockIdx.y);
     if (*J.done) return;
     const int nq = J.nq, ld = nq + 1;
     const long long nent = (long long)nq * nq, ntot = nent + nq;
@@ -544,6 +560,7 @@ __device__ __forceinline__ void ba_publish(const double (&a)[RM][CM], double* ro
 template <int RM, int CM, int G>
 __global__ __launch_bounds__(G * G) void k_ba_solve(BaJob J, int nparts)
 {
+    ba_select_window(J, blockIdx.y);
     (void)nparts;
     if (*J.done) return;
     static_assert(G % 2 == 0, "a pivot pair never straddles a group");
@@ -639,6 +656,7 @@ __global__ __launch_bounds__(G * G) void k_ba_solve(BaJob J, int nparts)
 // back-substitution dp = tp - Y dc, update x += 0.9 delta, rms(delta) and the stop flag (NLS.py:235-240)
 __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
 {
+    ba_select_window(J, blockIdx.y);
     if (*J.done) return;
     const int nt = J.nt, nc = J.nc, nq = J.nq, tid = threadIdx.x;
     __shared__ double sh[BA_THREADS / 64];
@@ -710,6 +728,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
 // iteration record from the (all-reduced) sums of a sharded run
 __global__ void k_ba_finalize(BaJob J, int it)
 {
+    ba_select_window(J, blockIdx.y);
     if (threadIdx.x != 0 || *J.done) return;
     const double f = sqrt(J.acc[0] / J.nz_total), xr = sqrt(J.acc[1] / J.nx_total);
     J.trace[2 * it] = f;
@@ -717,6 +736,17 @@ __global__ void k_ba_finalize(BaJob J, int it)
     J.info[0] = it + 1;
     if (xr < 1e-7) { J.info[1] = 1; *J.done = 1; }
     J.acc[0] = 0.0; J.acc[1] = 0.0;
+}
+
+// start of a solve: accumulators, flag block and the info record of every window
+__global__ void k_ba_init(BaJob J, double* flags0)
+{
+    ba_select_window(J, blockIdx.y);
+    double* flags = reinterpret_cast<double*>(reinterpret_cast<char*>(flags0) + (size_t)blockIdx.y * (J.nwin > 1 ? J.ws_stride : 0));
+    const int t = threadIdx.x;
+    if (t < 4) J.acc[t] = 0.0;
+    if (t < 32) flags[t] = 0.0;
+    if (t < 2) J.info[t] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -739,6 +769,8 @@ static void ba_layout(const BaProblem& P, BaJob& J, double*& flags)
     J.z = P.z; J.x = P.x; J.trace = P.trace; J.info = P.info;
     J.add_identity = P.add_identity; J.count_cams = P.count_cams; J.defer_finalize = P.defer_finalize;
     J.nx_total = P.nx_total; J.nz_total = P.nz_total;
+    J.nwin = P.nwin < 1 ? 1 : P.nwin;
+    J.ws_stride = P.ws_stride; J.z_stride = P.z_stride; J.x_stride = P.x_stride; J.trace_stride = P.trace_stride; J.info_stride = P.info_stride;
     char* w = reinterpret_cast<char*>(P.workspace);
     auto take = [&](size_t n) { double* p = reinterpret_cast<double*>(w); w += (n * sizeof(double) + 255) / 256 * 256; return p; };
     const size_t nf = nc + 1, m = (size_t)nt * nf;
@@ -780,29 +812,28 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     const int nmeas = nt * (nc + 1);
     // one wavefront per point, grid-strided: every block ends with an atomic on one address, so keep the block count low
     const int upd_blocks = std::min((nt + BA_THREADS / 64 - 1) / (BA_THREADS / 64), 256);
+    const unsigned nw = (unsigned)J.nwin;
     auto init = [&]() -> int {
-        hipError_t e = hipMemsetAsync(J.acc, 0, 4 * sizeof(double), s);
-        if (e == hipSuccess) e = hipMemsetAsync(flags, 0, 32 * sizeof(double), s);
-        if (e == hipSuccess) e = hipMemsetAsync(P.info, 0, 2 * sizeof(int), s);
-        return (int)e;
+        hipLaunchKernelGGL(k_ba_init, dim3(1, nw), dim3(64), 0, s, J, flags);
+        return (int)hipGetLastError();
     };
     auto normal_equations = [&](int it) {
-        if (it == 0) hipLaunchKernelGGL(k_ba_cams, dim3((nc + 1 + 63) / 64), dim3(64), 0, s, J);
-        hipLaunchKernelGGL(k_ba_jac, dim3((nmeas + BA_THREADS - 1) / BA_THREADS), dim3(BA_THREADS), 0, s, J);
+        if (it == 0) hipLaunchKernelGGL(k_ba_cams, dim3((nc + 1 + 63) / 64, nw), dim3(64), 0, s, J);
+        hipLaunchKernelGGL(k_ba_jac, dim3((nmeas + BA_THREADS - 1) / BA_THREADS, nw), dim3(BA_THREADS), 0, s, J);
         if (nq <= BA_NPAD && !P.force_valu && P.model == 0) {  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
-            hipLaunchKernelGGL(k_ba_points_mfma, dim3(nparts), dim3(BA_THREADS), lds_mfma, s, J);
+            hipLaunchKernelGGL(k_ba_points_mfma, dim3(nparts, nw), dim3(BA_THREADS), lds_mfma, s, J);
         } else {
             for (int pass = 0; pass < npass; pass++)  // later passes overwrite Spart entries of their own range only
-                hipLaunchKernelGGL(k_ba_points, dim3(nparts), dim3(BA_THREADS), lds, s, J, pass);
+                hipLaunchKernelGGL(k_ba_points, dim3(nparts, nw), dim3(BA_THREADS), lds, s, J, pass);
         }
-        hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((nent + nq + 63) / 64)), dim3(BA_THREADS), 0, s, J, nparts);
+        hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((nent + nq + 63) / 64), nw), dim3(BA_THREADS), 0, s, J, nparts);
     };
     auto solve_update = [&](int it) {
         // up to 127 unknowns: 256 threads x 64 doubles (same speed as 1024 x 16: the step is a latency chain, not work)
-        if (nq + 1 <= 128) hipLaunchKernelGGL((k_ba_solve<8, 8, 16>), dim3(1), dim3(256), 0, s, J, nparts);
-        else if (nq <= 192) hipLaunchKernelGGL((k_ba_solve<6, 7, 32>), dim3(1), dim3(1024), 0, s, J, nparts);
-        else hipLaunchKernelGGL((k_ba_solve<8, 9, 32>), dim3(1), dim3(1024), 0, s, J, nparts);
-        hipLaunchKernelGGL(k_ba_update, dim3(upd_blocks), dim3(BA_THREADS), 0, s, J, it);
+        if (nq + 1 <= 128) hipLaunchKernelGGL((k_ba_solve<8, 8, 16>), dim3(1, nw), dim3(256), 0, s, J, nparts);
+        else if (nq <= 192) hipLaunchKernelGGL((k_ba_solve<6, 7, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
+        else hipLaunchKernelGGL((k_ba_solve<8, 9, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
+        hipLaunchKernelGGL(k_ba_update, dim3(upd_blocks, nw), dim3(BA_THREADS), 0, s, J, it);
     };
     switch (P.phase) {
     case -1: {
@@ -814,7 +845,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     case 0: { int r = init(); if (r) return r; break; }
     case 1: normal_equations(P.it); break;
     case 2: solve_update(P.it); break;
-    case 3: hipLaunchKernelGGL(k_ba_finalize, dim3(1), dim3(64), 0, s, J, P.it); break;
+    case 3: hipLaunchKernelGGL(k_ba_finalize, dim3(1, nw), dim3(64), 0, s, J, P.it); break;
     default: return -4;
     }
     return (int)hipGetLastError();

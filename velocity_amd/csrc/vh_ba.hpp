@@ -29,6 +29,12 @@ struct BaJob {  // passed by value to every BA kernel
     int nq;     // reduced unknowns: 6 nc (model 0) or nc + 5 (model 1)
     int model;  // 0: fcnNLS_batch (free cameras, NLS.py:186-250); 1: fcnNLS_batch2 (joint rotation + straight-line trajectory, NLS.py:253-328)
     int add_identity, count_cams, defer_finalize;
+    // batched independent windows (vh_nls_batch_multi): blockIdx.y selects the window; every pointer above is window 0's
+    int nwin;
+    size_t ws_stride;                // bytes between the workspaces of consecutive windows
+    size_t z_stride, x_stride;       // doubles between consecutive windows' z / x
+    size_t trace_stride;             // doubles
+    size_t info_stride;              // ints
 };
 
 struct BaProblem {
@@ -44,6 +50,8 @@ struct BaProblem {
     double nx_total, nz_total;
     int model;       // see BaJob::model
     int force_valu;  // test hook: 1 = accumulate the reduced camera system on the VALU instead of the matrix cores
+    int nwin;        // independent windows solved by the same launches (>= 1); z, x, trace, info and workspace are arrays of nwin
+    size_t ws_stride, z_stride, x_stride, trace_stride, info_stride;  // see BaJob (ignored when nwin == 1)
 };
 
 size_t vh_ba_workspace_bytes(int nt, int nc, int nparts);

@@ -74,12 +74,13 @@ class PlaneMotion:
     translation at frame k is t_k = traj(k) -- the reference's own model (vidExample.py:119: every feature on the
     plate plane; pose = translation only).  Image motion: x_k = c + (x_0 - c) z0/(z0+tz) + f (tx,ty)/(z0+tz)."""
 
-    def __init__(self, K, z0=3.6, traj=None):
+    def __init__(self, K, z0=3.6, traj=None, roll=None):
         K = np.asarray(K, float)
         self.f = np.array([K[0, 0], K[1, 1]])
         self.c = np.array([K[2, 0], K[2, 1]])
         self.z0 = float(z0)
         self.traj = traj or (lambda k: np.array([0.02 * k, 0.005 * k, 0.10 * k]))
+        self.roll = roll  # optional camera roll about the optical axis, radians at frame k: the image rotates about the principal point
 
     def t(self, k):
         return np.asarray(self.traj(k), float)
@@ -88,7 +89,13 @@ class PlaneMotion:
         tx, ty, tz = self.t(k)
         s = self.z0 / (self.z0 + tz)
         b = self.c * (1 - s) + self.f * np.array([tx, ty]) / (self.z0 + tz)
-        return np.array([[s, 0, b[0]], [0, s, b[1]]])
+        if self.roll is None:
+            return np.array([[s, 0, b[0]], [0, s, b[1]]])
+        # x_k = c + s R(phi) (x_0 - c) + f (tx,ty)/(z0+tz): rotation + zoom about the principal point, then the translation term
+        phi = float(self.roll(k))
+        Lm = s * np.array([[math.cos(phi), -math.sin(phi)], [math.sin(phi), math.cos(phi)]])
+        bb = self.c - Lm @ self.c + self.f * np.array([tx, ty]) / (self.z0 + tz)
+        return np.array([[Lm[0, 0], Lm[0, 1], bb[0]], [Lm[1, 0], Lm[1, 1], bb[1]]])
 
     def apply(self, k, pts):
         A = self.matrix(k)
@@ -109,6 +116,13 @@ def oscillating_traj(period=60.0, ax=0.19, ay=0.04, az=0.25):
     """Bounded periodic scene motion for long benchmark sequences (max ~11 px/frame at 1080p, z0 = 3.6 m)."""
     w = 2 * math.pi / period
     return lambda k: np.array([ax * math.sin(w * k), ay * math.sin(2 * w * k), az * (1 - math.cos(w * k))])
+
+
+def oscillating_roll(period=60.0, max_deg_per_frame=0.05):
+    """Bounded periodic camera roll whose per-frame rate peaks at SURVEY §8d's theta = 0.05 deg / frame."""
+    w = 2 * math.pi / period
+    amp = math.radians(max_deg_per_frame) / w
+    return lambda k: amp * math.sin(w * k)
 
 
 def render_frame(width, height, motion, k, seed=0xC0FFEE, device="cpu"):
