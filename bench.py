@@ -56,6 +56,25 @@ def valu_peak():
     return N_SIMD * lanes * CLOCK_GHZ * 1e9 / 1e12, lanes, src
 
 
+def host_cores():
+    """Host cores this process may really use: the affinity mask capped by the container's CPU quota (cgroup v2 cpu.max or v1
+    cfs quota).  The GPU boxes show 256 logical CPUs under a 16-core quota: 256 OpenMP threads there are throttled to a crawl."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(math.ceil(int(q) / int(per)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(math.ceil(q / per))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +94,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each cpu_baseline leg (0 disables)")
     ap.add_argument("--exchange-every", type=int, default=30)
     ap.add_argument("--no-ba", action="store_true", help="skip the BA (config 5) leg")
+    ap.add_argument("--only-ba", action="store_true", help="run only the BA (config 5) leg and print its object (profiling aid)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (single stream, reference parameters, C3, roll scene)")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("VH_BENCH_GROUPS", 1)),
                     help="split the resident streams into this many sessions on separate HIP streams (their latency-bound stages overlap)")
@@ -140,10 +160,11 @@ def cpu_baseline(cfg, K, frames, p0, p3, vp, lkc, lkf, budget_s, threads):
     import contextlib
 
     orc = SessionOracle(K, host[0], p0, p3, vp, np.float32([0, 0, 3.6]), nhist=max_frames + 2, lk_coarse=lkc, lk_fine=lkf, msv_frame=0, native=True)
+    threads = threads if threads > 0 else host_cores()
     used = klt_oracle.set_threads(orc.lib, threads)
     with contextlib.ExitStack() as stack:
-        if threadpool_limits is not None and threads == 1:
-            stack.enter_context(threadpool_limits(limits=1))  # NumPy's BLAS pool (the NLS half) down to one core too
+        if threadpool_limits is not None:
+            stack.enter_context(threadpool_limits(limits=threads))  # NumPy's BLAS pool (the NLS half) on the same cores
         orc.step(host[1], np.float32(1 / 30), 1)  # warm-up (page faults, thread pool)
         t0, done = time.perf_counter(), 0
         for k in range(2, max_frames):
@@ -222,14 +243,24 @@ def bench_ba(nt=5000, nf=20, repeats=3, cpu_seconds=12.0, windows=(1, 8, 64)):
 
         z, x0, _, _ = synth.ba_pack(*first)
         Kd = K.astype(float)
-        NO.ba_schur_step(x0, z, Kd, nc, nt)  # warm-up (BLAS thread pool)
-        x, done, t0 = x0.copy(), 0, time.perf_counter()
-        while done < 10 and time.perf_counter() - t0 < cpu_seconds:
-            delta, f = NO.ba_schur_step(x, z, Kd, nc, nt)
-            x = x + delta
-            done += 1
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = dict(value=round(done / dt, 3), unit="LM iterations/s", cores=os.cpu_count(), kind="port",
+        cores = host_cores()
+        import contextlib
+
+        with contextlib.ExitStack() as stack:
+            try:
+                from threadpoolctl import threadpool_limits
+
+                stack.enter_context(threadpool_limits(limits=cores))
+            except ImportError:  # pragma: no cover
+                pass
+            NO.ba_schur_step(x0, z, Kd, nc, nt)  # warm-up (BLAS thread pool)
+            x, done, t0 = x0.copy(), 0, time.perf_counter()
+            while done < 10 and time.perf_counter() - t0 < cpu_seconds:
+                delta, f = NO.ba_schur_step(x, z, Kd, nc, nt)
+                x = x + delta
+                done += 1
+            dt = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=round(done / dt, 3), unit="LM iterations/s", cores=cores, kind="port",
                                    sample=f"{done} LM iterations of the same C5 window, structured (Schur) NumPy restatement, {dt:.1f} s; the dense "
                                           "reference path (utils/NLS.py:228-235) is infeasible at this size")
         out["gpu_over_cpu"] = round(one["iters_per_s"] / out["cpu_baseline"]["value"], 1)
@@ -498,6 +529,9 @@ def main():
     from velocity_amd import _lib as L
     from velocity_amd import dist as vdist
 
+    if a.only_ba:
+        print(json.dumps(bench_ba(cpu_seconds=0, windows=(1, 8, 64))))
+        return
     S, N = a.streams, cfg["n"]
     wl = Workload(a, cfg, a.params, a.scene, S, a.steps, a.warmup, dev, rank, groups=a.groups, host_frames=a.host_frames)
     ex = vdist.TrackStateExchange(S, N, every=a.exchange_every, device=dev) if use_dist else None
