@@ -50,6 +50,25 @@ KO_API int ko_set_threads(int n)
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* sensitivity modes (tests/test_oracle_klt_sensitivity.py): the parity contract is mode 0 everywhere */
+/* ------------------------------------------------------------------------------------------------ */
+/* LK window sums (A11, A12, A22, b1, b2):
+ *   0  exact int64 sums converted once to float32 -- THE contract (order independent, what the HIP kernels reproduce bit for bit);
+ *   1  OpenCV's plain C path of lkpyramid.cpp (`typedef float acctype, itemtype`): float32 accumulators, raster order,
+ *      `iA11 += (itemtype)(ixval * ixval)`, `ib1 += (itemtype)(diff * dIptr[0])`;
+ *   2  the accumulation STRUCTURE of OpenCV's 128-bit universal-intrinsics path as recalled from upstream (not verifiable here):
+ *      A: 4 float lanes (pixel x mod 4) of float(ix) * float(iy) multiply-adds over groups of 4 pixels, scalar float tail, lanes
+ *      summed at the end; b: groups of 8 pixels, exact int32 sums of the pixel pairs (x, x+4) converted to float and added to
+ *      float lanes, scalar float tail.
+ * Modes 1 and 2 exist only to BOUND how much the exact-integer choice can move results relative to a float-accumulating OpenCV. */
+static int g_accum_mode = 0;
+KO_API void ko_set_accum_mode(int m) { g_accum_mode = m; }
+/* estimateAffine2D refinement: 0 = closed-form least squares on the inliers (contract); 1 = OpenCV's sequence: the best 3-point
+ * model refined by 10 iterations of its LMSolver (calib3d levmarq.cpp: lambda, R ratio test) on the inliers */
+static int g_refine_mode = 0;
+KO_API void ko_set_refine_mode(int m) { g_refine_mode = m; }
+
+/* ------------------------------------------------------------------------------------------------ */
 /* small helpers                                                                                     */
 /* ------------------------------------------------------------------------------------------------ */
 static inline int reflect101(int i, int n)
@@ -264,6 +283,9 @@ static void lk_point_level(const level_t *I, const level_t *J, int win, int leve
 
     const int sI = I->stride, sD = I->stride * 2, sJ = J->stride;
     int64_t sA11 = 0, sA12 = 0, sA22 = 0;
+    const int amode = g_accum_mode;
+    float fA11 = 0.f, fA12 = 0.f, fA22 = 0.f;                 /* modes 1, 2: scalar float accumulators (mode 2: the row tails) */
+    float qA11[4] = {0, 0, 0, 0}, qA12[4] = {0, 0, 0, 0}, qA22[4] = {0, 0, 0, 0}; /* mode 2: lanes */
     for (int y = 0; y < win; y++) {
         const uint8_t *src = I->img + (size_t)(y + ipy + I->border) * sI + ipx + I->border;
         const int16_t *ds = I->der + ((size_t)(y + ipy + I->border) * sI + ipx + I->border) * 2;
@@ -277,9 +299,19 @@ static void lk_point_level(const level_t *I, const level_t *J, int win, int leve
             sA11 += (int64_t)ix * ix;
             sA12 += (int64_t)ix * iy;
             sA22 += (int64_t)iy * iy;
+            if (amode == 1 || (amode == 2 && x >= (win & ~3))) {
+                fA11 += (float)(ix * ix); fA12 += (float)(ix * iy); fA22 += (float)(iy * iy);
+            } else if (amode == 2) {
+                const float fx = (float)ix, fy = (float)iy;
+                qA11[x & 3] = fx * fx + qA11[x & 3]; qA12[x & 3] = fx * fy + qA12[x & 3]; qA22[x & 3] = fy * fy + qA22[x & 3];
+            }
         }
     }
     float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+    if (amode == 2) {
+        fA11 += qA11[0] + qA11[1] + qA11[2] + qA11[3]; fA12 += qA12[0] + qA12[1] + qA12[2] + qA12[3]; fA22 += qA22[0] + qA22[1] + qA22[2] + qA22[3];
+    }
+    if (amode) { A11 = fA11 * FLT_SCALE; A12 = fA12 * FLT_SCALE; A22 = fA22 * FLT_SCALE; }
     float D = A11 * A22 - A12 * A12;
     float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
     if (minEig < min_eig_thr || D < 1.1920929e-07f) {
@@ -298,15 +330,32 @@ static void lk_point_level(const level_t *I, const level_t *J, int win, int leve
         }
         bilinear_weights(nx - inx, ny - iny, &w00, &w01, &w10, &w11);
         int64_t sb1 = 0, sb2 = 0;
+        float fb1 = 0.f, fb2 = 0.f, qb1[4] = {0, 0, 0, 0}, qb2[4] = {0, 0, 0, 0};
+        int dbuf[8];
         for (int y = 0; y < win; y++) {
             const uint8_t *jp = J->img + (size_t)(y + iny + J->border) * sJ + inx + J->border;
             for (int x = 0; x < win; x++) {
                 int diff = descale(jp[x] * w00 + jp[x + 1] * w01 + jp[x + sJ] * w10 + jp[x + sJ + 1] * w11, W_BITS - 5) - Iwin[y * win + x];
                 sb1 += (int64_t)diff * dIwin[2 * (y * win + x)];
                 sb2 += (int64_t)diff * dIwin[2 * (y * win + x) + 1];
+                if (amode == 1 || (amode == 2 && x >= (win & ~7))) {
+                    fb1 += (float)(diff * dIwin[2 * (y * win + x)]);
+                    fb2 += (float)(diff * dIwin[2 * (y * win + x) + 1]);
+                } else if (amode == 2) {
+                    dbuf[x & 7] = diff;
+                    if ((x & 7) == 7) { /* a full group of 8: pixel pairs (k, k+4) summed exactly in int32, then float lanes */
+                        const int16_t *d = dIwin + 2 * (y * win + x - 7);
+                        for (int k = 0; k < 4; k++) {
+                            qb1[k] += (float)(dbuf[k] * d[2 * k] + dbuf[k + 4] * d[2 * (k + 4)]);
+                            qb2[k] += (float)(dbuf[k] * d[2 * k + 1] + dbuf[k + 4] * d[2 * (k + 4) + 1]);
+                        }
+                    }
+                }
             }
         }
         float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+        if (amode == 2) { fb1 += (qb1[0] + qb1[2]) + (qb1[1] + qb1[3]); fb2 += (qb2[0] + qb2[2]) + (qb2[1] + qb2[3]); }
+        if (amode) { b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE; }
         float dx = (A12 * b2 - A22 * b1) * D;
         float dy = (A12 * b1 - A11 * b2) * D;
         nx += dx; ny += dy;
@@ -573,6 +622,95 @@ static int hypothesis(const float *from, const float *to, int m, uint32_t hyp, d
 
 static int64_t fixq(double v, int bits) { return (int64_t)llrint(ldexp(v, bits)); }
 
+/* ---- OpenCV-style refinement of the RANSAC model (sensitivity mode, g_refine_mode == 1) ---------------------------------------- */
+/* Affine2DRefineCallback: residuals (M x - u, per inlier, 2 rows) and their Jacobian w.r.t. the 6 entries of M (linear). */
+static double lm_affine_residual(const float *from, const float *to, const uint8_t *inl, int m, const double h[6], double JtJ[36], double Jtr[6])
+{
+    double S = 0.0;
+    if (JtJ) { memset(JtJ, 0, sizeof(double) * 36); memset(Jtr, 0, sizeof(double) * 6); }
+    for (int i = 0; i < m; i++) {
+        if (!inl[i]) continue;
+        const double x = from[2 * i], y = from[2 * i + 1];
+        const double ex = h[0] * x + h[1] * y + h[2] - to[2 * i], ey = h[3] * x + h[4] * y + h[5] - to[2 * i + 1];
+        S += ex * ex + ey * ey;
+        if (JtJ) {
+            const double j[3] = {x, y, 1.0};
+            for (int a = 0; a < 3; a++) {
+                for (int b = 0; b < 3; b++) { JtJ[a * 6 + b] += j[a] * j[b]; JtJ[(a + 3) * 6 + b + 3] += j[a] * j[b]; }
+                Jtr[a] += j[a] * ex; Jtr[a + 3] += j[a] * ey;
+            }
+        }
+    }
+    return S;
+}
+static int solve6(const double A_[36], const double b_[6], double x[6])
+{
+    double A[6][7];
+    for (int r = 0; r < 6; r++) { for (int c = 0; c < 6; c++) A[r][c] = A_[r * 6 + c]; A[r][6] = b_[r]; }
+    for (int c = 0; c < 6; c++) {
+        int p = c;
+        for (int r = c + 1; r < 6; r++) if (fabs(A[r][c]) > fabs(A[p][c])) p = r;
+        if (A[p][c] == 0.0) return 0;
+        if (p != c) for (int k = 0; k < 7; k++) { double t = A[c][k]; A[c][k] = A[p][k]; A[p][k] = t; }
+        for (int r = 0; r < 6; r++) {
+            if (r == c) continue;
+            const double f = A[r][c] / A[c][c];
+            for (int k = c; k < 7; k++) A[r][k] -= f * A[c][k];
+        }
+    }
+    for (int r = 0; r < 6; r++) x[r] = A[r][6] / A[r][r];
+    return 1;
+}
+/* OpenCV LMSolverImpl::run (calib3d/src/levmarq.cpp, 4.x): lambda starts at 1, diag scaling, gain-ratio test with Rlo/Rhi. */
+static void lm_refine_affine(const float *from, const float *to, const uint8_t *inl, int m, double h[6], int max_iters)
+{
+    double A[36], v[6], D[6], d[6], xd[6], Ad[6];
+    double S = lm_affine_residual(from, to, inl, m, h, A, v);
+    for (int k = 0; k < 6; k++) D[k] = A[k * 6 + k];
+    const double Rlo = 0.25, Rhi = 0.75;
+    double lambda = 1.0, lc = 0.75;
+    for (int iter = 0; iter < max_iters; iter++) {
+        double Al[36];
+        memcpy(Al, A, sizeof(Al));
+        for (int k = 0; k < 6; k++) Al[k * 6 + k] += lambda * D[k];
+        if (!solve6(Al, v, d)) break;
+        for (int k = 0; k < 6; k++) xd[k] = h[k] - d[k];
+        const double Sd = lm_affine_residual(from, to, inl, m, xd, NULL, NULL);
+        double dS = 0.0, t = 0.0, dmax = 0.0;
+        for (int r = 0; r < 6; r++) {
+            double s_ = 0.0;
+            for (int c = 0; c < 6; c++) s_ += Al[r * 6 + c] * d[c];
+            Ad[r] = 2.0 * v[r] - s_;
+            dS += d[r] * Ad[r];
+            t += d[r] * v[r];
+            if (fabs(d[r]) > dmax) dmax = fabs(d[r]);
+        }
+        const double R = (S - Sd) / (fabs(dS) > 2.220446049250313e-16 ? dS : 1.0);
+        if (R > Rhi) { lambda *= 0.5; if (lambda < lc) lambda = 0.0; }
+        else if (R < Rlo) {
+            double nu = (Sd - S) / (fabs(t) > 2.220446049250313e-16 ? t : 1.0) + 2.0;
+            nu = nu < 2.0 ? 2.0 : (nu > 10.0 ? 10.0 : nu);
+            if (lambda == 0.0) {
+                double maxval = 2.220446049250313e-16;  /* 1 / max |diag(A^-1)|, via six solves */
+                for (int k = 0; k < 6; k++) {
+                    double e[6] = {0, 0, 0, 0, 0, 0}, col[6];
+                    e[k] = 1.0;
+                    if (solve6(A, e, col) && fabs(col[k]) > maxval) maxval = fabs(col[k]);
+                }
+                lambda = lc = 1.0 / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+            memcpy(h, xd, sizeof(xd));
+            S = lm_affine_residual(from, to, inl, m, h, A, v);
+        }
+        if (!(dmax >= 1.1920929e-07 && S > 0.0)) break; /* epsx = epsf = FLT_EPSILON in createLMSolver(cb, maxIters) */
+    }
+}
+
 /* from/to: m compacted pairs.  Out: M (2x3 row-major, float64), inl (m bytes).  Returns 1 on success. */
 KO_API int ko_ransac_affine(const float *from, const float *to, int m, double Mout[6], uint8_t *inl, int *iters_used)
 {
@@ -630,6 +768,10 @@ KO_API int ko_ransac_affine(const float *from, const float *to, int m, double Mo
         double d = (Sxv * Syy - Syv * Sxy) / det, e = (Sxx * Syv - Sxy * Sxv) / det;
         M[0] = a; M[1] = b; M[2] = (mu - a * mx) - b * my;
         M[3] = d; M[4] = e; M[5] = (mv - d * mx) - e * my;
+    }
+    if (g_refine_mode == 1) {  /* sensitivity mode: OpenCV's own sequence -- best minimal-sample model + 10 LM iterations on its inliers */
+        hypothesis(from, to, m, (uint32_t)best, M);
+        if (best_count > 3) lm_refine_affine(from, to, inl, m, M, 10);
     }
     for (int k = 0; k < 6; k++) Mout[k] = M[k];
     return 1;

@@ -68,6 +68,16 @@ def set_threads(L, n):
     return int(L.ko_set_threads(C.c_int(int(n))))
 
 
+def set_accum_mode(mode, L=None):
+    """LK window-sum arithmetic: 0 exact integer (the contract), 1 OpenCV C-path raster float32, 2 SIMD128-like float lanes."""
+    (L or lib()).ko_set_accum_mode(C.c_int(int(mode)))
+
+
+def set_refine_mode(mode, L=None):
+    """estimateAffine2D refinement: 0 closed-form least squares (the contract), 1 best minimal model + 10 OpenCV-style LM iterations."""
+    (L or lib()).ko_set_refine_mode(C.c_int(int(mode)))
+
+
 def _u8(a):
     a = np.ascontiguousarray(a, np.uint8)
     return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
