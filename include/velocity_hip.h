@@ -11,6 +11,9 @@
  *     borrowed and never modified, outputs are caller-allocated;
  *   - images are uint8, pixel (x,y) at base[y*stride + x]; points are float32 (x,y) pairs; poses follow the
  *     reference's row-vector layout (uv1 ~ [X Y Z] @ K, X_cam = X_w @ R + t, affine [x y 1] @ T with T 3x2);
+ *   - a vh_ctx serves ONE HIP stream at a time: the stateless entry points (vh_pyr_lk, vh_pose, vh_remap_affine, ...) park their small job
+ *     descriptors in slot 0 of the workspace they are given, so calls that may overlap on different streams / threads need their own vh_ctx
+ *     (both bindings do this: velocity_amd/_lib.py::workspace and vh_torch_ops.cpp keep one per (device, stream));
  *   - return value 0 = success, otherwise a hipError_t (or a negative vh error); vh_last_error() describes it.
  *     Numerical non-convergence is NOT an error: like the reference (NLS.py:126-127,178-179; KLT.py:129) the call
  *     succeeds and reports it through an info/flags output so the host shim can print the same warning.

@@ -239,6 +239,38 @@ def msv1_t(K, P, B, vg, ii, return_info=False):
     return (out, b0, it + 1, converged) if return_info else (out, b0)
 
 
+def msv2_t(K, P, B, vg, i, log=None):
+    """fcnMSV2_t (utils/MSV.py:52-94) restated BUG FOR BUG: two camera translations, N-ray triangulation inside.  The reference builds
+    J^T as [[JT1, 0], [0, JT2]] and then subtracts zhat from ALL of it (MSV.py:77-84), so the structural-zero blocks become -zhat/dx
+    (~1e9): J^T J + I is numerically singular and np.linalg.inv raises on realistic inputs (recorded in tests/golden: msv2_outcome).
+    Only i == 2 is callable at all (x.reshape((2, 3)), MSV.py:72).  No device kernel exists for it: there is no result to reproduce."""
+    nf = i + 1
+    ng = int(vg.sum())
+    U = np.zeros((3, nf, ng))
+    for j in range(nf):
+        U[:, j] = pixel_to_uvec(K, P[0:2, vg, j].T).T
+    u0 = B[0, 0:3] - B[:nf, 0:3]
+    x = -u0[1:].ravel()
+    z = P[0:2, vg, i - 1 : i + 1].ravel("F")
+    steps = np.eye(3) * FD_STEP
+    for it in range(300):
+        a = n_view_intercept(np.vstack((u0[:-2], -x.reshape((2, 3)))), U)
+        a1, a2 = a + x[:3], a + x[3:6]
+        zhat = project_cam(np.vstack((a1, a2)), K).ravel()
+        JT0 = np.zeros((3, ng * 2))
+        JT1 = project_cam(np.concatenate([a1 + steps[k] for k in range(3)], 0), K).reshape(3, ng * 2)
+        JT2 = project_cam(np.concatenate([a2 + steps[k] for k in range(3)], 0), K).reshape(3, ng * 2)
+        JT = np.concatenate((np.concatenate((JT1, JT0), 1), np.concatenate((JT0, JT2), 1)), 0)
+        JT = (JT - zhat) / FD_STEP  # the defect: zhat is subtracted from the zero blocks too
+        delta = np.linalg.inv(JT @ JT.T + np.eye(6)) @ JT @ (z - zhat) * min(((it + 1) * 0.01) ** 2, 1)
+        if log is not None:
+            log.append((rms(z - zhat), rms(delta)))
+        x = x + delta
+        if rms(delta) < 1e-8:
+            break
+    return x.astype(np.float32)
+
+
 # ----------------------------------------------------------------------------------------------------
 # dense bundle adjustment (fcnNLS_batch, utils/NLS.py:186-250)
 # ----------------------------------------------------------------------------------------------------

@@ -134,6 +134,19 @@ out["msv_P"], out["msv_B"], out["msv_vg"], out["msv_ii"] = P, B, vg, np.int64(ii
 out["msv_x"], out["msv_b0"] = x_msv, b0_msv
 
 
+# ---- fcnMSV2_t (utils/MSV.py:52-94): what the reference ACTUALLY does on the same history (ii = 2: its x.reshape((2, 3)) only works for 3 frames).
+# Its Jacobian subtracts zhat from the structural-zero blocks (MSV.py:77-84), J^T J + I is numerically singular -> the outcome is recorded as data.
+buf = io.StringIO()
+try:
+    with contextlib.redirect_stdout(buf):
+        x_msv2 = RM.fcnMSV2_t(K32, P, B, vg, 2)
+    out["msv2_outcome"] = np.array("returned")
+    out["msv2_x"] = x_msv2
+except Exception as e:  # noqa: BLE001
+    out["msv2_outcome"] = np.array(f"{type(e).__name__}: {e}")
+out["msv2_log"] = np.array(buf.getvalue())
+
+
 # ---- dense BA ------------------------------------------------------------------------------------
 def ba_scene(nt, nf, seed):
     r = np.random.default_rng(seed)

@@ -150,3 +150,17 @@ def test_structured_ba_vs_reference_run_at_1000x10(golden):
     np.testing.assert_allclose(tr[:, 1], ref[:, 1], rtol=1e-4)
     np.testing.assert_allclose(cw, golden[f"{tag}_cw"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(pw, golden[f"{tag}_pw"], rtol=1e-5, atol=1e-6)
+
+
+def test_msv2_t_reference_outcome_is_a_singular_matrix(golden):
+    """SURVEY section 8f item 2 lists fcnMSV2_t (utils/MSV.py:52-94).  Run by tests/gen_golden.py on the MSV history fixture, the REFERENCE raises
+    numpy.linalg.LinAlgError('Singular matrix') in its second iteration (its Jacobian subtracts zhat from the structural-zero blocks); the
+    bug-for-bug restatement hits the same exactly-singular pivot, one iteration EARLIER (rounding decides when LAPACK's LU meets a zero
+    pivot in a matrix whose entries are ~1e24 with a +1 damping below their ulp).  Not even two NumPy statements of the function agree on
+    its behaviour, so there is no output a device kernel could be equal to: the row is closed by this evidence, not by a kernel."""
+    assert str(golden["msv2_outcome"]).startswith("LinAlgError")
+    ref_first = str(golden["msv2_log"]).splitlines()[0]  # "0: f=0.0500796, x=4.16e-08"
+    log = []
+    with pytest.raises(np.linalg.LinAlgError):
+        O.msv2_t(golden["K32"], golden["msv_P"], golden["msv_B"], golden["msv_vg"], 2, log=log)
+    assert len(log) <= 1 and ref_first.startswith("0: f=")  # the reference printed exactly one iteration before failing

@@ -19,6 +19,34 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+TORCH_OUT = os.path.join(HERE, "libvelocity_torch.so")
+TORCH_SRC = os.path.join(CSRC, "vh_torch_ops.cpp")
+
+
+def build_torch_ops(force=False, verbose=False):
+    """libvelocity_torch.so: the TORCH_LIBRARY(velocity_hip, ...) registration layer over the C ABI (plain C++, no kernels), in-tree.
+    Linked against libvelocity_hip.so ($ORIGIN rpath) and the torch / c10 libraries of the running interpreter."""
+    deps = [TORCH_SRC, os.path.join(HERE, "..", "include", "velocity_hip.h"), OUT]
+    if not force and os.path.exists(TORCH_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(TORCH_OUT) for d in deps):
+        return TORCH_OUT
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    rocm = os.environ.get("ROCM_HOME", "/opt/rocm")
+    tlib = ce.library_paths()[0]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DUSE_ROCM", "-D__HIP_PLATFORM_AMD__=1", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations"]
+    cmd += [f"-I{p}" for p in ce.include_paths()] + [f"-I{rocm}/include", TORCH_SRC, "-o", TORCH_OUT]
+    cmd += [f"-L{HERE}", "-lvelocity_hip", f"-L{tlib}", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-lamdhip64",
+            "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"building libvelocity_torch.so failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr)
+    return TORCH_OUT
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True

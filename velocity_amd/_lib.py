@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvelocity_hip.so")
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()
 
 u8p, f32p, f64p, i32p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
 
@@ -184,20 +184,27 @@ class Workspace:
             pass
 
 
-_default_ws = None
+_default_ws = {}
 
 
 def workspace(w=0, h=0, n=0):
-    """Process-wide default workspace, grown on demand."""
-    global _default_ws
-    if _default_ws is None or not _default_ws.fits(w, h, n):
-        old = _default_ws
-        mw = max(w, old.max_w if old else 1920)
-        mh = max(h, old.max_h if old else 1080)
-        mp = max(n, old.max_pts if old else 8192)
-        torch_cuda().cuda.synchronize()
-        _default_ws = Workspace(1, mw, mh, mp)
-    return _default_ws
+    """Default workspace of the CURRENT (device, HIP stream), grown on demand.
+
+    The stateless C entry points park their job descriptors in slot 0 of their workspace (include/velocity_hip.h, "Conventions"), so a
+    workspace must never be shared by two HIP streams: calls issued on different streams (or from different threads, each with its own
+    current stream) get different workspaces here.  Growing replaces the workspace after a stream synchronisation."""
+    torch = torch_cuda()
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    with _lock:
+        old = _default_ws.get(key)
+        if old is None or not old.fits(w, h, n):
+            mw = max(w, old.max_w if old else 1920)
+            mh = max(h, old.max_h if old else 1080)
+            mp = max(n, old.max_pts if old else 8192)
+            if old is not None:
+                torch.cuda.current_stream().synchronize()  # kernels of earlier calls may still read the old arena
+            _default_ws[key] = Workspace(1, mw, mh, mp)
+        return _default_ws[key]
 
 
 def lk_params(d):
