@@ -27,9 +27,14 @@
         }                                                                                         \
     } while (0)
 
-enum Op { DOT2_I16, PERM, ADD_U32, MAD_I24, FMA_F32, PK_FMA_F32, PK_ADD_U16, ALIGNBYTE, MUL_LO, LSHL_ADD, DPP_ADD, MFMA_F64_DUMMY, N_OPS };
+enum Op { DOT2_I16, PERM, ADD_U32, MAD_I24, FMA_F32, PK_FMA_F32, PK_ADD_U16, ALIGNBYTE, MUL_LO, LSHL_ADD, DPP_ADD,
+          AND_B32, LSHLREV, ASHRREV, BFE_U32, ADD3, MAD_U24, MUL_I24, SUB_U32, MAX_I32, CNDMASK, CVT_F32_I32, DOT4_I8, PK_MUL_LO, PK_MAD_I16, AND_OR, MOV_DPP,
+          ADD_F32, MUL_F32, FMA_F64, SAD_U8, LSHL_OR, MAD_U32_U16, N_OPS };
 static const char* kNames[] = {"v_dot2_i32_i16", "v_perm_b32",       "v_add_u32",      "v_mad_i32_i24", "v_fma_f32", "v_pk_fma_f32",
-                               "v_pk_add_u16",   "v_alignbyte_b32", "v_mul_lo_u32",   "v_lshl_add_u32", "v_add_u32 row_shr:1 (DPP)"};
+                               "v_pk_add_u16",   "v_alignbyte_b32", "v_mul_lo_u32",   "v_lshl_add_u32", "v_add_u32 row_shr:1 (DPP)",
+                               "v_and_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_bfe_u32", "v_add3_u32", "v_mad_u32_u24", "v_mul_i32_i24", "v_sub_u32", "v_max_i32",
+                               "v_cndmask_b32", "v_cvt_f32_i32", "v_dot4_i32_i8", "v_pk_mul_lo_u16", "v_pk_mad_i16", "v_and_or_b32", "v_mov_b32 row_shr:1 (DPP)",
+                               "v_add_f32", "v_mul_f32", "v_fma_f64", "v_sad_u8", "v_lshl_or_b32", "v_mad_u32_u16"};
 
 template <int OP>
 __device__ __forceinline__ void one(unsigned& a, unsigned b, unsigned c, float& fa, float fb, float fc, float2& pa, float2 pb, float2 pc)
@@ -45,6 +50,28 @@ __device__ __forceinline__ void one(unsigned& a, unsigned b, unsigned c, float& 
     if (OP == MUL_LO) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a) : "v"(b));
     if (OP == LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a) : "v"(b));
     if (OP == DPP_ADD) asm volatile("v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b));
+    if (OP == AND_B32) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (OP == LSHLREV) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a));
+    if (OP == ASHRREV) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(a));
+    if (OP == BFE_U32) asm volatile("v_bfe_u32 %0, %0, 3, 17" : "+v"(a));
+    if (OP == ADD3) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (OP == MAD_U24) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));
+    if (OP == MUL_I24) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (OP == SUB_U32) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (OP == MAX_I32) asm volatile("v_max_i32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b));
+    if (OP == CVT_F32_I32) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(a));
+    if (OP == DOT4_I8) asm volatile("v_dot4_i32_i8 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));
+    if (OP == PK_MUL_LO) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (OP == PK_MAD_I16) asm volatile("v_pk_mad_i16 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));
+    if (OP == AND_OR) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (OP == MOV_DPP) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a));
+    if (OP == ADD_F32) asm volatile("v_add_f32 %0, %0, %1" : "+v"(fa) : "v"(fb));
+    if (OP == MUL_F32) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(fa) : "v"(fb));
+    if (OP == FMA_F64) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(pa) : "v"(pb), "v"(pc));
+    if (OP == SAD_U8) asm volatile("v_sad_u8 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));
+    if (OP == LSHL_OR) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a) : "v"(b));
+    if (OP == MAD_U32_U16) asm volatile("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));
 }
 
 template <int OP, int CHAINS>
@@ -114,7 +141,7 @@ static void run(int wps, int iters, unsigned* d_out, unsigned long long* d_cyc, 
 template <int OP>
 static void sweep(unsigned* d_out, unsigned long long* d_cyc, int ncu, double hz, bool& first)
 {
-    for (int wps : {1, 2, 4, 8}) {
+    for (int wps : {1, 2, 4}) {
         run<OP, 16>(wps, 16384, d_out, d_cyc, ncu, hz, first);
         first = false;
     }
@@ -145,6 +172,28 @@ int main()
     sweep<MUL_LO>(d_out, d_cyc, ncu, 0, first);
     sweep<LSHL_ADD>(d_out, d_cyc, ncu, 0, first);
     sweep<DPP_ADD>(d_out, d_cyc, ncu, 0, first);
+    sweep<AND_B32>(d_out, d_cyc, ncu, 0, first);
+    sweep<LSHLREV>(d_out, d_cyc, ncu, 0, first);
+    sweep<ASHRREV>(d_out, d_cyc, ncu, 0, first);
+    sweep<BFE_U32>(d_out, d_cyc, ncu, 0, first);
+    sweep<ADD3>(d_out, d_cyc, ncu, 0, first);
+    sweep<MAD_U24>(d_out, d_cyc, ncu, 0, first);
+    sweep<MUL_I24>(d_out, d_cyc, ncu, 0, first);
+    sweep<SUB_U32>(d_out, d_cyc, ncu, 0, first);
+    sweep<MAX_I32>(d_out, d_cyc, ncu, 0, first);
+    sweep<CNDMASK>(d_out, d_cyc, ncu, 0, first);
+    sweep<CVT_F32_I32>(d_out, d_cyc, ncu, 0, first);
+    sweep<DOT4_I8>(d_out, d_cyc, ncu, 0, first);
+    sweep<PK_MUL_LO>(d_out, d_cyc, ncu, 0, first);
+    sweep<PK_MAD_I16>(d_out, d_cyc, ncu, 0, first);
+    sweep<AND_OR>(d_out, d_cyc, ncu, 0, first);
+    sweep<MOV_DPP>(d_out, d_cyc, ncu, 0, first);
+    sweep<ADD_F32>(d_out, d_cyc, ncu, 0, first);
+    sweep<MUL_F32>(d_out, d_cyc, ncu, 0, first);
+    sweep<FMA_F64>(d_out, d_cyc, ncu, 0, first);
+    sweep<SAD_U8>(d_out, d_cyc, ncu, 0, first);
+    sweep<LSHL_OR>(d_out, d_cyc, ncu, 0, first);
+    sweep<MAD_U32_U16>(d_out, d_cyc, ncu, 0, first);
     printf("\n  ]\n}\n");
     return 0;
 }

@@ -19,7 +19,7 @@ __device__ __forceinline__ void ba_select_window(BaJob& J, int w)
 {
     if (w == 0) return;
     const size_t d = (size_t)w * (J.ws_stride / sizeof(double));
-    J.camR += d; J.r += d; J.Jp += d; J.Jc += d; J.tp += d; J.Y += d; J.Spart += d; J.Rpart += d; J.Sfull += d; J.dc += d; J.acc += d; J.rslot += d;
+    J.camR += d; J.r += d; J.Jp += d; J.Jc += d; J.tp += d; J.Lc += d; J.Y += d; J.Spart += d; J.Rpart += d; J.Sfull += d; J.dc += d; J.acc += d; J.rslot += d;
     J.done = reinterpret_cast<int*>(reinterpret_cast<char*>(J.done) + (size_t)w * J.ws_stride);
     J.ticket = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(J.ticket) + (size_t)w * J.ws_stride);
     J.z += (size_t)w * J.z_stride; J.x += (size_t)w * J.x_stride; J.trace += (size_t)w * J.trace_stride; J.info += (size_t)w * J.info_stride;
@@ -103,14 +103,21 @@ __global__ void k_ba_cams(BaJob J)
     if (c <= J.nc) ba_cam_tables(J, c, J.x + 3 * J.nt);
 }
 
-// residual and compact forward-difference Jacobian of every measurement pair (camera c, track i)
+// residual and compact forward-difference Jacobian of every measurement pair (camera c, track i).
+// A thread owns one measurement (20 doubles of output: r 2, Jp 6, Jc 12).  Written straight from the registers, a wave's store touched 64
+// separate 16 / 48 / 96-byte records per instruction; the values are transposed through LDS instead and leave as fully coalesced streams
+// (the block's 256 measurements are contiguous in all three arrays).
 __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
 {
     ba_select_window(J, blockIdx.y);
     if (*J.done) return;
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     const int nt = J.nt, nf = J.nc + 1;
+    __shared__ double s_out[20][BA_THREADS + 1];  // component-major, padded: conflict-free on the way in, spread on the way out
     double ss = 0.0;
+    double o[20];  // r (2) | Jp (6) | Jc (12)
+#pragma unroll
+    for (int k = 0; k < 20; k++) o[k] = 0.0;
     if (m < nt * nf) {
         const int c = m / nt, i = m - c * nt;
         double K[9];
@@ -123,69 +130,61 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
             double u, v, uk, vk;
             ba_project(K, R0, w, off, u, v);
             const double ru = J.z[m] - u, rv = J.z[(size_t)nt * nf + m] - v;
-            J.r[2 * (size_t)m] = ru;
-            J.r[2 * (size_t)m + 1] = rv;
+            o[0] = ru; o[1] = rv;
             ss = ru * ru + rv * rv;
-            double* Jp = J.Jp + 6 * (size_t)m;
             for (int k = 0; k < 3; k++) {
                 double wk[3] = {w[0], w[1], w[2]};
                 wk[k] += BA_FD;
                 ba_project(K, R0, wk, off, uk, vk);
-                Jp[k] = (uk - u) / BA_FD;
-                Jp[3 + k] = (vk - v) / BA_FD;
+                o[2 + k] = (uk - u) / BA_FD;
+                o[5 + k] = (vk - v) / BA_FD;
             }
-            double* Jc = J.Jc + 12 * (size_t)m;
             for (int k = 0; k < 3; k++) {  // joint roll / pitch / yaw
                 ba_project(K, R0 + 9 * (k + 1), w, off, uk, vk);
-                Jc[k] = (uk - u) / BA_FD;
-                Jc[6 + k] = (vk - v) / BA_FD;
+                o[8 + k] = (uk - u) / BA_FD;
+                o[14 + k] = (vk - v) / BA_FD;
             }
             for (int k = 0; k < 3; k++) {  // el, az, range of this camera (camera 0 is fixed: exact zeros, as the reference's FD gives)
                 if (c > 0) {
                     ba_project(K, R0, w, off + 3 * (k + 1), uk, vk);
-                    Jc[3 + k] = (uk - u) / BA_FD;
-                    Jc[9 + k] = (vk - v) / BA_FD;
-                } else {
-                    Jc[3 + k] = 0.0; Jc[9 + k] = 0.0;
+                    o[11 + k] = (uk - u) / BA_FD;
+                    o[17 + k] = (vk - v) / BA_FD;
                 }
             }
         } else {
-        const double* R = J.camR + (size_t)c * 36;
-        double t[3] = {0, 0, 0};
-        if (c > 0) for (int k = 0; k < 3; k++) t[k] = J.x[3 * nt + 3 * (c - 1) + k];
-        double u, v, uk, vk;
-        ba_project(K, R, w, t, u, v);
-        const double ru = J.z[m] - u, rv = J.z[(size_t)nt * nf + m] - v;  // z = [all u | all v], camera-major (NLS.py:198-199)
-        J.r[2 * (size_t)m] = ru;
-        J.r[2 * (size_t)m + 1] = rv;
-        ss = ru * ru + rv * rv;
-        double* Jp = J.Jp + 6 * (size_t)m;
-        for (int k = 0; k < 3; k++) {  // point coordinates
-            double wk[3] = {w[0], w[1], w[2]};
-            wk[k] += BA_FD;
-            ba_project(K, R, wk, t, uk, vk);
-            Jp[k] = (uk - u) / BA_FD;
-            Jp[3 + k] = (vk - v) / BA_FD;
-        }
-        double* Jc = J.Jc + 12 * (size_t)m;
-        if (c > 0) {
-            for (int k = 0; k < 3; k++) {  // camera position
-                double tk[3] = {t[0], t[1], t[2]};
-                tk[k] += BA_FD;
-                ba_project(K, R, w, tk, uk, vk);
-                Jc[k] = (uk - u) / BA_FD;
-                Jc[6 + k] = (vk - v) / BA_FD;
+            const double* R = J.camR + (size_t)c * 36;
+            double t[3] = {0, 0, 0};
+            if (c > 0) for (int k = 0; k < 3; k++) t[k] = J.x[3 * nt + 3 * (c - 1) + k];
+            double u, v, uk, vk;
+            ba_project(K, R, w, t, u, v);
+            const double ru = J.z[m] - u, rv = J.z[(size_t)nt * nf + m] - v;  // z = [all u | all v], camera-major (NLS.py:198-199)
+            o[0] = ru; o[1] = rv;
+            ss = ru * ru + rv * rv;
+            for (int k = 0; k < 3; k++) {  // point coordinates
+                double wk[3] = {w[0], w[1], w[2]};
+                wk[k] += BA_FD;
+                ba_project(K, R, wk, t, uk, vk);
+                o[2 + k] = (uk - u) / BA_FD;
+                o[5 + k] = (vk - v) / BA_FD;
             }
-            for (int k = 0; k < 3; k++) {  // camera roll / pitch / yaw
-                ba_project(K, R + 9 * (k + 1), w, t, uk, vk);
-                Jc[3 + k] = (uk - u) / BA_FD;
-                Jc[9 + k] = (vk - v) / BA_FD;
-            }
-        } else {
-            for (int k = 0; k < 12; k++) Jc[k] = 0.0;
-        }
+            if (c > 0) {
+                for (int k = 0; k < 3; k++) {  // camera position
+                    double tk[3] = {t[0], t[1], t[2]};
+                    tk[k] += BA_FD;
+                    ba_project(K, R, w, tk, uk, vk);
+                    o[8 + k] = (uk - u) / BA_FD;
+                    o[14 + k] = (vk - v) / BA_FD;
+                }
+                for (int k = 0; k < 3; k++) {  // camera roll / pitch / yaw
+                    ba_project(K, R + 9 * (k + 1), w, t, uk, vk);
+                    o[11 + k] = (uk - u) / BA_FD;
+                    o[17 + k] = (vk - v) / BA_FD;
+                }
+            }  // camera 0 is fixed: its 12 entries stay exact zeros
         }
     }
+#pragma unroll
+    for (int k = 0; k < 20; k++) s_out[k][threadIdx.x] = o[k];
     // sum of squared residuals of this iteration (trace only): one atomic per block, spread over 16 addresses -- thousands of
     // same-address atomics would serialise in L2 and dominate the kernel
     __shared__ double s_ss[BA_THREADS / 64];
@@ -196,6 +195,25 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
         double t = 0.0;
         for (int k = 0; k < BA_THREADS / 64; k++) t += s_ss[k];
         if (t != 0.0) atomicAdd(J.rslot + (blockIdx.x & 15), t);
+    }
+    // coalesced write-out of the block's contiguous spans: r [2 x 256], Jp [6 x 256], Jc [12 x 256] doubles
+    const size_t m0 = (size_t)blockIdx.x * BA_THREADS;
+    const int nval = min(BA_THREADS, nt * nf - (int)m0);
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int e = tid + BA_THREADS * q, t = e >> 1, k = e & 1;
+        if (t < nval) J.r[2 * m0 + e] = s_out[k][t];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        const int e = tid + BA_THREADS * q, t = e / 6, k = e - 6 * t;
+        if (t < nval) J.Jp[6 * m0 + e] = s_out[2 + k][t];
+    }
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+        const int e = tid + BA_THREADS * q, t = e / 12, k = e - 12 * t;
+        if (t < nval) J.Jc[12 * m0 + e] = s_out[8 + k][t];
     }
 }
 
@@ -337,137 +355,247 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
     }
 }
 
-// Schur stage 1 on the matrix cores (6 nc <= 128): the reduced camera system accumulates S -= W^T Y, a genuine dense
-// contraction of shape (6nc x 3nt) . (3nt x 6nc).  One workgroup (4 wavefronts) per chunk of points; points are processed
-// in groups of 4 (12 rows of W / Y staged in LDS, zero padded to 128 columns = 8 x 8 tiles of 16 x 16); wavefront w owns
-// tile rows 2w, 2w+1 and issues v_mfma_f64_16x16x4_f64 over the three K = 4 slabs of a group (A[i][k] = W[k][16 ti + i],
-// B[k][j] = Y[k][16 tj + j]).  The per-camera diagonal blocks Jc^T Jc stay on the VALU (thread-owned entries).
+// ---- Schur stage 1 on the matrix cores (6 nc <= 128) ------------------------------------------------------------------------------
+// (a) k_ba_prep, one thread per tie point: U_i + I over all cameras, its inverse, tp_i = (U_i+I)^-1 gp_i and the Cholesky factor L_i of the
+//     inverse ((U_i+I)^-1 = L L^T).  Tiny, but it takes the per-point reduction, the 3x3 inversion and their dependent-latency chain out of
+//     the matrix-core kernel.
+// (b) k_ba_schur_mfma: with Z_i = L_i^T W_i the reduced camera system is S = V + I - sum_i Z_i^T Z_i -- a SYMMETRIC rank-k update (the genuine
+//     dense contraction of BA, (6nc x 3nt) . (3nt x 6nc)): only the 36 upper-triangle tiles of the 8 x 8 grid of 16 x 16 tiles are computed,
+//     A and B operands of v_mfma_f64_16x16x4_f64 are the same LDS rows.  One workgroup (4 wavefronts) per chunk of points, points in groups of
+//     4 (12 rows of Z, double-buffered in LDS: ONE barrier per group); wavefront w owns tile rows w and 7-w (9 tiles, 72 accumulator
+//     registers), so two workgroups fit a CU and one's global-load latency hides behind the other's matrix-core time.
+//     Z is also what the back-substitution needs: dp_i = tp_i - L_i (Z_i dc).
 typedef double double4v __attribute__((ext_vector_type(4)));
 #define BA_NPAD 128
 
-__global__ __launch_bounds__(BA_THREADS) void k_ba_points_mfma(BaJob J)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_prep(BaJob J)
 {
     ba_select_window(J, blockIdx.y);
     if (*J.done) return;
-    const int nt = J.nt, nc = J.nc, nq = 6 * nc, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, nt = J.nt, nc = J.nc;
+    if (i >= nt) return;
+    double u0 = 1.0, u1 = 0.0, u2 = 0.0, u3 = 1.0, u4 = 0.0, u5 = 1.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;  // +I damping (NLS.py:220)
+#pragma unroll 4
+    for (int c = 0; c <= nc; c++) {
+        const size_t m = (size_t)c * nt + i;
+        const double* Jp = J.Jp + 6 * m;
+        const double a0 = Jp[0], a1 = Jp[1], a2 = Jp[2], b0 = Jp[3], b1 = Jp[4], b2 = Jp[5], ru = J.r[2 * m], rv = J.r[2 * m + 1];
+        u0 += a0 * a0 + b0 * b0; u1 += a0 * a1 + b0 * b1; u2 += a0 * a2 + b0 * b2;
+        u3 += a1 * a1 + b1 * b1; u4 += a1 * a2 + b1 * b2; u5 += a2 * a2 + b2 * b2;
+        g0 += a0 * ru + b0 * rv; g1 += a1 * ru + b1 * rv; g2 += a2 * ru + b2 * rv;
+    }
+    const double U[9] = {u0, u1, u2, u1, u3, u4, u2, u4, u5};
+    double Ui[9];
+    inv3_sym(U, Ui);
+    J.tp[3 * (size_t)i] = Ui[0] * g0 + Ui[1] * g1 + Ui[2] * g2;
+    J.tp[3 * (size_t)i + 1] = Ui[3] * g0 + Ui[4] * g1 + Ui[5] * g2;
+    J.tp[3 * (size_t)i + 2] = Ui[6] * g0 + Ui[7] * g1 + Ui[8] * g2;
+    // Cholesky of the SPD inverse: Ui = L L^T
+    const double l00 = sqrt(Ui[0]), l10 = Ui[3] / l00, l20 = Ui[6] / l00;
+    const double l11 = sqrt(Ui[4] - l10 * l10), l21 = (Ui[7] - l20 * l10) / l11;
+    const double l22 = sqrt(Ui[8] - l20 * l20 - l21 * l21);
+    double* Lo = J.Lc + 6 * (size_t)i;
+    Lo[0] = l00; Lo[1] = l10; Lo[2] = l11; Lo[3] = l20; Lo[4] = l21; Lo[5] = l22;
+}
+
+// raw inputs of one wavefront's point of a group, as the lanes hold them (software pipeline: loaded one group ahead)
+struct BaRaw {
+    double jcs[4];       // camera-Jacobian words q = lane + 64 j < 12 nc of the point (staged to LDS for the diagonal blocks)
+    double Jp[2][6];     // point Jacobian of the camera of column q = lane + 64 h
+    double ju[2], jv[2]; // camera Jacobian entries (u row, v row) of column q
+    double ru[2], rv[2]; // residuals of that camera
+    double L[6], tp[3];  // wave-uniform: Cholesky factor of (U+I)^-1 and (U+I)^-1 gp of the point
+};
+
+// per-lane element offsets of those inputs that do not change from group to group (camera / column dependent part); the point index is
+// wave-uniform, so a load address is (uniform base of the point) + (32-bit lane offset): no 64-bit vector address arithmetic in the loop
+struct BaLaneOff {
+    unsigned jc[4];   // 12 (c nt) + k            into Jc (+ 12 i)
+    unsigned jp[2];   // 6 (c+1) nt               into Jp (+ 6 i)
+    unsigned ju[2];   // 12 (c+1) nt + k          into Jc (+ 12 i); jv = + 6
+    unsigned r[2];    // 2 (c+1) nt               into r  (+ 2 i)
+};
+
+__device__ __forceinline__ void ba_lane_offsets(BaLaneOff& O, int nt, int nc, int nq, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int q = min(lane + 64 * j, 12 * nc - 1);  // clamped: out-of-range lanes load a valid word and mask the result
+        const int c = q / 12 + 1, k = q - (c - 1) * 12;
+        O.jc[j] = 12u * (unsigned)(c * nt) + (unsigned)k;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int q = min(lane + 64 * h, nq - 1);
+        const int c = q / 6, k = q - 6 * c;
+        O.jp[h] = 6u * (unsigned)((c + 1) * nt);
+        O.ju[h] = 12u * (unsigned)((c + 1) * nt) + (unsigned)k;
+        O.r[h] = 2u * (unsigned)((c + 1) * nt);
+    }
+}
+
+// Branch-free (out-of-range points are CLAMPED to the chunk's last point, their results are masked where they are used): every load is
+// unconditional and the whole batch is in flight at once -- predicated loads made the compiler wait for memory inside each branch.
+__device__ __forceinline__ void ba_raw_load(BaRaw& R, const BaJob& J, const BaLaneOff& O, int i, int i_last)
+{
+    i = min(i, i_last);
+    const double* __restrict__ pJc = J.Jc + 12 * (size_t)i;
+    const double* __restrict__ pJp = J.Jp + 6 * (size_t)i;
+    const double* __restrict__ pr = J.r + 2 * (size_t)i;
+#pragma unroll
+    for (int j = 0; j < 4; j++) R.jcs[j] = pJc[O.jc[j]];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int a = 0; a < 6; a++) R.Jp[h][a] = pJp[O.jp[h] + a];
+        R.ju[h] = pJc[O.ju[h]];
+        R.jv[h] = pJc[O.ju[h] + 6];
+        R.ru[h] = pr[O.r[h]];
+        R.rv[h] = pr[O.r[h] + 1];
+    }
+    const double* Lp = J.Lc + 6 * (size_t)i;
+    const double* tq = J.tp + 3 * (size_t)i;
+#pragma unroll
+    for (int a = 0; a < 6; a++) R.L[a] = Lp[a];
+#pragma unroll
+    for (int a = 0; a < 3; a++) R.tp[a] = tq[a];
+}
+
+// One group of 4 points for wavefront W in ONE basic block, so the scheduler can fill the matrix-core time: the 3 K-slabs of the 9 upper-triangle tiles of this wavefront (tile row W: columns W..7, tile row 7-W:
+// columns 7-W..7), interleaved with the thread-owned entries of the diagonal blocks V_c (sum over the 4 points of Jc^T Jc, from LDS).
+template <int W>
+__device__ __forceinline__ void ba_group(double4v (&acc)[9], double (&accD)[3], const BaJob& J, const double* __restrict__ sZ,
+                                         const double* __restrict__ sJ, int tid)
+{
+    constexpr int R1 = W, R2 = 7 - W, T0 = R1 < R2 ? R1 : R2;
+    const int lane = tid & 63, cc = lane & 15, nc = J.nc;
+#pragma unroll
+    for (int k0 = 0; k0 < 12; k0 += 4) {
+        const int kr = k0 + (lane >> 4);
+        double zf[8];
+#pragma unroll
+        for (int t = T0; t < 8; t++) zf[t] = sZ[kr * BA_NPAD + 16 * t + cc];
+#pragma unroll
+        for (int t = R1; t < 8; t++) acc[t - R1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R1], zf[t], acc[t - R1], 0, 0, 0);
+#pragma unroll
+        for (int t = R2; t < 8; t++) acc[8 - R1 + t - R2] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R2], zf[t], acc[8 - R1 + t - R2], 0, 0, 0);
+        // diagonal-block entry e = tid + 256 (k0 / 4), clamped (the store at the end is guarded)
+        const int e = min(tid + BA_THREADS * (k0 >> 2), nc * 36 - 1);
+        const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
+        double v = 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const double* jc = sJ + g * 12 * nc + 12 * c;
+            v += jc[ka] * jc[kb] + jc[6 + ka] * jc[6 + kb];
+        }
+        accD[k0 >> 2] += v;
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void ba_syrk_store(const double4v (&acc)[9], double* __restrict__ Sp, int lane, int nq)
+{
+    constexpr int R1 = W, R2 = 7 - W;
+    // f64 C/D layout of the 16x16x4 instruction: lane holds rows (lane >> 4) + 4 rg, column lane & 15
+#pragma unroll
+    for (int t = R1; t < 8; t++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = 16 * R1 + (lane >> 4) + 4 * rg, col = 16 * t + (lane & 15);
+            if (row < nq && col < nq) Sp[(size_t)row * nq + col] = -acc[t - R1][rg];
+        }
+#pragma unroll
+    for (int t = R2; t < 8; t++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = 16 * R2 + (lane >> 4) + 4 * rg, col = 16 * t + (lane & 15);
+            if (row < nq && col < nq) Sp[(size_t)row * nq + col] = -acc[8 - R1 + t - R2][rg];
+        }
+}
+
+// workgroup barrier that orders LDS traffic only: outstanding GLOBAL loads (the prefetch of the next group) stay in flight across it
+__device__ __forceinline__ void ba_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(BA_THREADS) void k_ba_schur_mfma(BaJob J)
+{
+    ba_select_window(J, blockIdx.y);
+    if (*J.done) return;
+    const int nt = J.nt, nc = J.nc, nq = 6 * nc, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sW = reinterpret_cast<double*>(smem);   // [12][128]
-    double* sY = sW + 12 * BA_NPAD;                 // [12][128]
-    double* sJc = sY + 12 * BA_NPAD;                // [4][nc][12]
-    double* sTp = sJc + 4 * 12 * nc;                // [4][12]: tp (3) + Ui (9)
-    double* sR = sTp + 48;                          // [4][128] rhs partials of the four waves
+    double* sZ = reinterpret_cast<double*>(smem);   // [2][12][128]
+    double* sJc = sZ + 2 * 12 * BA_NPAD;            // [2][4][nc][12]
+    double* sR = sJc + 2 * 4 * 12 * nc;             // [4][128] rhs partials of the four waves
     const int chunk = (nt + gridDim.x - 1) / gridDim.x;
     const int i0 = blockIdx.x * chunk, i1 = min(nt, i0 + chunk);
     const long long nent = (long long)nq * nq;
 
-    double4v acc[2][8];
+    double4v acc[9];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int t = 0; t < 8; t++) acc[a][t] = double4v{0.0, 0.0, 0.0, 0.0};
-    // diagonal-block entries owned by this thread: e = tid + 256 k < nc * 36
-    double accD[3] = {0.0, 0.0, 0.0};
-    double accR[2] = {0.0, 0.0};  // rhs entries q = lane, lane + 64 of the points this WAVE handled
-    for (int q = tid; q < 24 * BA_NPAD; q += BA_THREADS) sW[q] = 0.0;  // zero padding (covers sW and sY)
+    for (int t = 0; t < 9; t++) acc[t] = double4v{0.0, 0.0, 0.0, 0.0};
+    double accD[3] = {0.0, 0.0, 0.0};  // diagonal-block entries owned by this thread: e = tid + 256 k < nc * 36
+    double accR[2] = {0.0, 0.0};       // rhs entries q = lane, lane + 64 of the points this WAVE handled
+    for (int q = tid; q < 2 * 12 * BA_NPAD; q += BA_THREADS) sZ[q] = 0.0;  // zero padding of both buffers (columns >= nq stay zero)
+    BaRaw cur;
+    if (i0 >= i1) return;  // (never: every workgroup owns at least one point)
+    BaLaneOff off;
+    ba_lane_offsets(off, nt, nc, nq, lane);
+    ba_raw_load(cur, J, off, i0 + wave, i1 - 1);
+    __syncthreads();
 
-    for (int ig = i0; ig < i1; ig += 4) {
-        __syncthreads();
+    int buf = 0;
+    for (int ig = i0; ig < i1; ig += 4, buf ^= 1) {
         const int i = ig + wave;  // this wave's point of the group
         const bool live = i < i1;
-        // U_i, gp_i: lanes over cameras, wave reduction, lane 0 inverts
-        double u6[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (live)
-            for (int c = lane; c <= nc; c += 64) {
-                const size_t m = (size_t)c * nt + i;
-                const double* Jp = J.Jp + 6 * m;
-                const double ru = J.r[2 * m], rv = J.r[2 * m + 1];
-                const double a0 = Jp[0], a1 = Jp[1], a2 = Jp[2], b0 = Jp[3], b1 = Jp[4], b2 = Jp[5];
-                u6[0] += a0 * a0 + b0 * b0; u6[1] += a0 * a1 + b0 * b1; u6[2] += a0 * a2 + b0 * b2;
-                u6[3] += a1 * a1 + b1 * b1; u6[4] += a1 * a2 + b1 * b2; u6[5] += a2 * a2 + b2 * b2;
-                u6[6] += a0 * ru + b0 * rv; u6[7] += a1 * ru + b1 * rv; u6[8] += a2 * ru + b2 * rv;
-            }
+        double* Zb = sZ + buf * 12 * BA_NPAD;
+        double* Jb = sJc + buf * 4 * 12 * nc;
+        // camera Jacobians of the point -> LDS (the diagonal blocks need them from all four points)
 #pragma unroll
-        for (int k = 0; k < 9; k++) u6[k] = vh_wave_sum_f64(u6[k]);
-        if (lane == 0) {
-            const double U[9] = {u6[0] + 1.0, u6[1], u6[2], u6[1], u6[3] + 1.0, u6[4], u6[2], u6[4], u6[5] + 1.0};  // +I damping
-            double Ui[9];
-            inv3_sym(U, Ui);
-            double* T = sTp + 12 * wave;
-            for (int a = 0; a < 3; a++) T[a] = live ? Ui[a * 3] * u6[6] + Ui[a * 3 + 1] * u6[7] + Ui[a * 3 + 2] * u6[8] : 0.0;
-            for (int k = 0; k < 9; k++) T[3 + k] = Ui[k];
-            if (live) for (int a = 0; a < 3; a++) J.tp[3 * (size_t)i + a] = T[a];
+        for (int j = 0; j < 4; j++) {
+            const int q = lane + 64 * j;
+            if (q < 12 * nc) Jb[wave * 12 * nc + q] = live ? cur.jcs[j] : 0.0;
         }
-        for (int q = lane; q < 12 * nc; q += 64) {
-            const int c = q / 12 + 1, k = q - (c - 1) * 12;
-            sJc[wave * 12 * nc + q] = live ? J.Jc[12 * ((size_t)c * nt + i) + k] : 0.0;
-        }
-        __syncthreads();
-        // rows 3 wave .. 3 wave + 2 of the group's W and Y
-        {
-            const double* T = sTp + 12 * wave;
-            const double* Ui = T + 3;
+        // rows 3 wave .. 3 wave + 2 of the group's Z = L^T W
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int q = lane + 64 * h;
-                if (q < nq) {
-                    double w0 = 0, w1 = 0, w2 = 0, y0 = 0, y1 = 0, y2 = 0;
-                    if (live) {
-                        const int c = q / 6, k = q - 6 * c;
-                        const double* Jp = J.Jp + 6 * ((size_t)(c + 1) * nt + i);
-                        const double ju = sJc[wave * 12 * nc + 12 * c + k], jv = sJc[wave * 12 * nc + 12 * c + 6 + k];
-                        w0 = Jp[0] * ju + Jp[3] * jv; w1 = Jp[1] * ju + Jp[4] * jv; w2 = Jp[2] * ju + Jp[5] * jv;
-                        y0 = Ui[0] * w0 + Ui[1] * w1 + Ui[2] * w2; y1 = Ui[3] * w0 + Ui[4] * w1 + Ui[5] * w2; y2 = Ui[6] * w0 + Ui[7] * w1 + Ui[8] * w2;
-                        double* Yg = J.Y + ((size_t)i * nq + q) * 3;
-                        Yg[0] = y0; Yg[1] = y1; Yg[2] = y2;
-                        const size_t m = (size_t)(c + 1) * nt + i;
-                        accR[h] += ju * J.r[2 * m] + jv * J.r[2 * m + 1] - (w0 * T[0] + w1 * T[1] + w2 * T[2]);
-                    }
-                    sW[(3 * wave) * BA_NPAD + q] = w0; sW[(3 * wave + 1) * BA_NPAD + q] = w1; sW[(3 * wave + 2) * BA_NPAD + q] = w2;
-                    sY[(3 * wave) * BA_NPAD + q] = y0; sY[(3 * wave + 1) * BA_NPAD + q] = y1; sY[(3 * wave + 2) * BA_NPAD + q] = y2;
-                }
+        for (int h = 0; h < 2; h++) {
+            const int q = lane + 64 * h;
+            if (q < nq) {
+                const double ju = cur.ju[h], jv = cur.jv[h];
+                const double w0 = cur.Jp[h][0] * ju + cur.Jp[h][3] * jv, w1 = cur.Jp[h][1] * ju + cur.Jp[h][4] * jv, w2 = cur.Jp[h][2] * ju + cur.Jp[h][5] * jv;
+                // L^T is upper triangular: rows (l00 l10 l20), (0 l11 l21), (0 0 l22); L is stored l00 l10 l11 l20 l21 l22
+                double z0 = cur.L[0] * w0 + cur.L[1] * w1 + cur.L[3] * w2, z1 = cur.L[2] * w1 + cur.L[4] * w2, z2 = cur.L[5] * w2;
+                if (!live) { z0 = 0.0; z1 = 0.0; z2 = 0.0; }  // a clamped duplicate of the chunk's last point: contributes nothing
+                // (no global store in this loop: a store in flight next to the prefetch loads forces every wait to vmcnt(0) -- loads and
+                // stores retire out of order on one counter -- and put the L2 write latency on the critical path of every group; the
+                // back-substitution recomputes W_i dc from the Jacobians instead of reading a stored Z)
+                if (live) accR[h] += ju * cur.ru[h] + jv * cur.rv[h] - (w0 * cur.tp[0] + w1 * cur.tp[1] + w2 * cur.tp[2]);
+                Zb[(3 * wave) * BA_NPAD + q] = z0; Zb[(3 * wave + 1) * BA_NPAD + q] = z1; Zb[(3 * wave + 2) * BA_NPAD + q] = z2;
             }
         }
-        __syncthreads();
-        // diagonal blocks: sum over the 4 points of Jc^T Jc (both measurement rows)
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int e = tid + BA_THREADS * k;
-            if (e < nc * 36) {
-                const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
-                double v = 0.0;
-                for (int g = 0; g < 4; g++) {
-                    const double* jc = sJc + g * 12 * nc + 12 * c;
-                    v += jc[ka] * jc[kb] + jc[6 + ka] * jc[6 + kb];
-                }
-                accD[k] += v;
-            }
-        }
-        // matrix cores: acc[ti][tj] += W^T Y over the 12 rows of the group
-#pragma unroll
-        for (int k0 = 0; k0 < 12; k0 += 4) {
-            const int kr = k0 + (lane >> 4), cc = lane & 15;
-            double bf[8];
-#pragma unroll
-            for (int t = 0; t < 8; t++) bf[t] = sY[kr * BA_NPAD + 16 * t + cc];
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const double af = sW[kr * BA_NPAD + 16 * (2 * wave + a) + cc];
-#pragma unroll
-                for (int t = 0; t < 8; t++) acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf[t], acc[a][t], 0, 0, 0);
-            }
+        // the only barrier of a group: Z[buf] and Jc[buf] are complete; buffers buf ^ 1 are free (every wave has finished the previous
+        // group's reads before it arrived here)
+        ba_lds_barrier();
+        // next group's inputs, the matrix-core work and the diagonal blocks of this group (one basic block per wavefront specialisation)
+        // the next group's inputs are requested NOW (pinned here by the compiler barrier: the scheduler would otherwise sink the loads
+        // behind the matrix-core section, next to their first use) and arrive while this group runs on the matrix cores
+        ba_raw_load(cur, J, off, i + 4, i1 - 1);
+        asm volatile("" ::: "memory");
+        switch (wave) {
+        case 0: ba_group<0>(acc, accD, J, Zb, Jb, tid); break;
+        case 1: ba_group<1>(acc, accD, J, Zb, Jb, tid); break;
+        case 2: ba_group<2>(acc, accD, J, Zb, Jb, tid); break;
+        default: ba_group<3>(acc, accD, J, Zb, Jb, tid); break;
         }
     }
-    // write the partials: S_part = -W^T Y (+ diagonal blocks, added after the barrier), rhs partial
+    __syncthreads();
+    // write the partials: the upper-triangle tiles of -Z^T Z (+ diagonal blocks, added after the barrier), rhs partial
     double* Sp = J.Spart + (size_t)blockIdx.x * nent;
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int t = 0; t < 8; t++)
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-                const int row = 16 * (2 * wave + a) + (lane >> 4) + 4 * rg, col = 16 * t + (lane & 15);  // f64 C/D map
-                if (row < nq && col < nq) Sp[(size_t)row * nq + col] = -acc[a][t][rg];
-            }
+    switch (wave) {
+    case 0: ba_syrk_store<0>(acc, Sp, lane, nq); break;
+    case 1: ba_syrk_store<1>(acc, Sp, lane, nq); break;
+    case 2: ba_syrk_store<2>(acc, Sp, lane, nq); break;
+    default: ba_syrk_store<3>(acc, Sp, lane, nq); break;
+    }
     sR[wave * BA_NPAD + lane] = accR[0];
     sR[wave * BA_NPAD + lane + 64] = accR[1];
     __threadfence_block();
@@ -477,7 +605,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points_mfma(BaJob J)
         const int e = tid + BA_THREADS * k;
         if (e < nc * 36) {
             const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
-            Sp[(size_t)(6 * c + ka) * nq + 6 * c + kb] += accD[k];
+            // a 6x6 camera block can straddle two 16x16 tiles: entries with tile(row) > tile(col) are never read (k_ba_reduce mirrors the
+            // upper triangle), so only the others are stored
+            const int row = 6 * c + ka, col = 6 * c + kb;
+            if ((row >> 4) <= (col >> 4)) Sp[(size_t)row * nq + col] += accD[k];
         }
     }
     if (tid < nq) J.Rpart[(size_t)blockIdx.x * nq + tid] = sR[tid] + sR[BA_NPAD + tid] + sR[2 * BA_NPAD + tid] + sR[3 * BA_NPAD + tid];
@@ -496,7 +627,14 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts)
     const long long e = (long long)blockIdx.x * 64 + lane;
     __shared__ double sh[BA_THREADS / 64][64];
     double s = 0.0;
-    if (e < ntot) {
+    // zmode: only the tiles with tile(row) <= tile(col) were written; the owners of those entries also write the mirrored one, the
+    // entries below do nothing (reading the partials transposed instead cost 3.5x the kernel)
+    bool lower = false;
+    if (J.zmode && e < nent) {
+        const int a = (int)(e / nq), b = (int)(e - (long long)a * nq);
+        lower = (a >> 4) > (b >> 4);
+    }
+    if (e < ntot && !lower) {
         constexpr int NS = BA_THREADS / 64;
         const int per = (nparts + NS - 1) / NS, p0 = slice * per, p1 = min(nparts, p0 + per);
         const double* src = e < nent ? J.Spart + e : J.Rpart + (e - nent);
@@ -518,12 +656,13 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts)
         J.acc[0] += t;
     }
     __syncthreads();
-    if (slice == 0 && e < ntot) {
+    if (slice == 0 && e < ntot && !lower) {
         double t = 0.0;
         for (int k = 0; k < BA_THREADS / 64; k++) t += sh[k][lane];
         if (e < nent) {
             const int a = (int)(e / nq), b = (int)(e - (long long)a * nq);
             J.Sfull[(size_t)a * ld + b] = t + ((a == b && J.add_identity) ? 1.0 : 0.0);  // sharded runs: rank 0 adds the +I
+            if (J.zmode && (a >> 4) < (b >> 4)) J.Sfull[(size_t)b * ld + a] = t;
         } else {
             J.Sfull[(size_t)(e - nent) * ld + nq] = t;
         }
@@ -662,23 +801,59 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
     __shared__ double sh[BA_THREADS / 64];
     __shared__ double s_par[256];  // new camera-side parameters (block 0)
     double ss = 0.0;
-    // one wavefront per point: the lanes split the 6nc columns of the point's 3 x 6nc block of Y (consecutive lanes read
-    // consecutive 24-byte column triples -> coalesced; a thread-per-point walk of the 2.7 KB rows ran at 0.3 TB/s)
     const int lane = tid & 63, wave = tid >> 6;
-    for (int i = blockIdx.x * (BA_THREADS / 64) + wave; i < nt; i += gridDim.x * (BA_THREADS / 64)) {
-        const double* Y = J.Y + (size_t)i * nq * 3;
-        double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-        for (int q = lane; q < nq; q += 64) {
-            const double dq = J.dc[q];
-            d0 += Y[3 * q] * dq; d1 += Y[3 * q + 1] * dq; d2 += Y[3 * q + 2] * dq;
+    if (J.zmode) {
+        // matrix-core path: dp_i = tp_i - (U_i+I)^-1 W_i dc with W_i dc = sum_c Jp_c^T (Jc_c dc_c) recomputed from the compact Jacobians (the same
+        // bytes a stored Y / Z would cost to read, and nothing to write in the Schur kernel); 4 lanes share a point (cameras c = 1 + sub, 5 + sub, ...)
+        for (int q = tid; q < nq; q += BA_THREADS) s_par[q] = J.dc[q];
+        __syncthreads();
+        const int total = 4 * ((nt + 15) / 16) * 16;  // whole waves run the loop together (the shuffles below need their 4 partners)
+        for (int p4 = blockIdx.x * BA_THREADS + tid; p4 < total; p4 += gridDim.x * BA_THREADS) {
+            const int i = min(p4 >> 2, nt - 1), sub = p4 & 3;
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+            for (int c = 1 + sub; c <= nc; c += 4) {
+                const size_t m = (size_t)c * nt + i;
+                const double* Jc = J.Jc + 12 * m;
+                const double* Jp = J.Jp + 6 * m;
+                const double* dq = s_par + 6 * (c - 1);
+                double su = 0.0, sv = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { su += Jc[k] * dq[k]; sv += Jc[6 + k] * dq[k]; }
+                e0 += Jp[0] * su + Jp[3] * sv; e1 += Jp[1] * su + Jp[4] * sv; e2 += Jp[2] * su + Jp[5] * sv;
+            }
+            e0 += __shfl_xor(e0, 1, 64); e1 += __shfl_xor(e1, 1, 64); e2 += __shfl_xor(e2, 1, 64);
+            e0 += __shfl_xor(e0, 2, 64); e1 += __shfl_xor(e1, 2, 64); e2 += __shfl_xor(e2, 2, 64);
+            if (sub == 0 && (p4 >> 2) < nt) {
+                const double* Lp = J.Lc + 6 * (size_t)i;  // (U+I)^-1 = L L^T, L = l00 l10 l11 l20 l21 l22
+                const double z0 = Lp[0] * e0 + Lp[1] * e1 + Lp[3] * e2, z1 = Lp[2] * e1 + Lp[4] * e2, z2 = Lp[5] * e2;  // L^T e
+                const double d0 = Lp[0] * z0, d1 = Lp[1] * z0 + Lp[2] * z1, d2 = Lp[3] * z0 + Lp[4] * z1 + Lp[5] * z2;  // L (L^T e)
+                const double d[3] = {J.tp[3 * (size_t)i] - d0, J.tp[3 * (size_t)i + 1] - d1, J.tp[3 * (size_t)i + 2] - d2};
+                for (int k = 0; k < 3; k++) {
+                    const double dl = d[k] * 0.9;
+                    J.x[3 * (size_t)i + k] += dl;
+                    ss += dl * dl;
+                }
+            }
         }
-        d0 = vh_wave_sum_f64(d0); d1 = vh_wave_sum_f64(d1); d2 = vh_wave_sum_f64(d2);
-        if (lane == 0) {
-            const double d[3] = {J.tp[3 * (size_t)i] - d0, J.tp[3 * (size_t)i + 1] - d1, J.tp[3 * (size_t)i + 2] - d2};
-            for (int k = 0; k < 3; k++) {
-                const double dl = d[k] * 0.9;
-                J.x[3 * (size_t)i + k] += dl;
-                ss += dl * dl;
+        __syncthreads();  // s_par is reused for the camera parameters below
+    } else {
+        // VALU path: one wavefront per point: the lanes split the 6nc columns of the point's 3 x 6nc block of Y (consecutive lanes read
+        // consecutive 24-byte column triples -> coalesced; a thread-per-point walk of the 2.7 KB rows ran at 0.3 TB/s)
+        for (int i = blockIdx.x * (BA_THREADS / 64) + wave; i < nt; i += gridDim.x * (BA_THREADS / 64)) {
+            const double* Y = J.Y + (size_t)i * nq * 3;
+            double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+            for (int q = lane; q < nq; q += 64) {
+                const double dq = J.dc[q];
+                d0 += Y[3 * q] * dq; d1 += Y[3 * q + 1] * dq; d2 += Y[3 * q + 2] * dq;
+            }
+            d0 = vh_wave_sum_f64(d0); d1 = vh_wave_sum_f64(d1); d2 = vh_wave_sum_f64(d2);
+            if (lane == 0) {
+                const double d[3] = {J.tp[3 * (size_t)i] - d0, J.tp[3 * (size_t)i + 1] - d1, J.tp[3 * (size_t)i + 2] - d2};
+                for (int k = 0; k < 3; k++) {
+                    const double dl = d[k] * 0.9;
+                    J.x[3 * (size_t)i + k] += dl;
+                    ss += dl * dl;
+                }
             }
         }
     }
@@ -755,7 +930,7 @@ size_t vh_ba_workspace_bytes(int nt, int nc, int nparts)
     const size_t nf = nc + 1, nq = 6 * (size_t)nc, m = (size_t)nt * nf;
     size_t b = 0;
     auto add = [&](size_t n) { b += (n * sizeof(double) + 255) / 256 * 256; };
-    add(36 * nf); add(2 * m); add(6 * m); add(12 * m); add(3 * (size_t)nt); add(3 * nq * nt); add(nparts * nq * nq); add(nparts * nq);
+    add(36 * nf); add(2 * m); add(6 * m); add(12 * m); add(3 * (size_t)nt); add(6 * (size_t)nt); add(3 * nq * nt); add(nparts * nq * nq); add(nparts * nq);
     add(nq * (nq + 1) + 4); add(nq); add(32);
     return b + 1024;
 }
@@ -774,7 +949,7 @@ static void ba_layout(const BaProblem& P, BaJob& J, double*& flags)
     char* w = reinterpret_cast<char*>(P.workspace);
     auto take = [&](size_t n) { double* p = reinterpret_cast<double*>(w); w += (n * sizeof(double) + 255) / 256 * 256; return p; };
     const size_t nf = nc + 1, m = (size_t)nt * nf;
-    J.camR = take(36 * nf); J.r = take(2 * m); J.Jp = take(6 * m); J.Jc = take(12 * m); J.tp = take(3 * (size_t)nt); J.Y = take(3 * (size_t)nq * nt);
+    J.camR = take(36 * nf); J.r = take(2 * m); J.Jp = take(6 * m); J.Jc = take(12 * m); J.tp = take(3 * (size_t)nt); J.Lc = take(6 * (size_t)nt); J.Y = take(3 * (size_t)nq * nt);
     J.Spart = take((size_t)nparts * nq * nq); J.Rpart = take((size_t)nparts * nq);
     J.Sfull = take((size_t)nq * (nq + 1) + 4);     // augmented system followed by the 4 accumulators: ONE all-reduce span
     J.acc = J.Sfull + (size_t)nq * (nq + 1);
@@ -808,10 +983,13 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     const long long nent = (long long)nq * nq;
     const int npass = (int)((nent + (long long)BA_THREADS * BA_EPT - 1) / ((long long)BA_THREADS * BA_EPT));
     const size_t lds = sizeof(double) * (size_t)(6 * nq + 12 * (nc + 1) + 16);
-    const size_t lds_mfma = sizeof(double) * (size_t)(24 * BA_NPAD + 48 * nc + 48 + 4 * BA_NPAD);
+    const size_t lds_mfma = sizeof(double) * (size_t)(24 * BA_NPAD + 2 * 48 * nc + 4 * BA_NPAD);
+    const bool use_mfma = nq <= BA_NPAD && !P.force_valu && P.model == 0;  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
+    J.zmode = use_mfma ? 1 : 0;
     const int nmeas = nt * (nc + 1);
     // one wavefront per point, grid-strided: every block ends with an atomic on one address, so keep the block count low
-    const int upd_blocks = std::min((nt + BA_THREADS / 64 - 1) / (BA_THREADS / 64), 256);
+    const int upd_cap = J.nwin > 1 ? std::max(16, 1024 / J.nwin) : 256;
+    const int upd_blocks = std::min(use_mfma ? (4 * nt + BA_THREADS - 1) / BA_THREADS : (nt + BA_THREADS / 64 - 1) / (BA_THREADS / 64), upd_cap);
     const unsigned nw = (unsigned)J.nwin;
     auto init = [&]() -> int {
         hipLaunchKernelGGL(k_ba_init, dim3(1, nw), dim3(64), 0, s, J, flags);
@@ -820,8 +998,9 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     auto normal_equations = [&](int it) {
         if (it == 0) hipLaunchKernelGGL(k_ba_cams, dim3((nc + 1 + 63) / 64, nw), dim3(64), 0, s, J);
         hipLaunchKernelGGL(k_ba_jac, dim3((nmeas + BA_THREADS - 1) / BA_THREADS, nw), dim3(BA_THREADS), 0, s, J);
-        if (nq <= BA_NPAD && !P.force_valu && P.model == 0) {  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
-            hipLaunchKernelGGL(k_ba_points_mfma, dim3(nparts, nw), dim3(BA_THREADS), lds_mfma, s, J);
+        if (use_mfma) {
+            hipLaunchKernelGGL(k_ba_prep, dim3((nt + BA_THREADS - 1) / BA_THREADS, nw), dim3(BA_THREADS), 0, s, J);
+            hipLaunchKernelGGL(k_ba_schur_mfma, dim3(nparts, nw), dim3(BA_THREADS), lds_mfma, s, J);
         } else {
             for (int pass = 0; pass < npass; pass++)  // later passes overwrite Spart entries of their own range only
                 hipLaunchKernelGGL(k_ba_points, dim3(nparts, nw), dim3(BA_THREADS), lds, s, J, pass);

@@ -13,7 +13,8 @@ struct BaJob {  // passed by value to every BA kernel
     double* Jp;       // [m][2][3] d(u,v)/d(point)
     double* Jc;       // [m][2][6] d(u,v)/d(camera pos, rpy)
     double* tp;       // [nt][3]  (U+I)^-1 gp
-    double* Y;        // [nt][6 nc][3]  (U+I)^-1 W
+    double* Lc;       // [nt][6]  lower-triangular Cholesky factor of (U+I)^-1 = L L^T (l00 l10 l11 l20 l21 l22): matrix-core path only
+    double* Y;        // [nt][6 nc][3]  (U+I)^-1 W   (matrix-core path: Z = L^T W instead, zmode = 1)
     double* Spart;    // [nparts][(6 nc)^2]
     double* Rpart;    // [nparts][6 nc]
     double* Sfull;    // [6 nc][6 nc + 1]
@@ -29,6 +30,7 @@ struct BaJob {  // passed by value to every BA kernel
     int nq;     // reduced unknowns: 6 nc (model 0) or nc + 5 (model 1)
     int model;  // 0: fcnNLS_batch (free cameras, NLS.py:186-250); 1: fcnNLS_batch2 (joint rotation + straight-line trajectory, NLS.py:253-328)
     int add_identity, count_cams, defer_finalize;
+    int zmode;  // 1: Y holds Z = L^T W and Spart holds only the upper-triangle 16x16 tiles (k_ba_schur_mfma); 0: Y = (U+I)^-1 W, full Spart
     // batched independent windows (vh_nls_batch_multi): blockIdx.y selects the window; every pointer above is window 0's
     int nwin;
     size_t ws_stride;                // bytes between the workspaces of consecutive windows
