@@ -458,9 +458,10 @@ __device__ __forceinline__ void setup_hg_row(const int* V, int* H, int* G)
         G[c] = __mul24(V[c] + V[c + 2], 3) + __mul24(V[c + 1], 10);  // every V fits 22 bits
     }
 }
+// vmask: 0xffffffff for a strip inside the window, 0 for a strip of the last run that hangs below it (stored as zeros)
 template <bool FULL01>  // FULL01: every strip holds at least 2 samples (window width % 4 != 1): the first pair needs no mask
 __device__ __forceinline__ void setup_from_hg(const int* H0, const int* H1, const int* H2, const int* G0, const int* G2, const int* Vmid, int cnt,
-                                              uint2* tI, uint2* tX, uint2* tY, int slot, int& a11, int& a12, int& a22)
+                                              uint2* tI, uint2* tX, uint2* tY, int slot, int& a11, int& a12, int& a22, unsigned vmask = 0xffffffffu)
 {
     int iv[4], ix[4], iy[4];
 #pragma unroll
@@ -469,10 +470,10 @@ __device__ __forceinline__ void setup_from_hg(const int* H0, const int* H1, cons
         ix[c] = vh_descale(__mul24(H0[c] + H2[c], 3) + __mul24(H1[c], 10), W_BITS);
         iy[c] = vh_descale(G2[c] - G0[c], W_BITS);
     }
-    const unsigned m01 = (FULL01 || cnt >= 2) ? 0xffffffffu : 0x0000ffffu, m23 = cnt >= 4 ? 0xffffffffu : (cnt == 3 ? 0x0000ffffu : 0u);
-    const uint2 vI = make_uint2(FULL01 ? pack16(iv[0], iv[1]) : (pack16(iv[0], iv[1]) & m01), pack16(iv[2], iv[3]) & m23);
-    const uint2 vX = make_uint2(FULL01 ? pack16(ix[0], ix[1]) : (pack16(ix[0], ix[1]) & m01), pack16(ix[2], ix[3]) & m23);
-    const uint2 vY = make_uint2(FULL01 ? pack16(iy[0], iy[1]) : (pack16(iy[0], iy[1]) & m01), pack16(iy[2], iy[3]) & m23);
+    const unsigned m01 = ((FULL01 || cnt >= 2) ? 0xffffffffu : 0x0000ffffu) & vmask, m23 = (cnt >= 4 ? 0xffffffffu : (cnt == 3 ? 0x0000ffffu : 0u)) & vmask;
+    const uint2 vI = make_uint2(pack16(iv[0], iv[1]) & m01, pack16(iv[2], iv[3]) & m23);
+    const uint2 vX = make_uint2(pack16(ix[0], ix[1]) & m01, pack16(ix[2], ix[3]) & m23);
+    const uint2 vY = make_uint2(pack16(iy[0], iy[1]) & m01, pack16(iy[2], iy[3]) & m23);
     tI[slot] = vI; tX[slot] = vX; tY[slot] = vY;
     a11 = dot2(vX.y, vX.y, dot2(vX.x, vX.x, a11));
     a12 = dot2(vX.y, vY.y, dot2(vX.x, vY.x, a12));
@@ -833,17 +834,19 @@ struct LK3 {
     static constexpr int RJ = WIN + 1 + 2 * M;                                // search region rows / cols
     static constexpr int PJ_PITCH = ((((2 * M + 4 * (SPR - 1)) >> 2) * 4 + 12 + 3) / 4) * 4;
     static constexpr int OFF_TI = 0;
-    // template slots: exactly one per strip.  Full runs (K rows) first, k-major over their lanes; the last run (LAST_ROWS
-    // rows) behind them.  slot(k, tid) = slot_base + k * slot_stride, both per lane.
-    static constexpr int FULL_RUNS = WIN / K;                    // runs that own K rows
-    static constexpr int LAST_ROWS = WIN - FULL_RUNS * K;        // rows of the partial run (0: none)
-    static constexpr int FULL_LANES = FULL_RUNS * SPR;
-    static constexpr int SLOTS = NS;
+    // template slots: one per (k, active lane), slot(k, tid) = k * LANES + tid.  Every lane runs all K strips of its run
+    // with NO per-strip branch: strips below the window (the tail of the last run(s)) are computed from whatever the
+    // padded buffers hold and stored as ZEROS, so they add nothing to any window sum in the set-up or in the Newton
+    // iterations.  (Branching on `y < WIN` per strip split the unrolled K loop into exec-masked blocks joined by register
+    // moves: 17 % of the set-up's VALU instructions were v_mov.)
+    static constexpr int LANES = RUNS * SPR;                     // active lanes
+    static constexpr int SLOTS = K * LANES;
+    static constexpr int PAD_ROWS = RUNS * K - WIN;              // window rows the last run(s) hang over the bottom edge
     static constexpr int OFF_TX = OFF_TI + SLOTS * 8;
     static constexpr int OFF_TY = OFF_TX + SLOTS * 8;
     static constexpr int OFF_PI = OFF_TY + SLOTS * 8;
-    static constexpr int OFF_PJ = OFF_PI + PI_ROWS * PI_PITCH;
-    static constexpr int OFF_RED = ((OFF_PJ + RJ * PJ_PITCH + 15) / 16) * 16;
+    static constexpr int OFF_PJ = OFF_PI + (PI_ROWS + PAD_ROWS) * PI_PITCH + 8;
+    static constexpr int OFF_RED = ((OFF_PJ + (RJ + PAD_ROWS) * PJ_PITCH + 16 + 15) / 16) * 16;
     static constexpr int LDS_BYTES = OFF_RED + 2 * NW * 4 * 8;
 };
 
@@ -955,8 +958,8 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
     const int run = tid / C::SPR, j = tid - run * C::SPR, y0 = run * C::K;
     const bool lane_on = run < C::RUNS;
     const int cnt = min(4, WIN - 4 * j);
-    const int slot_base = tid < C::FULL_LANES ? tid : C::FULL_LANES * C::K + (tid - C::FULL_LANES);
-    const int slot_stride = tid < C::FULL_LANES ? C::FULL_LANES : C::SPR;
+    const int slot_base = tid;
+    constexpr int slot_stride = C::LANES;
     int part[3] = {0, 0, 0};
     if (lane_on && inside_I) {
         // interior: rolling V rows (see strip_setup_linear): patch rows y .. y+3 feed strip y; one new row per strip
@@ -981,14 +984,15 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
 #pragma unroll
         for (int k = 0; k < C::K; k++) {
             const int y = y0 + k;
-            if (y < WIN) {
+            {   // no branch on y < WIN: see LK3::SLOTS (rows past the patch read the padding / the next buffer: harmless garbage)
                 const unsigned* rn = col + (y + 3) * (C::PI_PITCH >> 2);
                 unsigned prN[6];
                 int V2[6], H2[4], G2[4];
                 setup_row_pairs(rn[0], rn[1], prN);
                 setup_v_row(prB, prN, wt, wb, V2);
                 setup_hg_row(V2, H2, G2);
-                setup_from_hg<(WIN % 4) != 1>(H0, H1, H2, G0, G2, Vm, cnt, tI, tX, tY, slot_base + k * slot_stride, part[0], part[1], part[2]);
+                setup_from_hg<(WIN % 4) != 1>(H0, H1, H2, G0, G2, Vm, cnt, tI, tX, tY, slot_base + k * slot_stride, part[0], part[1], part[2],
+                                              (C::PAD_ROWS > 0 && y >= WIN) ? 0u : 0xffffffffu);
 #pragma unroll
                 for (int c = 0; c < 4; c++) { H0[c] = H1[c]; H1[c] = H2[c]; G0[c] = G1[c]; G1[c] = G2[c]; Vm[c] = V2[c + 1]; }
 #pragma unroll
@@ -999,7 +1003,10 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
 #pragma unroll
         for (int k = 0; k < C::K; k++) {
             const int y = y0 + k;
-            if (y < WIN) {
+            if (y >= WIN) {  // strips below the window are zeros (the iterations read every slot)
+                const uint2 z = make_uint2(0u, 0u);
+                tI[slot_base + k * slot_stride] = z; tX[slot_base + k * slot_stride] = z; tY[slot_base + k * slot_stride] = z;
+            } else {
                 unsigned lo[4], hi[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1056,7 +1063,7 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
 #pragma unroll
             for (int k = 0; k < C::K; k++) {
                 const int y = y0 + k;
-                if (y < WIN) {
+                {   // every strip of the run, no branch: the gradients of strips below the window are zeros (set-up)
                     unsigned bot[4], p01, p23;
                     region_row_pairs(inx, iny, y + 1, bot);  // the bottom row of strip y is the top row of strip y+1
                     strip_bilinear_pairs(top, bot, w, p01, p23);
