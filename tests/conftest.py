@@ -10,6 +10,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+os.environ.setdefault("VH_POISON_WORKSPACE", "1")  # BA workspaces start as NaN bit patterns: reads of never-written memory fail loudly
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -6,6 +6,17 @@ from . import _lib as L
 from .transforms import dcm2rpy
 
 
+def _scratch(torch, shape):
+    """BA workspace.  VH_POISON_WORKSPACE=1 (set by the test-suite) fills it with NaN bit patterns first, so a kernel that reads workspace
+    memory it never wrote fails loudly instead of passing on whatever the caching allocator handed out."""
+    import os
+
+    t = torch.empty(shape, dtype=torch.uint8, device="cuda")
+    if os.environ.get("VH_POISON_WORKSPACE"):
+        t.fill_(0xFF)
+    return t
+
+
 def _pose(K, p, pw, x0, R, findR, want_proj=True):
     torch = L.torch_cuda()
     K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
@@ -87,7 +98,7 @@ def fcnNLS_batch(K, P, pw, cw, max_iter=10, return_info=False):
     info = torch.zeros(2, dtype=torch.int32, device="cuda")
     ws = L.workspace()
     nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    scratch = _scratch(torch, nbytes)
     L.check(ws.lib.vh_nls_batch(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, int(max_iter), L.dptr(trace), L.dptr(info),
                                 L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch")
     info = info.cpu().numpy()
@@ -133,7 +144,7 @@ def fcnNLS_batch_windows(K, Ps, pws, cws, max_iter=10, return_info=False):
     info = torch.zeros((nw, 2), dtype=torch.int32, device="cuda")
     ws = L.workspace()
     nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
-    scratch = torch.empty((nw, nbytes), dtype=torch.uint8, device="cuda")
+    scratch = _scratch(torch, (nw, nbytes))
     L.check(ws.lib.vh_nls_batch_multi(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, nw, int(max_iter), L.dptr(trace),
                                       L.dptr(info), L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
     info, x, tr = info.cpu().numpy(), xd.cpu().numpy(), trace.cpu().numpy()
@@ -183,7 +194,7 @@ def fcnNLS_batch2(K, P, pw, cw, max_iter=20, return_info=False):
     info = torch.zeros(2, dtype=torch.int32, device="cuda")
     ws = L.workspace()
     nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    scratch = _scratch(torch, nbytes)
     L.check(ws.lib.vh_nls_batch2(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, int(max_iter), L.dptr(trace), L.dptr(info),
                                  L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch2")
     info = info.cpu().numpy()

@@ -29,6 +29,7 @@ int vh_fail(int code, const char* msg)
 extern "C" VH_API int vh_version(void) { return 102; }
 void vh_lk_force_generic(int on);
 extern "C" VH_API void vh_debug_force_generic_lk(int on) { vh_lk_force_generic(on); }
+
 extern "C" VH_API int vh_copy_to_host(void* dst_host, const void* src_dev, size_t bytes, void* stream)
 {
     VH_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -151,10 +152,29 @@ __device__ void fill_lk_common(LKJob& J, const vh_lk_params& lk, const float* p_
 }
 
 // ---- stage 0: descriptors of the quarter-scale stage (KLT.py:110-114) -------------------------------------------
-__global__ void k_klt_setup(StreamWS* ws_all)
+__global__ void k_klt_setup(StreamWS* ws_all, const SessStream* ss_all, const uint8_t* const* frames, vh_lk_params coarse, vh_lk_params fine)
 {
     if (threadIdx.x != 0) return;
     StreamWS& ws = ws_all[blockIdx.x];
+    if (ss_all) {  // session mode: this frame's KLTmain call (vidExample.py:134) straight from the stream state
+        const SessStream& S = ss_all[blockIdx.x];
+        KltIO& o = ws.io;
+        o.im = frames[blockIdx.x];
+        o.im0 = S.im0;
+        o.im0_small = S.small[1 - S.pp];
+        o.im_small = S.small[S.pp];
+        o.p0 = S.p_cur;
+        o.n_ptr = &S.n_cur;
+        o.n = 0;
+        o.p_all = S.p_all;
+        o.v = S.v;
+        o.flags = const_cast<int*>(&S.klt_flags);
+        o.w = S.w; o.h = S.h; o.stride = S.stride; o.stride0 = S.stride;
+        o.reuse_prev_small = S.frame_i >= 1 ? 1 : 0;  // the previous step built the pyramid of what is now im0_small
+        o.coarse = coarse; o.fine = fine;
+        o.fbt_coarse = 1.0f; o.fbt_fine = 0.3f;
+        ws.pp = S.pp;
+    }
     const KltIO& io = ws.io;
     const StreamBufs& B = ws.bufs;
     const int n = io.n_ptr ? *io.n_ptr : io.n;
@@ -325,12 +345,13 @@ static int launch_lk_profiled(vh_ctx* c, int stage, const void* tab, size_t st, 
     return r;
 }
 
-int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine)
+int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine, const SessStream* sess,
+                    const uint8_t* const* frames)
 {
     StreamWS* ws = c->d_ws + slot;
     const size_t st = sizeof(StreamWS);
     const int lvl_c = min(coarse.max_level, VH_MAX_LEVELS - 1), lvl_f = min(fine.max_level, VH_MAX_LEVELS - 1);
-    hipLaunchKernelGGL(k_klt_setup, dim3(count), dim3(64), 0, s, ws);
+    hipLaunchKernelGGL(k_klt_setup, dim3(count), dim3(64), 0, s, ws, sess ? sess + slot : nullptr, frames, coarse, fine);
     vh_launch_resize_quarter(&ws->rs_src[0], &ws->rs_dst[0], st, 2, count, c->sw, c->sh, s);
     for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->sw, c->sh, s);
     int r = launch_lk_profiled(c, 0, &ws->lk, st, count, coarse.win, s);

@@ -537,7 +537,12 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_schur_mfma(BaJob J)
     double accR[2] = {0.0, 0.0};       // rhs entries q = lane, lane + 64 of the points this WAVE handled
     for (int q = tid; q < 2 * 12 * BA_NPAD; q += BA_THREADS) sZ[q] = 0.0;  // zero padding of both buffers (columns >= nq stay zero)
     BaRaw cur;
-    if (i0 >= i1) return;  // (never: every workgroup owns at least one point)
+    if (i0 >= i1) {  // the last workgroups of a launch can own no point (nt not a multiple of the chunk): their partials are zeros
+        double* Sp0 = J.Spart + (size_t)blockIdx.x * ((size_t)nq * nq);
+        for (long long e = tid; e < (long long)nq * nq; e += BA_THREADS) Sp0[e] = 0.0;
+        if (tid < nq) J.Rpart[(size_t)blockIdx.x * nq + tid] = 0.0;
+        return;
+    }
     BaLaneOff off;
     ba_lane_offsets(off, nt, nc, nq, lane);
     ba_raw_load(cur, J, off, i0 + wave, i1 - 1);

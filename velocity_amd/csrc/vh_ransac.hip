@@ -31,8 +31,13 @@ __device__ double det_log(double x)
     double m = __longlong_as_double((long long)u);
     if (m > 1.4142135623730951) { m = __dmul_rn(m, 0.5); e += 1; }
     const double s = __ddiv_rn(__dsub_rn(m, 1.0), __dadd_rn(m, 1.0)), s2 = __dmul_rn(s, s);
+    // 1 / (2k + 1): compile-time constants (correctly rounded, exactly what the division returns at run time) -- 13 dependent float64
+    // divisions per call were most of the single-thread selection replay
+    constexpr double R[13] = {1.0,        1.0 / 3.0,  1.0 / 5.0,  1.0 / 7.0,  1.0 / 9.0,  1.0 / 11.0, 1.0 / 13.0,
+                              1.0 / 15.0, 1.0 / 17.0, 1.0 / 19.0, 1.0 / 21.0, 1.0 / 23.0, 1.0 / 25.0};
     double acc = 0.0;
-    for (int k = 12; k >= 0; k--) acc = __dadd_rn(__dmul_rn(acc, s2), __ddiv_rn(1.0, (double)(2 * k + 1)));
+#pragma unroll
+    for (int k = 12; k >= 0; k--) acc = __dadd_rn(__dmul_rn(acc, s2), R[k]);
     return __dadd_rn(__dmul_rn((double)e, 0.6931471805599453), __dmul_rn(__dmul_rn(2.0, s), acc));
 }
 
@@ -178,13 +183,13 @@ __global__ __launch_bounds__(1024) void k_ransac_compact(const void* tab, size_t
             double M[6];
             int c = 0;
             if (ransac_hypothesis(J.from, J.to, J.idx, m, (uint32_t)wave, M)) c = score_pairs(J.pairs, m, M, lane);
-            if (lane == 0) J.counts[wave] = c;
+            if (lane == 0) { J.counts[wave] = c; wcount[wave] = c; }  // LDS copy: the replay below must not walk global memory
         }
         __syncthreads();
         if (tid == 0) {
             int best_count = 0, niters = VH_RANSAC_ITERS;
             for (int it = 0; it < RANSAC_HEAD && it < niters; it++) {
-                const int c = J.counts[it];
+                const int c = wcount[it];
                 if (c > max(best_count, 2)) {
                     best_count = c;
                     niters = ransac_update_iters(RANSAC_CONF, __ddiv_rn((double)(m - c), (double)m), niters);
@@ -221,12 +226,21 @@ __global__ __launch_bounds__(256) void k_ransac_select(const void* tab, size_t s
     __shared__ int s_best, s_count;
     __shared__ double s_M[6];
     __shared__ long long s_red[9 * 4];
+    // the scores of every reachable hypothesis in ONE coalesced round trip: the single-thread replay below walks them with data-dependent
+    // control flow, and from global memory every step of it was a full L2 latency (most of this kernel's 14 us)
+    __shared__ int s_counts[VH_RANSAC_ITERS];
+    {
+        // the replay reads entry `it` while it < (current) niters: the whole head (niters may only drop below 16 at its end) and then up to the bound
+        const int nb = min(max(*J.bound, RANSAC_HEAD), VH_RANSAC_ITERS);
+        for (int k = tid; k < nb; k += 256) s_counts[k] = J.counts[k];
+    }
+    __syncthreads();
     if (tid == 0) {
         int best = -1, best_count = 0;
         if (m >= 3 && m > J.min_valid) {
             int niters = VH_RANSAC_ITERS;
             for (int it = 0; it < niters; it++) {
-                const int c = J.counts[it];
+                const int c = s_counts[it];
                 if (c > max(best_count, 2)) {
                     best = it;
                     best_count = c;
@@ -307,6 +321,8 @@ __global__ __launch_bounds__(256) void k_ransac_select(const void* tab, size_t s
     }
 }
 
+// (Tried: the three stages fused into one 1024-thread workgroup per stream for the single-stream latency path -- 128 VGPRs per thread force 516
+// bytes of scratch per lane, 43 us instead of 33 us for the three launches: launch overhead is not what these stages cost.)
 void vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
     (void)max_n;

@@ -8,36 +8,7 @@
 #include <new>
 
 #include "vh_ws.hpp"
-
-struct SessStream {  // device resident, one per video stream
-    // track state (vidExample.py:125-129)
-    uint8_t* vg;     // N0  global validity of the initial tracks
-    uint8_t* vp;     // N0  tracks used for the pose fit
-    float* p_cur;    // n_cur x 2 compacted current points
-    int* ids;        // n_cur global ids of the compacted rows (= nonzero(vg))
-    double* p3;      // N0 x 3 world points
-    float* P;        // [5, N0, nhist] history, NaN padded
-    float* B;        // [nhist, 14]
-    float* S;        // [nhist, 9]
-    // per-frame scratch
-    float* p_all;    // KLTmain output before compaction
-    uint8_t* v;      // KLTmain status
-    int* sel_p;      // pose rows of p_cur      (p[vp[vg]], vidExample.py:139)
-    int* sel_pw;     // pose rows of p3         (p3[vp])
-    double* p_proj;  // n_pose x 2
-    double* msv_U;   // 3*16*N0 scratch of fcnMSV1_t
-    double* msv_b0;  // N0 x 3
-    uint8_t* small[2];
-    const uint8_t* im0;
-    PoseJob pose;
-    double K[9];
-    double res;
-    float t[3];
-    float msv_x[3];
-    float r_total, t0;
-    int pose_info[2], msv_info[2];
-    int N0, nhist, n_cur, n_pose, frame_i, pp, klt_flags, w, h, stride;
-};
+#include "vh_pose_dev.hpp"
 
 struct vh_session {
     vh_ctx* ctx;
@@ -56,103 +27,84 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // ---------------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void k_sess_prepare(SessStream* ss_all, StreamWS* ws_all, const uint8_t* const* frames, vh_lk_params coarse, vh_lk_params fine)
-{
-    if (threadIdx.x != 0) return;
-    SessStream& S = ss_all[blockIdx.x];
-    StreamWS& ws = ws_all[blockIdx.x];
-    KltIO& io = ws.io;
-    io.im = frames[blockIdx.x];
-    io.im0 = S.im0;
-    io.im0_small = S.small[1 - S.pp];
-    io.im_small = S.small[S.pp];
-    io.p0 = S.p_cur;
-    io.n_ptr = &S.n_cur;
-    io.n = 0;
-    io.p_all = S.p_all;
-    io.v = S.v;
-    io.flags = &S.klt_flags;
-    io.w = S.w; io.h = S.h; io.stride = S.stride; io.stride0 = S.stride;
-    io.reuse_prev_small = S.frame_i >= 1 ? 1 : 0;  // the previous step built the pyramid of what is now im0_small
-    io.coarse = coarse; io.fine = fine;
-    io.fbt_coarse = 1.0f; io.fbt_fine = 0.3f;
-    ws.pp = S.pp;
-}
-
-// order-preserving compaction helper: returns the number of selected items; dst index via callback
-template <typename F, typename G>
-__device__ int block_compact(int n, F pred, G emit, int* wcount /* [4] */, int* base /* [1] */)
-{
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) *base = 0;
-    __syncthreads();
-    for (int c = 0; c < n; c += 256) {
-        const int i = c + tid;
-        const bool f = i < n && pred(i);
-        const unsigned long long bal = __ballot(f);
-        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wcount[wave] = __popcll(bal);
-        __syncthreads();
-        int off = *base;
-        for (int q = 0; q < wave; q++) off += wcount[q];
-        if (f) emit(i, off + pre);
-        __syncthreads();
-        if (tid == 0) *base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
-        __syncthreads();
-    }
-    return *base;
-}
-
 // vg[vg] = v ; vp &= vg ; p = p[v] ; pose selection p[vp[vg]] / p3[vp]   (vidExample.py:134-139)
-__global__ __launch_bounds__(256) void k_sess_book_a(SessStream* ss_all)
+// A thread owns up to 16 CONSECUTIVE current tracks: it loads all of them at once (one memory round trip, not one per 256-track chunk), both
+// order-preserving compactions -- the surviving tracks and, among them, the pose tracks -- come from one block-wide exclusive scan of the two
+// per-thread counts.  `vp &= vg` only ever changes the entries of CURRENT tracks (a dropped track's vg and vp are already 0), so the two mask
+// updates are per-track stores instead of passes over all N0 entries.
+__device__ __forceinline__ void sess_book_a(SessStream& S)
 {
-    SessStream& S = ss_all[blockIdx.x];
-    const int tid = threadIdx.x, n = S.n_cur, N0 = S.N0;
-    __shared__ int wcount[4], base;
-    for (int r = tid; r < n; r += 256) S.vg[S.ids[r]] = S.v[r];
+    constexpr int EPT = 16;
+    const int tid = threadIdx.x, n = S.n_cur, wave = tid >> 6, lane = tid & 63;
+    __shared__ int s_tot[2][4], s_base[2];
+    uint8_t* const vg = S.vg;
+    uint8_t* const vp = S.vp;
+    int* const ids = S.ids;
+    if (tid == 0) { s_base[0] = 0; s_base[1] = 0; }
     __syncthreads();
-    for (int g = tid; g < N0; g += 256) S.vp[g] = S.vp[g] & S.vg[g];
-    __syncthreads();
-    // compaction: reads of ids happen chunk-wise before the writes of the same chunk; destinations never pass the source
-    {
-        const int wave = tid >> 6, lane = tid & 63;
-        if (tid == 0) base = 0;
-        __syncthreads();
-        for (int c = 0; c < n; c += 256) {
-            const int i = c + tid;
-            const bool f = i < n && S.v[i] != 0;
-            const int id = i < n ? S.ids[i] : 0;
-            const float px = f ? S.p_all[2 * i] : 0.f, py = f ? S.p_all[2 * i + 1] : 0.f;
-            const unsigned long long bal = __ballot(f);
-            const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) wcount[wave] = __popcll(bal);
-            __syncthreads();
-            int off = base;
-            for (int q = 0; q < wave; q++) off += wcount[q];
-            if (f) { S.ids[off + pre] = id; S.p_cur[2 * (off + pre)] = px; S.p_cur[2 * (off + pre) + 1] = py; }
-            __syncthreads();
-            if (tid == 0) base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
-            __syncthreads();
+    for (int c0 = 0; c0 < n || c0 == 0; c0 += 256 * EPT) {  // one pass for up to 4096 tracks
+        const int per = min(EPT, (min(n - c0, 256 * EPT) + 255) / 256);
+        const int b = c0 + tid * per, e = min(n, b + per);
+        int id[EPT];
+        float px[EPT], py[EPT];
+        unsigned fv = 0, fp = 0;  // bit k: track b + k survives / is a pose track
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const int i = b + k;
+            if (k < per && i < e) {
+                id[k] = ids[i];
+                px[k] = S.p_all[2 * i]; py[k] = S.p_all[2 * i + 1];
+                fv |= (S.v[i] != 0 ? 1u : 0u) << k;
+            }
         }
+#pragma unroll
+        for (int k = 0; k < EPT; k++)
+            if (k < per && b + k < e) {
+                const bool f = (fv >> k) & 1u;
+                const bool pv = f && vp[id[k]] != 0;
+                vg[id[k]] = f ? 1 : 0;
+                vp[id[k]] = pv ? 1 : 0;
+                fp |= (pv ? 1u : 0u) << k;
+            }
+        const int cv = __popc(fv), cp = __popc(fp);
+        // block-wide exclusive scan of (cv, cp): wave scan by shuffles, wave totals through LDS
+        int sv = cv, sp = cp;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int tv = __shfl_up(sv, o, 64), tp = __shfl_up(sp, o, 64);
+            if (lane >= o) { sv += tv; sp += tp; }
+        }
+        if (lane == 63) { s_tot[0][wave] = sv; s_tot[1][wave] = sp; }
+        __syncthreads();  // also: every thread has LOADED its tracks before anybody overwrites ids / p_cur below
+        int ov = s_base[0] + sv - cv, op = s_base[1] + sp - cp;
+        for (int w = 0; w < wave; w++) { ov += s_tot[0][w]; op += s_tot[1][w]; }
+#pragma unroll
+        for (int k = 0; k < EPT; k++)
+            if (k < per && ((fv >> k) & 1u)) {
+                ids[ov] = id[k];
+                S.p_cur[2 * ov] = px[k]; S.p_cur[2 * ov + 1] = py[k];
+                if ((fp >> k) & 1u) { S.sel_p[op] = ov; S.sel_pw[op] = id[k]; op++; }
+                ov++;
+            }
+        __syncthreads();
+        if (tid == 0) {
+            s_base[0] += s_tot[0][0] + s_tot[0][1] + s_tot[0][2] + s_tot[0][3];
+            s_base[1] += s_tot[1][0] + s_tot[1][1] + s_tot[1][2] + s_tot[1][3];
+        }
+        __syncthreads();
     }
-    const int n_new = base;
-    __syncthreads();
-    const int n_pose = block_compact(
-        n_new, [&](int k) { return S.vp[S.ids[k]] != 0; },
-        [&](int k, int j) { S.sel_p[j] = k; S.sel_pw[j] = S.ids[k]; }, wcount, &base);
     if (tid == 0) {
-        S.n_cur = n_new;
-        S.n_pose = n_pose;
+        S.n_cur = s_base[0];
+        S.n_pose = s_base[1];
     }
 }
 
 // results records B, S and history P (vidExample.py:142-146, 151-153, 164); then advance the frame state
-__global__ __launch_bounds__(256) void k_sess_book_b(SessStream* ss_all, const uint8_t* const* frames, float time_s, float frame_no,
-                                                     const float* times, const float* frame_nos)
+__device__ __forceinline__ void sess_book_b(SessStream& S, const uint8_t* const* frames, float time_s, float frame_no, const float* times,
+                                            const float* frame_nos)
 {
     if (times) time_s = times[blockIdx.x];          // independent videos: per-stream timestamp (B[i,12] = CAP_PROP_POS_MSEC / 1000)
     if (frame_nos) frame_no = frame_nos[blockIdx.x];
-    SessStream& S = ss_all[blockIdx.x];
     const int tid = threadIdx.x, i = S.frame_i + 1, nh = S.nhist, N0 = S.N0;
     if (i < nh) {
         for (int k = tid; k < S.n_cur; k += 256) {
@@ -194,6 +146,30 @@ __global__ __launch_bounds__(256) void k_sess_book_b(SessStream* ss_all, const u
         S.pp ^= 1;
         S.frame_i = i;
     }
+}
+
+__global__ __launch_bounds__(256) void k_sess_book_a(SessStream* ss_all) { sess_book_a(ss_all[blockIdx.x]); }
+__global__ __launch_bounds__(256) void k_sess_book_b(SessStream* ss_all, const uint8_t* const* frames, float time_s, float frame_no,
+                                                     const float* times, const float* frame_nos)
+{
+    sess_book_b(ss_all[blockIdx.x], frames, time_s, frame_no, times, frame_nos);
+}
+
+// The whole post-tracking part of a frame in ONE launch (N0 <= 4096): vg[vg] = v, vp &= vg, compaction and pose-track selection
+// (vidExample.py:135-139), estimateWorldCameraPose(findR=False) with every LM iteration (NLS.py:9-33,102-129), then the B / S / P records
+// (vidExample.py:142-153,164).  Three dependent launches of one workgroup each before; same code, same results.
+__global__ __launch_bounds__(256) void k_sess_frame(SessStream* ss_all, const uint8_t* const* frames, float time_s, float frame_no,
+                                                    const float* times, const float* frame_nos)
+{
+    SessStream& S = ss_all[blockIdx.x];
+    sess_book_a(S);
+    __threadfence_block();
+    __syncthreads();
+    const PoseJob J = S.pose;
+    pose_solve<0, 256>(J);
+    __threadfence_block();
+    __syncthreads();
+    sess_book_b(S, frames, time_s, frame_no, times, frame_nos);
 }
 
 // p3[vg] = p3hat - t ; vp = vg   (vidExample.py:159-160)
@@ -330,12 +306,15 @@ static int session_step(vh_session* s, const uint8_t* const* frames_dev, float t
     hipStream_t st = (hipStream_t)stream;
     vh_ctx* c = s->ctx;
     const int nb = s->batch;
-    hipLaunchKernelGGL(k_sess_prepare, dim3(nb), dim3(64), 0, st, s->d_ss, c->d_ws, frames_dev, s->coarse, s->fine);
-    int r = vh_run_klt_main(c, 0, nb, st, s->coarse, s->fine);
+    int r = vh_run_klt_main(c, 0, nb, st, s->coarse, s->fine, s->d_ss, frames_dev);  // the set-up kernel also fetches this frame's KltIO from the session
     if (r) return r;
-    hipLaunchKernelGGL(k_sess_book_a, dim3(nb), dim3(256), 0, st, s->d_ss);
-    vh_launch_pose(&s->d_ss[0].pose, sizeof(SessStream), nb, 0, s->N0, st);
-    hipLaunchKernelGGL(k_sess_book_b, dim3(nb), dim3(256), 0, st, s->d_ss, frames_dev, time_s, frame_no, times_dev, frame_nos_dev);
+    if (s->N0 <= 4096) {
+        hipLaunchKernelGGL(k_sess_frame, dim3(nb), dim3(256), 0, st, s->d_ss, frames_dev, time_s, frame_no, times_dev, frame_nos_dev);
+    } else {  // more pose tracks than 256 threads keep in registers: the 1024-thread pose kernel between the two bookkeeping halves
+        hipLaunchKernelGGL(k_sess_book_a, dim3(nb), dim3(256), 0, st, s->d_ss);
+        vh_launch_pose(&s->d_ss[0].pose, sizeof(SessStream), nb, 0, s->N0, st);
+        hipLaunchKernelGGL(k_sess_book_b, dim3(nb), dim3(256), 0, st, s->d_ss, frames_dev, time_s, frame_no, times_dev, frame_nos_dev);
+    }
     // fcnMSV1_t fires when a stream reaches ITS frame msv_frame (vidExample.py:155), whenever that stream was initialised
     const bool msv_ok = s->msv_frame >= 1 && s->msv_frame + 1 <= 16 && s->msv_frame < s->nhist;
     bool any = false;

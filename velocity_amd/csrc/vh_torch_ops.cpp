@@ -10,8 +10,8 @@
 // Reference call sites: utils/KLT.py:99-134 (KLTmain), :37-51 (cv2calcOpticalFlowPyrLK), utils/NLS.py:9-33,102-183 (estimateWorldCameraPose ->
 // fcnNLS_t / fcnNLS_Rt), utils/common.py:58-64 (world2image), utils/MSV.py:8-49,98-142 (fcnMSV1_t, fcn2vintercept), utils/NLS.py:186-250 (fcnNLS_batch).
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
 #include <map>
@@ -82,8 +82,8 @@ std::tuple<Tensor, Tensor, Tensor> klt_main(const Tensor& im, const Tensor& im0,
     check_image(im, "klt_main(im)");
     check_image(im0, "klt_main(im0)");
     TORCH_CHECK(im.sizes() == im0.sizes(), "klt_main: im and im0 differ in size");
-    c10::hip::HIPGuard guard(im.device());
-    void* s = (void*)c10::hip::getCurrentHIPStream().stream();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(im.device());
+    void* s = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
     const int h = (int)im.size(0), w = (int)im.size(1);
     Tensor p = as_points(p0, "klt_main(p0)");
     const int n = (int)p.size(0);
@@ -114,8 +114,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> pyr_lk(const Tensor& prev, const Tens
     check_image(prev, "pyr_lk(prev)");
     check_image(next, "pyr_lk(next)");
     TORCH_CHECK(prev.sizes() == next.sizes(), "pyr_lk: images differ in size");
-    c10::hip::HIPGuard guard(prev.device());
-    void* s = (void*)c10::hip::getCurrentHIPStream().stream();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(prev.device());
+    void* s = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
     const int h = (int)prev.size(0), w = (int)prev.size(1);
     Tensor p = as_points(pts, "pyr_lk(pts)");
     const int n = (int)p.size(0);
@@ -135,8 +135,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> pose(const Tensor& K, const T
 {
     TORCH_CHECK(p.is_cuda() && pw.is_cuda() && p.dim() == 2 && p.size(1) == 2 && pw.dim() == 2 && pw.size(1) == 3 && p.size(0) == pw.size(0),
                 "pose: p [n,2] and pw [n,3] must be CUDA tensors with the same number of rows");
-    c10::hip::HIPGuard guard(p.device());
-    void* s = (void*)c10::hip::getCurrentHIPStream().stream();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(p.device());
+    void* s = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
     float Kh[9];
     host_K(K, Kh);
     Tensor pf = p.to(at::kFloat).contiguous(), pwd = pw.to(at::kDouble).contiguous();
@@ -178,8 +178,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> estimate_pose(const Tensor& K
 Tensor project(const Tensor& K, const Tensor& R, const Tensor& t, const Tensor& pw)
 {
     TORCH_CHECK(pw.is_cuda() && pw.dim() == 2 && pw.size(1) == 3, "project: pw must be CUDA [n,3]");
-    c10::hip::HIPGuard guard(pw.device());
-    void* s = (void*)c10::hip::getCurrentHIPStream().stream();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(pw.device());
+    void* s = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
     Tensor Kd = K.detach().to(at::kCPU, at::kDouble).reshape({3, 3}), Rd = R.detach().to(at::kCPU, at::kDouble).reshape({3, 3}),
            td = t.detach().to(at::kCPU, at::kDouble).reshape({1, 3});
     Tensor Cm = at::matmul(at::cat({Rd, td}, 0), Kd).contiguous();
@@ -193,8 +193,8 @@ Tensor project(const Tensor& K, const Tensor& R, const Tensor& t, const Tensor& 
 Tensor two_view_intercept(const Tensor& A, const Tensor& U)
 {
     TORCH_CHECK(A.is_cuda() && U.is_cuda() && A.dim() == 2 && A.size(1) == 3 && U.dim() == 3 && U.size(0) == 3 && U.size(1) == A.size(0), "two_view_intercept: A [nf,3], U [3,nf,nv] on the GPU");
-    c10::hip::HIPGuard guard(A.device());
-    void* s = (void*)c10::hip::getCurrentHIPStream().stream();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(A.device());
+    void* s = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
     Tensor Ad = A.to(at::kDouble).contiguous(), Ud = U.to(at::kDouble).contiguous();
     Tensor out = at::zeros({Ud.size(2), 3}, Ad.options());
     vh_check(vh_two_view_intercept(workspace(A, 0, 0, 0, s), Ad.data_ptr<double>(), Ud.data_ptr<double>(), (int)Ad.size(0), (int)Ud.size(2), out.data_ptr<double>(), s),
@@ -207,8 +207,8 @@ std::tuple<Tensor, Tensor, Tensor> msv1_t(const Tensor& K, const Tensor& P, cons
 {
     TORCH_CHECK(P.is_cuda() && B.is_cuda() && ids.is_cuda() && P.dim() == 3 && P.size(0) == 5 && B.dim() == 2 && B.size(1) == 14 && B.size(0) == P.size(2),
                 "msv1_t: P [5,N0,nhist], B [nhist,14], ids [ng] on the GPU");
-    c10::hip::HIPGuard guard(P.device());
-    void* s = (void*)c10::hip::getCurrentHIPStream().stream();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(P.device());
+    void* s = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
     float Kh[9];
     host_K(K, Kh);
     Tensor Pf = P.to(at::kFloat).contiguous(), Bf = B.to(at::kFloat).contiguous(), id = ids.to(at::kInt).contiguous();
@@ -229,8 +229,8 @@ std::tuple<Tensor, Tensor, Tensor> ba_solve(const Tensor& K, const Tensor& z, co
     TORCH_CHECK(z.is_cuda() && x0.is_cuda() && z.dim() == x0.dim() && (z.dim() == 1 || z.dim() == 2), "ba_solve: z and x0 must be CUDA tensors, both [..] or both [nwin, ..]");
     const int64_t nz = 2 * nt * (nc + 1), nx = 3 * nt + 6 * nc;
     TORCH_CHECK(z.size(-1) == nz && x0.size(-1) == nx, "ba_solve: z must hold 2 nt (nc+1) and x0 3 nt + 6 nc values");
-    c10::hip::HIPGuard guard(z.device());
-    void* s = (void*)c10::hip::getCurrentHIPStream().stream();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(z.device());
+    void* s = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
     float Kh[9];
     host_K(K, Kh);
     const bool multi = z.dim() == 2;

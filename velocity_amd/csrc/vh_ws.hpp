@@ -69,6 +69,40 @@ struct vh_ctx {
 };
 
 
+// tracker-session state of one video stream (vh_session.hip); declared here because the KLTmain set-up kernel (vh_api.hip) fetches a
+// frame's inputs straight from it (one launch less per frame than a separate "prepare" kernel)
+struct SessStream {  // device resident, one per video stream
+    // track state (vidExample.py:125-129)
+    uint8_t* vg;     // N0  global validity of the initial tracks
+    uint8_t* vp;     // N0  tracks used for the pose fit
+    float* p_cur;    // n_cur x 2 compacted current points
+    int* ids;        // n_cur global ids of the compacted rows (= nonzero(vg))
+    double* p3;      // N0 x 3 world points
+    float* P;        // [5, N0, nhist] history, NaN padded
+    float* B;        // [nhist, 14]
+    float* S;        // [nhist, 9]
+    // per-frame scratch
+    float* p_all;    // KLTmain output before compaction
+    uint8_t* v;      // KLTmain status
+    int* sel_p;      // pose rows of p_cur      (p[vp[vg]], vidExample.py:139)
+    int* sel_pw;     // pose rows of p3         (p3[vp])
+    double* p_proj;  // n_pose x 2
+    double* msv_U;   // 3*16*N0 scratch of fcnMSV1_t
+    double* msv_b0;  // N0 x 3
+    uint8_t* small[2];
+    const uint8_t* im0;
+    PoseJob pose;
+    double K[9];
+    double res;
+    float t[3];
+    float msv_x[3];
+    float r_total, t0;
+    int pose_info[2], msv_info[2];
+    int N0, nhist, n_cur, n_pose, frame_i, pp, klt_flags, w, h, stride;
+};
+
+
 // runs KLTmain (KLT.py:99-134) for streams [slot, slot+count) whose KltIO has been written (host or device side)
-int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine);
+int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine,
+                    const SessStream* sess = nullptr, const uint8_t* const* frames = nullptr);
 int vh_fail(int code, const char* msg);

@@ -123,6 +123,10 @@ def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None):
     ws = L.workspace()
     nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
     scratch = tc.empty(nbytes // 8 + 1, dtype=tc.float64, device="cuda")  # float64 so that the exchange span is a view of it
+    import os
+
+    if os.environ.get("VH_POISON_WORKSPACE"):
+        scratch.fill_(float("nan"))
     off, cnt = C.c_size_t(), C.c_size_t()
 
     def phase(ph, it=0):
