@@ -222,6 +222,10 @@ VH_API int vh_session_pack_state(vh_session* s, float* out, void* stream);
  * All are bit-identical. */
 VH_API void vh_debug_force_generic_lk(int on);
 
+/* test hook: estimateAffine2D stand-in -- 1: always the three-kernel path (hypotheses spread over the chip), 2: the fused
+ * one-workgroup-per-stream kernel whenever the problem fits it (latency path), 0: default routing by batch size.  Bit-identical results. */
+VH_API void vh_debug_ransac_path(int mode);
+
 /* test hook: 1 accumulates the reduced camera system of vh_nls_batch on the VALU instead of the f64 matrix cores */
 VH_API void vh_debug_ba_force_valu(int on);
 

@@ -215,10 +215,18 @@ def test_pyr_lk_textureless_and_small_images():
     assert np.array_equal(v, ev) and np.array_equal(p2, e2) and np.array_equal(err.ravel(), eerr)
 
 
-def test_ransac_affine_bit_exact():
+@pytest.mark.parametrize("path", [1, 2])
+def test_ransac_affine_bit_exact(path):
+    """path 1: compaction / scoring / selection as three launches (hypotheses spread over the chip); path 2: the fused one-workgroup kernel
+    of the latency path (pairs and scores resident in LDS).  Both equal the oracle bit for bit."""
+    from velocity_amd import _lib as L
     from velocity_amd.KLT import estimateAffine2D
 
-    _ransac_cases(estimateAffine2D)
+    L.load().vh_debug_ransac_path(path)
+    try:
+        _ransac_cases(estimateAffine2D)
+    finally:
+        L.load().vh_debug_ransac_path(0)
 
 
 def _ransac_cases(estimateAffine2D):

@@ -77,6 +77,7 @@ _SIGS = {
     "vh_session_ptrs": (C.c_int, [vp, C.c_int, C.POINTER(SessionView)]),
     "vh_session_pack_state": (C.c_int, [vp, vp, vp]),
     "vh_debug_force_generic_lk": (None, [C.c_int]),
+    "vh_debug_ransac_path": (None, [C.c_int]),
     "vh_debug_ba_force_valu": (None, [C.c_int]),
     "vh_profile_begin": (C.c_int, [vp, C.c_int]),
     "vh_profile_end": (C.c_int, [vp, f64p, i32p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),

@@ -29,6 +29,8 @@ int vh_fail(int code, const char* msg)
 extern "C" VH_API int vh_version(void) { return 102; }
 void vh_lk_force_generic(int on);
 extern "C" VH_API void vh_debug_force_generic_lk(int on) { vh_lk_force_generic(on); }
+void vh_ransac_force_path(int mode);
+extern "C" VH_API void vh_debug_ransac_path(int mode) { vh_ransac_force_path(mode); }
 
 extern "C" VH_API int vh_copy_to_host(void* dst_host, const void* src_dev, size_t bytes, void* stream)
 {
@@ -333,11 +335,11 @@ __global__ void k_klt_glue2(StreamWS* ws_all)
     if (io.flags) *io.flags = ws.flags;
 }
 
-static int launch_lk_profiled(vh_ctx* c, int stage, const void* tab, size_t st, int count, int win, hipStream_t s)
+static int launch_lk_profiled(vh_ctx* c, int stage, const void* tab, size_t st, int count, int win, hipStream_t s, int mn)
 {
     const bool on = c->prof_on && c->prof_n < c->prof_cap;
     if (on) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], s);
-    const int r = vh_launch_lk(tab, st, count, c->max_pts, win, s);
+    const int r = vh_launch_lk(tab, st, count, mn, win, s);
     if (on) {
         (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s);
         c->prof_stage[c->prof_n++] = stage;
@@ -346,27 +348,28 @@ static int launch_lk_profiled(vh_ctx* c, int stage, const void* tab, size_t st, 
 }
 
 int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine, const SessStream* sess,
-                    const uint8_t* const* frames)
+                    const uint8_t* const* frames, int n_max)
 {
+    const int mn = n_max > 0 && n_max < c->max_pts ? n_max : c->max_pts;  // launch extent over the tracks (the kernels read the real count)
     StreamWS* ws = c->d_ws + slot;
     const size_t st = sizeof(StreamWS);
     const int lvl_c = min(coarse.max_level, VH_MAX_LEVELS - 1), lvl_f = min(fine.max_level, VH_MAX_LEVELS - 1);
     hipLaunchKernelGGL(k_klt_setup, dim3(count), dim3(64), 0, s, ws, sess ? sess + slot : nullptr, frames, coarse, fine);
     vh_launch_resize_quarter(&ws->rs_src[0], &ws->rs_dst[0], st, 2, count, c->sw, c->sh, s);
     for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->sw, c->sh, s);
-    int r = launch_lk_profiled(c, 0, &ws->lk, st, count, coarse.win, s);
+    int r = launch_lk_profiled(c, 0, &ws->lk, st, count, coarse.win, s, mn);
     if (r) return vh_fail(r, "vh_launch_lk failed (window too large for LDS?)");
-    vh_launch_ransac(&ws->ransac, st, count, c->max_pts, s);
+    vh_launch_ransac(&ws->ransac, st, count, mn, s);
     hipLaunchKernelGGL(k_klt_glue1, dim3(count), dim3(256), 0, s, ws);
     vh_launch_roi_warp(&ws->warp, st, count, c->max_w, c->max_h, s);
     for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->max_w, c->max_h, s);
-    r = launch_lk_profiled(c, 1, &ws->lk, st, count, coarse.win, s);
+    r = launch_lk_profiled(c, 1, &ws->lk, st, count, coarse.win, s, mn);
     if (r) return vh_fail(r, "vh_launch_lk failed");
-    vh_launch_ransac(&ws->ransac, st, count, c->max_pts, s);
+    vh_launch_ransac(&ws->ransac, st, count, mn, s);
     hipLaunchKernelGGL(k_klt_glue2, dim3(count), dim3(64), 0, s, ws);
     vh_launch_roi_warp(&ws->warp, st, count, c->max_w, c->max_h, s);
     for (int l = 0; l < lvl_f; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->max_w, c->max_h, s);
-    r = launch_lk_profiled(c, 2, &ws->lk, st, count, fine.win, s);
+    r = launch_lk_profiled(c, 2, &ws->lk, st, count, fine.win, s, mn);
     if (r) return vh_fail(r, "vh_launch_lk failed");
     VH_LAUNCH_CHECK();
     return 0;
@@ -427,7 +430,7 @@ extern "C" VH_API int vh_klt_main(vh_ctx* c, int slot, const uint8_t* im, const 
     io.reuse_prev_small = 0; io.coarse = *coarse; io.fine = *fine; io.fbt_coarse = 1.0f; io.fbt_fine = 0.3f;
     hipStream_t s = (hipStream_t)stream;
     VH_CHECK(vh_store(&c->d_ws[slot].io, io, s));
-    return vh_run_klt_main(c, slot, 1, s, *coarse, *fine);
+    return vh_run_klt_main(c, slot, 1, s, *coarse, *fine, nullptr, nullptr, n);
 }
 
 extern "C" VH_API int vh_klt_stage_ptrs(vh_ctx* c, int slot, vh_klt_stages* out)

@@ -321,11 +321,230 @@ __global__ __launch_bounds__(256) void k_ransac_select(const void* tab, size_t s
     }
 }
 
-// (Tried: the three stages fused into one 1024-thread workgroup per stream for the single-stream latency path -- 128 VGPRs per thread force 516
-// bytes of scratch per lane, 43 us instead of 33 us for the three launches: launch overhead is not what these stages cost.)
+// ---- latency path: the three stages in ONE 512-thread workgroup per stream, the compacted pairs resident in LDS -------------------------------
+// With few streams in flight the three launches above are a chain of ~13 dependent global-memory round trips (job -> count -> points -> index
+// list -> sample -> pairs -> scores -> ...), about 1 us each, for a few microseconds of arithmetic.  Here the compacted (from, to) pairs and
+// the scores live in LDS, so after the first read of the points nothing waits on global memory.  Same arithmetic, same integers: bit-identical
+// to the three-kernel path (tests/test_gpu_klt.py runs both).  512 threads: a 1024-thread version is capped at 128 VGPRs and spills 516 B / lane.
+#define RANSAC_FUSED_MAX 3072  // pairs held in LDS (48 KB)
+__device__ bool ransac_hypothesis_lds(const float4* pairs, int m, uint32_t hyp, double* M)
+{
+    int id[3];
+    for (int k = 0; k < 3; k++) {
+        bool ok = false;
+        for (uint32_t a = 0; a < 16 && !ok; a++) {
+            id[k] = (int)ransac_draw(hyp, (uint32_t)k, a, (uint32_t)m);
+            ok = true;
+            for (int q = 0; q < k; q++) ok = ok && (id[q] != id[k]);
+        }
+        if (!ok) return false;
+    }
+    double f[3][2], t[3][2];
+    for (int k = 0; k < 3; k++) {
+        const float4 q = pairs[id[k]];
+        f[k][0] = q.x; f[k][1] = q.y; t[k][0] = q.z; t[k][1] = q.w;
+    }
+    if (collinear(f[0], f[1], f[2]) || collinear(t[0], t[1], t[2])) return false;
+    const double ax = __dsub_rn(f[0][0], f[2][0]), ay = __dsub_rn(f[0][1], f[2][1]);
+    const double bx = __dsub_rn(f[1][0], f[2][0]), by = __dsub_rn(f[1][1], f[2][1]);
+    const double det = __dsub_rn(__dmul_rn(ax, by), __dmul_rn(bx, ay));
+    if (det == 0.0) return false;
+    for (int r = 0; r < 2; r++) {
+        const double u0 = __dsub_rn(t[0][r], t[2][r]), u1 = __dsub_rn(t[1][r], t[2][r]);
+        const double a = __ddiv_rn(__dsub_rn(__dmul_rn(u0, by), __dmul_rn(u1, ay)), det);
+        const double b = __ddiv_rn(__dsub_rn(__dmul_rn(ax, u1), __dmul_rn(bx, u0)), det);
+        M[3 * r] = a;
+        M[3 * r + 1] = b;
+        M[3 * r + 2] = __dsub_rn(__dsub_rn(t[2][r], __dmul_rn(a, f[2][0])), __dmul_rn(b, f[2][1]));
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(512) void k_ransac_fused(const void* tab, size_t stride)
+{
+    const RansacJob J = rjob(tab, stride, blockIdx.x);
+    const int n = J.n_ptr ? *J.n_ptr : J.n;  // <= RANSAC_FUSED_MAX (the launcher routes larger problems to the three-kernel path)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* s_pairs = reinterpret_cast<float4*>(smem);                            // [RANSAC_FUSED_MAX] compacted pairs
+    int* s_idx = reinterpret_cast<int*>(s_pairs + RANSAC_FUSED_MAX);              // [RANSAC_FUSED_MAX] their point indices
+    int* s_counts = s_idx + RANSAC_FUSED_MAX;                                     // [VH_RANSAC_ITERS]
+    __shared__ int wcount[8], base, s_bound, s_best, s_count;
+    __shared__ double s_M[6];
+    __shared__ long long s_red[7 * 8];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int c = 0; c < n; c += 512) {
+        const int i = c + tid;
+        const bool f = i < n && J.valid[i] != 0;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f) {
+            const float2 a = reinterpret_cast<const float2*>(J.from)[i], b = reinterpret_cast<const float2*>(J.to)[i];
+            q = make_float4(a.x, a.y, b.x, b.y);
+        }
+        const unsigned long long bal = __ballot(f);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const int cw = wcount[w];
+            off += w < wave ? cw : 0;
+            tot += cw;
+        }
+        if (f) { s_idx[off + pre] = i; s_pairs[off + pre] = q; }
+        __syncthreads();
+        if (tid == 0) base += tot;
+        __syncthreads();
+    }
+    const int m = base;
+    if (tid == 0) { *J.m_out = m; s_bound = VH_RANSAC_ITERS; }
+    __syncthreads();
+    const bool run = m >= 3 && m > J.min_valid;
+    if (run) {
+        // the head of 16 hypotheses, then the rest of the reachable ones, 8 per round (one wavefront each)
+        for (int h0 = 0; h0 < s_bound; h0 += 8) {
+            const int hyp = h0 + wave;
+            if (hyp < VH_RANSAC_ITERS) {
+                double M[6];
+                int c = 0;
+                if (ransac_hypothesis_lds(s_pairs, m, (uint32_t)hyp, M)) c = score_pairs(s_pairs, m, M, lane);
+                if (lane == 0) s_counts[hyp] = c;
+            }
+            __syncthreads();
+            if (h0 == RANSAC_HEAD - 8 && tid == 0) {  // bound of the reachable hypotheses after the head (as k_ransac_compact)
+                int best_count = 0, niters = VH_RANSAC_ITERS;
+                for (int it = 0; it < RANSAC_HEAD && it < niters; it++) {
+                    const int c = s_counts[it];
+                    if (c > max(best_count, 2)) {
+                        best_count = c;
+                        niters = ransac_update_iters(RANSAC_CONF, __ddiv_rn((double)(m - c), (double)m), niters);
+                    }
+                }
+                s_bound = niters;
+            }
+            __syncthreads();
+        }
+    }
+    // sequential selection rule (as k_ransac_select)
+    if (tid == 0) {
+        int best = -1, best_count = 0;
+        if (run) {
+            int niters = VH_RANSAC_ITERS;
+            for (int it = 0; it < niters; it++) {
+                const int c = s_counts[it];
+                if (c > max(best_count, 2)) {
+                    best = it;
+                    best_count = c;
+                    niters = ransac_update_iters(RANSAC_CONF, __ddiv_rn((double)(m - c), (double)m), niters);
+                }
+            }
+        }
+        s_best = best;
+        s_count = best_count;
+        *J.bound = s_bound;
+        if (best >= 0) {
+            double M[6];
+            ransac_hypothesis_lds(s_pairs, m, (uint32_t)best, M);
+            for (int k = 0; k < 6; k++) s_M[k] = M[k];
+        }
+    }
+    __syncthreads();
+    const int best = s_best;
+    if (best < 0) {
+        for (int i = tid; i < n; i += 512) {
+            J.inl[i] = 0;
+            if (J.gate_valid) J.valid[i] = 0;
+        }
+        if (tid == 0) *J.status = 0;
+        return;
+    }
+    double M[6];
+    for (int k = 0; k < 6; k++) M[k] = s_M[k];
+    auto block_sum = [&](long long* v, int nv) {  // exact int64 sums over the 8 wavefronts
+        for (int k = 0; k < nv; k++) v[k] = vh_wave_sum_i64(v[k]);
+        __syncthreads();
+        if (lane == 0) for (int k = 0; k < nv; k++) s_red[k * 8 + wave] = v[k];
+        __syncthreads();
+        for (int k = 0; k < nv; k++) {
+            long long t = 0;
+            for (int w = 0; w < 8; w++) t += s_red[k * 8 + w];
+            v[k] = t;
+        }
+    };
+    // inlier mask over ALL points (0 where !valid) + the refit sums over the compacted pairs in LDS (the same points, the same integers)
+    for (int i = tid; i < n; i += 512) J.inl[i] = 0;
+    __syncthreads();
+    long long s1[4] = {0, 0, 0, 0};
+    unsigned in_bits = 0;  // this thread's pairs k = tid + 512 j, j < 6
+#pragma unroll
+    for (int j = 0; j < RANSAC_FUSED_MAX / 512; j++) {
+        const int k = tid + 512 * j;
+        if (k < m) {
+            const float4 q = s_pairs[k];
+            if (is_inlier(M, q.x, q.y, q.z, q.w)) {
+                in_bits |= 1u << j;
+                s1[0] += vh_fixq((double)q.x, 32); s1[1] += vh_fixq((double)q.y, 32);
+                s1[2] += vh_fixq((double)q.z, 32); s1[3] += vh_fixq((double)q.w, 32);
+                J.inl[s_idx[k]] = 1;
+            }
+        }
+    }
+    block_sum(s1, 4);
+    const double cnt = (double)s_count;
+    const double mx = __ddiv_rn(ldexp((double)s1[0], -32), cnt), my = __ddiv_rn(ldexp((double)s1[1], -32), cnt);
+    const double mu = __ddiv_rn(ldexp((double)s1[2], -32), cnt), mv = __ddiv_rn(ldexp((double)s1[3], -32), cnt);
+    long long q7[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < RANSAC_FUSED_MAX / 512; j++) {
+        if ((in_bits >> j) & 1u) {
+            const float4 q = s_pairs[tid + 512 * j];
+            const double x = __dsub_rn((double)q.x, mx), y = __dsub_rn((double)q.y, my);
+            const double u = __dsub_rn((double)q.z, mu), v = __dsub_rn((double)q.w, mv);
+            q7[0] += vh_fixq(__dmul_rn(x, x), 20); q7[1] += vh_fixq(__dmul_rn(x, y), 20); q7[2] += vh_fixq(__dmul_rn(y, y), 20);
+            q7[3] += vh_fixq(__dmul_rn(x, u), 20); q7[4] += vh_fixq(__dmul_rn(y, u), 20);
+            q7[5] += vh_fixq(__dmul_rn(x, v), 20); q7[6] += vh_fixq(__dmul_rn(y, v), 20);
+        }
+    }
+    block_sum(q7, 7);  // (its barriers also order the J.inl stores above before the reads below)
+    if (J.gate_valid)
+        for (int i = tid; i < n; i += 512) J.valid[i] = J.inl[i];
+    if (tid == 0) {
+        const double Sxx = ldexp((double)q7[0], -20), Sxy = ldexp((double)q7[1], -20), Syy = ldexp((double)q7[2], -20);
+        const double Sxu = ldexp((double)q7[3], -20), Syu = ldexp((double)q7[4], -20);
+        const double Sxv = ldexp((double)q7[5], -20), Syv = ldexp((double)q7[6], -20);
+        const double det = __dsub_rn(__dmul_rn(Sxx, Syy), __dmul_rn(Sxy, Sxy));
+        const double tr = __dadd_rn(Sxx, Syy);
+        if (s_count >= 3 && det > __dmul_rn(__dmul_rn(1e-9, tr), tr) && det > 0) {
+            const double a = __ddiv_rn(__dsub_rn(__dmul_rn(Sxu, Syy), __dmul_rn(Syu, Sxy)), det);
+            const double b = __ddiv_rn(__dsub_rn(__dmul_rn(Sxx, Syu), __dmul_rn(Sxy, Sxu)), det);
+            const double d = __ddiv_rn(__dsub_rn(__dmul_rn(Sxv, Syy), __dmul_rn(Syv, Sxy)), det);
+            const double e = __ddiv_rn(__dsub_rn(__dmul_rn(Sxx, Syv), __dmul_rn(Sxy, Sxv)), det);
+            M[0] = a; M[1] = b; M[2] = __dsub_rn(__dsub_rn(mu, __dmul_rn(a, mx)), __dmul_rn(b, my));
+            M[3] = d; M[4] = e; M[5] = __dsub_rn(__dsub_rn(mv, __dmul_rn(d, mx)), __dmul_rn(e, my));
+        }
+        for (int k = 0; k < 6; k++) J.M[k] = M[k];
+        *J.status = 1;
+    }
+}
+
+static int g_ransac_force = 0;  // test hook: 1 = always the three-kernel path, 2 = the fused kernel whenever the problem fits it
+void vh_ransac_force_path(int mode) { g_ransac_force = mode; }
+
 void vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
-    (void)max_n;
+    // up to 16 streams in flight: one fused workgroup per stream (latency); above: hypotheses spread over the chip (throughput)
+    if (max_n <= RANSAC_FUSED_MAX && (g_ransac_force == 2 || (g_ransac_force == 0 && batch <= 16))) {
+        const size_t lds = (size_t)RANSAC_FUSED_MAX * (16 + 4) + (size_t)VH_RANSAC_ITERS * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ransac_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_ransac_fused, dim3(batch), dim3(512), lds, s, job_tab, tab_stride);
+        return;
+    }
     hipLaunchKernelGGL(k_ransac_compact, dim3(batch), dim3(1024), 0, s, job_tab, tab_stride);
     hipLaunchKernelGGL(k_ransac_score, dim3((VH_RANSAC_ITERS + 3) / 4, batch), dim3(256), 0, s, job_tab, tab_stride);
     hipLaunchKernelGGL(k_ransac_select, dim3(batch), dim3(256), 0, s, job_tab, tab_stride);

@@ -306,7 +306,7 @@ static int session_step(vh_session* s, const uint8_t* const* frames_dev, float t
     hipStream_t st = (hipStream_t)stream;
     vh_ctx* c = s->ctx;
     const int nb = s->batch;
-    int r = vh_run_klt_main(c, 0, nb, st, s->coarse, s->fine, s->d_ss, frames_dev);  // the set-up kernel also fetches this frame's KltIO from the session
+    int r = vh_run_klt_main(c, 0, nb, st, s->coarse, s->fine, s->d_ss, frames_dev, s->N0);  // the set-up kernel also fetches this frame's KltIO from the session
     if (r) return r;
     if (s->N0 <= 4096) {
         hipLaunchKernelGGL(k_sess_frame, dim3(nb), dim3(256), 0, st, s->d_ss, frames_dev, time_s, frame_no, times_dev, frame_nos_dev);

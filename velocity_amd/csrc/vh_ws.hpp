@@ -104,5 +104,5 @@ struct SessStream {  // device resident, one per video stream
 
 // runs KLTmain (KLT.py:99-134) for streams [slot, slot+count) whose KltIO has been written (host or device side)
 int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine,
-                    const SessStream* sess = nullptr, const uint8_t* const* frames = nullptr);
+                    const SessStream* sess = nullptr, const uint8_t* const* frames = nullptr, int n_max = 0);
 int vh_fail(int code, const char* msg);
