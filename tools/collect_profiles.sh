@@ -1,29 +1,84 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): bench line, stream sweep, rocprofv3 kernel stats and the two HBM-traffic PMC passes.
-# Usage: bash tools/collect_profiles.sh <streams> ; results under gpurun_out/prof/
+# Runs on the GPU box (via gpurun): bench line, stream sweep, rocprofv3 kernel stats, the HBM-traffic PMC passes, the SQ passes of the LK and BA
+# kernels, the single-stream launch timeline, the PCIe-inclusive rates and the VALU issue-rate micro-benchmark.
+# Usage: bash tools/collect_profiles.sh <streams> ; results under gpurun_out/prof/ ; then: python tools/summarize_profiles.py r02
 S=${1:-128}
 R=/root/repo
 OUT=$R/gpurun_out/prof
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --streams $S > $OUT/bench_default.json 2> $OUT/bench_default.err
 for s in 1 2 4 8 16 32 64 128 256; do
-  python $R/bench.py --streams $s --steps 60 --warmup 10 --cpu-seconds 0 --no-ba 2>/dev/null | tail -1 > $OUT/sweep_$s.json
+  python $R/bench.py --streams $s --steps 60 --warmup 10 --cpu-seconds 0 --no-ba --no-extras --min-seconds 1 2>/dev/null | tail -1 > $OUT/sweep_$s.json
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --streams $S --steps 40 --warmup 5 --cpu-seconds 0 --no-ba > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --streams $S --steps 40 --warmup 5 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/stats.log 2>&1
 find $OUT/stats -name "*kernel_trace.csv" -delete   # tens of MB; the per-kernel summary is what is kept
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_q|k_lk_strip|k_pyr_down|k_roi_warp' --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --streams $S --steps 6 --warmup 2 --cpu-seconds 0 --no-ba > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_q|k_lk_strip|k_pyr_down|k_roi_warp' --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --streams $S --steps 6 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/pmc_$c.log 2>&1
   find $OUT/pmc_$c -name "*kernel_trace.csv" -delete
 done
-# BA (C5): per-kernel stats of bench.bench_ba()
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ba -- python -c "
-import sys; sys.path.insert(0, '$R')
-import bench, json
-print(json.dumps(bench.bench_ba()))" > $OUT/ba.log 2>&1
+# SQ counters of the LK kernels (two passes of <= 8 counters)
+P1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU"
+P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_LDS"
+i=0
+for P in "$P1" "$P2"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_q' --pmc $P --output-format csv -d $OUT/sq_lk$i -- python $R/bench.py --streams $S --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/sq_lk$i.log 2>&1
+  find $OUT/sq_lk$i -name "*kernel_trace.csv" -delete
+done
+# BA (C5): per-kernel stats of bench.bench_ba() (1, 8 and 64 windows) + SQ / MFMA counters of its kernels
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ba -- python $R/bench.py --only-ba > $OUT/ba.log 2>&1
+python - <<PY
+import csv, glob, json
+f = glob.glob("$OUT/ba/**/*kernel_trace.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(("k_ba", "void k_ba"))]
+# per window count (grid z... the window index is grid.y): average duration per kernel
+acc = {}
+for r in rows:
+    nw = int(r["Grid_Size_Y"]) // max(int(r["Workgroup_Size_Y"]), 1)
+    k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    acc.setdefault(nw, {}).setdefault(k, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+json.dump({str(nw): {k: dict(launches=len(v), avg_us=round(sum(v) / len(v) / 1e3, 2)) for k, v in d.items()} for nw, d in sorted(acc.items())},
+          open("$OUT/ba_by_windows.json", "w"), indent=1)
+PY
 find $OUT/ba -name "*kernel_trace.csv" -delete
+PB1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU"
+PB2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES"
+i=0
+for P in "$PB1" "$PB2"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --kernel-include-regex 'k_ba_' --pmc $P --output-format csv -d $OUT/sq_ba$i -- python $R/bench.py --only-ba > $OUT/sq_ba$i.log 2>&1
+  python - <<PY
+import csv, glob, json
+f = glob.glob("$OUT/sq_ba$i/**/*kernel_trace.csv", recursive=True)
+dur = {}
+if f:
+    for r in csv.DictReader(open(f[0])):
+        dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_Y"]) // max(int(r["Workgroup_Size_Y"]), 1))
+json.dump(dur, open("$OUT/sq_ba${i}_dispatch.json", "w"))
+PY
+  find $OUT/sq_ba$i -name "*kernel_trace.csv" -delete
+done
+# single stream: launch timeline of one steady-state frame
+rocprofv3 --kernel-trace --output-format csv -d $OUT/s1 -- python $R/bench.py --streams 1 --steps 200 --warmup 20 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/s1.log 2>&1
+python - <<PY
+import csv, glob, json
+f = glob.glob("$OUT/s1/**/*kernel_trace.csv", recursive=True)[0]
+ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f)))
+idx = [i for i, k in enumerate(ks) if k[2].startswith("k_klt_setup")]
+a, b = idx[150], idx[151]
+t0 = ks[a][0]
+json.dump(dict(_comment="rocprofv3 --kernel-trace of python bench.py --streams 1: the launches of ONE steady-state frame step (start offset, duration; "
+                        "the tracer adds a few microseconds to every launch: bench.py reports the untraced step time)",
+               step_us=round((ks[b][0] - t0) / 1e3, 1),
+               launches=[dict(t_us=round((s - t0) / 1e3, 1), dur_us=round((e - s) / 1e3, 1), kernel=n.split("(")[0].replace("void ", "")) for s, e, n in ks[a:b]]),
+          open("$OUT/s1_timeline.json", "w"), indent=1)
+PY
+rm -rf $OUT/s1
 # PCIe-inclusive rate (frames uploaded from pinned host memory every step)
 for s in 1 8 64; do
-  python $R/bench.py --streams $s --steps 60 --warmup 10 --cpu-seconds 0 --no-ba --host-frames 2>/dev/null | tail -1 > $OUT/hostframes_$s.json
+  python $R/bench.py --streams $s --steps 60 --warmup 10 --cpu-seconds 0 --no-ba --no-extras --min-seconds 1 --host-frames 2>/dev/null | tail -1 > $OUT/hostframes_$s.json
 done
-du -sh $OUT; tail -2 $OUT/bench_default.err; ls -R $OUT | head -40
+# VALU issue rates per instruction class
+timeout 600 $R/tools/ubench/valu_rate > $OUT/valu_rate.json 2> $OUT/valu_rate.err
+du -sh $OUT; tail -2 $OUT/bench_default.err; ls $OUT | head -60

@@ -4,7 +4,8 @@
   rNN_stream_sweep.json         frames/s vs resident streams
   rNN_kernel_stats.csv          rocprofv3 --kernel-trace --stats summary of the same bench command (library kernels only)
   rNN_hbm_traffic.json          FETCH_SIZE / WRITE_SIZE per launch of the LK / pyrDown / remap kernels (separate PMC passes)
-Usage: python tools/summarize_profiles.py [round_tag]   (default r01)"""
+  rNN_ba_by_windows.json, rNN_ba_pmc.json, rNN_lk_sq_pmc.json, rNN_single_stream_timeline.json, rNN_valu_rate.json, rNN_host_frames.json
+Usage: python tools/summarize_profiles.py [round_tag]   (default r02)"""
 import csv
 import glob
 import json
@@ -14,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def newest(pattern):
@@ -63,11 +64,88 @@ for cname, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
         v = v[n // 4:]  # drop the warm-up quarter
         traffic.setdefault(k, {})[key] = round(sum(v) / len(v), 1)
         traffic[k]["launches"] = len(v)
-# VALU issue utilisation from the SQ passes (tools/pmc_lk.sh, profiles/rNN_lk_sq_pmc.md): kept across regenerations
-sq_path = os.path.join(DST, f"{tag}_lk_sq_util.json")
-if os.path.exists(sq_path):
-    traffic["sq_valu_issue_utilisation"] = json.load(open(sq_path))
+
+
+def pmc_table(dirname):
+    """counter_collection.csv of one rocprofv3 --pmc pass -> {kernel: {counter: [values per dispatch]}, ...} plus dispatch ids"""
+    out = {}
+    fs = glob.glob(os.path.join(SRC, dirname, "**", "*counter_collection.csv"), recursive=True)
+    if not fs:
+        return out
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
+        k = r["Kernel_Name"].replace("void ", "").split("(")[0]
+        out.setdefault(k, {}).setdefault(r["Counter_Name"], []).append((r.get("Dispatch_Id"), float(r["Counter_Value"])))
+    return out
+
+
+# SQ counters of the LK kernels: averages over the steady-state launches + derived issue utilisation
+lk_sq = {}
+for i in (1, 2):
+    for k, d in pmc_table(f"sq_lk{i}").items():
+        for c, v in d.items():
+            vals = [x[1] for x in v][len(v) // 2:]
+            lk_sq.setdefault(k, {})[c] = round(sum(vals) / len(vals))
+util = {}
+for k, d in lk_sq.items():
+    if d.get("SQ_BUSY_CYCLES") and d.get("SQ_ACTIVE_INST_VALU"):
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs of the chip; SQ_BUSY_CYCLES is per shader engine (x32) -> see r01_lk_sq_pmc.md
+        d["valu_cycles_per_inst"] = round(4.0 * d["SQ_ACTIVE_INST_VALU"] / max(d["SQ_INSTS_VALU"], 1), 3)
+if lk_sq:
+    json.dump(dict(_comment="rocprofv3 --pmc passes (<= 8 SQ counters each) of python bench.py --streams %d --steps 4: averages per launch over the "
+                            "steady-state launches.  valu_cycles_per_inst = 4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU" % S, kernels=lk_sq),
+              open(os.path.join(DST, f"{tag}_lk_sq_pmc.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(DST, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+
+# BA: per-window-count kernel times, SQ / MFMA counters of the 64-window launches
+for name in ("ba_by_windows.json", "s1_timeline.json"):
+    src = os.path.join(SRC, name)
+    if os.path.exists(src):
+        dst = {"ba_by_windows.json": f"{tag}_ba_by_windows.json", "s1_timeline.json": f"{tag}_single_stream_timeline.json"}[name]
+        json.dump(json.load(open(src)), open(os.path.join(DST, dst), "w"), indent=1)
+ba_pmc = {}
+for i in (1, 2):
+    dpath = os.path.join(SRC, f"sq_ba{i}_dispatch.json")
+    disp = json.load(open(dpath)) if os.path.exists(dpath) else {}
+    for k, d in pmc_table(f"sq_ba{i}").items():
+        for c, v in d.items():
+            # keep the launches of the largest window count (64)
+            nwmax = max((disp.get(x[0], (0, 1))[1] for x in v), default=1)
+            sel = [x for x in v if disp.get(x[0], (0, 1))[1] == nwmax] or v
+            ba_pmc.setdefault(k, {})[c] = round(sum(x[1] for x in sel) / len(sel))
+            ba_pmc[k]["windows"] = nwmax
+            durs = [disp[x[0]][0] for x in sel if x[0] in disp]
+            if durs:
+                ba_pmc[k]["avg_us"] = round(sum(durs) / len(durs) / 1e3, 1)
+if "k_ba_schur_mfma" in ba_pmc and ba_pmc["k_ba_schur_mfma"].get("SQ_VALU_MFMA_BUSY_CYCLES"):
+    d = ba_pmc["k_ba_schur_mfma"]
+    simd_cycles = d["avg_us"] * 1e-6 * 2.4e9 * 1024
+    d["mfma_busy_frac"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, 3)
+    d["note"] = "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 2.4 GHz x 1024 SIMDs); the time is the traced duration of the same PMC pass"
+if ba_pmc:
+    json.dump(dict(_comment="rocprofv3 --pmc passes of python bench.py --only-ba: averages per launch over the launches with the most windows",
+                   kernels=ba_pmc), open(os.path.join(DST, f"{tag}_ba_pmc.json"), "w"), indent=1)
+
+# VALU issue rates
+vr = os.path.join(SRC, "valu_rate.json")
+if os.path.exists(vr) and os.path.getsize(vr) > 100:
+    j = json.load(open(vr))
+    cls = {}
+    for r in j["results"]:
+        if r["chains"] == 16 and r["waves_per_simd"] == 4 and "cndmask" not in r["inst"]:
+            cls[r["inst"]] = r["lanes_per_ns_per_simd"]
+    full = {k: v for k, v in cls.items() if v > 48}
+    half = {k: v for k, v in cls.items() if v <= 48}
+    j["summary"] = dict(
+        clock_ghz_nominal=2.4,
+        full_rate_class=sorted(full), full_rate_lanes_per_ns_per_simd=round(sum(full.values()) / max(len(full), 1), 1),
+        half_rate_class=sorted(half), half_rate_lanes_per_ns_per_simd=round(sum(half.values()) / max(len(half), 1), 1),
+        int_valu_lanes_per_clk_per_simd=16.0,
+        conclusion="A wave64 instruction of the half-rate class (every integer multiply / dot / perm / shift-left / bit-field / packed-16 / DPP / "
+                   "3-operand integer op and v_fma_f64) occupies its SIMD for 4 cycles = 16 lanes/clk (sustained %.1f lanes/ns/SIMD = %.1f lanes/clk at "
+                   "2.4 GHz); only plain add / sub / and / ashr and the fp32 add / mul / fma issue in 2 cycles = 32 lanes/clk (sustained %.1f lanes/ns/SIMD).  "
+                   "The LK kernels are built from the half-rate class, so their VALU peak is 1024 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-instructions/s."
+                   % (sum(half.values()) / max(len(half), 1), sum(half.values()) / max(len(half), 1) / 2.4, sum(full.values()) / max(len(full), 1)))
+    json.dump(j, open(os.path.join(DST, f"{tag}_valu_rate.json"), "w"), indent=1)
 
 # BA per-kernel stats + the bench line of the profiled run
 ba_rows, ba_line = [], None
@@ -93,13 +171,15 @@ if host:
 lib = sum(float(r["TotalDurationNs"]) for r in keep if not r["Name"].startswith("k_sess_init"))
 steps = [int(r["Calls"]) for r in keep if "k_lk3" in r["Name"]][0]
 rf, cb = bench["roofline"], bench["cpu_baseline"]
+cb1 = bench.get("cpu_baseline_1core", {})
 kname = rf["kernel"].split(" (")[0]
 o = [f"# Round {tag[1:]} profiles (1x MI355X)\n",
      f"Regenerate: `gpurun -- bash tools/collect_profiles.sh {S}` then `python tools/summarize_profiles.py {tag}`.\n",
      f"## Default bench: C2 (1080p, 2000 tracks, 3 pyramid levels), {S} streams resident per GPU\n",
      f"`python bench.py` -> `profiles/{tag}_bench_default.json`: **{bench['value']:.0f} tracked frames/s** ({bench['ms_per_step']} ms per step of {S} "
-     f"frames), CPU port {cb['value']:.1f} frames/s on {cb['cores']} host cores ({bench['gpu_over_cpu']}x), BA {bench['ba']['iters_per_s']:.0f} LM iterations/s.\n",
-     f"`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --streams {S} --steps 40 --warmup 5 --cpu-seconds 0 --no-ba` -> "
+     f"frames), CPU port {cb['value']:.1f} frames/s on {cb['cores']} host cores ({bench['gpu_over_cpu']}x), {cb1.get('value', 0):.1f} frames/s on 1 core; "
+     f"BA {bench['ba']['iters_per_s']:.0f} LM iterations/s (one window), CPU {bench['ba'].get('cpu_baseline', {}).get('value', 0):.1f} it/s.\n",
+     f"`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --streams {S} --steps 40 --warmup 5 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0` -> "
      f"`profiles/{tag}_kernel_stats.csv`\n({steps} frame steps of {S} streams incl. warm-up; library kernels only, the `at::native::*` rows that render "
      "the synthetic frame rings before the timed region are dropped.)\n",
      "| kernel | calls | total ms | avg us | % of library time |\n|---|---|---|---|---|"]
@@ -117,7 +197,8 @@ o.append(f"Dominant kernel `{kname}` (fine LK stage): {float(k['AverageNs']) / 1
 o.append(f"HBM traffic of that kernel (`profiles/{tag}_hbm_traffic.json`, separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes at {traffic['streams']} streams, "
          f"FETCH_SIZE doubled per MI355X_MICROARCH.md): {(2 * kk['fetch_kib'] + kk['write_kib']) * 1024 / traffic['streams'] / 1e6:.1f} MB per stream and launch vs "
          f"22.05 MB algorithmic gather bytes; `roofline.achieved` = {rf['achieved']} GB/s of gather bytes ({100 * rf['frac']:.1f} % of 8 TB/s) - the kernel is VALU "
-         f"bound: {100 * rf['valu']['frac']:.0f} % of the 39.3 T lane-instruction/s integer VALU peak by the SURVEY op model, {100 * (rf['valu'].get('sq_valu_issue_utilisation') or 0):.0f} % VALU issue utilisation by the SQ counters (`profiles/{tag}_lk_sq_pmc.md`).\n")
+         f"bound: {100 * rf['valu']['frac']:.0f} % of the {rf['valu']['peak_tops']} T lane-instruction/s VALU peak of its (half-rate) instruction class by the SURVEY op model "
+         f"(`profiles/{tag}_valu_rate.json` settles the issue rates; SQ counters of the kernel in `profiles/{tag}_lk_sq_pmc.json`).\n")
 o.append(f"Throughput vs resident streams (`profiles/{tag}_stream_sweep.json`, 60 steps each): "
          + ", ".join(f"{s_} -> {v['frames_per_s'] / 1e3:.2f} k" for s_, v in sweep.items()) + " frames/s.\n")
 if host:
@@ -128,10 +209,12 @@ if ba_rows:
     o.append(f"`profiles/{tag}_ba_kernel_stats.csv` (rocprofv3 --stats of `bench.bench_ba()`): {ba_line['ms_per_iter']} ms per LM iteration = "
              f"{ba_line['iters_per_s']:.0f} iterations/s; per iteration: "
              + ", ".join(f"{r['Name'].split('(')[0].replace('void ', '')} {float(r['AverageNs']) / 1e3:.0f} us" for r in ba_rows) + ".")
-    pm = os.path.join(DST, "r01_ba_mfma_pmc.csv")
-    if os.path.exists(pm):
-        o.append("PMC of `k_ba_points_mfma` (`profiles/r01_ba_mfma_pmc.csv`): 240 000 `v_mfma_f64_16x16x4_f64` per launch = 2 * 114^2 * 15000 flop on 16x16x4 "
-                 "tiles (128-padded); SQ_VALU_MFMA_BUSY_CYCLES 15.36 M = 64 cycles per instruction; the 44 us kernel spans 108 M SIMD-cycles -> 14 % MFMA "
-                 "utilisation (latency-bound: 240 MFMAs per wavefront).")
+    if ba_line.get("by_windows"):
+        o.append("Batched windows (`vh_nls_batch_multi`): " + ", ".join(f"{k} windows {v['iters_per_s']:.0f} it/s ({1e3 * v['ms_per_window_iter']:.1f} us per window-iteration)"
+                                                                        for k, v in ba_line["by_windows"].items()) + f" (`profiles/{tag}_ba_by_windows.json`).")
+    if ba_pmc.get("k_ba_schur_mfma", {}).get("mfma_busy_frac"):
+        d = ba_pmc["k_ba_schur_mfma"]
+        o.append(f"PMC of `k_ba_schur_mfma` at {d['windows']} windows (`profiles/{tag}_ba_pmc.json`): SQ_VALU_MFMA_BUSY_CYCLES {d['SQ_VALU_MFMA_BUSY_CYCLES'] / 1e6:.1f} M over "
+                 f"{d['avg_us']} us x 1024 SIMDs -> {100 * d['mfma_busy_frac']:.0f} % MFMA busy (round 1: 14 % for one window).")
 open(os.path.join(DST, f"{tag}_summary.md"), "w").write("\n".join(o) + "\n")
 print("\n".join(o))
