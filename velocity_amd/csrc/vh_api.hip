@@ -846,7 +846,7 @@ extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const float* K_host, const d
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.force_valu = g_ba_force_valu;
     // fewer partial systems per window when many windows fill the chip anyway (the partials are reduced through HBM)
-    int parts = ba_parts(nt), cap = 512 / nwin < 32 ? 32 : 512 / nwin;
+    int parts = ba_parts(nt), cap = 512 / nwin < 16 ? 16 : 512 / nwin;
     P.nparts = nwin > 1 && parts > cap ? cap : parts;
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 0;
     P.nx_total = 3.0 * nt + 6.0 * nc; P.nz_total = 2.0 * nt * (nc + 1);

@@ -9,6 +9,7 @@
 // Everything stays on the device for all iterations (the convergence test only sets a device flag).
 #include "vh_ba.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 #define BA_FD 1e-6
 #define BA_THREADS 256
@@ -398,97 +399,113 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_prep(BaJob J)
     Lo[0] = l00; Lo[1] = l10; Lo[2] = l11; Lo[3] = l20; Lo[4] = l21; Lo[5] = l22;
 }
 
-// raw inputs of one wavefront's point of a group, as the lanes hold them (software pipeline: loaded one group ahead)
-struct BaRaw {
-    double jcs[4];       // camera-Jacobian words q = lane + 64 j < 12 nc of the point (staged to LDS for the diagonal blocks)
-    double Jp[2][6];     // point Jacobian of the camera of column q = lane + 64 h
-    double ju[2], jv[2]; // camera Jacobian entries (u row, v row) of column q
-    double ru[2], rv[2]; // residuals of that camera
-    double L[6], tp[3];  // wave-uniform: Cholesky factor of (U+I)^-1 and (U+I)^-1 gp of the point
+// ---- k_ba_schur_mfma: data flow --------------------------------------------------------------------------------------------------------
+// The inputs of one tie point ("raw record": its camera Jacobians Jc [nc][12], point Jacobians Jp [nc][6], residuals r [nc][2], L (6), tp (3);
+// 20 nc + 9 doubles) are fetched ONCE per lane-word (7 global loads per lane and point, no duplicate addresses), two groups ahead of their use,
+// and parked in LDS (double buffered).  A group = 4 points (one per wavefront).  Per group and wavefront, in ONE basic block:
+//     matrix cores : the 9 upper-triangle tiles of Z_g^T Z_g (3 K-slabs, 27 v_mfma_f64_16x16x4_f64) from the LDS copy of Z_g
+//     VALU / LDS   : Z_{g+1} = L^T W of the NEXT group from its raw record (-> the other Z buffer), the reduced right-hand side and the
+//                    thread-owned entries of the diagonal blocks V_c of the next group
+// so the vector work of a group hides behind the matrix-core time of the previous one, and there is exactly one workgroup barrier per group.
+#define BA_RAW_WORDS 7  // ceil((20 * 21 + 9) / 64): lane-words of a raw record for nc <= 21
+
+struct BaRawOff {                 // loop-invariant per lane: where its words of a raw record live in global memory
+    const double* base[BA_RAW_WORDS];
+    int stride[BA_RAW_WORDS];     // doubles per point (0: lane has no such word)
 };
 
-// per-lane element offsets of those inputs that do not change from group to group (camera / column dependent part); the point index is
-// wave-uniform, so a load address is (uniform base of the point) + (32-bit lane offset): no 64-bit vector address arithmetic in the loop
-struct BaLaneOff {
-    unsigned jc[4];   // 12 (c nt) + k            into Jc (+ 12 i)
-    unsigned jp[2];   // 6 (c+1) nt               into Jp (+ 6 i)
-    unsigned ju[2];   // 12 (c+1) nt + k          into Jc (+ 12 i); jv = + 6
-    unsigned r[2];    // 2 (c+1) nt               into r  (+ 2 i)
-};
-
-__device__ __forceinline__ void ba_lane_offsets(BaLaneOff& O, int nt, int nc, int nq, int lane)
+__device__ __forceinline__ void ba_raw_offsets(BaRawOff& O, const BaJob& J, int lane)
 {
+    const int nt = J.nt, nc = J.nc, nw = 20 * nc + 9;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int q = min(lane + 64 * j, 12 * nc - 1);  // clamped: out-of-range lanes load a valid word and mask the result
-        const int c = q / 12 + 1, k = q - (c - 1) * 12;
-        O.jc[j] = 12u * (unsigned)(c * nt) + (unsigned)k;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int q = min(lane + 64 * h, nq - 1);
-        const int c = q / 6, k = q - 6 * c;
-        O.jp[h] = 6u * (unsigned)((c + 1) * nt);
-        O.ju[h] = 12u * (unsigned)((c + 1) * nt) + (unsigned)k;
-        O.r[h] = 2u * (unsigned)((c + 1) * nt);
+    for (int j = 0; j < BA_RAW_WORDS; j++) {
+        const int w = min(lane + 64 * j, nw - 1);  // clamped: surplus lanes re-load the last word (never stored)
+        const double* b;
+        int st;
+        if (w < 12 * nc) { const int c = w / 12, k = w - 12 * c; b = J.Jc + 12 * (size_t)(c + 1) * nt + k; st = 12; }
+        else if (w < 18 * nc) { const int q = w - 12 * nc, c = q / 6, a = q - 6 * c; b = J.Jp + 6 * (size_t)(c + 1) * nt + a; st = 6; }
+        else if (w < 20 * nc) { const int q = w - 18 * nc, c = q >> 1, k = q & 1; b = J.r + 2 * (size_t)(c + 1) * nt + k; st = 2; }
+        else if (w < 20 * nc + 6) { b = J.Lc + (w - 20 * nc); st = 6; }
+        else { b = J.tp + (w - 20 * nc - 6); st = 3; }
+        O.base[j] = b;
+        O.stride[j] = st;
     }
 }
 
-// Branch-free (out-of-range points are CLAMPED to the chunk's last point, their results are masked where they are used): every load is
-// unconditional and the whole batch is in flight at once -- predicated loads made the compiler wait for memory inside each branch.
-__device__ __forceinline__ void ba_raw_load(BaRaw& R, const BaJob& J, const BaLaneOff& O, int i, int i_last)
+// the lane's words of the raw record of point min(i, i_last) (branch-free: unconditional loads, all in flight together)
+__device__ __forceinline__ void ba_raw_fetch(double (&R)[BA_RAW_WORDS], const BaRawOff& O, int i, int i_last)
 {
     i = min(i, i_last);
-    const double* __restrict__ pJc = J.Jc + 12 * (size_t)i;
-    const double* __restrict__ pJp = J.Jp + 6 * (size_t)i;
-    const double* __restrict__ pr = J.r + 2 * (size_t)i;
 #pragma unroll
-    for (int j = 0; j < 4; j++) R.jcs[j] = pJc[O.jc[j]];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-#pragma unroll
-        for (int a = 0; a < 6; a++) R.Jp[h][a] = pJp[O.jp[h] + a];
-        R.ju[h] = pJc[O.ju[h]];
-        R.jv[h] = pJc[O.ju[h] + 6];
-        R.ru[h] = pr[O.r[h]];
-        R.rv[h] = pr[O.r[h] + 1];
-    }
-    const double* Lp = J.Lc + 6 * (size_t)i;
-    const double* tq = J.tp + 3 * (size_t)i;
-#pragma unroll
-    for (int a = 0; a < 6; a++) R.L[a] = Lp[a];
-#pragma unroll
-    for (int a = 0; a < 3; a++) R.tp[a] = tq[a];
+    for (int j = 0; j < BA_RAW_WORDS; j++) R[j] = O.base[j][(size_t)O.stride[j] * i];
 }
 
-// One group of 4 points for wavefront W in ONE basic block, so the scheduler can fill the matrix-core time: the 3 K-slabs of the 9 upper-triangle tiles of this wavefront (tile row W: columns W..7, tile row 7-W:
-// columns 7-W..7), interleaved with the thread-owned entries of the diagonal blocks V_c (sum over the 4 points of Jc^T Jc, from LDS).
-template <int W>
-__device__ __forceinline__ void ba_group(double4v (&acc)[9], double (&accD)[3], const BaJob& J, const double* __restrict__ sZ,
-                                         const double* __restrict__ sJ, int tid)
+__device__ __forceinline__ void ba_raw_park(const double (&R)[BA_RAW_WORDS], double* __restrict__ rec, int lane, int nwords, bool live)
+{
+#pragma unroll
+    for (int j = 0; j < BA_RAW_WORDS; j++) {
+        const int w = lane + 64 * j;
+        if (w < nwords) rec[w] = live ? R[j] : 0.0;  // a dead point (past the chunk) is all zeros: it adds nothing anywhere
+    }
+}
+
+// per-lane LDS offsets (doubles, inside a raw record) of what the Z rows of column q = lane + 64 h need
+struct BaColOff {
+    int jp[2], ju[2], rr[2];
+    int da[3], db[3];  // diagonal-block entry e = tid + 256 k of this thread: offsets 12 c + ka, 12 c + kb inside a record (clamped)
+};
+
+// One group for wavefront W: matrix cores on Z of THIS group; Z, rhs and diagonal blocks of the NEXT group from its raw records.
+template <int W, bool MFMA_ON>
+__device__ __forceinline__ void ba_group(double4v (&acc)[9], double (&accD)[3], double (&accR)[2], const double* __restrict__ sZc, double* __restrict__ sZn,
+                                         const double* __restrict__ rawn /* [4][RAWW] */, int RAWW, const BaColOff& C, int nc, int nq, int tid, int wave, int dbg = 0)
 {
     constexpr int R1 = W, R2 = 7 - W, T0 = R1 < R2 ? R1 : R2;
-    const int lane = tid & 63, cc = lane & 15, nc = J.nc;
+    const int lane = tid & 63, cc = lane & 15;
+    const double* rec = rawn + wave * RAWW;
+    // ---- next group: L, tp (wave-uniform), then the two columns of this lane
+    const double* lt = rec + 20 * nc;
+    const double L0 = lt[0], L1 = lt[1], L2 = lt[2], L3 = lt[3], L4 = lt[4], L5 = lt[5], t0 = lt[6], t1 = lt[7], t2 = lt[8];
+    double zn[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    if (!(dbg & 2))
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const double* jp = rec + C.jp[h];
+        const double ju = rec[C.ju[h]], jv = rec[C.ju[h] + 6], ru = rec[C.rr[h]], rv = rec[C.rr[h] + 1];
+        const double w0 = jp[0] * ju + jp[3] * jv, w1 = jp[1] * ju + jp[4] * jv, w2 = jp[2] * ju + jp[5] * jv;
+        // L^T is upper triangular: rows (l00 l10 l20), (0 l11 l21), (0 0 l22); L is stored l00 l10 l11 l20 l21 l22
+        zn[h][0] = L0 * w0 + L1 * w1 + L3 * w2; zn[h][1] = L2 * w1 + L4 * w2; zn[h][2] = L5 * w2;
+        accR[h] += ju * ru + jv * rv - (w0 * t0 + w1 * t1 + w2 * t2);  // a dead point's record is zeros; lanes with q >= nq hold a duplicate that is never stored
+    }
+    // ---- this group: 3 K-slabs of the 9 upper-triangle tiles (tile row W: columns W..7, tile row 7-W: columns 7-W..7); the diagonal-block
+    // entries e = tid + 256 (k0 / 4) of the next group ride along, one per slab
 #pragma unroll
     for (int k0 = 0; k0 < 12; k0 += 4) {
         const int kr = k0 + (lane >> 4);
         double zf[8];
+        if (MFMA_ON && !(dbg & 1)) {
 #pragma unroll
-        for (int t = T0; t < 8; t++) zf[t] = sZ[kr * BA_NPAD + 16 * t + cc];
+            for (int t = T0; t < 8; t++) zf[t] = sZc[kr * BA_NPAD + 16 * t + cc];
 #pragma unroll
-        for (int t = R1; t < 8; t++) acc[t - R1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R1], zf[t], acc[t - R1], 0, 0, 0);
+            for (int t = R1; t < 8; t++) acc[t - R1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R1], zf[t], acc[t - R1], 0, 0, 0);
 #pragma unroll
-        for (int t = R2; t < 8; t++) acc[8 - R1 + t - R2] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R2], zf[t], acc[8 - R1 + t - R2], 0, 0, 0);
-        // diagonal-block entry e = tid + 256 (k0 / 4), clamped (the store at the end is guarded)
-        const int e = min(tid + BA_THREADS * (k0 >> 2), nc * 36 - 1);
-        const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
+            for (int t = R2; t < 8; t++) acc[8 - R1 + t - R2] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R2], zf[t], acc[8 - R1 + t - R2], 0, 0, 0);
+        }
         double v = 0.0;
+        if (!(dbg & 2))
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const double* jc = sJ + g * 12 * nc + 12 * c;
-            v += jc[ka] * jc[kb] + jc[6 + ka] * jc[6 + kb];
+            const double* ja = rawn + g * RAWW + C.da[k0 >> 2];
+            const double* jb = rawn + g * RAWW + C.db[k0 >> 2];
+            v += ja[0] * jb[0] + ja[6] * jb[6];
         }
         accD[k0 >> 2] += v;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int q = lane + 64 * h;  // < 128 = the row pitch: columns >= nq are written as zeros (no branch: the group stays ONE basic block)
+        const bool on = q < nq;
+        sZn[(3 * wave) * BA_NPAD + q] = on ? zn[h][0] : 0.0; sZn[(3 * wave + 1) * BA_NPAD + q] = on ? zn[h][1] : 0.0; sZn[(3 * wave + 2) * BA_NPAD + q] = on ? zn[h][2] : 0.0;
     }
 }
 
@@ -513,83 +530,82 @@ __device__ __forceinline__ void ba_syrk_store(const double4v (&acc)[9], double* 
         }
 }
 
-// workgroup barrier that orders LDS traffic only: outstanding GLOBAL loads (the prefetch of the next group) stay in flight across it
+// workgroup barrier that orders LDS traffic only: outstanding GLOBAL loads (the prefetch) stay in flight across it
 __device__ __forceinline__ void ba_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(BA_THREADS) void k_ba_schur_mfma(BaJob J)
+__global__ __launch_bounds__(BA_THREADS, 2) void k_ba_schur_mfma(BaJob J)
 {
     ba_select_window(J, blockIdx.y);
     if (*J.done) return;
     const int nt = J.nt, nc = J.nc, nq = 6 * nc, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int RAWW = 20 * nc + 10, nwords = 20 * nc + 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sZ = reinterpret_cast<double*>(smem);   // [2][12][128]
-    double* sJc = sZ + 2 * 12 * BA_NPAD;            // [2][4][nc][12]
-    double* sR = sJc + 2 * 4 * 12 * nc;             // [4][128] rhs partials of the four waves
+    double* sRaw = sZ + 2 * 12 * BA_NPAD;           // [2][4][RAWW] raw records
+    double* sR = sRaw + 2 * 4 * RAWW;               // [4][128] rhs partials of the four waves
     const int chunk = (nt + gridDim.x - 1) / gridDim.x;
     const int i0 = blockIdx.x * chunk, i1 = min(nt, i0 + chunk);
     const long long nent = (long long)nq * nq;
-
-    double4v acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++) acc[t] = double4v{0.0, 0.0, 0.0, 0.0};
-    double accD[3] = {0.0, 0.0, 0.0};  // diagonal-block entries owned by this thread: e = tid + 256 k < nc * 36
-    double accR[2] = {0.0, 0.0};       // rhs entries q = lane, lane + 64 of the points this WAVE handled
-    for (int q = tid; q < 2 * 12 * BA_NPAD; q += BA_THREADS) sZ[q] = 0.0;  // zero padding of both buffers (columns >= nq stay zero)
-    BaRaw cur;
     if (i0 >= i1) {  // the last workgroups of a launch can own no point (nt not a multiple of the chunk): their partials are zeros
         double* Sp0 = J.Spart + (size_t)blockIdx.x * ((size_t)nq * nq);
         for (long long e = tid; e < (long long)nq * nq; e += BA_THREADS) Sp0[e] = 0.0;
         if (tid < nq) J.Rpart[(size_t)blockIdx.x * nq + tid] = 0.0;
         return;
     }
-    BaLaneOff off;
-    ba_lane_offsets(off, nt, nc, nq, lane);
-    ba_raw_load(cur, J, off, i0 + wave, i1 - 1);
-    __syncthreads();
+    double4v acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) acc[t] = double4v{0.0, 0.0, 0.0, 0.0};
+    double accD[3] = {0.0, 0.0, 0.0};  // diagonal-block entries owned by this thread: e = tid + 256 k < nc * 36
+    double accR[2] = {0.0, 0.0};       // rhs entries q = lane, lane + 64 of the points this WAVE handled
+    for (int q = tid; q < 2 * 12 * BA_NPAD; q += BA_THREADS) sZ[q] = 0.0;  // zero padding of both buffers (columns >= nq stay zero)
 
+    BaRawOff off;
+    ba_raw_offsets(off, J, lane);
+    BaColOff col;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int q = min(lane + 64 * h, nq - 1), c = q / 6, k = q - 6 * c;  // clamped: columns >= nq compute garbage that is never stored
+        col.jp[h] = 12 * nc + 6 * c; col.ju[h] = 12 * c + k; col.rr[h] = 18 * nc + 2 * c;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int e = min(tid + BA_THREADS * k, nc * 36 - 1);  // clamped: the final store is guarded
+        const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
+        col.da[k] = 12 * c + ka; col.db[k] = 12 * c + kb;
+    }
+    const int i_last = i1 - 1;
+    // prologue: raw(0) -> LDS, then Z(0) / diagonal blocks / rhs of group 0 (ba_group without its matrix-core half)
+    double Ra[BA_RAW_WORDS], Rb[BA_RAW_WORDS];
+    ba_raw_fetch(Ra, off, i0 + wave, i_last);
+    ba_raw_fetch(Rb, off, i0 + 4 + wave, i_last);
+    ba_raw_park(Ra, sRaw + wave * RAWW, lane, nwords, i0 + wave < i1);
+    ba_raw_fetch(Ra, off, i0 + 8 + wave, i_last);
+    __syncthreads();
+    switch (wave) {
+    case 0: ba_group<0, false>(acc, accD, accR, sZ, sZ, sRaw, RAWW, col, nc, nq, tid, wave); break;
+    case 1: ba_group<1, false>(acc, accD, accR, sZ, sZ, sRaw, RAWW, col, nc, nq, tid, wave); break;
+    case 2: ba_group<2, false>(acc, accD, accR, sZ, sZ, sRaw, RAWW, col, nc, nq, tid, wave); break;
+    default: ba_group<3, false>(acc, accD, accR, sZ, sZ, sRaw, RAWW, col, nc, nq, tid, wave); break;
+    }
+    // steady state, group g: Rb = raw(g+1), Ra = raw(g+2) at the top; Z(g) lives in sZ[buf], raw(g) in sRaw[buf]
     int buf = 0;
     for (int ig = i0; ig < i1; ig += 4, buf ^= 1) {
-        const int i = ig + wave;  // this wave's point of the group
-        const bool live = i < i1;
-        double* Zb = sZ + buf * 12 * BA_NPAD;
-        double* Jb = sJc + buf * 4 * 12 * nc;
-        // camera Jacobians of the point -> LDS (the diagonal blocks need them from all four points)
+        if (!(J.dbg & 16)) ba_raw_park(Rb, sRaw + ((buf ^ 1) * 4 + wave) * RAWW, lane, nwords, ig + 4 + wave < i1);
+        if (!(J.dbg & 8)) ba_lds_barrier();  // Z(g) and raw(g+1) complete for every wave; the Z buffer of group g-1 is free (fully consumed)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int q = lane + 64 * j;
-            if (q < 12 * nc) Jb[wave * 12 * nc + q] = live ? cur.jcs[j] : 0.0;
-        }
-        // rows 3 wave .. 3 wave + 2 of the group's Z = L^T W
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int q = lane + 64 * h;
-            if (q < nq) {
-                const double ju = cur.ju[h], jv = cur.jv[h];
-                const double w0 = cur.Jp[h][0] * ju + cur.Jp[h][3] * jv, w1 = cur.Jp[h][1] * ju + cur.Jp[h][4] * jv, w2 = cur.Jp[h][2] * ju + cur.Jp[h][5] * jv;
-                // L^T is upper triangular: rows (l00 l10 l20), (0 l11 l21), (0 0 l22); L is stored l00 l10 l11 l20 l21 l22
-                double z0 = cur.L[0] * w0 + cur.L[1] * w1 + cur.L[3] * w2, z1 = cur.L[2] * w1 + cur.L[4] * w2, z2 = cur.L[5] * w2;
-                if (!live) { z0 = 0.0; z1 = 0.0; z2 = 0.0; }  // a clamped duplicate of the chunk's last point: contributes nothing
-                // (no global store in this loop: a store in flight next to the prefetch loads forces every wait to vmcnt(0) -- loads and
-                // stores retire out of order on one counter -- and put the L2 write latency on the critical path of every group; the
-                // back-substitution recomputes W_i dc from the Jacobians instead of reading a stored Z)
-                if (live) accR[h] += ju * cur.ru[h] + jv * cur.rv[h] - (w0 * cur.tp[0] + w1 * cur.tp[1] + w2 * cur.tp[2]);
-                Zb[(3 * wave) * BA_NPAD + q] = z0; Zb[(3 * wave + 1) * BA_NPAD + q] = z1; Zb[(3 * wave + 2) * BA_NPAD + q] = z2;
-            }
-        }
-        // the only barrier of a group: Z[buf] and Jc[buf] are complete; buffers buf ^ 1 are free (every wave has finished the previous
-        // group's reads before it arrived here)
-        ba_lds_barrier();
-        // next group's inputs, the matrix-core work and the diagonal blocks of this group (one basic block per wavefront specialisation)
-        // the next group's inputs are requested NOW (pinned here by the compiler barrier: the scheduler would otherwise sink the loads
-        // behind the matrix-core section, next to their first use) and arrive while this group runs on the matrix cores
-        ba_raw_load(cur, J, off, i + 4, i1 - 1);
-        asm volatile("" ::: "memory");
+        for (int j = 0; j < BA_RAW_WORDS; j++) Rb[j] = Ra[j];
+        if (!(J.dbg & 4)) ba_raw_fetch(Ra, off, ig + 12 + wave, i_last);  // raw(g+3): two groups of matrix-core time to arrive
+        asm volatile("" ::: "memory");  // pins the loads here (the scheduler would otherwise sink them next to their use)
+        const double* Zc = sZ + buf * 12 * BA_NPAD;
+        double* Zn = sZ + (buf ^ 1) * 12 * BA_NPAD;
+        const double* rawn = sRaw + (buf ^ 1) * 4 * RAWW;
+        if (!(J.dbg & 32))
         switch (wave) {
-        case 0: ba_group<0>(acc, accD, J, Zb, Jb, tid); break;
-        case 1: ba_group<1>(acc, accD, J, Zb, Jb, tid); break;
-        case 2: ba_group<2>(acc, accD, J, Zb, Jb, tid); break;
-        default: ba_group<3>(acc, accD, J, Zb, Jb, tid); break;
+        case 0: ba_group<0, true>(acc, accD, accR, Zc, Zn, rawn, RAWW, col, nc, nq, tid, wave, J.dbg); break;
+        case 1: ba_group<1, true>(acc, accD, accR, Zc, Zn, rawn, RAWW, col, nc, nq, tid, wave, J.dbg); break;
+        case 2: ba_group<2, true>(acc, accD, accR, Zc, Zn, rawn, RAWW, col, nc, nq, tid, wave, J.dbg); break;
+        default: ba_group<3, true>(acc, accD, accR, Zc, Zn, rawn, RAWW, col, nc, nq, tid, wave, J.dbg); break;
         }
     }
     __syncthreads();
@@ -612,8 +628,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_schur_mfma(BaJob J)
             const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
             // a 6x6 camera block can straddle two 16x16 tiles: entries with tile(row) > tile(col) are never read (k_ba_reduce mirrors the
             // upper triangle), so only the others are stored
-            const int row = 6 * c + ka, col = 6 * c + kb;
-            if ((row >> 4) <= (col >> 4)) Sp[(size_t)row * nq + col] += accD[k];
+            const int row = 6 * c + ka, col_ = 6 * c + kb;
+            if ((row >> 4) <= (col_ >> 4)) Sp[(size_t)row * nq + col_] += accD[k];
         }
     }
     if (tid < nq) J.Rpart[(size_t)blockIdx.x * nq + tid] = sR[tid] + sR[BA_NPAD + tid] + sR[2 * BA_NPAD + tid] + sR[3 * BA_NPAD + tid];
@@ -988,9 +1004,10 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     const long long nent = (long long)nq * nq;
     const int npass = (int)((nent + (long long)BA_THREADS * BA_EPT - 1) / ((long long)BA_THREADS * BA_EPT));
     const size_t lds = sizeof(double) * (size_t)(6 * nq + 12 * (nc + 1) + 16);
-    const size_t lds_mfma = sizeof(double) * (size_t)(24 * BA_NPAD + 2 * 48 * nc + 4 * BA_NPAD);
+    const size_t lds_mfma = sizeof(double) * (size_t)(24 * BA_NPAD + 2 * 4 * (20 * nc + 10) + 4 * BA_NPAD);
     const bool use_mfma = nq <= BA_NPAD && !P.force_valu && P.model == 0;  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
     J.zmode = use_mfma ? 1 : 0;
+    { const char* e = getenv("VH_BA_DBG"); J.dbg = e ? atoi(e) : 0; }
     const int nmeas = nt * (nc + 1);
     // one wavefront per point, grid-strided: every block ends with an atomic on one address, so keep the block count low
     const int upd_cap = J.nwin > 1 ? std::max(16, 1024 / J.nwin) : 256;

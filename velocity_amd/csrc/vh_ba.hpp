@@ -30,6 +30,7 @@ struct BaJob {  // passed by value to every BA kernel
     int nq;     // reduced unknowns: 6 nc (model 0) or nc + 5 (model 1)
     int model;  // 0: fcnNLS_batch (free cameras, NLS.py:186-250); 1: fcnNLS_batch2 (joint rotation + straight-line trajectory, NLS.py:253-328)
     int add_identity, count_cams, defer_finalize;
+    int dbg;    // experiment switches (VH_BA_DBG): 1 skip MFMA, 2 skip Z / diag VALU, 4 skip global fetch, 8 skip barrier
     int zmode;  // 1: Y holds Z = L^T W and Spart holds only the upper-triangle 16x16 tiles (k_ba_schur_mfma); 0: Y = (U+I)^-1 W, full Spart
     // batched independent windows (vh_nls_batch_multi): blockIdx.y selects the window; every pointer above is window 0's
     int nwin;
