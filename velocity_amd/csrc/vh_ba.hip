@@ -455,57 +455,59 @@ struct BaColOff {
     int da[3], db[3];  // diagonal-block entry e = tid + 256 k of this thread: offsets 12 c + ka, 12 c + kb inside a record (clamped)
 };
 
-// One group for wavefront W: matrix cores on Z of THIS group; Z, rhs and diagonal blocks of the NEXT group from its raw records.
-template <int W, bool MFMA_ON>
-__device__ __forceinline__ void ba_group(double4v (&acc)[9], double (&accD)[3], double (&accR)[2], const double* __restrict__ sZc, double* __restrict__ sZn,
-                                         const double* __restrict__ rawn /* [4][RAWW] */, int RAWW, const BaColOff& C, int nc, int nq, int tid, int wave, int dbg = 0)
+// consumer wavefront W (matrix cores): the 3 K-slabs of its 9 upper-triangle tiles (tile row W: columns W..7, tile row 7-W: columns 7-W..7)
+template <int W>
+__device__ __forceinline__ void ba_consume(double4v (&acc)[9], const double* __restrict__ sZc, int lane)
 {
     constexpr int R1 = W, R2 = 7 - W, T0 = R1 < R2 ? R1 : R2;
-    const int lane = tid & 63, cc = lane & 15;
-    const double* rec = rawn + wave * RAWW;
-    // ---- next group: L, tp (wave-uniform), then the two columns of this lane
-    const double* lt = rec + 20 * nc;
+    const int cc = lane & 15;
+#pragma unroll
+    for (int k0 = 0; k0 < 12; k0 += 4) {
+        const int kr = k0 + (lane >> 4);
+        double zf[8];
+#pragma unroll
+        for (int t = T0; t < 8; t++) zf[t] = sZc[kr * BA_NPAD + 16 * t + cc];
+#pragma unroll
+        for (int t = R1; t < 8; t++) acc[t - R1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R1], zf[t], acc[t - R1], 0, 0, 0);
+#pragma unroll
+        for (int t = R2; t < 8; t++) acc[8 - R1 + t - R2] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R2], zf[t], acc[8 - R1 + t - R2], 0, 0, 0);
+    }
+}
+
+// producer wavefront pw: Z rows 3 pw .. 3 pw + 2 of its point from the point's raw record (already parked in LDS by this very wavefront),
+// plus the point's share of the reduced right-hand side
+__device__ __forceinline__ void ba_produce_z(double (&accR)[2], double* __restrict__ sZn, const double* __restrict__ rec, const BaColOff& C, int nc, int nq,
+                                             int lane, int pw)
+{
+    const double* lt = rec + 20 * nc;  // L, tp: wave-uniform
     const double L0 = lt[0], L1 = lt[1], L2 = lt[2], L3 = lt[3], L4 = lt[4], L5 = lt[5], t0 = lt[6], t1 = lt[7], t2 = lt[8];
-    double zn[2][3] = {{0, 0, 0}, {0, 0, 0}};
-    if (!(dbg & 2))
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const double* jp = rec + C.jp[h];
         const double ju = rec[C.ju[h]], jv = rec[C.ju[h] + 6], ru = rec[C.rr[h]], rv = rec[C.rr[h] + 1];
         const double w0 = jp[0] * ju + jp[3] * jv, w1 = jp[1] * ju + jp[4] * jv, w2 = jp[2] * ju + jp[5] * jv;
         // L^T is upper triangular: rows (l00 l10 l20), (0 l11 l21), (0 0 l22); L is stored l00 l10 l11 l20 l21 l22
-        zn[h][0] = L0 * w0 + L1 * w1 + L3 * w2; zn[h][1] = L2 * w1 + L4 * w2; zn[h][2] = L5 * w2;
+        const double z0 = L0 * w0 + L1 * w1 + L3 * w2, z1 = L2 * w1 + L4 * w2, z2 = L5 * w2;
         accR[h] += ju * ru + jv * rv - (w0 * t0 + w1 * t1 + w2 * t2);  // a dead point's record is zeros; lanes with q >= nq hold a duplicate that is never stored
+        const int q = lane + 64 * h;  // < 128 = the row pitch: columns >= nq are written as zeros
+        const bool on = q < nq;
+        sZn[(3 * pw) * BA_NPAD + q] = on ? z0 : 0.0; sZn[(3 * pw + 1) * BA_NPAD + q] = on ? z1 : 0.0; sZn[(3 * pw + 2) * BA_NPAD + q] = on ? z2 : 0.0;
     }
-    // ---- this group: 3 K-slabs of the 9 upper-triangle tiles (tile row W: columns W..7, tile row 7-W: columns 7-W..7); the diagonal-block
-    // entries e = tid + 256 (k0 / 4) of the next group ride along, one per slab
+}
+
+// producer threads: their entries of the diagonal blocks V_c, summed over the 4 points of a group (records of all four producers)
+__device__ __forceinline__ void ba_produce_diag(double (&accD)[3], const double* __restrict__ raw4, int RAWW, const BaColOff& C)
+{
 #pragma unroll
-    for (int k0 = 0; k0 < 12; k0 += 4) {
-        const int kr = k0 + (lane >> 4);
-        double zf[8];
-        if (MFMA_ON && !(dbg & 1)) {
-#pragma unroll
-            for (int t = T0; t < 8; t++) zf[t] = sZc[kr * BA_NPAD + 16 * t + cc];
-#pragma unroll
-            for (int t = R1; t < 8; t++) acc[t - R1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R1], zf[t], acc[t - R1], 0, 0, 0);
-#pragma unroll
-            for (int t = R2; t < 8; t++) acc[8 - R1 + t - R2] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R2], zf[t], acc[8 - R1 + t - R2], 0, 0, 0);
-        }
+    for (int k = 0; k < 3; k++) {
         double v = 0.0;
-        if (!(dbg & 2))
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const double* ja = rawn + g * RAWW + C.da[k0 >> 2];
-            const double* jb = rawn + g * RAWW + C.db[k0 >> 2];
+            const double* ja = raw4 + g * RAWW + C.da[k];
+            const double* jb = raw4 + g * RAWW + C.db[k];
             v += ja[0] * jb[0] + ja[6] * jb[6];
         }
-        accD[k0 >> 2] += v;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int q = lane + 64 * h;  // < 128 = the row pitch: columns >= nq are written as zeros (no branch: the group stays ONE basic block)
-        const bool on = q < nq;
-        sZn[(3 * wave) * BA_NPAD + q] = on ? zn[h][0] : 0.0; sZn[(3 * wave + 1) * BA_NPAD + q] = on ? zn[h][1] : 0.0; sZn[(3 * wave + 2) * BA_NPAD + q] = on ? zn[h][2] : 0.0;
+        accD[k] += v;
     }
 }
 
@@ -533,106 +535,123 @@ __device__ __forceinline__ void ba_syrk_store(const double4v (&acc)[9], double* 
 // workgroup barrier that orders LDS traffic only: outstanding GLOBAL loads (the prefetch) stay in flight across it
 __device__ __forceinline__ void ba_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(BA_THREADS, 2) void k_ba_schur_mfma(BaJob J)
+// 8 wavefronts, specialised: wavefronts 0-3 CONSUME (matrix cores: 9 tiles each of Z_g^T Z_g), wavefronts 4-7 PRODUCE (fetch the raw records two
+// groups ahead, park them in LDS, turn them into Z_{g+1}, the reduced right-hand side and the diagonal blocks).  Every SIMD hosts one wavefront
+// of each kind, so its matrix pipe and its vector pipe are fed by different instruction streams and really run at the same time -- a single
+// wavefront issues in order and serialised the two (measured: MFMA, VALU and memory time simply added up).  One workgroup barrier per group.
+#define BA_SCHUR_THREADS 512
+__global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur_mfma(BaJob J)
 {
     ba_select_window(J, blockIdx.y);
     if (*J.done) return;
     const int nt = J.nt, nc = J.nc, nq = 6 * nc, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;
+    const int pw = wave & 3;           // point slot (producer) / tile-row pair (consumer)
+    const int ptid = tid & 255;        // thread index within its half
     const int RAWW = 20 * nc + 10, nwords = 20 * nc + 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sZ = reinterpret_cast<double*>(smem);   // [2][12][128]
     double* sRaw = sZ + 2 * 12 * BA_NPAD;           // [2][4][RAWW] raw records
-    double* sR = sRaw + 2 * 4 * RAWW;               // [4][128] rhs partials of the four waves
+    double* sR = sRaw + 2 * 4 * RAWW;               // [4][128] rhs partials of the four producer waves
     const int chunk = (nt + gridDim.x - 1) / gridDim.x;
     const int i0 = blockIdx.x * chunk, i1 = min(nt, i0 + chunk);
     const long long nent = (long long)nq * nq;
     if (i0 >= i1) {  // the last workgroups of a launch can own no point (nt not a multiple of the chunk): their partials are zeros
         double* Sp0 = J.Spart + (size_t)blockIdx.x * ((size_t)nq * nq);
-        for (long long e = tid; e < (long long)nq * nq; e += BA_THREADS) Sp0[e] = 0.0;
+        for (long long e = tid; e < (long long)nq * nq; e += BA_SCHUR_THREADS) Sp0[e] = 0.0;
         if (tid < nq) J.Rpart[(size_t)blockIdx.x * nq + tid] = 0.0;
         return;
     }
-    double4v acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++) acc[t] = double4v{0.0, 0.0, 0.0, 0.0};
-    double accD[3] = {0.0, 0.0, 0.0};  // diagonal-block entries owned by this thread: e = tid + 256 k < nc * 36
-    double accR[2] = {0.0, 0.0};       // rhs entries q = lane, lane + 64 of the points this WAVE handled
-    for (int q = tid; q < 2 * 12 * BA_NPAD; q += BA_THREADS) sZ[q] = 0.0;  // zero padding of both buffers (columns >= nq stay zero)
-
-    BaRawOff off;
-    ba_raw_offsets(off, J, lane);
-    BaColOff col;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int q = min(lane + 64 * h, nq - 1), c = q / 6, k = q - 6 * c;  // clamped: columns >= nq compute garbage that is never stored
-        col.jp[h] = 12 * nc + 6 * c; col.ju[h] = 12 * c + k; col.rr[h] = 18 * nc + 2 * c;
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int e = min(tid + BA_THREADS * k, nc * 36 - 1);  // clamped: the final store is guarded
-        const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
-        col.da[k] = 12 * c + ka; col.db[k] = 12 * c + kb;
-    }
+    for (int q = tid; q < 2 * 12 * BA_NPAD; q += BA_SCHUR_THREADS) sZ[q] = 0.0;  // zero padding of both buffers (columns >= nq stay zero)
     const int i_last = i1 - 1;
-    // prologue: raw(0) -> LDS, then Z(0) / diagonal blocks / rhs of group 0 (ba_group without its matrix-core half)
-    double Ra[BA_RAW_WORDS], Rb[BA_RAW_WORDS];
-    ba_raw_fetch(Ra, off, i0 + wave, i_last);
-    ba_raw_fetch(Rb, off, i0 + 4 + wave, i_last);
-    ba_raw_park(Ra, sRaw + wave * RAWW, lane, nwords, i0 + wave < i1);
-    ba_raw_fetch(Ra, off, i0 + 8 + wave, i_last);
-    __syncthreads();
-    switch (wave) {
-    case 0: ba_group<0, false>(acc, accD, accR, sZ, sZ, sRaw, RAWW, col, nc, nq, tid, wave); break;
-    case 1: ba_group<1, false>(acc, accD, accR, sZ, sZ, sRaw, RAWW, col, nc, nq, tid, wave); break;
-    case 2: ba_group<2, false>(acc, accD, accR, sZ, sZ, sRaw, RAWW, col, nc, nq, tid, wave); break;
-    default: ba_group<3, false>(acc, accD, accR, sZ, sZ, sRaw, RAWW, col, nc, nq, tid, wave); break;
-    }
-    // steady state, group g: Rb = raw(g+1), Ra = raw(g+2) at the top; Z(g) lives in sZ[buf], raw(g) in sRaw[buf]
-    int buf = 0;
-    for (int ig = i0; ig < i1; ig += 4, buf ^= 1) {
-        if (!(J.dbg & 16)) ba_raw_park(Rb, sRaw + ((buf ^ 1) * 4 + wave) * RAWW, lane, nwords, ig + 4 + wave < i1);
-        if (!(J.dbg & 8)) ba_lds_barrier();  // Z(g) and raw(g+1) complete for every wave; the Z buffer of group g-1 is free (fully consumed)
-#pragma unroll
-        for (int j = 0; j < BA_RAW_WORDS; j++) Rb[j] = Ra[j];
-        if (!(J.dbg & 4)) ba_raw_fetch(Ra, off, ig + 12 + wave, i_last);  // raw(g+3): two groups of matrix-core time to arrive
-        asm volatile("" ::: "memory");  // pins the loads here (the scheduler would otherwise sink them next to their use)
-        const double* Zc = sZ + buf * 12 * BA_NPAD;
-        double* Zn = sZ + (buf ^ 1) * 12 * BA_NPAD;
-        const double* rawn = sRaw + (buf ^ 1) * 4 * RAWW;
-        if (!(J.dbg & 32))
-        switch (wave) {
-        case 0: ba_group<0, true>(acc, accD, accR, Zc, Zn, rawn, RAWW, col, nc, nq, tid, wave, J.dbg); break;
-        case 1: ba_group<1, true>(acc, accD, accR, Zc, Zn, rawn, RAWW, col, nc, nq, tid, wave, J.dbg); break;
-        case 2: ba_group<2, true>(acc, accD, accR, Zc, Zn, rawn, RAWW, col, nc, nq, tid, wave, J.dbg); break;
-        default: ba_group<3, true>(acc, accD, accR, Zc, Zn, rawn, RAWW, col, nc, nq, tid, wave, J.dbg); break;
-        }
-    }
-    __syncthreads();
-    // write the partials: the upper-triangle tiles of -Z^T Z (+ diagonal blocks, added after the barrier), rhs partial
     double* Sp = J.Spart + (size_t)blockIdx.x * nent;
-    switch (wave) {
-    case 0: ba_syrk_store<0>(acc, Sp, lane, nq); break;
-    case 1: ba_syrk_store<1>(acc, Sp, lane, nq); break;
-    case 2: ba_syrk_store<2>(acc, Sp, lane, nq); break;
-    default: ba_syrk_store<3>(acc, Sp, lane, nq); break;
-    }
-    sR[wave * BA_NPAD + lane] = accR[0];
-    sR[wave * BA_NPAD + lane + 64] = accR[1];
-    __threadfence_block();
-    __syncthreads();
+
+    if (producer) {
+        double accD[3] = {0.0, 0.0, 0.0};  // diagonal-block entries e = ptid + 256 k < nc * 36
+        double accR[2] = {0.0, 0.0};       // rhs entries q = lane, lane + 64 of the points this wave handled
+        BaRawOff off;
+        ba_raw_offsets(off, J, lane);
+        BaColOff col;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int e = tid + BA_THREADS * k;
-        if (e < nc * 36) {
-            const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
-            // a 6x6 camera block can straddle two 16x16 tiles: entries with tile(row) > tile(col) are never read (k_ba_reduce mirrors the
-            // upper triangle), so only the others are stored
-            const int row = 6 * c + ka, col_ = 6 * c + kb;
-            if ((row >> 4) <= (col_ >> 4)) Sp[(size_t)row * nq + col_] += accD[k];
+        for (int h = 0; h < 2; h++) {
+            const int q = min(lane + 64 * h, nq - 1), c = q / 6, k = q - 6 * c;  // clamped: columns >= nq compute garbage that is stored as zeros
+            col.jp[h] = 12 * nc + 6 * c; col.ju[h] = 12 * c + k; col.rr[h] = 18 * nc + 2 * c;
         }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int e = min(ptid + 256 * k, nc * 36 - 1);  // clamped: the final store is guarded
+            const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
+            col.da[k] = 12 * c + ka; col.db[k] = 12 * c + kb;
+        }
+        // prologue: record and Z of group 0 (buffers 0)
+        double Ra[BA_RAW_WORDS], Rb[BA_RAW_WORDS];
+        ba_raw_fetch(Ra, off, i0 + pw, i_last);
+        ba_raw_fetch(Rb, off, i0 + 4 + pw, i_last);
+        __syncthreads();  // (A) sZ zero-fill complete
+        ba_raw_park(Ra, sRaw + pw * RAWW, lane, nwords, i0 + pw < i1);
+        ba_raw_fetch(Ra, off, i0 + 8 + pw, i_last);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own record is readable by this wave (LDS ops of a wave complete in order)
+        ba_produce_z(accR, sZ, sRaw + pw * RAWW, col, nc, nq, lane, pw);
+        ba_lds_barrier();  // (B) Z(0) and the records of group 0 complete
+        // steady state, iteration g (consumers run MFMA(g) meanwhile): Rb = raw(g+1), Ra = raw(g+2); raw(g) lives in sRaw[buf]
+        int buf = 0;
+        for (int ig = i0; ig < i1; ig += 4, buf ^= 1) {
+            double* recn = sRaw + ((buf ^ 1) * 4 + pw) * RAWW;
+            ba_raw_park(Rb, recn, lane, nwords, ig + 4 + pw < i1);
+#pragma unroll
+            for (int j = 0; j < BA_RAW_WORDS; j++) Rb[j] = Ra[j];
+            ba_raw_fetch(Ra, off, ig + 12 + pw, i_last);  // raw(g+3)
+            asm volatile("" ::: "memory");
+            ba_produce_diag(accD, sRaw + buf * 4 * RAWW, RAWW, col);  // group g: all four records are complete since the last barrier
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ba_produce_z(accR, sZ + (buf ^ 1) * 12 * BA_NPAD, recn, col, nc, nq, lane, pw);  // Z(g+1)
+            ba_lds_barrier();  // Z(g+1) and records g+1 complete; consumers are done with Z(g)
+        }
+        // epilogue: after the consumers stored their tiles, add the diagonal blocks and write the rhs partial
+        sR[pw * BA_NPAD + lane] = accR[0];
+        sR[pw * BA_NPAD + lane + 64] = accR[1];
+        __threadfence_block();
+        __syncthreads();  // (C)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int e = ptid + 256 * k;
+            if (e < nc * 36) {
+                const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
+                // a 6x6 camera block can straddle two 16x16 tiles: entries with tile(row) > tile(col) are never read (k_ba_reduce mirrors the
+                // upper triangle), so only the others are stored
+                const int row = 6 * c + ka, col_ = 6 * c + kb;
+                if ((row >> 4) <= (col_ >> 4)) Sp[(size_t)row * nq + col_] += accD[k];
+            }
+        }
+        if (ptid < nq) J.Rpart[(size_t)blockIdx.x * nq + ptid] = sR[ptid] + sR[BA_NPAD + ptid] + sR[2 * BA_NPAD + ptid] + sR[3 * BA_NPAD + ptid];
+    } else {
+        double4v acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) acc[t] = double4v{0.0, 0.0, 0.0, 0.0};
+        __syncthreads();   // (A)
+        ba_lds_barrier();  // (B)
+        int buf = 0;
+        for (int ig = i0; ig < i1; ig += 4, buf ^= 1) {
+            const double* Zc = sZ + buf * 12 * BA_NPAD;
+            switch (pw) {
+            case 0: ba_consume<0>(acc, Zc, lane); break;
+            case 1: ba_consume<1>(acc, Zc, lane); break;
+            case 2: ba_consume<2>(acc, Zc, lane); break;
+            default: ba_consume<3>(acc, Zc, lane); break;
+            }
+            ba_lds_barrier();
+        }
+        // the upper-triangle tiles of -Z^T Z
+        switch (pw) {
+        case 0: ba_syrk_store<0>(acc, Sp, lane, nq); break;
+        case 1: ba_syrk_store<1>(acc, Sp, lane, nq); break;
+        case 2: ba_syrk_store<2>(acc, Sp, lane, nq); break;
+        default: ba_syrk_store<3>(acc, Sp, lane, nq); break;
+        }
+        __threadfence_block();
+        __syncthreads();  // (C)
     }
-    if (tid < nq) J.Rpart[(size_t)blockIdx.x * nq + tid] = sR[tid] + sR[BA_NPAD + tid] + sR[2 * BA_NPAD + tid] + sR[3 * BA_NPAD + tid];
 }
 
 // Schur stage 2a: sum the per-workgroup partials into the augmented system and add +I.  A block handles 64 consecutive
@@ -1022,7 +1041,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         hipLaunchKernelGGL(k_ba_jac, dim3((nmeas + BA_THREADS - 1) / BA_THREADS, nw), dim3(BA_THREADS), 0, s, J);
         if (use_mfma) {
             hipLaunchKernelGGL(k_ba_prep, dim3((nt + BA_THREADS - 1) / BA_THREADS, nw), dim3(BA_THREADS), 0, s, J);
-            hipLaunchKernelGGL(k_ba_schur_mfma, dim3(nparts, nw), dim3(BA_THREADS), lds_mfma, s, J);
+            hipLaunchKernelGGL(k_ba_schur_mfma, dim3(nparts, nw), dim3(BA_SCHUR_THREADS), lds_mfma, s, J);
         } else {
             for (int pass = 0; pass < npass; pass++)  // later passes overwrite Spart entries of their own range only
                 hipLaunchKernelGGL(k_ba_points, dim3(nparts, nw), dim3(BA_THREADS), lds, s, J, pass);
