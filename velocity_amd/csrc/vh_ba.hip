@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
 #pragma unroll
     for (int k = 0; k < 20; k++) o[k] = 0.0;
     if (m < nt * nf) {
-        const int c = m / nt, i = m - c * nt;
+        const int i = m / nf, c = m - i * nf;  // POINT-major measurement index m = i (nc+1) + c: a point's Jacobians are contiguous
         double K[9];
         for (int k = 0; k < 9; k++) K[k] = J.K[k];
         double w[3] = {J.x[3 * i], J.x[3 * i + 1], J.x[3 * i + 2]};
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
             const double* off = J.camR + 36 + 12 * (size_t)c;
             double u, v, uk, vk;
             ba_project(K, R0, w, off, u, v);
-            const double ru = J.z[m] - u, rv = J.z[(size_t)nt * nf + m] - v;
+            const size_t mz = (size_t)c * nt + i;  // z stays in the reference's order: [all u | all v], camera-major (NLS.py:198-199)
+            const double ru = J.z[mz] - u, rv = J.z[(size_t)nt * nf + mz] - v;
             o[0] = ru; o[1] = rv;
             ss = ru * ru + rv * rv;
             for (int k = 0; k < 3; k++) {
@@ -158,7 +159,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
             if (c > 0) for (int k = 0; k < 3; k++) t[k] = J.x[3 * nt + 3 * (c - 1) + k];
             double u, v, uk, vk;
             ba_project(K, R, w, t, u, v);
-            const double ru = J.z[m] - u, rv = J.z[(size_t)nt * nf + m] - v;  // z = [all u | all v], camera-major (NLS.py:198-199)
+            const size_t mz = (size_t)c * nt + i;  // z = [all u | all v], camera-major (NLS.py:198-199)
+            const double ru = J.z[mz] - u, rv = J.z[(size_t)nt * nf + mz] - v;
             o[0] = ru; o[1] = rv;
             ss = ru * ru + rv * rv;
             for (int k = 0; k < 3; k++) {  // point coordinates
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
         if (tid == 0) {
             double U[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, gp[3] = {0, 0, 0};  // +I damping (NLS.py:220)
             for (int c = 0; c <= nc; c++) {
-                const size_t m = (size_t)c * nt + i;
+                const size_t m = (size_t)i * (nc + 1) + c;
                 const double* Jp = J.Jp + 6 * m;
                 const double ru = J.r[2 * m], rv = J.r[2 * m + 1];
                 for (int a = 0; a < 3; a++) {
@@ -276,12 +278,12 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
         if (J.model == 1) {
             for (int q = tid; q < 12 * (nc + 1); q += BA_THREADS) {
                 const int c = q / 12, k = q - c * 12;
-                sJc[q] = J.Jc[12 * ((size_t)c * nt + i) + k];
+                sJc[q] = J.Jc[12 * ((size_t)i * (nc + 1) + c) + k];
             }
         } else {
             for (int q = tid; q < 12 * nc; q += BA_THREADS) {
                 const int c = q / 12 + 1, k = q - (c - 1) * 12;
-                sJc[q] = J.Jc[12 * ((size_t)c * nt + i) + k];
+                sJc[q] = J.Jc[12 * ((size_t)i * (nc + 1) + c) + k];
             }
         }
         __syncthreads();
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
                 // column q < 5 (joint rpy, el, az) collects every camera, column q >= 5 is the range of camera q - 4
                 const int c_lo = q < 5 ? 0 : q - 4, c_hi = q < 5 ? nc : q - 4, k = q < 5 ? q : 5;
                 for (int c = c_lo; c <= c_hi; c++) {
-                    const size_t m = (size_t)c * nt + i;
+                    const size_t m = (size_t)i * (nc + 1) + c;
                     const double* Jp = J.Jp + 6 * m;
                     const double ju = sJc[12 * c + k], jv = sJc[12 * c + 6 + k];
                     w0 += Jp[0] * ju + Jp[3] * jv; w1 += Jp[1] * ju + Jp[4] * jv; w2 += Jp[2] * ju + Jp[5] * jv;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
                 }
             } else {
                 const int c = q / 6, k = q - 6 * c;  // camera c+1, parameter k (0..2 pos, 3..5 rpy)
-                const size_t m = (size_t)(c + 1) * nt + i;
+                const size_t m = (size_t)i * (nc + 1) + (c + 1);
                 const double* Jp = J.Jp + 6 * m;
                 const double ju = sJc[12 * c + k], jv = sJc[12 * c + 6 + k];
                 w0 = Jp[0] * ju + Jp[3] * jv; w1 = Jp[1] * ju + Jp[4] * jv; w2 = Jp[2] * ju + Jp[5] * jv;
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_prep(BaJob J)
     double u0 = 1.0, u1 = 0.0, u2 = 0.0, u3 = 1.0, u4 = 0.0, u5 = 1.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;  // +I damping (NLS.py:220)
 #pragma unroll 4
     for (int c = 0; c <= nc; c++) {
-        const size_t m = (size_t)c * nt + i;
+        const size_t m = (size_t)i * (nc + 1) + c;
         const double* Jp = J.Jp + 6 * m;
         const double a0 = Jp[0], a1 = Jp[1], a2 = Jp[2], b0 = Jp[3], b1 = Jp[4], b2 = Jp[5], ru = J.r[2 * m], rv = J.r[2 * m + 1];
         u0 += a0 * a0 + b0 * b0; u1 += a0 * a1 + b0 * b1; u2 += a0 * a2 + b0 * b2;
@@ -422,9 +424,10 @@ __device__ __forceinline__ void ba_raw_offsets(BaRawOff& O, const BaJob& J, int 
         const int w = min(lane + 64 * j, nw - 1);  // clamped: surplus lanes re-load the last word (never stored)
         const double* b;
         int st;
-        if (w < 12 * nc) { const int c = w / 12, k = w - 12 * c; b = J.Jc + 12 * (size_t)(c + 1) * nt + k; st = 12; }
-        else if (w < 18 * nc) { const int q = w - 12 * nc, c = q / 6, a = q - 6 * c; b = J.Jp + 6 * (size_t)(c + 1) * nt + a; st = 6; }
-        else if (w < 20 * nc) { const int q = w - 18 * nc, c = q >> 1, k = q & 1; b = J.r + 2 * (size_t)(c + 1) * nt + k; st = 2; }
+        // point-major arrays: the words of cameras 1..nc of one point are CONTIGUOUS (camera 0 comes first and is skipped): fully coalesced loads
+        if (w < 12 * nc) { b = J.Jc + 12 + w; st = 12 * (nc + 1); }
+        else if (w < 18 * nc) { b = J.Jp + 6 + (w - 12 * nc); st = 6 * (nc + 1); }
+        else if (w < 20 * nc) { b = J.r + 2 + (w - 18 * nc); st = 2 * (nc + 1); }
         else if (w < 20 * nc + 6) { b = J.Lc + (w - 20 * nc); st = 6; }
         else { b = J.tp + (w - 20 * nc - 6); st = 3; }
         O.base[j] = b;
@@ -598,15 +601,15 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur_mfma(BaJob J)
         int buf = 0;
         for (int ig = i0; ig < i1; ig += 4, buf ^= 1) {
             double* recn = sRaw + ((buf ^ 1) * 4 + pw) * RAWW;
-            ba_raw_park(Rb, recn, lane, nwords, ig + 4 + pw < i1);
+            if (!(J.dbg & 16)) ba_raw_park(Rb, recn, lane, nwords, ig + 4 + pw < i1);
 #pragma unroll
             for (int j = 0; j < BA_RAW_WORDS; j++) Rb[j] = Ra[j];
-            ba_raw_fetch(Ra, off, ig + 12 + pw, i_last);  // raw(g+3)
+            if (!(J.dbg & 4)) ba_raw_fetch(Ra, off, ig + 12 + pw, i_last);  // raw(g+3): two groups ahead (three measured no different)
             asm volatile("" ::: "memory");
-            ba_produce_diag(accD, sRaw + buf * 4 * RAWW, RAWW, col);  // group g: all four records are complete since the last barrier
+            if (!(J.dbg & 2)) ba_produce_diag(accD, sRaw + buf * 4 * RAWW, RAWW, col);  // group g: all four records are complete since the last barrier
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            ba_produce_z(accR, sZ + (buf ^ 1) * 12 * BA_NPAD, recn, col, nc, nq, lane, pw);  // Z(g+1)
-            ba_lds_barrier();  // Z(g+1) and records g+1 complete; consumers are done with Z(g)
+            if (!(J.dbg & 32)) ba_produce_z(accR, sZ + (buf ^ 1) * 12 * BA_NPAD, recn, col, nc, nq, lane, pw);  // Z(g+1)
+            if (!(J.dbg & 8)) ba_lds_barrier();  // Z(g+1) and records g+1 complete; consumers are done with Z(g)
         }
         // epilogue: after the consumers stored their tiles, add the diagonal blocks and write the rhs partial
         sR[pw * BA_NPAD + lane] = accR[0];
@@ -634,13 +637,14 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur_mfma(BaJob J)
         int buf = 0;
         for (int ig = i0; ig < i1; ig += 4, buf ^= 1) {
             const double* Zc = sZ + buf * 12 * BA_NPAD;
+            if (!(J.dbg & 1))
             switch (pw) {
             case 0: ba_consume<0>(acc, Zc, lane); break;
             case 1: ba_consume<1>(acc, Zc, lane); break;
             case 2: ba_consume<2>(acc, Zc, lane); break;
             default: ba_consume<3>(acc, Zc, lane); break;
             }
-            ba_lds_barrier();
+            if (!(J.dbg & 8)) ba_lds_barrier();
         }
         // the upper-triangle tiles of -Z^T Z
         switch (pw) {
@@ -852,7 +856,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
             const int i = min(p4 >> 2, nt - 1), sub = p4 & 3;
             double e0 = 0.0, e1 = 0.0, e2 = 0.0;
             for (int c = 1 + sub; c <= nc; c += 4) {
-                const size_t m = (size_t)c * nt + i;
+                const size_t m = (size_t)i * (nc + 1) + c;
                 const double* Jc = J.Jc + 12 * m;
                 const double* Jp = J.Jp + 6 * m;
                 const double* dq = s_par + 6 * (c - 1);
