@@ -120,6 +120,8 @@ VH_API int vh_world2image(vh_ctx* ctx, const double* C_host, const double* pw, i
 VH_API int vh_image2world(vh_ctx* ctx, const double* Hi_host, const double* p, int n, double* out, void* stream);
 /* pixel2uvec(K, p), utils/common.py:122-126.  out n x 3 */
 VH_API int vh_pixel2uvec(vh_ctx* ctx, double cx, double cy, double f, const double* p, int n, double* out, void* stream);
+/* the same when K and p are float32 on the caller's side: numpy then computes (and returns) float32.  p n x 2, out n x 3 float32 */
+VH_API int vh_pixel2uvec_f32(vh_ctx* ctx, float cx, float cy, float f, const float* p, int n, float* out, void* stream);
 
 /* ---- triangulation (K15, K16) ---------------------------------------------------------------------------------- */
 /* fcn2vintercept(A, U), utils/MSV.py:98-142.  A [nf,3], U [3,nf,nv], out [nv,3] (all device, float64) */

@@ -450,7 +450,7 @@ def ba_compact_jacobian(x, K, nc, nt):
     return uv, Jp, Jc
 
 
-def ba_schur_step(x, z, K, nc, nt, gain=0.9):
+def ba_schur_step(x, z, K, nc, nt, gain=0.9, bad=None):
     """One LM step of fcnNLS_batch: delta = inv(J^T J + I) J^T (z - zhat) * gain (NLS.py:235), computed through
         H = [[U W],[W^T V]] + I,  S = V + I - W^T (U+I)^-1 W,  S dc = gc - W^T (U+I)^-1 gp,  dp = (U+I)^-1 (gp - W dc)
     with 3x3 point blocks U_i and 6x6 camera blocks V_c -- algebraically the dense inverse.  Returns (delta, rms residual)."""
@@ -459,6 +459,14 @@ def ba_schur_step(x, z, K, nc, nt, gain=0.9):
     zu = z[: nf * nt].reshape(nf, nt)
     zv = z[nf * nt :].reshape(nf, nt)
     r = np.stack([zu - uv[..., 0], zv - uv[..., 1]], -1)  # [nf, nt, 2]
+    if bad is not None and bad.any():
+        # measurements without an observation (NaN in P[0:2]) take no part: zero residual and zero Jacobian rows.  The reference zeroes z and zhat
+        # there (NLS.py:200-201,225) but its forward differences keep f(x + dx e_j) - 0 (rows of ~1e9): resolved by intent, see vh_ba.hip::k_ba_jac
+        mb = (bad[: nf * nt] | bad[nf * nt :]).reshape(nf, nt)
+        r[mb] = 0.0
+        Jp = Jp.copy(); Jc = Jc.copy()
+        Jp[mb] = 0.0
+        Jc[mb] = 0.0
     U = np.einsum("cima,cimb->iab", Jp, Jp) + np.eye(3)
     gp = np.einsum("cima,cim->ia", Jp, r)
     Ui = np.linalg.inv(U)
@@ -484,8 +492,7 @@ def nls_batch_schur(K, P, pw, cw, max_iter=10, return_info=False):
     to the reference's own run) in tests/test_oracle_nls.py."""
     K = np.asarray(K).astype(float)
     z, bad, x, nt, nc = ba_pack(K, np.asarray(P), np.asarray(pw, float), np.asarray(cw, float))
-    assert not bad.any(), "full-length tracks only (NLS.py:190); NaN measurements are the dense oracle's business"
-    x, trace = ba_schur_solve(K, z, x, nt, nc, max_iter)
+    x, trace = ba_schur_solve(K, z, x, nt, nc, max_iter, bad=bad)
     j = nt * 3
     pw_out = x[:j].reshape(nt, 3)
     cw_out = np.concatenate((np.zeros((1, 3)), x[j : j + nc * 3].reshape(nc, 3)), 0)
@@ -494,12 +501,12 @@ def nls_batch_schur(K, P, pw, cw, max_iter=10, return_info=False):
     return cw_out, pw_out
 
 
-def ba_schur_solve(K, z, x, nt, nc, max_iter=10):
+def ba_schur_solve(K, z, x, nt, nc, max_iter=10, bad=None):
     """LM loop on an already packed problem (z, x as vh_nls_batch takes them).  Returns (x, trace [(rms residual, rms delta)])."""
     x = np.asarray(x, float).copy()
     trace = []
     for _ in range(max_iter):
-        delta, f = ba_schur_step(x, z, K, nc, nt)
+        delta, f = ba_schur_step(x, z, K, nc, nt, bad=bad)
         x = x + delta
         trace.append((f, rms(delta)))
         if rms(delta) < 1e-7:

@@ -288,3 +288,65 @@ def test_nls_batch_windows_equal_single_calls(golden, capsys):
     capsys.readouterr()
     with pytest.raises(ValueError):
         fcnNLS_batch_windows(K32, [scenes[0][0], synth.ba_scene(40, 8)[0]], [scenes[0][1], synth.ba_scene(40, 8)[1]], [scenes[0][2], synth.ba_scene(40, 8)[2]])
+
+
+def test_nls_batch_ignores_measurements_without_an_observation(golden, capsys):
+    """P[0:2] NaN where P[4] is finite (a track that passed NLS.py:190's filter but has a hole): the measurement takes no part -- zero residual,
+    zero Jacobian rows -- on the device and in the structured oracle alike (the reference leaves ~1e9 forward-difference rows there: a defect,
+    resolved by intent).  Both device paths (matrix cores / VALU)."""
+    from velocity_amd import _lib as L
+    from velocity_amd.NLS import fcnNLS_batch
+
+    tag = "ba_50_6"
+    P = golden[f"{tag}_P"].copy()
+    holes = [(3, 1), (17, 4), (17, 5), (40, 2), (49, 0)]
+    for i, f in holes:
+        P[0:2, i, f] = np.nan
+    args = (golden["K32"], P, golden[f"{tag}_pw0"], golden[f"{tag}_cw0"])
+    ecw, epw, ex, etr = O.nls_batch_schur(*[a.copy() if hasattr(a, "copy") else a for a in args], return_info=True)
+    for force_valu in (0, 1):
+        L.load().vh_debug_ba_force_valu(force_valu)
+        try:
+            cw, pw, x, tr = fcnNLS_batch(args[0], P.copy(), args[2], args[3], return_info=True)
+        finally:
+            L.load().vh_debug_ba_force_valu(0)
+        assert np.all(np.isfinite(x)) and len(tr) == len(etr)
+        close(tr[:, 0], etr[:, 0], 1e-7)
+        close(x, ex, 1e-6, 1e-8)
+    capsys.readouterr()
+
+
+def test_pixel2uvec_keeps_float32_like_numpy(golden):
+    """common.pixel2uvec: float32 K and p -> float32 result computed in float32 (what numpy does in the reference, common.py:122-126);
+    anything else -> float64."""
+    from velocity_amd import common
+
+    rng = np.random.default_rng(3)
+    K32 = golden["K32"]
+    p32 = rng.uniform([0, 0], [1920, 1080], (500, 2)).astype(np.float32)
+    out = common.pixel2uvec(K32, p32)
+    ref = O.pixel_to_uvec(K32, p32)
+    assert out.dtype == np.float32 and ref.dtype == np.float32
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1.2e-7)  # float32 ulp of values <= 1 (numpy's pairwise sum of 3 squares may round differently)
+    out64 = common.pixel2uvec(K32.astype(float), p32.astype(float))
+    assert out64.dtype == np.float64
+    np.testing.assert_allclose(out64, O.pixel_to_uvec(K32.astype(float), p32.astype(float)), rtol=1e-14)
+
+
+def test_bad_arguments_are_rejected():
+    """max_level < 0, images smaller than 4 x 4 and row strides below the width are errors, not silent no-ops."""
+    import ctypes as C
+
+    import torch
+
+    from velocity_amd import _lib as L
+
+    ws = L.workspace()
+    im = torch.zeros((64, 64), dtype=torch.uint8, device="cuda")
+    p = torch.zeros((4, 2), dtype=torch.float32, device="cuda")
+    out = torch.zeros((4, 2), dtype=torch.float32, device="cuda")
+    v = torch.zeros(4, dtype=torch.uint8, device="cuda")
+    for lk, w, h, s1 in ((L.LKParams(15, -1, 10, 0.1), 64, 64, 64), (L.LKParams(15, 2, 10, 0.1), 3, 64, 64), (L.LKParams(15, 2, 10, 0.1), 64, 64, 32)):
+        rc = ws.lib.vh_pyr_lk(ws.handle, L.dptr(im), L.dptr(im), w, h, s1, 64, L.dptr(p), 4, C.byref(lk), C.c_float(-1.0), L.dptr(out), L.dptr(v), None, None,
+                              L.stream_ptr())
+        assert rc != 0 and b"vh_pyr_lk" in ws.lib.vh_last_error()

@@ -139,3 +139,100 @@ def test_session_survives_total_track_loss():
         assert st["n_cur"] == 0 and st["n_pose"] == 0
         assert not st["vg"].any() and st["p"].shape == (0, 2)
         assert np.all(np.isfinite(st["t"])) and np.isfinite(st["res"])
+
+
+def test_streams_started_at_different_times_keep_their_own_clock_and_msv_frame():
+    """Two streams in one session; stream 1 is RE-INITIALISED with a new clip after 3 steps and gets its own timestamps.  Each stream must equal
+    its own reference loop: fcnMSV1_t fires at frame 5 OF EACH CLIP (vidExample.py:155), dt / time / speed come from the stream's own clock."""
+    import torch
+
+    from velocity_amd.driver import TrackerSession
+
+    W, H, n0, nfr = 480, 270, 220, 8
+    t0 = np.float32([1.5, 0.45, 3.6])
+    A = _scene(W, H, n0, nfr + 3, 555)     # stream 0: runs nfr + 2 steps
+    B1 = _scene(W, H, n0, 4, 777)          # stream 1, first clip (3 steps)
+    B2 = _scene(W, H, n0, nfr, 999)        # stream 1, second clip, started at global step 3
+    ses = TrackerSession(A[4], W, H, n0, nhist=nfr + 3, batch=2, msv_frame=5)
+    ses.init_stream(0, A[0][0], A[1], A[2], A[3], t0, time0=0.0)
+    ses.init_stream(1, B1[0][0], B1[1], B1[2], B1[3], t0, time0=10.0)
+    oA = SessionOracle(A[4], A[0][0], A[1], A[2], A[3], t0, time0=0.0, nhist=nfr + 3, msv_frame=5)
+    oB = SessionOracle(B1[4], B1[0][0], B1[1], B1[2], B1[3], t0, time0=10.0, nhist=nfr + 3, msv_frame=5)
+    kB, clipB = 0, B1
+    for g in range(1, nfr + 2):
+        if g == 4:  # new clip in slot 1
+            ses.init_stream(1, B2[0][0], B2[1], B2[2], B2[3], t0, time0=20.0)
+            oB = SessionOracle(B2[4], B2[0][0], B2[1], B2[2], B2[3], t0, time0=20.0, nhist=nfr + 3, msv_frame=5)
+            kB, clipB = 0, B2
+        kB += 1
+        tA, tB = np.float32(g / 29.97), np.float32((20.0 if clipB is B2 else 10.0) + kB / 25.0)
+        ses.step([torch.from_numpy(A[0][g]).cuda(), torch.from_numpy(clipB[0][kB]).cuda()], time_s=[tA, tB], frame_no=[g, kB])
+        oA.step(A[0][g], tA, g)
+        oB.step(clipB[0][kB], tB, kB)
+        for slot, orc in ((0, oA), (1, oB)):
+            st = ses.state(slot)
+            assert st["frame_i"] == orc.i
+            assert np.array_equal(st["vg"], orc.vg) and np.array_equal(st["vp"], orc.vp), (g, slot)
+            assert np.array_equal(st["p"], orc.p), (g, slot)
+            np.testing.assert_allclose(st["p3"], orc.p3, rtol=1e-4, atol=1e-5)
+    for slot, orc in ((0, oA), (1, oB)):
+        st = ses.state(slot)
+        n = orc.i + 1
+        np.testing.assert_allclose(st["B"][:n, 12:14], orc.B[:n, 12:14], rtol=0, atol=0)          # the stream's own time / frame number
+        np.testing.assert_allclose(st["S"][1:n, [0, 2, 4, 5]], orc.S[1:n, [0, 2, 4, 5]], rtol=0, atol=0)  # i, #tracks, dt, time since start
+        np.testing.assert_allclose(st["S"][1:n, [3, 6, 7, 8]], orc.S[1:n, [3, 6, 7, 8]], rtol=1e-4)
+    assert oA.i == nfr + 1 and oB.i == nfr - 2 and oB.i >= 5  # both clips passed THEIR frame 5: both re-triangulated
+
+
+def test_session_with_more_than_4096_tracks_takes_the_unfused_path():
+    """N0 > 4096: the pose fit no longer fits the 256-thread fused frame kernel (bookkeeping, 1024-thread pose, records as three launches)."""
+    import torch
+
+    from velocity_amd.driver import TrackerSession
+
+    W, H, n0, nframes = 960, 540, 4500, 4
+    frames, p, p3, vp, K = _scene(W, H, n0, nframes, 31337)
+    t0 = np.float32([1.5, 0.45, 3.6])
+    orc = SessionOracle(K, frames[0], p, p3, vp, t0, nhist=nframes, msv_frame=0)
+    ses = TrackerSession(K, W, H, n0, nhist=nframes, batch=1, msv_frame=0)
+    ses.init_stream(0, frames[0], p, p3, vp, t0)
+    for i in range(1, nframes):
+        ts = np.float32(i / 30.0)
+        orc.step(frames[i], ts, i)
+        ses.step([torch.from_numpy(frames[i]).cuda()], time_s=ts, frame_no=i)
+        st = ses.state(0)
+        assert np.array_equal(st["vg"], orc.vg) and np.array_equal(st["vp"], orc.vp) and np.array_equal(st["p"], orc.p), i
+        np.testing.assert_allclose(st["t"], orc.t, rtol=1e-5)
+        np.testing.assert_allclose(st["res"], orc.residuals, rtol=1e-6)
+
+
+def test_session_on_a_rolling_zooming_scene():
+    """Camera roll + zoom + translation (SURVEY section 8d's rotation): the stage-3 affine warp leaves its near-identity fast path and gathers;
+    tracks, masks and compaction stay bit-identical to the reference loop."""
+    import torch
+
+    from velocity_amd.driver import TrackerSession
+
+    W, H, n0, nframes = 800, 450, 500, 7
+    K = synth.K_1080P.copy()
+    K[0, 0] = K[1, 1] = 900.0
+    K[2, 0], K[2, 1] = W / 2 + 0.5, H / 2 + 0.5
+    m = synth.PlaneMotion(K, z0=3.6, traj=lambda k: np.array([0.03 * k, -0.01 * k, 0.12 * k]), roll=lambda k: np.radians(0.9 * k))
+    frames = [synth.render_frame(W, H, m, k, seed=2024).numpy() for k in range(nframes)]
+    p = synth.grid_tracks(n0, W, H, seed=9)
+    p3 = m.world_points(p)
+    vp = np.ones(n0, bool)
+    t0 = np.float32([0, 0, 0])
+    orc = SessionOracle(K, frames[0], p, p3, vp, t0, nhist=nframes, msv_frame=0)
+    ses = TrackerSession(K, W, H, n0, nhist=nframes, batch=1, msv_frame=0)
+    ses.init_stream(0, frames[0], p, p3, vp, t0)
+    for i in range(1, nframes):
+        ts = np.float32(i / 30.0)
+        orc.step(frames[i], ts, i)
+        ses.step([torch.from_numpy(frames[i]).cuda()], time_s=ts, frame_no=i)
+        st = ses.state(0)
+        assert np.array_equal(st["vg"], orc.vg) and np.array_equal(st["p"], orc.p), i
+        np.testing.assert_allclose(st["res"], orc.residuals, rtol=1e-6)
+    assert st["vg"].sum() > 0.8 * n0  # the tracker really follows the rotating scene
+    truth = m.apply(nframes - 1, p.astype(float))[st["vg"]]
+    assert np.median(np.abs(st["p"] - truth)) < 0.1

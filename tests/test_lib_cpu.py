@@ -74,3 +74,11 @@ def test_torch_ops_library_registers_every_op_and_has_no_cpu_kernel():
         ops.klt_main(im, im, None, torch.zeros((4, 2)))
     with pytest.raises((RuntimeError, NotImplementedError)):
         ops.nls_t(torch.eye(3), torch.zeros((4, 2)), torch.zeros((4, 3), dtype=torch.float64), torch.tensor([0.0, 0.0, 1.0]))
+
+
+def test_every_shim_module_imports_without_a_gpu():
+    """The host shims import (and parse) on a machine without a GPU; only CALLING an op needs one."""
+    import importlib
+
+    for mod in ("NLS", "KLT", "MSV", "common", "dist", "driver", "images", "transforms", "synth", "torch_ops"):
+        importlib.import_module(f"velocity_amd.{mod}")

@@ -89,7 +89,6 @@ def fcnNLS_batch(K, P, pw, cw, max_iter=10, return_info=False):
     _, nt, nf = P.shape
     nc = nf - 1
     z = np.concatenate([P[0].T.reshape(-1), P[1].T.reshape(-1)]).astype(np.float64)  # NLS.py:198-199
-    z[np.isnan(z)] = 0
     x0 = np.concatenate((pw, cw[1:], np.zeros((nc, 3)))).reshape(-1)  # NLS.py:202-203
     K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
     zd = L.to_dev(z, torch.float64)
@@ -131,8 +130,7 @@ def fcnNLS_batch_windows(K, Ps, pws, cws, max_iter=10, return_info=False):
             shape = (nt, nf)
         elif shape != (nt, nf):
             raise ValueError(f"fcnNLS_batch_windows: window shapes differ ({shape} vs {(nt, nf)})")
-        z = np.concatenate([P[0].T.reshape(-1), P[1].T.reshape(-1)]).astype(np.float64)  # NLS.py:198-199
-        z[np.isnan(z)] = 0
+        z = np.concatenate([P[0].T.reshape(-1), P[1].T.reshape(-1)]).astype(np.float64)  # NLS.py:198-199 (NaN = no observation: kept, see k_ba_jac)
         zs.append(z)
         xs.append(np.concatenate((pw, cw[1:], np.zeros((nf - 1, 3)))).reshape(-1))  # NLS.py:202-203
     nt, nf = shape
@@ -180,7 +178,6 @@ def fcnNLS_batch2(K, P, pw, cw, max_iter=20, return_info=False):
     _, nt, nf = P.shape
     nc = nf - 1
     z = np.concatenate([P[0].T.reshape(-1), P[1].T.reshape(-1)]).astype(np.float64)  # NLS.py:266-267
-    z[np.isnan(z)] = 0
     C = _cam2ned()
     d = C @ (cw[1] - cw[0])  # cam -> ned (NLS.py:272), then cc2sc (common.py:81-94)
     r = np.linalg.norm(d)

@@ -59,6 +59,7 @@ _SIGS = {
     "vh_world2image": (C.c_int, [vp, f64p, vp, C.c_int, vp, vp]),
     "vh_image2world": (C.c_int, [vp, f64p, vp, C.c_int, vp, vp]),
     "vh_pixel2uvec": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp, vp]),
+    "vh_pixel2uvec_f32": (C.c_int, [vp, C.c_float, C.c_float, C.c_float, vp, C.c_int, vp, vp]),
     "vh_two_view_intercept": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "vh_n_view_intercept": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "vh_nls_batch_workspace": (C.c_size_t, [C.c_int, C.c_int]),

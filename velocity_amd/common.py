@@ -81,8 +81,17 @@ def image2world(K, R, t, p):
 
 
 def pixel2uvec(K, p):
-    """Unit rays through pixels (common.py:122-126)."""
+    """Unit rays through pixels (common.py:122-126).  float32 K and p give a float32 result computed in float32, as numpy does there."""
     torch = L.torch_cuda()
+    if np.asarray(K).dtype == np.float32 and np.asarray(p).dtype == np.float32:
+        K32 = np.asarray(K, np.float32)
+        pd = L.to_dev(np.asarray(p, np.float32), torch.float32).reshape(-1, 2)
+        n = pd.shape[0]
+        out = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        ws = L.workspace()
+        L.check(ws.lib.vh_pixel2uvec_f32(ws.handle, float(K32[2, 0]), float(K32[2, 1]), float(K32[0, 0]), L.dptr(pd), n, L.dptr(out), L.stream_ptr()),
+                "vh_pixel2uvec_f32")
+        return out.cpu().numpy()
     K = np.asarray(K, float)
     pd = _dev_f64(p).reshape(-1, 2)
     n = pd.shape[0]

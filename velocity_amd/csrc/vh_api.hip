@@ -422,7 +422,9 @@ extern "C" VH_API int vh_klt_main(vh_ctx* c, int slot, const uint8_t* im, const 
 {
     if (!c || slot < 0 || slot >= c->batch) return vh_fail(-1, "vh_klt_main: bad slot");
     if (w > c->max_w || h > c->max_h || n > c->max_pts || n < 0) return vh_fail(-1, "vh_klt_main: frame or point count exceeds the workspace");
-    if (!coarse || !fine || coarse->win < 3 || fine->win < 3) return vh_fail(-1, "vh_klt_main: bad LK parameters");
+    if (!coarse || !fine || coarse->win < 3 || fine->win < 3 || coarse->max_level < 0 || fine->max_level < 0)
+        return vh_fail(-1, "vh_klt_main: bad LK parameters (need win >= 3, max_level >= 0)");
+    if (w < 4 || h < 4 || stride < w || stride0 < w) return vh_fail(-1, "vh_klt_main: frames must be at least 4 x 4 with row strides >= width");
     KltIO io;
     memset(&io, 0, sizeof(io));
     io.im = im; io.im0 = im0; io.im0_small = im0_small; io.p0 = p0; io.n_ptr = nullptr; io.p_all = p_all; io.v = v;
@@ -576,7 +578,8 @@ static void host_fill_pyramid(PyrDesc& P, const uint8_t* lv0, int w, int h, int 
 extern "C" VH_API int vh_pyr_lk(vh_ctx* c, const uint8_t* im1, const uint8_t* im2, int w, int h, int stride1, int stride2, const float* p1,
                                 int n, const vh_lk_params* lk, float fbt, float* p2, uint8_t* v, float* err, float* fbe, void* stream)
 {
-    if (!c || !lk || lk->win < 3) return vh_fail(-1, "vh_pyr_lk: bad arguments");
+    if (!c || !lk || lk->win < 3 || lk->max_level < 0 || w < 4 || h < 4 || stride1 < w || stride2 < w || n < 0)
+        return vh_fail(-1, "vh_pyr_lk: bad arguments (need win >= 3, max_level >= 0, w, h >= 4, strides >= w)");
     if (w > c->max_w || h > c->max_h || n > c->max_pts) return vh_fail(-1, "vh_pyr_lk: image or point count exceeds the workspace");
     if (n <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -685,7 +688,8 @@ extern "C" VH_API int vh_klt_regional(vh_ctx* c, const uint8_t* im0, const uint8
                                       int n, const float* T_host, const vh_lk_params* lk, float fbt, int translate, float* p_out,
                                       uint8_t* v_out, int* roi_out, void* stream)
 {
-    if (!c || !lk || !T_host || lk->win < 3 || n < 1) return vh_fail(-1, "vh_klt_regional: bad arguments");
+    if (!c || !lk || !T_host || lk->win < 3 || lk->max_level < 0 || n < 1 || w < 4 || h < 4 || stride0 < w || stride < w)
+        return vh_fail(-1, "vh_klt_regional: bad arguments (need win >= 3, max_level >= 0, w, h >= 4, strides >= w)");
     if (w > c->max_w || h > c->max_h || n > c->max_pts) return vh_fail(-1, "vh_klt_regional: image or point count exceeds the workspace");
     hipStream_t s = (hipStream_t)stream;
     RegionalIO io;
@@ -772,6 +776,14 @@ extern "C" VH_API int vh_pixel2uvec(vh_ctx* c, double cx, double cy, double f, c
 {
     if (!c) return vh_fail(-1, "null ctx");
     vh_launch_pixel2uvec(cx, cy, f, p, n, out, (hipStream_t)stream);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_pixel2uvec_f32(vh_ctx* c, float cx, float cy, float f, const float* p, int n, float* out, void* stream)
+{
+    if (!c) return vh_fail(-1, "null ctx");
+    vh_launch_pixel2uvec_f32(cx, cy, f, p, n, out, (hipStream_t)stream);
     VH_LAUNCH_CHECK();
     return 0;
 }

@@ -186,6 +186,14 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
             }  // camera 0 is fixed: its 12 entries stay exact zeros
         }
     }
+    // a NaN measurement (no observation of this track in this frame) takes no part: zero residual, zero Jacobian rows.  (The reference zeroes
+    // z and zhat there, NLS.py:200-201,225, but leaves f(x + dx e_j) - 0 in its forward differences: rows of ~1e9.  Resolved by intent; with the
+    // full-length track filter of NLS.py:190 it only happens when P[0:2] is NaN where P[4] is not.)
+    if (ss != ss) {
+        ss = 0.0;
+#pragma unroll
+        for (int k = 0; k < 20; k++) o[k] = 0.0;
+    }
 #pragma unroll
     for (int k = 0; k < 20; k++) s_out[k][threadIdx.x] = o[k];
     // sum of squared residuals of this iteration (trace only): one atomic per block, spread over 16 addresses -- thousands of

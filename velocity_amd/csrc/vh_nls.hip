@@ -54,6 +54,16 @@ __global__ void k_pixel2uvec(double cx, double cy, double f, const double* p, in
     out[3 * i] = r[0]; out[3 * i + 1] = r[1]; out[3 * i + 2] = r[2];
 }
 
+// the same in float32 when K and p are float32 (numpy then computes in float32; uvec's sum of squares and square root included)
+__global__ void k_pixel2uvec_f32(float cx, float cy, float f, const float* p, int n, float* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r[3];
+    uvec_f32(p[2 * i], p[2 * i + 1], cx, cy, f, r);  // float32 arithmetic, results exactly representable in float32
+    out[3 * i] = (float)r[0]; out[3 * i + 1] = (float)r[1]; out[3 * i + 2] = (float)r[2];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // fcn2vintercept (MSV.py:98-142): mean of the pairwise closest-approach points over all C(nf,2) frame pairs.
 // A: [nf,3] origins, U: [3,nf,nv] unit directions, out: [nv,3]
@@ -218,6 +228,10 @@ void vh_launch_image2world(const double* Hi, const double* p, int n, double* out
 void vh_launch_pixel2uvec(double cx, double cy, double f, const double* p, int n, double* out, hipStream_t s)
 {
     if (n > 0) hipLaunchKernelGGL(k_pixel2uvec, dim3((n + 255) / 256), dim3(256), 0, s, cx, cy, f, p, n, out);
+}
+void vh_launch_pixel2uvec_f32(float cx, float cy, float f, const float* p, int n, float* out, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(k_pixel2uvec_f32, dim3((n + 255) / 256), dim3(256), 0, s, cx, cy, f, p, n, out);
 }
 void vh_launch_two_view(const double* A, const double* U, int nf, int nv, double* out, hipStream_t s)
 {

@@ -41,6 +41,7 @@ void vh_launch_pose(const void* tab, size_t stride, int batch, int mode, int max
 void vh_launch_world2image(const double* C, const double* pw, int n, double* out, hipStream_t s);
 void vh_launch_image2world(const double* Hi, const double* p, int n, double* out, hipStream_t s);
 void vh_launch_pixel2uvec(double cx, double cy, double f, const double* p, int n, double* out, hipStream_t s);
+void vh_launch_pixel2uvec_f32(float cx, float cy, float f, const float* p, int n, float* out, hipStream_t s);
 void vh_launch_two_view(const double* A, const double* U, int nf, int nv, double* out, hipStream_t s);
 void vh_launch_n_view(const double* A, const double* U, int nf, int nv, double* out, hipStream_t s);
 void vh_launch_msv1(const MsvJob& job, hipStream_t s);

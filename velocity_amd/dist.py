@@ -113,7 +113,6 @@ def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None):
         raise ValueError("more ranks than tie points")
     Pl = P[:, lo:hi]
     z = np.concatenate([Pl[0].T.reshape(-1), Pl[1].T.reshape(-1)]).astype(np.float64)  # NLS.py:198-199 on the local tracks
-    z[np.isnan(z)] = 0
     x0 = np.concatenate((pw[lo:hi], cw[1:], np.zeros((nc, 3)))).reshape(-1)
     K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
     zd = L.to_dev(z, tc.float64)

@@ -66,8 +66,8 @@ class TrackerSession:
             L.check(self.lib.vh_session_step(self.handle, L.dptr(tab), float(time_s), float(frame_no), L.stream_ptr()), "vh_session_step")
             return
         torch = self.torch
-        tv = L.to_dev(time_s if hasattr(time_s, "is_cuda") else np.broadcast_to(np.asarray(time_s, np.float32), (self.batch,)), torch.float32)
-        fv = L.to_dev(frame_no if hasattr(frame_no, "is_cuda") else np.broadcast_to(np.asarray(frame_no, np.float32), (self.batch,)), torch.float32)
+        tv = L.to_dev(time_s if hasattr(time_s, "is_cuda") else np.array(np.broadcast_to(np.asarray(time_s, np.float32), (self.batch,))), torch.float32)
+        fv = L.to_dev(frame_no if hasattr(frame_no, "is_cuda") else np.array(np.broadcast_to(np.asarray(frame_no, np.float32), (self.batch,))), torch.float32)
         assert tv.numel() == self.batch and fv.numel() == self.batch
         self._clock_keep = (tv, fv)
         L.check(self.lib.vh_session_step_v(self.handle, L.dptr(tab), L.dptr(tv), L.dptr(fv), L.stream_ptr()), "vh_session_step_v")
