@@ -220,8 +220,8 @@ VH_API int vh_session_ptrs(vh_session* s, int slot, vh_session_view* out_host);
 VH_API int vh_session_pack_state(vh_session* s, float* out, void* stream);
 
 /* test hook: route every LK window through one implementation -- 1: per-sample kernel, 2: strip kernel, 3: LDS-staged
- * kernel, 4: 4-tracks-per-wavefront kernel (15x15 windows; others as in 2), 0: default routing per window and load.
- * All are bit-identical. */
+ * kernel, 4: 4-tracks-per-wavefront kernel (15x15 windows; others as in 2), 5 / 6 / 7: LDS-staged 51x51 kernel with 1 / 2 / 4
+ * wavefronts per track (other windows: default routing), 0: default routing per window and load.  All are bit-identical. */
 VH_API void vh_debug_force_generic_lk(int on);
 
 /* test hook: estimateAffine2D stand-in -- 1: always the three-kernel path (hypotheses spread over the chip), 2: the fused

@@ -165,7 +165,8 @@ def test_strip_and_per_sample_lk_kernels_agree(seq):
     pts = np.concatenate([p0, rng.uniform(-20, 30, (60, 2)).astype(np.float32), rng.uniform([W - 30, H - 30], [W + 20, H + 20], (60, 2)).astype(np.float32)])
     for lk in (CV_COARSE, CV_FINE, dict(winSize=(9, 9), maxLevel=3, criteria=(3, 20, 0.03)), dict(winSize=(31, 31), maxLevel=1, criteria=(3, 20, 0.03))):
         a = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=0.5, **lk)
-        for mode in (1, 2, 3, 4):  # 1: per-sample, 2: strip, 3: LDS-staged, 4: 4-tracks-per-wave (15x15 only); default: routed
+        # 1: per-sample, 2: strip, 3: LDS-staged, 4: 4-tracks-per-wave (15x15 only), 5 / 6 / 7: LDS-staged 51x51 with 1 / 2 / 4 wavefronts per track; default: routed
+        for mode in (1, 2, 3, 4, 5, 6, 7):
             L.load().vh_debug_force_generic_lk(mode)
             try:
                 b = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=0.5, **lk)
@@ -189,7 +190,7 @@ def test_pyr_lk_large_motion_restages_search_region():
                    (dict(winSize=(51, 51), maxLevel=0, criteria=(3, 30, 0.001)), dict(win=51, max_level=0, max_count=30, eps=0.001)),
                    (dict(winSize=(15, 15), maxLevel=1, criteria=(3, 10, 0.1)), dict(win=15, max_level=1, max_count=10, eps=0.1))):
         e2, ev, eerr = KO.lk_fb(f0, f1, pts, fbt=2.0, **kw)
-        for mode in (0, 3, 4):  # default routing, the LDS-staged kernel for both windows, 4 tracks per wave for 15x15
+        for mode in (0, 3, 4, 5, 6):  # default routing, the LDS-staged kernel for both windows, 4 tracks per wave for 15x15, 1 / 2 waves per 51x51 track
             L.load().vh_debug_force_generic_lk(mode)
             try:
                 p2, v, err = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=2.0, **lk)
@@ -412,7 +413,7 @@ def test_pyr_lk_fuzz_all_kernels_vs_oracle():
         cnt, eps = int(rng.integers(1, 31)), float(rng.choice([0.1, 0.03, 0.01, 0.001]))
         fbt = [None, 1.0, 0.3][int(rng.integers(0, 3))]
         exp = KO.lk_fb(f0, f1, pts, fbt=fbt, win=win, max_level=lvl, max_count=cnt, eps=eps)
-        for mode in (0, 1, 2, 3, 4):
+        for mode in (0, 1, 2, 3, 4, 5, 6, 7):
             L.load().vh_debug_force_generic_lk(mode)
             try:
                 got = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=fbt, winSize=(win, win), maxLevel=lvl, criteria=(3, cnt, eps))

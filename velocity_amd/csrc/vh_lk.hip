@@ -323,6 +323,33 @@ __device__ __forceinline__ long long wave_sum_i32_rows(int v)
 __device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
 __device__ __forceinline__ short2v as_s2(unsigned v) { return __builtin_bit_cast(short2v, v); }
 __device__ __forceinline__ int dot2(unsigned a, unsigned b, int c) { return __builtin_amdgcn_sdot2(as_s2(a), as_s2(b), c, false); }
+// First link of a dot2 chain.  For the builtin hipcc selects v_dot2c_i32_i16 (accumulator tied to the destination), which needs a v_mov to
+// seed every chain; the VOP3P form takes the inline constant 0 as its accumulator.
+__device__ __forceinline__ int dot2_first(unsigned a, unsigned b)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// a * K + c for 24-bit a and an inline-constant K as ONE v_mad_i32_i24 (hipcc emits v_mul_i32_i24 + v_add for `__mul24(a, K) + c`); the _s form takes a
+// wave-uniform addend from an SGPR
+template <int K>
+__device__ __forceinline__ int mad24_v(int a, int c)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(K), "v"(c));
+    return d;
+}
+template <int K>
+__device__ __forceinline__ int mad24_s(int a, int c)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(K), "s"(c));
+    return d;
+}
+// (lo >> 16) & 0xffff | (hi >> 16) << 16 in one v_perm: descale-by-shift and int16 packing of two values that were scaled so that the
+// wanted 16 bits sit in the upper half
+__device__ __forceinline__ unsigned pack_hi16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x07060302u); }
 
 // NR rows x 8 bytes starting at pixel (gx, gy): lo = bytes 0..3, hi = bytes 4..7 of every row (interior fast path)
 typedef const unsigned __attribute__((address_space(1)))* gptr_u32;  // global (not flat) loads
@@ -382,11 +409,13 @@ __device__ __forceinline__ void strip_row_pairs(unsigned lo, unsigned hi, unsign
 // bilinear x32 samples of the 4 strip positions from the packed pairs of the top and bottom row
 __device__ __forceinline__ void strip_bilinear_pairs(const unsigned* t, const unsigned* b, const StripWeights& w, unsigned& p01, unsigned& p23)
 {
+    // descale(acc, 9) = (acc + 256) >> 9 = upper half of (acc + 256) << 7  (acc < 2^22): one v_lshl_add per sample, one v_perm per pair
     int v[4];
 #pragma unroll
-    for (int c = 0; c < 4; c++) v[c] = dot2(b[c], w.wb, dot2(t[c], w.wt, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-    p01 = pack16(v[0], v[1]);
-    p23 = pack16(v[2], v[3]);
+    for (int c = 0; c < 4; c++)
+        v[c] = (dot2(b[c], w.wb, dot2_first(t[c], w.wt)) << (16 - (W_BITS - 5))) + (1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5)));
+    p01 = pack_hi16(v[0], v[1]);
+    p23 = pack_hi16(v[2], v[3]);
 }
 // bilinear x32 samples of the 4 strip positions from 2 rows (lo,hi): returns packed pairs (v0,v1), (v2,v3)
 __device__ __forceinline__ void strip_bilinear(const unsigned* lo, const unsigned* hi, const StripWeights& w, unsigned& p01, unsigned& p23)
@@ -417,7 +446,7 @@ __device__ __forceinline__ void setup_row_pairs(unsigned lo, unsigned hi, unsign
 __device__ __forceinline__ void setup_v_row(const unsigned* top, const unsigned* bot, unsigned wt, unsigned wb, int* V)
 {
 #pragma unroll
-    for (int c = 0; c < 6; c++) V[c] = dot2(bot[c], wb, dot2(top[c], wt, 0));
+    for (int c = 0; c < 6; c++) V[c] = dot2(bot[c], wb, dot2_first(top[c], wt));
 }
 // template samples, gradients and structure-tensor partials of one strip from its three V rows
 __device__ __forceinline__ void setup_from_v(const int* V0, const int* V1, const int* V2, int cnt, uint2* tI, uint2* tX, uint2* tY, int slot,
@@ -450,12 +479,14 @@ __device__ __forceinline__ void setup_from_v(const int* V0, const int* V1, const
 // Rolling form for a vertical run of strips: per V row keep its horizontal differences H[c] = V[c+2] - V[c] and its
 // horizontally smoothed values G[c] = 3 (V[c] + V[c+2]) + 10 V[c+1], c = 0..3.  Then (exact integer identities)
 //   Scharr_x = 3 (H0 + H2) + 10 H1,   Scharr_y = G2 - G0,   so a new strip costs one H row and one G row, not a 3 x 6 block of S / D
-__device__ __forceinline__ void setup_hg_row(const int* V, int* H, int* G)
+// Both gradients are kept x4 with the descale rounding folded in, so that descale(., 14) + int16 packing is the upper half of the word
+// (pack_hi16): G4 row g carries the addend 2^14 * g, hence G4[g+2] - G4[g] = 4 (G2 - G0) + 4 * 2^13; |4 * Scharr| < 2^29.
+__device__ __forceinline__ void setup_hg_row(const int* V, int* H, int* G4, int g)
 {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         H[c] = V[c + 2] - V[c];
-        G[c] = __mul24(V[c] + V[c + 2], 3) + __mul24(V[c + 1], 10);  // every V fits 22 bits
+        G4[c] = mad24_v<40>(V[c + 1], mad24_s<12>(V[c] + V[c + 2], g << W_BITS));  // every V fits 22 bits
     }
 }
 // vmask: 0xffffffff for a strip inside the window, 0 for a strip of the last run that hangs below it (stored as zeros)
@@ -463,17 +494,17 @@ template <bool FULL01>  // FULL01: every strip holds at least 2 samples (window 
 __device__ __forceinline__ void setup_from_hg(const int* H0, const int* H1, const int* H2, const int* G0, const int* G2, const int* Vmid, int cnt,
                                               uint2* tI, uint2* tX, uint2* tY, int slot, int& a11, int& a12, int& a22, unsigned vmask = 0xffffffffu)
 {
-    int iv[4], ix[4], iy[4];
+    int iv[4], ix[4], iy[4];  // the wanted int16 in the upper half of each
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        iv[c] = vh_descale(Vmid[c], W_BITS - 5);
-        ix[c] = vh_descale(__mul24(H0[c] + H2[c], 3) + __mul24(H1[c], 10), W_BITS);
-        iy[c] = vh_descale(G2[c] - G0[c], W_BITS);
+        iv[c] = (Vmid[c] << (16 - (W_BITS - 5))) + (1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5)));
+        ix[c] = mad24_v<40>(H1[c], mad24_s<12>(H0[c] + H2[c], 4 << (W_BITS - 1)));
+        iy[c] = G2[c] - G0[c];
     }
     const unsigned m01 = ((FULL01 || cnt >= 2) ? 0xffffffffu : 0x0000ffffu) & vmask, m23 = (cnt >= 4 ? 0xffffffffu : (cnt == 3 ? 0x0000ffffu : 0u)) & vmask;
-    const uint2 vI = make_uint2(pack16(iv[0], iv[1]) & m01, pack16(iv[2], iv[3]) & m23);
-    const uint2 vX = make_uint2(pack16(ix[0], ix[1]) & m01, pack16(ix[2], ix[3]) & m23);
-    const uint2 vY = make_uint2(pack16(iy[0], iy[1]) & m01, pack16(iy[2], iy[3]) & m23);
+    const uint2 vI = make_uint2(pack_hi16(iv[0], iv[1]) & m01, pack_hi16(iv[2], iv[3]) & m23);
+    const uint2 vX = make_uint2(pack_hi16(ix[0], ix[1]) & m01, pack_hi16(ix[2], ix[3]) & m23);
+    const uint2 vY = make_uint2(pack_hi16(iy[0], iy[1]) & m01, pack_hi16(iy[2], iy[3]) & m23);
     tI[slot] = vI; tX[slot] = vX; tY[slot] = vY;
     a11 = dot2(vX.y, vX.y, dot2(vX.x, vX.x, a11));
     a12 = dot2(vX.y, vY.y, dot2(vX.x, vY.x, a12));
@@ -832,19 +863,17 @@ struct LK3 {
     static constexpr int PI_ROWS = WIN + 3;                                   // template patch rows
     static constexpr int PI_PITCH = ((4 * (SPR - 1) + 8 + 3) / 4) * 4;        // bytes read per patch row, dword multiple
     static constexpr int RJ = WIN + 1 + 2 * M;                                // search region rows / cols
-    static constexpr int PJ_PITCH = ((((2 * M + 4 * (SPR - 1)) >> 2) * 4 + 12 + 3) / 4) * 4;
-    static constexpr int OFF_TI = 0;
-    // template slots: one per (k, active lane), slot(k, tid) = k * LANES + tid.  Every lane runs all K strips of its run
-    // with NO per-strip branch: strips below the window (the tail of the last run(s)) are computed from whatever the
-    // padded buffers hold and stored as ZEROS, so they add nothing to any window sum in the set-up or in the Newton
-    // iterations.  (Branching on `y < WIN` per strip split the unrolled K loop into exec-masked blocks joined by register
-    // moves: 17 % of the set-up's VALU instructions were v_mov.)
+    static constexpr int PJ_WIDTH = ((2 * M + 4 * (SPR - 1)) >> 2) * 4 + 8;   // a row read takes two dwords
+    static constexpr int PJ_PITCH = PJ_WIDTH + 4;                                // odd dword pitch (LDS banks)
+    // The template of a lane's K strips (samples x32, Scharr gradients: 3 x 8 bytes per strip) stays in REGISTERS for the whole level: LDS then
+    // holds the two image regions only (~7.7 KB per workgroup for 51x51) and the VGPR file, not LDS, bounds the occupancy.  With the template in
+    // LDS (24.5 KB per workgroup: 6 workgroups = 3 wavefronts per SIMD) the kernel lost 14 % per workgroup of occupancy taken away.
+    // Every lane runs all K strips of its run with NO per-strip branch: strips below the window (the tail of the last run(s)) are computed from
+    // whatever the padded buffers hold and kept as ZEROS, so they add nothing to any window sum in the set-up or in the Newton iterations.
+    // (Branching on `y < WIN` per strip split the unrolled K loop into exec-masked blocks joined by register moves.)
     static constexpr int LANES = RUNS * SPR;                     // active lanes
-    static constexpr int SLOTS = K * LANES;
     static constexpr int PAD_ROWS = RUNS * K - WIN;              // window rows the last run(s) hang over the bottom edge
-    static constexpr int OFF_TX = OFF_TI + SLOTS * 8;
-    static constexpr int OFF_TY = OFF_TX + SLOTS * 8;
-    static constexpr int OFF_PI = OFF_TY + SLOTS * 8;
+    static constexpr int OFF_PI = 0;
     static constexpr int OFF_PJ = OFF_PI + (PI_ROWS + PAD_ROWS) * PI_PITCH + 8;
     static constexpr int OFF_RED = ((OFF_PJ + (RJ + PAD_ROWS) * PJ_PITCH + 16 + 15) / 16) * 16;
     static constexpr int LDS_BYTES = OFF_RED + 2 * NW * 4 * 8;
@@ -855,35 +884,47 @@ typedef const uint2 __attribute__((address_space(1)))* gptr_u32x2;
 // stage ROWS x PITCH bytes of image `im` starting at pixel (rx, ry) into LDS (region-aligned rows).  Compile-time
 // extents: the loop is fully unrolled and every global load of the batch is issued before the first LDS store, so a
 // staging costs one memory round trip.
-template <int T, int ROWS, int PITCH>
+template <int T, int ROWS, int WIDTH, int PITCH = WIDTH>  // WIDTH bytes of every row are staged, rows are PITCH bytes apart in LDS
 __device__ __forceinline__ void stage_region(const ImgDesc& im, int rx, int ry, unsigned* dst, int tid)
 {
-    constexpr int DPR = PITCH >> 2, TOTAL = ROWS * DPR, NIT = (TOTAL + T - 1) / T;
-    const bool fast = rx >= 0 && ry >= 0 && rx + PITCH + 4 <= im.w && ry + ROWS <= im.h;
+    constexpr int DPR = WIDTH >> 2, LP = PITCH >> 2;
+    // LPR lanes per region row, T / LPR rows per batch of loads: a lane keeps its dword column, so the address of batch `it` is the first one
+    // plus the wave-uniform it * RPI * stride (no per-element division, one 32-bit add per load; hipcc's form of the flat index q / DPR cost
+    // ~12 VALU instructions per element)
+    constexpr int LPR = DPR <= 4 ? 4 : DPR <= 8 ? 8 : DPR <= 16 ? 16 : 32;
+    static_assert(DPR <= 32 && T % LPR == 0, "region rows wider than 32 dwords are not staged by this layout");
+    constexpr int RPI = T / LPR, NIT = (ROWS + RPI - 1) / RPI;
+    const bool fast = rx >= 0 && ry >= 0 && rx + WIDTH + 4 <= im.w && ry + ROWS <= im.h;
     if (fast) {
+        const int l = tid & (LPR - 1), r0 = tid / LPR;
+        const int d = min(l, DPR - 1);
+        const unsigned bsh = (unsigned)(reinterpret_cast<uintptr_t>(im.p) & 3);
+        const uint8_t* bp = im.p - bsh;  // dword aligned, wave uniform
+        const unsigned off0 = (unsigned)(__mul24(ry + r0, im.stride) + rx + 4 * d) + bsh;
         unsigned d0[NIT], d1[NIT], sh[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            // unconditional loads (index clamped): a branch around a load makes hipcc wait vmcnt(0) per element
-            const int q = min(tid + it * T, TOTAL - 1);
-            const int r = q / DPR, d = q - r * DPR;
-            const uintptr_t a = reinterpret_cast<uintptr_t>(im.p + (ptrdiff_t)(ry + r) * im.stride + rx + 4 * d);
-            sh[it] = (unsigned)(a & 3);
-            gptr_u32 ap = (gptr_u32)(a - sh[it]);
+            // unconditional loads (row clamped in the last batch): a branch around a load makes hipcc wait vmcnt(0) per element
+            unsigned off;
+            if ((it + 1) * RPI <= ROWS) off = off0 + (unsigned)(it * RPI) * (unsigned)im.stride;
+            else off = off0 + (unsigned)__mul24(min(it * RPI, ROWS - 1 - r0), im.stride);
+            sh[it] = off & 3u;
+            gptr_u32 ap = (gptr_u32)(bp + (off & ~3u));
             d0[it] = ap[0]; d1[it] = ap[1];
         }
+        if (l < DPR) {
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int q = tid + it * T;
-            if (q < TOTAL) dst[q] = __builtin_amdgcn_alignbyte(d1[it], d0[it], sh[it]);
+            for (int it = 0; it < NIT; it++)
+                if ((it + 1) * RPI <= ROWS || r0 + it * RPI < ROWS) dst[(r0 + it * RPI) * LP + l] = __builtin_amdgcn_alignbyte(d1[it], d0[it], sh[it]);
         }
     } else {
+        constexpr int TOTAL = ROWS * DPR;
         for (int q = tid; q < TOTAL; q += T) {
             const int r = q / DPR, d = q - r * DPR;
             unsigned v = 0;
 #pragma unroll
             for (int c = 0; c < 4; c++) v |= (unsigned)pix_r(im, rx + 4 * d + c, ry + r) << (8 * c);
-            dst[q] = v;
+            dst[r * LP + d] = v;
         }
     }
 }
@@ -916,13 +957,15 @@ __device__ __forceinline__ void block_sum_wide(const int* part, long long* tot, 
 }
 
 template <int WIN, int NW, int M>
-__device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_level, int max_count, double eps2, float p0x, float p0y,
+__device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_level, int max_count, double eps2, float p0x, float p0y,
                           float& nxo, float& nyo, int& status, float& err, char* smem, int tid, int& phase, int& n_iter, int& n_setup, bool want_err)
 {
     using C = LK3<WIN, NW, M>;
-    uint2* tI = reinterpret_cast<uint2*>(smem + C::OFF_TI);
-    uint2* tX = reinterpret_cast<uint2*>(smem + C::OFF_TX);
-    uint2* tY = reinterpret_cast<uint2*>(smem + C::OFF_TY);
+    // this lane's template gradients (registers: every index below is a compile-time constant).  The template SAMPLES are not kept: with
+    // c = sum I * (Ix, Iy) over the lane's strips, sum (J - I) * Ix = sum J * Ix - c  exactly, so the Newton accumulators start at -c
+    // (same per-lane partial sums as subtracting per sample; 12 registers and a v_pk_sub per pair less)
+    uint2 tI[C::K], tX[C::K], tY[C::K];
+    int cI[2] = {0, 0};
     unsigned* pI = reinterpret_cast<unsigned*>(smem + C::OFF_PI);
     unsigned* pJ = reinterpret_cast<unsigned*>(smem + C::OFF_PJ);
     long long* red = reinterpret_cast<long long*>(smem + C::OFF_RED);
@@ -950,7 +993,7 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
     int rjx = vh_floor(nx) - M, rjy = vh_floor(ny) - M;
     __syncthreads();  // previous users of the patch buffers are done
     stage_region<C::T, C::PI_ROWS, C::PI_PITCH>(I, ipx - 1, ipy - 1, pI, tid);
-    stage_region<C::T, C::RJ, C::PJ_PITCH>(J, rjx, rjy, pJ, tid);
+    stage_region<C::T, C::RJ, C::PJ_WIDTH, C::PJ_PITCH>(J, rjx, rjy, pJ, tid);
     __syncthreads();
 
     const bool inside_I = ipx >= 1 && ipy >= 1 && ipx + WIN + 1 <= I.w - 1 && ipy + WIN + 1 <= I.h - 1;
@@ -958,8 +1001,7 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
     const int run = tid / C::SPR, j = tid - run * C::SPR, y0 = run * C::K;
     const bool lane_on = run < C::RUNS;
     const int cnt = min(4, WIN - 4 * j);
-    const int slot_base = tid;
-    constexpr int slot_stride = C::LANES;
+    constexpr int slot_base = 0, slot_stride = 1;
     int part[3] = {0, 0, 0};
     if (lane_on && inside_I) {
         // interior: rolling V rows (see strip_setup_linear): patch rows y .. y+3 feed strip y; one new row per strip
@@ -976,27 +1018,41 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
             setup_row_pairs(r0[2 * (C::PI_PITCH >> 2)], r0[2 * (C::PI_PITCH >> 2) + 1], prB);
             setup_v_row(pr0, prA, wt, wb, V0);
             setup_v_row(prA, prB, wt, wb, V1);
-            setup_hg_row(V0, H0, G0);
-            setup_hg_row(V1, H1, G1);
+            setup_hg_row(V0, H0, G0, 0);
+            setup_hg_row(V1, H1, G1, 1);
 #pragma unroll
             for (int c = 0; c < 4; c++) Vm[c] = V1[c + 1];
+        }
+        // One patch row is read one strip ahead of its use and a scheduling barrier closes every strip: left alone, hipcc hoists the LDS reads of all
+        // K strips to the top of the unrolled loop and interleaves the strips (248 VGPRs for K = 13)
+        unsigned nlo, nhi;
+        {
+            const unsigned* rn = col + (y0 + 3) * (C::PI_PITCH >> 2);
+            nlo = rn[0]; nhi = rn[1];
         }
 #pragma unroll
         for (int k = 0; k < C::K; k++) {
             const int y = y0 + k;
-            {   // no branch on y < WIN: see LK3::SLOTS (rows past the patch read the padding / the next buffer: harmless garbage)
-                const unsigned* rn = col + (y + 3) * (C::PI_PITCH >> 2);
+            {   // no branch on y < WIN: see LK3 (rows past the patch read the padding / the next buffer: harmless garbage)
+                const unsigned clo = nlo, chi = nhi;
+                if (k + 1 < C::K) {
+                    const unsigned* rn = col + (y + 4) * (C::PI_PITCH >> 2);
+                    nlo = rn[0]; nhi = rn[1];
+                }
                 unsigned prN[6];
                 int V2[6], H2[4], G2[4];
-                setup_row_pairs(rn[0], rn[1], prN);
+                setup_row_pairs(clo, chi, prN);
                 setup_v_row(prB, prN, wt, wb, V2);
-                setup_hg_row(V2, H2, G2);
+                setup_hg_row(V2, H2, G2, k + 2);
                 setup_from_hg<(WIN % 4) != 1>(H0, H1, H2, G0, G2, Vm, cnt, tI, tX, tY, slot_base + k * slot_stride, part[0], part[1], part[2],
                                               (C::PAD_ROWS > 0 && y >= WIN) ? 0u : 0xffffffffu);
+                cI[0] = dot2(tI[k].y, tX[k].y, dot2(tI[k].x, tX[k].x, cI[0]));
+                cI[1] = dot2(tI[k].y, tY[k].y, dot2(tI[k].x, tY[k].x, cI[1]));
 #pragma unroll
                 for (int c = 0; c < 4; c++) { H0[c] = H1[c]; H1[c] = H2[c]; G0[c] = G1[c]; G1[c] = G2[c]; Vm[c] = V2[c + 1]; }
 #pragma unroll
                 for (int c = 0; c < 6; c++) prB[c] = prN[c];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     } else if (lane_on) {
@@ -1014,7 +1070,10 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
                     lo[r] = row[0]; hi[r] = row[1];
                 }
                 strip_setup<false>(lo, hi, w0, I, ipx, ipy, 4 * j, y, cnt, tI, tX, tY, slot_base + k * slot_stride, part[0], part[1], part[2]);
+                cI[0] = dot2(tI[k].y, tX[k].y, dot2(tI[k].x, tX[k].x, cI[0]));
+                cI[1] = dot2(tI[k].y, tY[k].y, dot2(tI[k].x, tY[k].x, cI[1]));
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the K strips of this (rare) border path sequential: register pressure
         }
     }
     long long sA[3];
@@ -1031,18 +1090,21 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
     D = __fdiv_rn(1.f, D);
 
     // packed byte pairs of window row y (strip column j) of the staged search region at window origin (inx, iny)
+    // The strip starts at byte `off` of the staged row: its 5 bytes lie inside the two dwords at off >> 2, and the byte pair (c, c+1) is ONE
+    // v_perm of those two dwords with the selector 0x0c000c00 + (c + sh) * 0x00010001 + 0x00010000, sh = off & 3 (wave uniform: no alignbyte)
     auto region_row_pairs = [&](int inx, int iny, int y, unsigned* t) {
         const int off = (inx - rjx) + 4 * j;
-        const unsigned sh = (unsigned)(off & 3);
+        const unsigned sel0 = 0x0c010c00u + (unsigned)__builtin_amdgcn_readfirstlane((inx - rjx) & 3) * 0x00010001u;
         const unsigned* row = pJ + (iny - rjy + y) * (C::PJ_PITCH >> 2) + (off >> 2);
-        const unsigned d0 = row[0], d1 = row[1], d2 = row[2];
-        strip_row_pairs(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh), t);
+        const unsigned d0 = row[0], d1 = row[1];
+#pragma unroll
+        for (int c = 0; c < 4; c++) t[c] = __builtin_amdgcn_perm(d1, d0, sel0 + (unsigned)c * 0x00010001u);
     };
     auto region_holds = [&](int inx, int iny) { return inx >= rjx && iny >= rjy && inx + WIN + 1 <= rjx + C::RJ && iny + WIN + 1 <= rjy + C::RJ; };
     auto restage = [&](int inx, int iny) {
         rjx = inx - M; rjy = iny - M;
         __syncthreads();
-        stage_region<C::T, C::RJ, C::PJ_PITCH>(J, rjx, rjy, pJ, tid);
+        stage_region<C::T, C::RJ, C::PJ_WIDTH, C::PJ_PITCH>(J, rjx, rjy, pJ, tid);
         __syncthreads();
     };
 
@@ -1056,25 +1118,38 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
         if (!region_holds(inx, iny)) restage(inx, iny);
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny)));
         n_iter++;
-        int b[2] = {0, 0};
+        int b[2] = {-cI[0], -cI[1]};
         if (lane_on) {
+            // rows are read one strip ahead of their use, a scheduling barrier closes every strip (see the set-up loop)
+            const int off = (inx - rjx) + 4 * j;
+            const unsigned sel0 = 0x0c010c00u + (unsigned)__builtin_amdgcn_readfirstlane((inx - rjx) & 3) * 0x00010001u;
+            const unsigned* row = pJ + (iny - rjy + y0) * (C::PJ_PITCH >> 2) + (off >> 2);
             unsigned top[4];
-            region_row_pairs(inx, iny, y0, top);
+            {
+                const unsigned d0 = row[0], d1 = row[1];
+#pragma unroll
+                for (int c = 0; c < 4; c++) top[c] = __builtin_amdgcn_perm(d1, d0, sel0 + (unsigned)c * 0x00010001u);
+            }
+            unsigned n0 = row[C::PJ_PITCH >> 2], n1 = row[(C::PJ_PITCH >> 2) + 1];
 #pragma unroll
             for (int k = 0; k < C::K; k++) {
-                const int y = y0 + k;
                 {   // every strip of the run, no branch: the gradients of strips below the window are zeros (set-up)
-                    unsigned bot[4], p01, p23;
-                    region_row_pairs(inx, iny, y + 1, bot);  // the bottom row of strip y is the top row of strip y+1
+                    const unsigned c0 = n0, c1 = n1;
+                    if (k + 1 < C::K) {
+                        n0 = row[(k + 2) * (C::PJ_PITCH >> 2)];
+                        n1 = row[(k + 2) * (C::PJ_PITCH >> 2) + 1];
+                    }
+                    unsigned bot[4], p01, p23;  // the bottom row of strip y is the top row of strip y+1
+#pragma unroll
+                    for (int c = 0; c < 4; c++) bot[c] = __builtin_amdgcn_perm(c1, c0, sel0 + (unsigned)c * 0x00010001u);
                     strip_bilinear_pairs(top, bot, w, p01, p23);
                     const int slot = slot_base + k * slot_stride;
-                    const uint2 vI = tI[slot], vX = tX[slot], vY = tY[slot];
-                    const unsigned d01 = __builtin_bit_cast(unsigned, as_s2(p01) - as_s2(vI.x));
-                    const unsigned d23 = __builtin_bit_cast(unsigned, as_s2(p23) - as_s2(vI.y));
-                    b[0] = dot2(d23, vX.y, dot2(d01, vX.x, b[0]));
-                    b[1] = dot2(d23, vY.y, dot2(d01, vY.x, b[1]));
+                    const uint2 vX = tX[slot], vY = tY[slot];
+                    b[0] = dot2(p23, vX.y, dot2(p01, vX.x, b[0]));
+                    b[1] = dot2(p23, vY.y, dot2(p01, vY.x, b[1]));
 #pragma unroll
                     for (int c = 0; c < 4; c++) top[c] = bot[c];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -1112,7 +1187,16 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
                     unsigned bot[4], p01, p23;
                     region_row_pairs(inx, iny, y + 1, bot);
                     strip_bilinear_pairs(top, bot, w, p01, p23);
-                    const uint2 vI = tI[slot_base + k * slot_stride];
+                    // template samples of strip y again from the staged patch (rows y+1, y+2; byte columns 1..5 of the lane's 8 bytes)
+                    uint2 vI;
+                    {
+                        const unsigned* r1 = pI + (y + 1) * (C::PI_PITCH >> 2) + j;
+                        const unsigned* r2 = r1 + (C::PI_PITCH >> 2);
+                        unsigned tp[4], bt[4];
+                        strip_row_pairs(__builtin_amdgcn_alignbyte(r1[1], r1[0], 1), r1[1] >> 8, tp);
+                        strip_row_pairs(__builtin_amdgcn_alignbyte(r2[1], r2[0], 1), r2[1] >> 8, bt);
+                        strip_bilinear_pairs(tp, bt, strip_weights(w0), vI.x, vI.y);
+                    }
                     const short2v d01 = as_s2(p01) - as_s2(vI.x), d23 = as_s2(p23) - as_s2(vI.y);
                     const int d[4] = {d01.x, d01.y, d23.x, d23.y};
 #pragma unroll
@@ -1120,6 +1204,7 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
 #pragma unroll
                     for (int c = 0; c < 4; c++) top[c] = bot[c];
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         long long sse[1];
@@ -1129,7 +1214,7 @@ __device__ void lk3_level(const ImgDesc I, const ImgDesc J, int level, int top_l
 }
 
 template <int WIN, int NW, int M>
-__device__ void lk3_track(const PyrDesc& PI, const PyrDesc& PJ, int max_count, double eps2, float px, float py, float& ox, float& oy,
+__device__ __forceinline__ void lk3_track(const PyrDesc& PI, const PyrDesc& PJ, int max_count, double eps2, float px, float py, float& ox, float& oy,
                           int& status, float& err, char* smem, int tid, int& phase, int& n_iter, int& n_setup, bool want_err)
 {
     const int nl = min(PI.nlevels, PJ.nlevels);
@@ -1144,7 +1229,7 @@ __device__ void lk3_track(const PyrDesc& PI, const PyrDesc& PJ, int max_count, d
 // (forcing 5 or 6 workgroups per CU through the second launch bound spills and measured 3-8 % slower; a 128-VGPR cap
 // + a 3-pixel search margin to fit 7 workgroups of the 2-wave variant per CU: 11 spilled registers, 5 % slower: not used)
 template <int WIN, int NW, int M>
-__global__ __launch_bounds__(64 * NW) void k_lk3(const void* job_tab, size_t tab_stride)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? 3 : 4))) void k_lk3(const void* job_tab, size_t tab_stride)
 {
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
@@ -1461,7 +1546,9 @@ static int launch_strip(const void* job_tab, size_t tab_stride, int batch, int m
     return 0;
 }
 
-static int g_lk_force_generic = 0;  // test hook: 1 = per-sample kernel, 2 = strip kernel, 3 = LDS-staged kernel, 4 = 4-tracks-per-wave kernel (15x15), 0 = default routing
+// test hook: 1 = per-sample kernel, 2 = strip kernel, 3 = LDS-staged kernel, 4 = 4-tracks-per-wave kernel (15x15), 5 / 6 / 7 = LDS-staged 51x51 kernel with
+// 1 / 2 / 4 wavefronts per track, 0 = default routing
+static int g_lk_force_generic = 0;
 void vh_lk_force_generic(int on) { g_lk_force_generic = on; }
 
 int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s)
@@ -1470,20 +1557,26 @@ int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, i
     // Default routing (measured on MI355X, profiles/): the LDS-staged 4-wave kernel for the 51x51 fine stage (equal
     // throughput, 25% lower latency than the strip kernel), the strip kernel for the 15x15 coarse stages (the staged
     // variant is 2.5x slower there).  Mode 3 forces the staged kernel for both windows (tests).
-    if (g_lk_force_generic == 0 || g_lk_force_generic == 3) {
+    const bool force_nw = g_lk_force_generic >= 5 && g_lk_force_generic <= 7;
+    if (g_lk_force_generic == 0 || g_lk_force_generic == 3 || (force_nw && win == 51)) {
         if (win == 15 && g_lk_force_generic == 3) return launch_lk3<15, 1, 6>(job_tab, tab_stride, batch, max_n, s);
-        // 4 wavefronts per track minimise latency (few tracks in flight); 2 per track halve the replicated uniform work and
-        // measured 17 % faster once the chip is full (1 per track starves occupancy: 2x slower)
+        // Wavefronts per 51x51 track, measured on MI355X (C2, frame step with 1 .. 128 streams): ONE wavefront per track (13 strips per lane, no
+        // barrier, no LDS exchange of the window sums, the replicated wave-uniform work done once per track) wins from ~4000 tracks in flight
+        // up: 2.32 ms vs 2.99 ms (2 per track) vs 4.5 ms (4 per track) at 256 000 tracks; 2 and 4 per track shorten the critical path of a
+        // single track and are used below that (67 us vs 72 us for 2000 tracks).
         if (win == 51) {
-            if (g_lk_force_generic == 0 && (long long)max_n * batch >= 6144) return launch_lk3<51, 2, 4>(job_tab, tab_stride, batch, max_n, s);
+            const long long tracks = (long long)max_n * batch;
+            const int nw = force_nw ? (1 << (g_lk_force_generic - 5)) : (g_lk_force_generic == 3 ? 4 : tracks >= 3000 ? 1 : tracks >= 1024 ? 2 : 4);
+            if (nw == 1) return launch_lk3<51, 1, 4>(job_tab, tab_stride, batch, max_n, s);
+            if (nw == 2) return launch_lk3<51, 2, 4>(job_tab, tab_stride, batch, max_n, s);
             return launch_lk3<51, 4, 4>(job_tab, tab_stride, batch, max_n, s);
         }
     }
     // 15x15: 4 tracks per wavefront once there are enough tracks to fill the chip that way (11 % faster frame step at 64
     // streams); below that the one-wave-per-track strip kernel has the shorter critical path.  Mode 4 forces it (tests).
-    if (win == 15 && (g_lk_force_generic == 4 || (g_lk_force_generic == 0 && (long long)max_n * batch >= 6144)))
+    if (win == 15 && (g_lk_force_generic == 4 || ((g_lk_force_generic == 0 || force_nw) && (long long)max_n * batch >= 6144)))
         return launch_lkq<15>(job_tab, tab_stride, batch, max_n, s);
-    if (g_lk_force_generic != 1 && win <= 63) {
+    if (g_lk_force_generic != 1 && win <= 63) {  // (modes 5..7 with another window than 51: default routing)
         // int32 per-lane partial sums are exact up to 16 strips per lane (win <= 63)
         if (win == 15) return launch_strip<15>(job_tab, tab_stride, batch, max_n, win, s);
         if (win == 51) return launch_strip<51>(job_tab, tab_stride, batch, max_n, win, s);
