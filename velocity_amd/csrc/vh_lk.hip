@@ -1304,6 +1304,39 @@ __device__ __forceinline__ unsigned dpp_from_next_lane(unsigned v)
 {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);  // row_shl:1 -> lane i reads lane i+1
 }
+// acc += dot2(a of lane i+1, b): the second link of a bilinear chain takes the packed pair of the row below straight from the neighbour lane
+__device__ __forceinline__ int dot2c_next_lane(int acc, unsigned a, unsigned b)
+{
+    asm("v_dot2c_i32_i16_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(a), "v"(b));
+    return acc;
+}
+// packed byte pair (c, c+1) of a row held as aligned words a[0..]
+__device__ __forceinline__ unsigned row_pair(const unsigned* a, int c)
+{
+    const int w = c >> 2, q = c & 3;
+    return q == 0 ? __builtin_amdgcn_perm(0u, a[w], 0x0c010c00u)
+         : q == 1 ? __builtin_amdgcn_perm(0u, a[w], 0x0c020c01u)
+         : q == 2 ? __builtin_amdgcn_perm(0u, a[w], 0x0c030c02u)
+                  : __builtin_amdgcn_perm(a[w + 1], a[w], 0x0c040c03u);
+}
+// bilinear x32 samples of row r's NS strips at (x0, y0 + r) of image im: lane r holds row y0 + r, the row below comes from lane r + 1
+template <int NS>
+__device__ __forceinline__ void lkq_sample_row(const ImgDesc& im, int x0, int y0, int r, bool fast, unsigned wt, unsigned wb, unsigned* p01, unsigned* p23)
+{
+    unsigned top[NS + 1];
+    load_row_words<NS + 1>(im, x0, y0 + r, fast, top);
+    int v[4 * NS];
+#pragma unroll
+    for (int c = 0; c < 4 * NS; c++) {
+        const unsigned pr = row_pair(top, c);
+        v[c] = (dot2c_next_lane(dot2_first(pr, wt), pr, wb) << (16 - (W_BITS - 5))) + (1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5)));
+    }
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        p01[j] = pack_hi16(v[4 * j], v[4 * j + 1]);
+        p23[j] = pack_hi16(v[4 * j + 2], v[4 * j + 3]);
+    }
+}
 
 // NW5 = number of aligned 4-byte words a lane needs from one image row, starting at pixel (gx, gy): word i = bytes 4i..4i+3
 template <int NWORDS>
@@ -1354,21 +1387,93 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
     n_setup++;
 
     int a11 = 0, a12 = 0, a22 = 0;
-    uint2 tI[NS], tX[NS], tY[NS];
+    // template gradients of this lane's row (registers); the template SAMPLES are not kept: sum (J - I) Ix = sum J Ix - cI (see lk3_level)
+    uint2 tX[NS], tY[NS];
+    int cI[2] = {0, 0};
 #pragma unroll
-    for (int j = 0; j < NS; j++) { tI[j] = make_uint2(0, 0); tX[j] = make_uint2(0, 0); tY[j] = make_uint2(0, 0); }
-    {
-        const bool fast = ipx >= 4 && ipy >= 1 && ipx + WIN + 12 <= I.w && ipy + WIN + 2 <= I.h;
+    for (int j = 0; j < NS; j++) { tX[j] = make_uint2(0, 0); tY[j] = make_uint2(0, 0); }
+    const bool fast_I = ipx >= 4 && ipy >= 1 && ipx + WIN + 12 <= I.w && ipy + WIN + 2 <= I.h;
+    const unsigned w0t = pack16(w0.w00, w0.w01), w0b = pack16(w0.w10, w0.w11);
+    if (fast_I) {
+        // Interior window, all 16 lanes of the track (lane WIN feeds lane WIN-1).  Lane r reads patch rows r .. r+2 and builds V rows r and r+1 over
+        // the NC = 4 NS + 2 columns its NS adjacent strips share (V = bilinear weights . patch, no rounding: see strip_setup_linear); V row r+2 is
+        // the neighbour's second row (DPP).  Scharr of V, vertical pass first:  S = 3 (V_r + V_r+2) + 10 V_r+1,  dV = V_r+2 - V_r,
+        //   Ix = S[c+2] - S[c],   Iy = 3 (dV[c] + dV[c+2]) + 10 dV[c+1]
+        // both kept x4 with the rounding folded in (column c of S carries 2^14 c), so descale + int16 packing is the upper half (pack_hi16).
+        constexpr int NC = 4 * NS + 2;
+        unsigned a[3][NS + 1];
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) load_row_words<NS + 1>(I, ipx - 1, ipy + r - 1 + rr, true, a[rr]);
+        int S4[NC], dV[NC], V1[NC];
+        auto column = [&](int c) {
+            const unsigned q0 = row_pair(a[0], c), q1 = row_pair(a[1], c), q2 = row_pair(a[2], c);
+            const int v0 = dot2(q1, w0b, dot2_first(q0, w0t));
+            V1[c] = dot2(q2, w0b, dot2_first(q1, w0t));
+            const int v2 = (int)dpp_from_next_lane((unsigned)V1[c]);
+            S4[c] = mad24_v<40>(V1[c], mad24_s<12>(v0 + v2, c << W_BITS));
+            dV[c] = v2 - v0;
+        };
+        column(0); column(1);
+        const unsigned vmask = r < WIN ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            // strip j needs columns 4j .. 4j+5: four new ones per strip, and a scheduling barrier per strip keeps the column window short
+            // (left alone hipcc builds all 18 columns first: 157 VGPRs)
+#pragma unroll
+            for (int c = 0; c < 4; c++) column(4 * j + 2 + c);
+            constexpr int full = 4;
+            const int cnt = WIN - 4 * j < full ? WIN - 4 * j : full;
+            int iv[4], ix[4], iy[4];  // the wanted int16 in the upper half of each
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int col = 4 * j + c;
+                iv[c] = (V1[col + 1] << (16 - (W_BITS - 5))) + (1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5)));
+                ix[c] = S4[col + 2] - S4[col];
+                iy[c] = mad24_v<40>(dV[col + 1], mad24_s<12>(dV[col] + dV[col + 2], 4 << (W_BITS - 1)));
+            }
+            const unsigned m01 = (cnt >= 2 ? 0xffffffffu : 0x0000ffffu) & vmask, m23 = (cnt >= 4 ? 0xffffffffu : (cnt == 3 ? 0x0000ffffu : 0u)) & vmask;
+            const uint2 vI = make_uint2(pack_hi16(iv[0], iv[1]), pack_hi16(iv[2], iv[3]));
+            const uint2 vX = make_uint2(pack_hi16(ix[0], ix[1]) & m01, pack_hi16(ix[2], ix[3]) & m23);
+            const uint2 vY = make_uint2(pack_hi16(iy[0], iy[1]) & m01, pack_hi16(iy[2], iy[3]) & m23);
+            tX[j] = vX; tY[j] = vY;
+            a11 = dot2(vX.y, vX.y, dot2(vX.x, vX.x, a11));
+            a12 = dot2(vX.y, vY.y, dot2(vX.x, vY.x, a12));
+            a22 = dot2(vY.y, vY.y, dot2(vY.x, vY.x, a22));
+            cI[0] = dot2(vI.y, vX.y, dot2(vI.x, vX.x, cI[0]));
+            cI[1] = dot2(vI.y, vY.y, dot2(vI.x, vY.x, cI[1]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // Window at the image border (a quarter of the tracks on the coarsest level): gradients of integer pixels, zero outside the image, then
+        // interpolated (strip_setup<false>).  One strip at a time in a ROLLED loop, the lane's patch words and results staged through its private
+        // LDS column: unrolled, this path alone needs 152 VGPRs (3 wavefronts per SIMD for the whole kernel instead of 5).
+        extern __shared__ unsigned lkq_lds[];  // [4 * (NS + 1)][64]
+        unsigned* mine = lkq_lds + (threadIdx.x & 63);
         if (r < WIN) {
-            unsigned a[4][NS + 1];
 #pragma unroll
-            for (int rr = 0; rr < 4; rr++) load_row_words<NS + 1>(I, ipx - 1, ipy + r - 1 + rr, fast, a[rr]);
+            for (int rr = 0; rr < 4; rr++) {
+                unsigned a[NS + 1];
+                load_row_words<NS + 1>(I, ipx - 1, ipy + r - 1 + rr, false, a);
+#pragma unroll
+                for (int i = 0; i <= NS; i++) mine[(4 * i + rr) * 64] = a[i];
+            }
+#pragma unroll 1
+            for (int j = 0; j < NS; j++) {
+                unsigned lo[4], hi[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) { lo[rr] = mine[(4 * j + rr) * 64]; hi[rr] = mine[(4 * j + 4 + rr) * 64]; }
+                const int cnt = WIN - 4 * j < 4 ? WIN - 4 * j : 4;
+                uint2 sI[1], sX[1], sY[1];
+                strip_setup<false>(lo, hi, w0, I, ipx, ipy, 4 * j, r, cnt, sI, sX, sY, 0, a11, a12, a22);
+                cI[0] = dot2(sI[0].y, sX[0].y, dot2(sI[0].x, sX[0].x, cI[0]));
+                cI[1] = dot2(sI[0].y, sY[0].y, dot2(sI[0].x, sY[0].x, cI[1]));
+                mine[(4 * j + 0) * 64] = sX[0].x; mine[(4 * j + 1) * 64] = sX[0].y;  // word j of the four rows is dead now
+                mine[(4 * j + 2) * 64] = sY[0].x; mine[(4 * j + 3) * 64] = sY[0].y;
+            }
 #pragma unroll
             for (int j = 0; j < NS; j++) {
-                const unsigned lo[4] = {a[0][j], a[1][j], a[2][j], a[3][j]}, hi[4] = {a[0][j + 1], a[1][j + 1], a[2][j + 1], a[3][j + 1]};
-                const int cnt = WIN - 4 * j < 4 ? WIN - 4 * j : 4;
-                if (fast) strip_setup<true>(lo, hi, w0, I, ipx, ipy, 4 * j, r, cnt, tI, tX, tY, j, a11, a12, a22);
-                else strip_setup<false>(lo, hi, w0, I, ipx, ipy, 4 * j, r, cnt, tI, tX, tY, j, a11, a12, a22);
+                tX[j] = make_uint2(mine[(4 * j + 0) * 64], mine[(4 * j + 1) * 64]);
+                tY[j] = make_uint2(mine[(4 * j + 2) * 64], mine[(4 * j + 3) * 64]);
             }
         }
     }
@@ -1395,21 +1500,14 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny)));
         const bool fast = inx >= 3 && iny >= 0 && inx + WIN + 12 <= J.w && iny + WIN + 1 <= J.h;
         n_iter++;
-        unsigned top[NS + 1], bot[NS + 1];
-        load_row_words<NS + 1>(J, inx, iny + r, fast, top);  // lane r = row r (lane WIN holds the last bottom row)
-#pragma unroll
-        for (int i = 0; i <= NS; i++) bot[i] = dpp_from_next_lane(top[i]);
-        int b1 = 0, b2 = 0;
+        unsigned p01[NS], p23[NS];
+        lkq_sample_row<NS>(J, inx, iny, r, fast, w.wt, w.wb, p01, p23);  // lane r = row r (lane WIN holds the last bottom row)
+        int b1 = -cI[0], b2 = -cI[1];
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-            const unsigned lo[2] = {top[j], bot[j]}, hi[2] = {top[j + 1], bot[j + 1]};
-            unsigned p01, p23;
-            strip_bilinear(lo, hi, w, p01, p23);
-            const unsigned d01 = __builtin_bit_cast(unsigned, as_s2(p01) - as_s2(tI[j].x));
-            const unsigned d23 = __builtin_bit_cast(unsigned, as_s2(p23) - as_s2(tI[j].y));
             // rows >= WIN and samples beyond the window edge carry Ix = Iy = 0, so they add nothing
-            b1 = dot2(d23, tX[j].y, dot2(d01, tX[j].x, b1));
-            b2 = dot2(d23, tY[j].y, dot2(d01, tY[j].x, b2));
+            b1 = dot2(p23[j], tX[j].y, dot2(p01[j], tX[j].x, b1));
+            b2 = dot2(p23[j], tY[j].y, dot2(p01[j], tY[j].x, b2));
         }
         const float fb1 = __fmul_rn(i64_to_f32(row16_sum_wide(b1)), LK_FLT_SCALE), fb2 = __fmul_rn(i64_to_f32(row16_sum_wide(b2)), LK_FLT_SCALE);
         const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
@@ -1432,17 +1530,14 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
         if (!want_err) return;
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny)));
         const bool fast = inx >= 3 && iny >= 0 && inx + WIN + 12 <= J.w && iny + WIN + 1 <= J.h;
-        unsigned top[NS + 1], bot[NS + 1];
-        load_row_words<NS + 1>(J, inx, iny + r, fast, top);
-#pragma unroll
-        for (int i = 0; i <= NS; i++) bot[i] = dpp_from_next_lane(top[i]);
+        unsigned p01[NS], p23[NS], i01[NS], i23[NS];
+        lkq_sample_row<NS>(J, inx, iny, r, fast, w.wt, w.wb, p01, p23);
+        // the template samples again (not kept by the set-up): the same bilinear sampling of I at the template origin
+        lkq_sample_row<NS>(I, ipx, ipy, r, fast_I, w0t, w0b, i01, i23);
         int se = 0;
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-            const unsigned lo[2] = {top[j], bot[j]}, hi[2] = {top[j + 1], bot[j + 1]};
-            unsigned p01, p23;
-            strip_bilinear(lo, hi, w, p01, p23);
-            const short2v d01 = as_s2(p01) - as_s2(tI[j].x), d23 = as_s2(p23) - as_s2(tI[j].y);
+            const short2v d01 = as_s2(p01[j]) - as_s2(i01[j]), d23 = as_s2(p23[j]) - as_s2(i23[j]);
             const int d[4] = {d01.x, d01.y, d23.x, d23.y};
             const int cnt = WIN - 4 * j < 4 ? WIN - 4 * j : 4;
 #pragma unroll
@@ -1465,7 +1560,7 @@ __device__ __forceinline__ void lkq_track(const PyrDesc& PI, const PyrDesc& PJ, 
 }
 
 template <int WIN>
-__global__ __launch_bounds__(64) void k_lk_q(const void* job_tab, size_t tab_stride)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_lk_q(const void* job_tab, size_t tab_stride)
 {
     static_assert(WIN <= 15, "lane WIN of every 16-lane row carries the extra bottom row");
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
@@ -1521,7 +1616,8 @@ __global__ __launch_bounds__(64) void k_lk_q(const void* job_tab, size_t tab_str
 template <int WIN>
 static int launch_lkq(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lk_q<WIN>, dim3((max_n + 3) / 4, batch), dim3(64), 0, s, job_tab, tab_stride);
+    constexpr int lds = 4 * (((WIN + 3) >> 2) + 1) * 64 * 4;  // the border set-up's lane-private staging
+    hipLaunchKernelGGL(k_lk_q<WIN>, dim3((max_n + 3) / 4, batch), dim3(64), lds, s, job_tab, tab_stride);
     return 0;
 }
 
