@@ -50,7 +50,7 @@ typedef struct {
     const float* p_coarse;    /* n x 2  stage-2 result (KLT.py:124)                         */
     const uint8_t* v_coarse;  /* n                                                          */
     const double* t23;        /* 6      2x3 affine (KLT.py:127)                             */
-    const uint8_t* warped;    /* ROI-sized affine warp, row stride = roi width (KLT.py:73)  */
+    const uint8_t* warped;    /* ROI-sized affine warp, row stride = roi width rounded up to a multiple of 4 (KLT.py:73)  */
     const int* flags;         /* 1      bit0: coarse-affine failure (KLT.py:128-130)        */
 } vh_klt_stages;
 

@@ -154,4 +154,4 @@ def klt_stages(n):
     return dict(p_small=rd(st.p_small, 2 * n, np.float32).reshape(n, 2), v_small=rd(st.v_small, n, np.uint8),
                 T_trans=rd(st.t_trans, 2, np.float64), roi=roi, p_coarse=rd(st.p_coarse, 2 * n, np.float32).reshape(n, 2),
                 v_coarse=rd(st.v_coarse, n, np.uint8), T23=rd(st.t23, 6, np.float64).reshape(2, 3),
-                warped=rd(st.warped, rw * rh, np.uint8).reshape(rh, rw), flags=int(rd(st.flags, 1, np.int32)[0]))
+                warped=rd(st.warped, ((rw + 3) & ~3) * rh, np.uint8).reshape(rh, (rw + 3) & ~3)[:, :rw].copy(), flags=int(rd(st.flags, 1, np.int32)[0]))

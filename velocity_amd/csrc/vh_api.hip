@@ -84,7 +84,7 @@ extern "C" VH_API int vh_ctx_create(vh_ctx** out, int batch, int max_w, int max_
                 }
                 B.roi_lv[k][0] = nullptr;
             }
-            B.warp = (uint8_t*)(base + carve((size_t)max_w * max_h));
+            B.warp = (uint8_t*)(base + carve((size_t)((max_w + 3) & ~3) * max_h));
             B.p_small = (float*)(base + carve(sizeof(float) * 2 * max_pts));
             B.p_coarse = (float*)(base + carve(sizeof(float) * 2 * max_pts));
             B.v_small = (uint8_t*)(base + carve(max_pts));
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_klt_glue1(StreamWS* ws_all)
     // shifted crop: a view when it stays inside the frame, a zero-padded copy otherwise
     WarpJob& W = ws.warp;
     W.src = ImgDesc{io.im, io.w, io.h, io.stride, 0};
-    W.dst = B.warp; W.dst_stride = rw;
+    W.dst = B.warp; W.dst_stride = (rw + 3) & ~3;  // dword rows: the warp kernel stores packed dwords
     W.x0 = x0; W.x1 = x1; W.y0 = y0; W.y1 = y1; W.dx = dx; W.dy = dy;
     const bool inside = x0 + dx >= 0 && x1 + dx <= io.w && y0 + dy >= 0 && y1 + dy <= io.h;
     W.mode = (inside || n == 0) ? -1 : 0;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_klt_glue1(StreamWS* ws_all)
     const vh_lk_params& lk = io.coarse;
     fill_pyramid(J.I, io.im0 + (size_t)y0 * io.stride0 + x0, rw, rh, io.stride0, B.roi_lv[0], lk.win, lk.max_level);
     if (inside) fill_pyramid(J.J, io.im + (ptrdiff_t)(y0 + dy) * io.stride + (x0 + dx), rw, rh, io.stride, B.roi_lv[1], lk.win, lk.max_level);
-    else fill_pyramid(J.J, B.warp, rw, rh, rw, B.roi_lv[1], lk.win, lk.max_level);
+    else fill_pyramid(J.J, B.warp, rw, rh, (rw + 3) & ~3, B.roi_lv[1], lk.win, lk.max_level);
     ws.pb[0] = PyrBuild{&J.I, 1, 0};
     ws.pb[1] = PyrBuild{&J.J, 1, 0};
     fill_lk_common(J, lk, io.p0, nullptr, n);
@@ -317,12 +317,12 @@ __global__ void k_klt_glue2(StreamWS* ws_all)
     const int rw = max(x1 - x0, 0), rh = max(y1 - y0, 0);
     WarpJob& W = ws.warp;
     W.mode = ws.n > 0 ? 1 : -1;
-    W.dst = B.warp; W.dst_stride = rw;
+    W.dst = B.warp; W.dst_stride = (rw + 3) & ~3;  // dword rows: the warp kernel stores packed dwords
     for (int k = 0; k < 6; k++) W.T[k] = T[k];
     LKJob& J = ws.lk;
     const vh_lk_params& lk = io.fine;
     fill_pyramid(J.I, io.im0 + (size_t)y0 * io.stride0 + x0, rw, rh, io.stride0, B.roi_lv[0], lk.win, lk.max_level);
-    fill_pyramid(J.J, B.warp, rw, rh, rw, B.roi_lv[1], lk.win, lk.max_level);
+    fill_pyramid(J.J, B.warp, rw, rh, (rw + 3) & ~3, B.roi_lv[1], lk.win, lk.max_level);
     ws.pb[0] = PyrBuild{&J.I, 1, 0};
     ws.pb[1] = PyrBuild{&J.J, 1, 0};
     fill_lk_common(J, lk, io.p0, nullptr, ws.n);
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void k_regional_setup(StreamWS* ws_p, Regional
     ws.roi[0] = x0; ws.roi[1] = x1; ws.roi[2] = y0; ws.roi[3] = y1;
     WarpJob& W = ws.warp;
     W.src = ImgDesc{io.im, io.w, io.h, io.stride, 0};
-    W.dst = B.warp; W.dst_stride = rw;
+    W.dst = B.warp; W.dst_stride = (rw + 3) & ~3;  // dword rows: the warp kernel stores packed dwords
     W.x0 = x0; W.x1 = x1; W.y0 = y0; W.y1 = y1;
     LKJob& J = ws.lk;
     fill_pyramid(J.I, io.im0 + (size_t)y0 * io.stride0 + x0, rw, rh, io.stride0, B.roi_lv[0], io.lk.win, io.lk.max_level);
@@ -672,12 +672,12 @@ __global__ __launch_bounds__(256) void k_regional_setup(StreamWS* ws_p, Regional
         const bool inside = x0 + dx >= 0 && x1 + dx <= io.w && y0 + dy >= 0 && y1 + dy <= io.h;
         W.mode = inside ? -1 : 0;
         if (inside) fill_pyramid(J.J, io.im + (ptrdiff_t)(y0 + dy) * io.stride + (x0 + dx), rw, rh, io.stride, B.roi_lv[1], io.lk.win, io.lk.max_level);
-        else fill_pyramid(J.J, B.warp, rw, rh, rw, B.roi_lv[1], io.lk.win, io.lk.max_level);
+        else fill_pyramid(J.J, B.warp, rw, rh, (rw + 3) & ~3, B.roi_lv[1], io.lk.win, io.lk.max_level);
         J.out_mode = VH_OUT_TRANSLATE; J.out_off[0] = (float)dx; J.out_off[1] = (float)dy;
     } else {
         W.mode = 1;
         for (int k = 0; k < 6; k++) { W.T[k] = io.T[k]; J.T[k] = io.T[k]; }
-        fill_pyramid(J.J, B.warp, rw, rh, rw, B.roi_lv[1], io.lk.win, io.lk.max_level);
+        fill_pyramid(J.J, B.warp, rw, rh, (rw + 3) & ~3, B.roi_lv[1], io.lk.win, io.lk.max_level);
         J.out_mode = VH_OUT_AFFINE;
     }
     ws.pb[0] = PyrBuild{&J.I, 1, 0};

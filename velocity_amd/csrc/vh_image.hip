@@ -2,6 +2,7 @@
 // affine remap (K9).  All are HBM-bound byte kernels; descriptors are read from device memory because ROI sizes are
 // data dependent (bounding box of the tracks) and the whole frame pipeline runs without a host round trip.
 #include "vh_kernels.hpp"
+#include "vh_valu.hpp"
 
 // descriptor b of a strided descriptor table (tables live inside per-stream structs)
 __device__ __forceinline__ const ImgDesc& desc_at(const void* base, size_t stride, int b)
@@ -230,8 +231,13 @@ __global__ __launch_bounds__(256) void k_roi_warp(const void* job_tab, size_t ta
         xb[k] = __fmul_rn(x, J.T[1]);
     }
     int fx[RW_ROWS][4], fy[RW_ROWS][4];
-    bool run[RW_ROWS];
     unsigned t0[RW_ROWS], t1[RW_ROWS], b0[RW_ROWS], b1[RW_ROWS], sh0[RW_ROWS], sh1[RW_ROWS];
+    // near-identity maps (the tracker's case): the 4 pixels of a row sample one source row pair at consecutive columns, so the 2 x 5 source
+    // bytes come from two aligned dword pairs instead of 16 byte gathers.  The whole thread (4 rows) takes that path or none of it does:
+    // one branch per thread, straight-line code inside (per-row branches cost a third of the kernel's instructions in exec juggling).
+    unsigned bad = (cnt != 4 || ry0 + RW_ROWS > rh) ? ~0u : 0u;
+    const unsigned bsh = (unsigned)(reinterpret_cast<uintptr_t>(s.p) & 3);
+    const uint8_t* bp = s.p - bsh;  // dword aligned, wave uniform
 #pragma unroll
     for (int r = 0; r < RW_ROWS; r++) {
         const float y = (float)(J.y0 + ry0 + r);
@@ -245,40 +251,53 @@ __global__ __launch_bounds__(256) void k_roi_warp(const void* job_tab, size_t ta
             fy[r][k] = vh_round(__fmul_rn(my, 32.f));
         }
         const int sx0 = fx[r][0] >> 5, sy0 = fy[r][0] >> 5;
-        // near-identity maps (the tracker's case): the 4 pixels sample one source row pair at consecutive columns, so the
-        // 2 x 5 source bytes come from two aligned dword pairs instead of 16 byte gathers
-        run[r] = cnt == 4 && ry0 + r < rh && (fx[r][1] >> 5) == sx0 + 1 && (fx[r][2] >> 5) == sx0 + 2 && (fx[r][3] >> 5) == sx0 + 3 &&
-                 (fy[r][1] >> 5) == sy0 && (fy[r][2] >> 5) == sy0 && (fy[r][3] >> 5) == sy0 && sx0 >= 3 && sx0 + 8 <= s.w && sy0 >= 0 &&
-                 sy0 + 1 < s.h;
-        // unconditional loads (a branch around a load makes the compiler wait per row): rows that do not qualify read a safe address
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(s.p + (run[r] ? (ptrdiff_t)sy0 * s.stride + sx0 : 0)), a1 = a0 + (run[r] ? s.stride : 0);
-        sh0[r] = (unsigned)(a0 & 3); sh1[r] = (unsigned)(a1 & 3);
-        pd_gptr p0 = (pd_gptr)(a0 - sh0[r]), p1 = (pd_gptr)(a1 - sh1[r]);
+        // (fx[k] >> 5) == sx0 + k  <=>  0 <= fx[k] - 32 (sx0 + k) < 32;  (fy[k] >> 5) == sy0  <=>  (fy[k] ^ fy[0]) < 32: one unsigned compare of the OR;
+        // source window inside the frame: sx0 >= 3, sx0 + 8 <= w, 0 <= sy0 < h - 1 as unsigned range tests
+        const int bx = fx[r][0] & ~31;
+        const unsigned spread = (unsigned)(fx[r][1] - bx - 32) | (unsigned)(fx[r][2] - bx - 64) | (unsigned)(fx[r][3] - bx - 96) |
+                                (unsigned)(fy[r][1] ^ fy[r][0]) | (unsigned)(fy[r][2] ^ fy[r][0]) | (unsigned)(fy[r][3] ^ fy[r][0]);
+        const bool ok = spread < 32u && (unsigned)(sx0 - 3) <= (unsigned)(s.w - 11) && (unsigned)sy0 < (unsigned)(s.h - 1) && s.w >= 11;
+        bad |= ok ? 0u : ~0u;
+        // unconditional loads (a branch around a load makes the compiler wait per row): rows that do not qualify read the first bytes of the frame
+        const unsigned o0 = (ok ? (unsigned)(__mul24(sy0, s.stride) + sx0) : 0u) + bsh, o1 = o0 + (ok ? (unsigned)s.stride : 0u);
+        sh0[r] = o0 & 3u; sh1[r] = o1 & 3u;
+        pd_gptr p0 = (pd_gptr)(bp + (o0 & ~3u)), p1 = (pd_gptr)(bp + (o1 & ~3u));
         t0[r] = p0[0]; t1[r] = p0[1]; b0[r] = p1[0]; b1[r] = p1[1];
     }
+    if (((reinterpret_cast<uintptr_t>(J.dst) | (uintptr_t)J.dst_stride) & 3) != 0) bad = ~0u;  // packed dword stores need dword rows (x4 is a multiple of 4)
+    if (bad == 0u) {
 #pragma unroll
-    for (int r = 0; r < RW_ROWS; r++) {
-        if (ry0 + r >= rh) break;
-        uint32_t pack = 0;
-        if (run[r]) {
-            const unsigned tl = __builtin_amdgcn_alignbyte(t1[r], t0[r], sh0[r]), th = (t1[r] >> (8 * sh0[r])) & 0xffu;
-            const unsigned bl = __builtin_amdgcn_alignbyte(b1[r], b0[r], sh1[r]), bh = (b1[r] >> (8 * sh1[r])) & 0xffu;
+        for (int r = 0; r < RW_ROWS; r++) {
+            // remap_blend on packed int16 pairs: t = (32-ax) s00 + ax s01 and b likewise are two v_dot2 of the byte pairs (k, k+1) with
+            // (32-ax | ax << 16) = 65535 ax + 32; the result (32-ay) t + ay b + 2^9 is a third one (t, b <= 8160).  Same integers.
+            const unsigned tl = __builtin_amdgcn_alignbyte(t1[r], t0[r], sh0[r]), th = t1[r] >> (8 * sh0[r]);
+            const unsigned bl = __builtin_amdgcn_alignbyte(b1[r], b0[r], sh1[r]), bh = b1[r] >> (8 * sh1[r]);
+            unsigned tp[4], bq[4];
+            tp[0] = __builtin_amdgcn_perm(0u, tl, 0x0c010c00u); bq[0] = __builtin_amdgcn_perm(0u, bl, 0x0c010c00u);
+            tp[1] = __builtin_amdgcn_perm(0u, tl, 0x0c020c01u); bq[1] = __builtin_amdgcn_perm(0u, bl, 0x0c020c01u);
+            tp[2] = __builtin_amdgcn_perm(0u, tl, 0x0c030c02u); bq[2] = __builtin_amdgcn_perm(0u, bl, 0x0c030c02u);
+            tp[3] = __builtin_amdgcn_perm(th, tl, 0x0c040c03u); bq[3] = __builtin_amdgcn_perm(bh, bl, 0x0c040c03u);
+            uint32_t pack = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int s00 = (tl >> (8 * k)) & 0xff, s01 = k < 3 ? (int)((tl >> (8 * k + 8)) & 0xff) : (int)th;
-                const int s10 = (bl >> (8 * k)) & 0xff, s11 = k < 3 ? (int)((bl >> (8 * k + 8)) & 0xff) : (int)bh;
-                pack |= remap_blend(s00, s01, s10, s11, fx[r][k] & 31, fy[r][k] & 31) << (8 * k);
+                const unsigned wx = __umul24((unsigned)(fx[r][k] & 31), 65535u) + 32u, wy = __umul24((unsigned)(fy[r][k] & 31), 65535u) + 32u;
+                const unsigned tb = (unsigned)dot2_first(tp[k], wx) | ((unsigned)dot2_first(bq[k], wx) << 16);
+                pack |= (uint32_t)(dot2_s(tb, wy, 1 << 9) >> 10) << (8 * k);
             }
-        } else {
-            for (int k = 0; k < cnt; k++) {
-                const int sx = fx[r][k] >> 5, sy = fy[r][k] >> 5;
-                const bool x0in = sx >= 0 && sx < s.w, x1in = sx + 1 >= 0 && sx + 1 < s.w;
-                const bool y0in = sy >= 0 && sy < s.h, y1in = sy + 1 >= 0 && sy + 1 < s.h;
-                const uint8_t* r0 = s.p + (ptrdiff_t)sy * s.stride + sx;
-                const int s00 = (y0in && x0in) ? r0[0] : 0, s01 = (y0in && x1in) ? r0[1] : 0;
-                const int s10 = (y1in && x0in) ? r0[s.stride] : 0, s11 = (y1in && x1in) ? r0[s.stride + 1] : 0;
-                pack |= remap_blend(s00, s01, s10, s11, fx[r][k] & 31, fy[r][k] & 31) << (8 * k);
-            }
+            *reinterpret_cast<uint32_t*>(J.dst + (size_t)(ry0 + r) * J.dst_stride + x4) = pack;
+        }
+        return;
+    }
+    for (int r = 0; r < RW_ROWS && ry0 + r < rh; r++) {
+        uint32_t pack = 0;
+        for (int k = 0; k < cnt; k++) {
+            const int sx = fx[r][k] >> 5, sy = fy[r][k] >> 5;
+            const bool x0in = sx >= 0 && sx < s.w, x1in = sx + 1 >= 0 && sx + 1 < s.w;
+            const bool y0in = sy >= 0 && sy < s.h, y1in = sy + 1 >= 0 && sy + 1 < s.h;
+            const uint8_t* r0 = s.p + (ptrdiff_t)sy * s.stride + sx;
+            const int s00 = (y0in && x0in) ? r0[0] : 0, s01 = (y0in && x1in) ? r0[1] : 0;
+            const int s10 = (y1in && x0in) ? r0[s.stride] : 0, s11 = (y1in && x1in) ? r0[s.stride + 1] : 0;
+            pack |= remap_blend(s00, s01, s10, s11, fx[r][k] & 31, fy[r][k] & 31) << (8 * k);
         }
         roi_store4(J.dst + (size_t)(ry0 + r) * J.dst_stride, x4, cnt, pack);
     }

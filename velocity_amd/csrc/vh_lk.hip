@@ -10,6 +10,7 @@
 //   k_lk3<W,NW,M>   LDS-staged patch + search region, NW wavefronts per track, vertical strip runs (the 51x51 fine stage)
 //   k_lk_q<W>       4 tracks per wavefront, one 16-lane DPP row per track, template in registers (the 15x15 coarse stages)
 #include "vh_kernels.hpp"
+#include "vh_valu.hpp"
 
 #define W_BITS 14
 #define LK_FLT_SCALE (1.f / (1 << 20))
@@ -290,7 +291,6 @@ __global__ __launch_bounds__(64) void k_lk(const void* job_tab, size_t tab_strid
 // (conflict-free ds_read_b64), and the exact wave sums are DPP row reductions of 16-bit halves (order independent).
 // Integer arithmetic is identical to the per-sample kernel above, so results are bit-identical.
 // =================================================================================================================
-typedef short short2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int dpp_row_sum(int v)
 {
@@ -320,36 +320,6 @@ __device__ __forceinline__ long long wave_sum_i32_rows(int v)
            (long long)__builtin_amdgcn_readlane(r, 32) + (long long)__builtin_amdgcn_readlane(r, 48);
 }
 
-__device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
-__device__ __forceinline__ short2v as_s2(unsigned v) { return __builtin_bit_cast(short2v, v); }
-__device__ __forceinline__ int dot2(unsigned a, unsigned b, int c) { return __builtin_amdgcn_sdot2(as_s2(a), as_s2(b), c, false); }
-// First link of a dot2 chain.  For the builtin hipcc selects v_dot2c_i32_i16 (accumulator tied to the destination), which needs a v_mov to
-// seed every chain; the VOP3P form takes the inline constant 0 as its accumulator.
-__device__ __forceinline__ int dot2_first(unsigned a, unsigned b)
-{
-    int d;
-    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-// a * K + c for 24-bit a and an inline-constant K as ONE v_mad_i32_i24 (hipcc emits v_mul_i32_i24 + v_add for `__mul24(a, K) + c`); the _s form takes a
-// wave-uniform addend from an SGPR
-template <int K>
-__device__ __forceinline__ int mad24_v(int a, int c)
-{
-    int d;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(K), "v"(c));
-    return d;
-}
-template <int K>
-__device__ __forceinline__ int mad24_s(int a, int c)
-{
-    int d;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(K), "s"(c));
-    return d;
-}
-// (lo >> 16) & 0xffff | (hi >> 16) << 16 in one v_perm: descale-by-shift and int16 packing of two values that were scaled so that the
-// wanted 16 bits sit in the upper half
-__device__ __forceinline__ unsigned pack_hi16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x07060302u); }
 
 // NR rows x 8 bytes starting at pixel (gx, gy): lo = bytes 0..3, hi = bytes 4..7 of every row (interior fast path)
 typedef const unsigned __attribute__((address_space(1)))* gptr_u32;  // global (not flat) loads

@@ -534,8 +534,9 @@ void vh_ransac_force_path(int mode) { g_ransac_force = mode; }
 
 void vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
-    // up to 16 streams in flight: one fused workgroup per stream (latency); above: hypotheses spread over the chip (throughput)
-    if (max_n <= RANSAC_FUSED_MAX && (g_ransac_force == 2 || (g_ransac_force == 0 && batch <= 16))) {
+    // up to RANSAC_FUSED_MAX pairs: one fused workgroup per stream, pairs / indices / counts resident in LDS (measured faster than the three
+    // launches at every stream count, 1 .. 256: 4.53 -> 4.48 ms per step at 128 streams); more pairs: hypotheses spread over the chip
+    if (max_n <= RANSAC_FUSED_MAX && (g_ransac_force == 2 || g_ransac_force == 0)) {
         const size_t lds = (size_t)RANSAC_FUSED_MAX * (16 + 4) + (size_t)VH_RANSAC_ITERS * 4;
         static bool attr_set = false;
         if (!attr_set) {
