@@ -442,7 +442,8 @@ def roofline_of(wl, m, world):
     it_f = iters[2] / max(launches[2], 1)
     su_f = setups[2] / max(launches[2], 1)
     ops_fine = wf * wf * (47.0 * su_f + 12.0 * it_f)  # SURVEY §8d op model: 47 op/px set-up, 12 op/px per Newton iteration
-    fine_kernel = "k_lk3<51, 2, 4>" if N * SG >= 6144 else "k_lk3<51, 4, 4>"  # routing of vh_launch_lk (wavefronts per track)
+    # routing of vh_launch_lk (wavefronts per 51x51 track by the number of tracks in flight)
+    fine_kernel = "k_lk3<51, 1, 4>" if N * SG >= 3000 else ("k_lk3<51, 2, 4>" if N * SG >= 1024 else "k_lk3<51, 4, 4>")
     # HBM bytes and SQ issue utilisation of that kernel are NOT measured by this run: they come from the PMC passes committed under
     # profiles/ (collected at the stream count stored in the file, scaled linearly); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     traffic, sq_util, tsrc = None, None, None
@@ -457,15 +458,33 @@ def roofline_of(wl, m, world):
             tsrc = f"profiles/{name} (rocprofv3 --pmc pass of an earlier run, scaled to {SG} streams; not measured in this run)"
             break
     peak_tops, lanes, peak_src = valu_peak()
-    ach_tops = ops_fine / (us_fine * 1e-6) / 1e12 if us_fine > 0 else 0.0
+    model_tops = ops_fine / (us_fine * 1e-6) / 1e12 if us_fine > 0 else 0.0
+    # VALU instructions the kernel really issues per launch: SQ_INSTS_VALU (wavefront instructions) x 64 lanes from the committed PMC pass of the
+    # same workload, scaled to this run's stream count; divided by THIS run's launch time
+    issued, isrc = None, None
+    ppath = os.path.join(ROOT, "profiles", "r02_lk_sq_pmc.json")
+    if wl.cfg is CONFIGS["c2"] and wl.params == "baseline" and os.path.exists(ppath):
+        pj = json.load(open(ppath))
+        k = pj.get("kernels", {}).get(fine_kernel)
+        if k and pj.get("streams"):
+            issued = 64.0 * k["SQ_INSTS_VALU"] * SG / pj["streams"]
+            sq_util = k.get("valu_issue_utilisation", sq_util)
+            isrc = f"profiles/r02_lk_sq_pmc.json (SQ_INSTS_VALU x 64 lanes of a rocprofv3 --pmc pass at {pj['streams']} streams, scaled to {SG})"
+    issued_tops = issued / (us_fine * 1e-6) / 1e12 if issued and us_fine > 0 else None
     return dict(bound="hbm", kernel=fine_kernel + " (fine stage: 51x51 window, level 0, fwd+bwd)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=tsrc, us_per_launch=round(us_fine, 2),
                 alg_bytes_per_launch=bytes_fine,
-                valu=dict(model_gops_per_launch=round(ops_fine / 1e9, 4), achieved_tops=round(ach_tops, 3), peak_tops=round(peak_tops, 1),
-                          peak_lanes_per_clk_per_simd=lanes, peak_source=peak_src, frac=round(ach_tops / peak_tops, 4),
+                valu=dict(issued_ginstr_per_launch=round(issued / 1e9, 3) if issued else None, issued_source=isrc,
+                          achieved_tops=round(issued_tops, 3) if issued_tops else None, peak_tops=round(peak_tops, 1),
+                          peak_lanes_per_clk_per_simd=lanes, peak_source=peak_src,
+                          frac=round(issued_tops / peak_tops, 4) if issued_tops else None,
+                          op_model_gops_per_launch=round(ops_fine / 1e9, 4), op_model_tops=round(model_tops, 3),
+                          op_model_note="SURVEY §8d counts 47 op/px per set-up and 12 op/px per Newton iteration for a straightforward kernel; this "
+                                        "kernel issues fewer instructions than that for the same integers (gradients of the interpolated patch, "
+                                        "packed int16 dot products), so op_model_tops may exceed the issue peak -- frac prices issued instructions",
                           newton_iters_per_track_dir=round(it_f / (2 * N * SG), 2), sq_valu_issue_utilisation=sq_util,
-                          sq_valu_issue_utilisation_source=tsrc),
-                note="track solve is VALU/LDS bound (SURVEY §8d); the HBM figure prices its algorithmic gather bytes",
+                          sq_valu_issue_utilisation_source=isrc or tsrc),
+                note="track solve is VALU bound (SURVEY §8d); the HBM figure prices its algorithmic gather bytes",
                 lk_us_per_launch=[round(1e3 * ms_sum[k] / max(launches[k], 1), 2) for k in range(3)],
                 lk_newton_iters_per_setup=[round(iters[k] / max(setups[k], 1), 2) for k in range(3)],
                 lk_setups_per_track=[round(setups[k] / max(launches[k], 1) / (N * SG), 2) for k in range(3)])

@@ -90,9 +90,13 @@ for k, d in lk_sq.items():
     if d.get("SQ_BUSY_CYCLES") and d.get("SQ_ACTIVE_INST_VALU"):
         # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs of the chip; SQ_BUSY_CYCLES is per shader engine (x32) -> see r01_lk_sq_pmc.md
         d["valu_cycles_per_inst"] = round(4.0 * d["SQ_ACTIVE_INST_VALU"] / max(d["SQ_INSTS_VALU"], 1), 3)
+        # SQ_ACTIVE_INST_VALU: quad-cycles summed over the 1024 SIMDs; SQ_BUSY_CYCLES: cycles summed over the 32 shader engines
+        d["valu_issue_utilisation"] = round(d["SQ_ACTIVE_INST_VALU"] / (8.0 * d["SQ_BUSY_CYCLES"]), 4)
+        if d.get("SQ_WAVES"):
+            d["valu_insts_per_wave"] = round(d["SQ_INSTS_VALU"] / d["SQ_WAVES"], 1)
 if lk_sq:
     json.dump(dict(_comment="rocprofv3 --pmc passes (<= 8 SQ counters each) of python bench.py --streams %d --steps 4: averages per launch over the "
-                            "steady-state launches.  valu_cycles_per_inst = 4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU" % S, kernels=lk_sq),
+                            "steady-state launches.  valu_cycles_per_inst = 4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU" % S, streams=S, kernels=lk_sq),
               open(os.path.join(DST, f"{tag}_lk_sq_pmc.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(DST, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 
@@ -190,6 +194,7 @@ for r in keep:
     o.append(f"| `{r['Name'][:72]}` | {r['Calls']} | {t / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.2f} | {100 * t / lib:.1f} |")
 k = [r for r in keep if "k_lk3" in r["Name"]][0]
 kk = traffic[kname]
+ksq = lk_sq.get(kname, {})
 o.append(f"\nLibrary kernel time {lib / 1e6:.1f} ms over {steps} steps = {lib / 1e3 / steps:.0f} us per step; bench wall {1e3 * bench['ms_per_step']:.0f} us per "
          "step -> launches run back to back.")
 o.append(f"Dominant kernel `{kname}` (fine LK stage): {float(k['AverageNs']) / 1e3:.1f} us average in the trace vs {rf['us_per_launch']} us from the HIP events "
@@ -197,8 +202,11 @@ o.append(f"Dominant kernel `{kname}` (fine LK stage): {float(k['AverageNs']) / 1
 o.append(f"HBM traffic of that kernel (`profiles/{tag}_hbm_traffic.json`, separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes at {traffic['streams']} streams, "
          f"FETCH_SIZE doubled per MI355X_MICROARCH.md): {(2 * kk['fetch_kib'] + kk['write_kib']) * 1024 / traffic['streams'] / 1e6:.1f} MB per stream and launch vs "
          f"22.05 MB algorithmic gather bytes; `roofline.achieved` = {rf['achieved']} GB/s of gather bytes ({100 * rf['frac']:.1f} % of 8 TB/s) - the kernel is VALU "
-         f"bound: {100 * rf['valu']['frac']:.0f} % of the {rf['valu']['peak_tops']} T lane-instruction/s VALU peak of its (half-rate) instruction class by the SURVEY op model "
-         f"(`profiles/{tag}_valu_rate.json` settles the issue rates; SQ counters of the kernel in `profiles/{tag}_lk_sq_pmc.json`).\n")
+         f"bound: {ksq.get('valu_insts_per_wave', 0):.0f} VALU instructions per wavefront (= per track, both directions), "
+         f"{64e-9 * ksq.get('SQ_INSTS_VALU', 0):.1f} G lane-instructions per launch = {64e-12 * ksq.get('SQ_INSTS_VALU', 0) / (1e-6 * rf['us_per_launch']):.1f} T/s of the "
+         f"{rf['valu']['peak_tops']} T lane-instruction/s issue peak of its (half-rate) instruction class; SQ issue utilisation "
+         f"{100 * ksq.get('valu_issue_utilisation', 0):.0f} % (`profiles/{tag}_valu_rate.json` settles the issue rates; SQ counters in `profiles/{tag}_lk_sq_pmc.json`). "
+         f"SURVEY's op model (47 op/px set-up, 12 op/px/iteration) prices the same launch at {rf['valu'].get('op_model_gops_per_launch', rf['valu'].get('model_gops_per_launch'))} G operations.\n")
 o.append(f"Throughput vs resident streams (`profiles/{tag}_stream_sweep.json`, 60 steps each): "
          + ", ".join(f"{s_} -> {v['frames_per_s'] / 1e3:.2f} k" for s_, v in sweep.items()) + " frames/s.\n")
 if host:
