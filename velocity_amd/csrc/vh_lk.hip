@@ -1614,7 +1614,7 @@ static int launch_strip(const void* job_tab, size_t tab_stride, int batch, int m
 
 // test hook: 1 = per-sample kernel, 2 = strip kernel, 3 = LDS-staged kernel, 4 = 4-tracks-per-wave kernel (15x15), 5 / 6 / 7 = LDS-staged 51x51 kernel with
 // 1 / 2 / 4 wavefronts per track, 0 = default routing
-static int g_lk_force_generic = 0;
+static int g_lk_force_generic = getenv("VH_LK_FORCE") ? atoi(getenv("VH_LK_FORCE")) : 0;  // (environment: experiments only)
 void vh_lk_force_generic(int on) { g_lk_force_generic = on; }
 
 int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s)
@@ -1638,9 +1638,10 @@ int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, i
             return launch_lk3<51, 4, 4>(job_tab, tab_stride, batch, max_n, s);
         }
     }
-    // 15x15: 4 tracks per wavefront once there are enough tracks to fill the chip that way (11 % faster frame step at 64
-    // streams); below that the one-wave-per-track strip kernel has the shorter critical path.  Mode 4 forces it (tests).
-    if (win == 15 && (g_lk_force_generic == 4 || ((g_lk_force_generic == 0 || force_nw) && (long long)max_n * batch >= 6144)))
+    // 15x15: 4 tracks per wavefront from ~3000 tracks in flight (measured: 53 / 89 us vs 55 / 99 us for the two coarse stages at 4000 tracks,
+    // 0.43 / 0.81 ms vs 0.9 / 1.7 ms at 256 000); below that the one-wave-per-track strip kernel has the shorter critical path (43 / 73 us vs
+    // 51 / 82 us at 2000 tracks).  Mode 4 forces it (tests).
+    if (win == 15 && (g_lk_force_generic == 4 || ((g_lk_force_generic == 0 || force_nw) && (long long)max_n * batch >= 3000)))
         return launch_lkq<15>(job_tab, tab_stride, batch, max_n, s);
     if (g_lk_force_generic != 1 && win <= 63) {  // (modes 5..7 with another window than 51: default routing)
         // int32 per-lane partial sums are exact up to 16 strips per lane (win <= 63)
