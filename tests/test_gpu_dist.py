@@ -43,7 +43,7 @@ def _run_ranks(tmp_path, body, world=2, timeout=600, extra_env=None):
 def test_sharded_ba_world_n_equals_single_call(tmp_path, tag, world):
     """fcnNLS_batch_sharded over 2 (even shards) and 3 (ragged shards: 17/17/16 points) ranks == the single-call BA: trace (rms residual
     AND rms delta per iteration: the residual sum must be all-reduced exactly once) and the final state.  The ranks sum their partial
-    systems in a different order than one rank does (observed 2e-10 relative on the residual trace), hence 1e-8 rather than bit equality."""
+    systems in a different order than one rank does (observed 2e-10 relative on the residual trace), hence tolerances rather than bit equality."""
     body = (
         "from velocity_amd.NLS import fcnNLS_batch\n"
         "from velocity_amd.dist import fcnNLS_batch_sharded\n"
@@ -57,8 +57,10 @@ def test_sharded_ba_world_n_equals_single_call(tmp_path, tag, world):
         "assert len(tr2) == len(tr) == 10, (len(tr2), len(tr))\n"
         "np.testing.assert_allclose(tr2[:, 0], tr[:, 0], rtol=1e-8)\n"
         "np.testing.assert_allclose(tr2[:, 1], tr[:, 1], rtol=1e-5)\n"
-        "np.testing.assert_allclose(cw2, cw, rtol=1e-8, atol=2e-9)\n"   # observed 1.8e-10 abs on a ~4e-4 m coordinate: the slow gauge
-        "np.testing.assert_allclose(pw2, pw, rtol=1e-8, atol=2e-9)\n"   # mode amplifies the summation-order rounding
+        # the ranks add their partial systems in another order than one rank does; the weakly damped gauge modes of BA amplify
+        # that rounding by ~1e8: observed up to 1.3e-8 relative on single coordinates (1.5e-7 m at 11 m), 2e-10 on the residual trace
+        "np.testing.assert_allclose(cw2, cw, rtol=2e-7, atol=2e-8)\n"
+        "np.testing.assert_allclose(pw2, pw, rtol=2e-7, atol=2e-8)\n"
 
         "np.testing.assert_allclose(tr2[:, 0], g[tag + '_trace'][:, 0], rtol=2e-5)\n"
     )

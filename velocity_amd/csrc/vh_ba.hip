@@ -104,23 +104,29 @@ __global__ void k_ba_cams(BaJob J)
     if (c <= J.nc) ba_cam_tables(J, c, J.x + 3 * J.nt);
 }
 
+__device__ void inv3_sym(const double* U, double* Ui);
+
 // residual and compact forward-difference Jacobian of every measurement pair (camera c, track i).
 // A thread owns one measurement (20 doubles of output: r 2, Jp 6, Jc 12).  Written straight from the registers, a wave's store touched 64
 // separate 16 / 48 / 96-byte records per instruction; the values are transposed through LDS instead and leave as fully coalesced streams
-// (the block's 256 measurements are contiguous in all three arrays).
+// (the block's measurements are contiguous in all three arrays).  A block owns WHOLE points (256 / (nc+1) of them, the last threads idle), so
+// with PREP it also finishes what the point-block Schur complement needs per point -- U_i + I, its inverse, tp_i, the Cholesky factor of the
+// inverse -- straight from the LDS copy of the rows: the separate pass re-read 8 of the 20 planes from HBM (0.8 GB per iteration at 64 C5 windows).
+template <bool PREP>
 __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
 {
     ba_select_window(J, blockIdx.y);
     if (*J.done) return;
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
     const int nt = J.nt, nf = J.nc + 1;
+    const int ppb = BA_THREADS / nf, i0 = blockIdx.x * ppb, npts = min(ppb, nt - i0);
+    const int il = threadIdx.x / nf;
     __shared__ double s_out[20][BA_THREADS + 1];  // component-major, padded: conflict-free on the way in, spread on the way out
     double ss = 0.0;
     double o[20];  // r (2) | Jp (6) | Jc (12)
 #pragma unroll
     for (int k = 0; k < 20; k++) o[k] = 0.0;
-    if (m < nt * nf) {
-        const int i = m / nf, c = m - i * nf;  // POINT-major measurement index m = i (nc+1) + c: a point's Jacobians are contiguous
+    if (il < npts) {
+        const int i = i0 + il, c = threadIdx.x - il * nf;  // POINT-major measurement index m = i (nc+1) + c: a point's Jacobians are contiguous
         double K[9];
         for (int k = 0; k < 9; k++) K[k] = J.K[k];
         double w[3] = {J.x[3 * i], J.x[3 * i + 1], J.x[3 * i + 2]};
@@ -207,9 +213,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
         for (int k = 0; k < BA_THREADS / 64; k++) t += s_ss[k];
         if (t != 0.0) atomicAdd(J.rslot + (blockIdx.x & 15), t);
     }
-    // coalesced write-out of the block's contiguous spans: r [2 x 256], Jp [6 x 256], Jc [12 x 256] doubles
-    const size_t m0 = (size_t)blockIdx.x * BA_THREADS;
-    const int nval = min(BA_THREADS, nt * nf - (int)m0);
+    // coalesced write-out of the block's contiguous spans: r [2 x nval], Jp [6 x nval], Jc [12 x nval] doubles
+    const size_t m0 = (size_t)i0 * nf;
+    const int nval = npts * nf;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
@@ -226,6 +232,38 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
         const int e = tid + BA_THREADS * q, t = e / 12, k = e - 12 * t;
         if (t < nval) J.Jc[12 * m0 + e] = s_out[8 + k][t];
     }
+    if (!PREP) return;
+    // per point (4 lanes each, measurements c = q, q+4, ...): U_i = I + sum Jp^T Jp, g_i = sum Jp^T r  ->  tp_i = U^-1 g, U^-1 = L L^T
+    const int pl = tid >> 2, q = tid & 3;
+    if (pl >= npts) return;  // whole quads leave together
+    double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0, u4 = 0.0, u5 = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+    for (int c = q; c < nf; c += 4) {
+        const int t = pl * nf + c;
+        const double ru = s_out[0][t], rv = s_out[1][t], a0 = s_out[2][t], a1 = s_out[3][t], a2 = s_out[4][t], b0 = s_out[5][t], b1 = s_out[6][t], b2 = s_out[7][t];
+        u0 += a0 * a0 + b0 * b0; u1 += a0 * a1 + b0 * b1; u2 += a0 * a2 + b0 * b2;
+        u3 += a1 * a1 + b1 * b1; u4 += a1 * a2 + b1 * b2; u5 += a2 * a2 + b2 * b2;
+        g0 += a0 * ru + b0 * rv; g1 += a1 * ru + b1 * rv; g2 += a2 * ru + b2 * rv;
+    }
+    double acc[9] = {u0, u1, u2, u3, u4, u5, g0, g1, g2};
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        acc[k] += __shfl_xor(acc[k], 1);
+        acc[k] += __shfl_xor(acc[k], 2);
+    }
+    if (q != 0) return;
+    const int i = i0 + pl;
+    const double U[9] = {acc[0] + 1.0, acc[1], acc[2], acc[1], acc[3] + 1.0, acc[4], acc[2], acc[4], acc[5] + 1.0};  // +I damping (NLS.py:220)
+    double Ui[9];
+    inv3_sym(U, Ui);
+    J.tp[3 * (size_t)i] = Ui[0] * acc[6] + Ui[1] * acc[7] + Ui[2] * acc[8];
+    J.tp[3 * (size_t)i + 1] = Ui[3] * acc[6] + Ui[4] * acc[7] + Ui[5] * acc[8];
+    J.tp[3 * (size_t)i + 2] = Ui[6] * acc[6] + Ui[7] * acc[7] + Ui[8] * acc[8];
+    // Cholesky of the SPD inverse: Ui = L L^T
+    const double l00 = sqrt(Ui[0]), l10 = Ui[3] / l00, l20 = Ui[6] / l00;
+    const double l11 = sqrt(Ui[4] - l10 * l10), l21 = (Ui[7] - l20 * l10) / l11;
+    const double l22 = sqrt(Ui[8] - l20 * l20 - l21 * l21);
+    double* Lo = J.Lc + 6 * (size_t)i;
+    Lo[0] = l00; Lo[1] = l10; Lo[2] = l11; Lo[3] = l20; Lo[4] = l21; Lo[5] = l22;
 }
 
 __device__ void inv3_sym(const double* U, double* Ui)
@@ -367,7 +405,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
 }
 
 // ---- Schur stage 1 on the matrix cores (6 nc <= 128) ------------------------------------------------------------------------------
-// (a) k_ba_prep, one thread per tie point: U_i + I over all cameras, its inverse, tp_i = (U_i+I)^-1 gp_i and the Cholesky factor L_i of the
+// (a) the tail of k_ba_jac<true>, four lanes per tie point: U_i + I over all cameras, its inverse, tp_i = (U_i+I)^-1 gp_i and the Cholesky factor L_i of the
 //     inverse ((U_i+I)^-1 = L L^T).  Tiny, but it takes the per-point reduction, the 3x3 inversion and their dependent-latency chain out of
 //     the matrix-core kernel.
 // (b) k_ba_schur_mfma: with Z_i = L_i^T W_i the reduced camera system is S = V + I - sum_i Z_i^T Z_i -- a SYMMETRIC rank-k update (the genuine
@@ -378,36 +416,6 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
 //     Z is also what the back-substitution needs: dp_i = tp_i - L_i (Z_i dc).
 typedef double double4v __attribute__((ext_vector_type(4)));
 #define BA_NPAD 128
-
-__global__ __launch_bounds__(BA_THREADS) void k_ba_prep(BaJob J)
-{
-    ba_select_window(J, blockIdx.y);
-    if (*J.done) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, nt = J.nt, nc = J.nc;
-    if (i >= nt) return;
-    double u0 = 1.0, u1 = 0.0, u2 = 0.0, u3 = 1.0, u4 = 0.0, u5 = 1.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;  // +I damping (NLS.py:220)
-#pragma unroll 4
-    for (int c = 0; c <= nc; c++) {
-        const size_t m = (size_t)i * (nc + 1) + c;
-        const double* Jp = J.Jp + 6 * m;
-        const double a0 = Jp[0], a1 = Jp[1], a2 = Jp[2], b0 = Jp[3], b1 = Jp[4], b2 = Jp[5], ru = J.r[2 * m], rv = J.r[2 * m + 1];
-        u0 += a0 * a0 + b0 * b0; u1 += a0 * a1 + b0 * b1; u2 += a0 * a2 + b0 * b2;
-        u3 += a1 * a1 + b1 * b1; u4 += a1 * a2 + b1 * b2; u5 += a2 * a2 + b2 * b2;
-        g0 += a0 * ru + b0 * rv; g1 += a1 * ru + b1 * rv; g2 += a2 * ru + b2 * rv;
-    }
-    const double U[9] = {u0, u1, u2, u1, u3, u4, u2, u4, u5};
-    double Ui[9];
-    inv3_sym(U, Ui);
-    J.tp[3 * (size_t)i] = Ui[0] * g0 + Ui[1] * g1 + Ui[2] * g2;
-    J.tp[3 * (size_t)i + 1] = Ui[3] * g0 + Ui[4] * g1 + Ui[5] * g2;
-    J.tp[3 * (size_t)i + 2] = Ui[6] * g0 + Ui[7] * g1 + Ui[8] * g2;
-    // Cholesky of the SPD inverse: Ui = L L^T
-    const double l00 = sqrt(Ui[0]), l10 = Ui[3] / l00, l20 = Ui[6] / l00;
-    const double l11 = sqrt(Ui[4] - l10 * l10), l21 = (Ui[7] - l20 * l10) / l11;
-    const double l22 = sqrt(Ui[8] - l20 * l20 - l21 * l21);
-    double* Lo = J.Lc + 6 * (size_t)i;
-    Lo[0] = l00; Lo[1] = l10; Lo[2] = l11; Lo[3] = l20; Lo[4] = l21; Lo[5] = l22;
-}
 
 // ---- k_ba_schur_mfma: data flow --------------------------------------------------------------------------------------------------------
 // The inputs of one tie point ("raw record": its camera Jacobians Jc [nc][12], point Jacobians Jp [nc][6], residuals r [nc][2], L (6), tp (3);
@@ -1039,7 +1047,6 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     const bool use_mfma = nq <= BA_NPAD && !P.force_valu && P.model == 0;  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
     J.zmode = use_mfma ? 1 : 0;
     { const char* e = getenv("VH_BA_DBG"); J.dbg = e ? atoi(e) : 0; }
-    const int nmeas = nt * (nc + 1);
     // one wavefront per point, grid-strided: every block ends with an atomic on one address, so keep the block count low
     const int upd_cap = J.nwin > 1 ? std::max(16, 1024 / J.nwin) : 256;
     const int upd_blocks = std::min(use_mfma ? (4 * nt + BA_THREADS - 1) / BA_THREADS : (nt + BA_THREADS / 64 - 1) / (BA_THREADS / 64), upd_cap);
@@ -1050,11 +1057,12 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     };
     auto normal_equations = [&](int it) {
         if (it == 0) hipLaunchKernelGGL(k_ba_cams, dim3((nc + 1 + 63) / 64, nw), dim3(64), 0, s, J);
-        hipLaunchKernelGGL(k_ba_jac, dim3((nmeas + BA_THREADS - 1) / BA_THREADS, nw), dim3(BA_THREADS), 0, s, J);
+        const int ppb = BA_THREADS / (nc + 1);  // k_ba_jac: whole points per block
         if (use_mfma) {
-            hipLaunchKernelGGL(k_ba_prep, dim3((nt + BA_THREADS - 1) / BA_THREADS, nw), dim3(BA_THREADS), 0, s, J);
+            hipLaunchKernelGGL(k_ba_jac<true>, dim3((nt + ppb - 1) / ppb, nw), dim3(BA_THREADS), 0, s, J);
             hipLaunchKernelGGL(k_ba_schur_mfma, dim3(nparts, nw), dim3(BA_SCHUR_THREADS), lds_mfma, s, J);
         } else {
+            hipLaunchKernelGGL(k_ba_jac<false>, dim3((nt + ppb - 1) / ppb, nw), dim3(BA_THREADS), 0, s, J);
             for (int pass = 0; pass < npass; pass++)  // later passes overwrite Spart entries of their own range only
                 hipLaunchKernelGGL(k_ba_points, dim3(nparts, nw), dim3(BA_THREADS), lds, s, J, pass);
         }
