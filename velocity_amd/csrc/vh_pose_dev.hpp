@@ -27,6 +27,27 @@ __device__ void block_sum_f64(double* v, double* sh)
     }
 }
 
+// block-wide sum of NV doubles, valid in EVERY thread after ONE barrier: the per-wave sums go to the buffer `sh` ([NV * NLS_WAVES]; the caller
+// alternates between two buffers), every thread adds them in the same order.  What follows a reduction in the LM loop (the dense solve, the
+// state update, the stop rule) is then computed redundantly by all threads from identical inputs: no broadcast, no second and third barrier.
+template <int NV, int NLS_WAVES>
+__device__ __forceinline__ void block_sum_f64_all(double* v, double* sh)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = vh_wave_sum_f64(v[k]);
+    if (lane == 0)
+        for (int k = 0; k < NV; k++) sh[k * NLS_WAVES + wave] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < NLS_WAVES; q++) s += sh[k * NLS_WAVES + q];
+        v[k] = s;
+    }
+}
+
 // uv of camera-frame point b:  pscale(b @ K)   (fzK, NLS.py:71-78)
 __device__ __forceinline__ void project_cam(const double* K, double b0, double b1, double b2, double& u, double& v)
 {
@@ -150,19 +171,16 @@ __device__ __forceinline__ void pose_solve(const PoseJob& J)
     constexpr int NLS_WAVES = NLS_THREADS / 64;
     const int n = J.n_ptr ? *J.n_ptr : J.n;
     const int tid = threadIdx.x;
-    __shared__ double sh[(MODE == 0 ? 9 : 27) * NLS_WAVES];
-    __shared__ double s_x[6];
-    __shared__ int s_stop, s_iters;
+    __shared__ double sh2[2][(MODE == 0 ? 9 : 27) * NLS_WAVES];  // two reduction buffers, alternated: one barrier per reduction
+    double* sh = sh2[0];
+    int par = 0;
+    // the state, the stop flag and the iteration count are wave-uniform REGISTERS: every thread runs the (tiny) solve itself
+    double s_x[6];
+    int s_stop = 0, s_iters = 0;
     double K[9];
     for (int k = 0; k < 9; k++) K[k] = J.K[k];
-
-    if (tid == 0) {
-        if (MODE == 0) { for (int k = 0; k < 3; k++) s_x[k] = J.x0[3 + k]; }
-        else { for (int k = 0; k < 6; k++) s_x[k] = J.x0[k]; }
-        s_stop = 0;
-        s_iters = 0;
-    }
-    __syncthreads();
+    if (MODE == 0) { for (int k = 0; k < 3; k++) s_x[k] = J.x0[3 + k]; }
+    else { for (int k = 0; k < 6; k++) s_x[k] = J.x0[k]; }
 
     // the points of this thread stay in registers across the LM iterations (n <= PPT * NLS_THREADS), so an iteration
     // is arithmetic + one reduction, not a chain of dependent global loads
@@ -208,8 +226,9 @@ __device__ __forceinline__ void pose_solve(const PoseJob& J)
                     fd_rows_t(K, b0, b1, b2, u, v, ju, jv);
                     accumulate<3>(acc, ju, jv, (double)J.p[2 * ip] - u, (double)J.p[2 * ip + 1] - v);
                 }
-                block_sum_f64<9, NLS_WAVES>(acc, sh);
-                if (tid == 0) {
+                block_sum_f64_all<9, NLS_WAVES>(acc, sh2[par]);
+                par ^= 1;
+                {
                     double x[3] = {x0, x1, x2};
                     const double r = lm_update<3>(acc, gain, x);
                     s_x[0] = x[0]; s_x[1] = x[1]; s_x[2] = x[2];
@@ -247,15 +266,15 @@ __device__ __forceinline__ void pose_solve(const PoseJob& J)
                     project_cam(K, a0 + x[3], a1 + x[4], a2 + (x[5] + FD_STEP), uk, vk); ju[5] = (uk - u) / FD_STEP; jv[5] = (vk - v) / FD_STEP;
                     accumulate<6>(acc, ju, jv, (double)J.p[2 * ip] - u, (double)J.p[2 * ip + 1] - v);
                 }
-                block_sum_f64<27, NLS_WAVES>(acc, sh);
-                if (tid == 0) {
+                block_sum_f64_all<27, NLS_WAVES>(acc, sh2[par]);
+                par ^= 1;
+                {
                     const double r = lm_update<6>(acc, gain, x);
                     for (int k = 0; k < 6; k++) s_x[k] = x[k];
                     s_iters = it + 1;
                     if (r < 1e-8) s_stop = 1;
                 }
             }
-            __syncthreads();
             if (s_stop) { converged = 1; break; }
         }
     }
@@ -287,7 +306,8 @@ __device__ __forceinline__ void pose_solve(const PoseJob& J)
         const double du = (double)J.p[2 * ip] - u, dv = (double)J.p[2 * ip + 1] - v;
         ss[0] += du * du + dv * dv;
     }
-    block_sum_f64<1, NLS_WAVES>(ss, sh);
+    sh = sh2[par];
+    block_sum_f64_all<1, NLS_WAVES>(ss, sh);
     if (tid == 0) {
         for (int k = 0; k < 3; k++) J.t_out[k] = (float)t[k];
         if (J.R_out) for (int k = 0; k < 9; k++) J.R_out[k] = R[k];
