@@ -254,7 +254,10 @@ __global__ __launch_bounds__(256) void k_klt_glue1(StreamWS* ws_all)
     }
     mnx = block_min_f(mnx, sh_f, false); mny = block_min_f(mny, sh_f, false);
     mxx = block_min_f(mxx, sh_f, true);  mxy = block_min_f(mxy, sh_f, true);
-    if (tid != 0) return;
+    __shared__ int s_copy, s_box[6];
+    if (tid == 0) s_copy = 0;
+    __syncthreads();
+    if (tid == 0) {
 
     const double cnt = (double)s[2];
     const double tx = s[2] ? __ddiv_rn(ldexp((double)s[0], -32), cnt) : 0.0;
@@ -277,7 +280,11 @@ __global__ __launch_bounds__(256) void k_klt_glue1(StreamWS* ws_all)
     W.dst = B.warp; W.dst_stride = (rw + 3) & ~3;  // dword rows: the warp kernel stores packed dwords
     W.x0 = x0; W.x1 = x1; W.y0 = y0; W.y1 = y1; W.dx = dx; W.dy = dy;
     const bool inside = x0 + dx >= 0 && x1 + dx <= io.w && y0 + dy >= 0 && y1 + dy <= io.h;
-    W.mode = (inside || n == 0) ? -1 : 0;
+    // the copy (rare: the shifted crop leaves the frame) is done by this workgroup below, not by a k_roi_warp launch that is a no-op on almost
+    // every frame (5 us of dependent launch latency for one stream, 30 us at 128 streams)
+    W.mode = -1;
+    s_copy = (inside || n == 0) ? 0 : 1;
+    s_box[0] = x0; s_box[1] = x1; s_box[2] = y0; s_box[3] = y1; s_box[4] = dx; s_box[5] = dy;
     LKJob& J = ws.lk;
     const vh_lk_params& lk = io.coarse;
     fill_pyramid(J.I, io.im0 + (size_t)y0 * io.stride0 + x0, rw, rh, io.stride0, B.roi_lv[0], lk.win, lk.max_level);
@@ -294,6 +301,24 @@ __global__ __launch_bounds__(256) void k_klt_glue1(StreamWS* ws_all)
     // RANSAC 2: affine from the survivors, only when more than 10 of them (KLT.py:126-127)
     RansacJob& R = ws.ransac;
     R.to = B.p_coarse; R.valid = B.v_coarse; R.min_valid = 10; R.gate_valid = 0;
+    }
+    __syncthreads();
+    if (s_copy) {  // integer-shifted crop, zero outside the frame (KLT.py:65-68), one dword of 4 pixels per thread and step
+        const int bx0 = s_box[0], by0 = s_box[2], bdx = s_box[4], bdy = s_box[5];
+        const int rw = max(s_box[1] - bx0, 0), rh = max(s_box[3] - by0, 0), rw4 = (rw + 3) >> 2;
+        for (int e = tid; e < rw4 * rh; e += 256) {
+            const int ry = e / rw4, x4 = (e - ry * rw4) * 4;
+            const int sy = by0 + ry + bdy;
+            const bool yin = sy >= 0 && sy < io.h;
+            uint32_t pack = 0;
+            for (int k = 0; k < 4; k++) {
+                const int sx = bx0 + x4 + k + bdx;
+                const uint32_t v = (yin && x4 + k < rw && sx >= 0 && sx < io.w) ? io.im[(size_t)sy * io.stride + sx] : 0u;
+                pack |= v << (8 * k);
+            }
+            *reinterpret_cast<uint32_t*>(B.warp + (size_t)ry * (size_t)(rw4 * 4) + x4) = pack;  // warp rows are dword padded
+        }
+    }
 }
 
 // ---- stage 2 -> 3: affine (or fallback), remap job, job C (KLT.py:126-133) ---------------------------------------
@@ -360,8 +385,7 @@ int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_p
     int r = launch_lk_profiled(c, 0, &ws->lk, st, count, coarse.win, s, mn);
     if (r) return vh_fail(r, "vh_launch_lk failed (window too large for LDS?)");
     vh_launch_ransac(&ws->ransac, st, count, mn, s);
-    hipLaunchKernelGGL(k_klt_glue1, dim3(count), dim3(256), 0, s, ws);
-    vh_launch_roi_warp(&ws->warp, st, count, c->max_w, c->max_h, s);
+    hipLaunchKernelGGL(k_klt_glue1, dim3(count), dim3(256), 0, s, ws);  // (does the zero-padded shifted crop itself when one is needed)
     for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->max_w, c->max_h, s);
     r = launch_lk_profiled(c, 1, &ws->lk, st, count, coarse.win, s, mn);
     if (r) return vh_fail(r, "vh_launch_lk failed");
