@@ -835,7 +835,8 @@ struct LK3 {
     static constexpr int RJ = WIN + 1 + 2 * M;                                // search region rows / cols
     static constexpr int PJ_WIDTH = ((2 * M + 4 * (SPR - 1)) >> 2) * 4 + 8;   // a row read takes two dwords
     static constexpr int PJ_PITCH = PJ_WIDTH + 4;                                // odd dword pitch (LDS banks)
-    // The template of a lane's K strips (samples x32, Scharr gradients: 3 x 8 bytes per strip) stays in REGISTERS for the whole level: LDS then
+    // The template of a lane's K strips (its Scharr gradients, 2 x 8 bytes per strip; the samples themselves enter only through the sums c, see
+    // lk3_level) stays in REGISTERS for the whole level: LDS then
     // holds the two image regions only (~7.7 KB per workgroup for 51x51) and the VGPR file, not LDS, bounds the occupancy.  With the template in
     // LDS (24.5 KB per workgroup: 6 workgroups = 3 wavefronts per SIMD) the kernel lost 14 % per workgroup of occupancy taken away.
     // Every lane runs all K strips of its run with NO per-strip branch: strips below the window (the tail of the last run(s)) are computed from
