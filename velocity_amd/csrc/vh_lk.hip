@@ -304,10 +304,13 @@ __device__ __forceinline__ int dpp_row_sum(int v)
 __device__ __forceinline__ long long wave_sum_i32_wide(int v)
 {
     int lo = dpp_row_sum(v & 0xffff), hi = dpp_row_sum(v >> 16);
-    const int lo_t = __builtin_amdgcn_readlane(lo, 0) + __builtin_amdgcn_readlane(lo, 16) + __builtin_amdgcn_readlane(lo, 32) +
-                     __builtin_amdgcn_readlane(lo, 48);
-    const int hi_t = __builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) + __builtin_amdgcn_readlane(hi, 32) +
-                     __builtin_amdgcn_readlane(hi, 48);
+    // rows 0..3 -> lane 63: row_bcast:15 adds the previous row's total to rows 1 and 3, row_bcast:31 the total of rows 0+1 to rows 2 and 3
+    // (two DPP adds and one v_readlane per half instead of four v_readlane and three scalar adds)
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, false);
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, false);
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, false);
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, false);
+    const int lo_t = __builtin_amdgcn_readlane(lo, 63), hi_t = __builtin_amdgcn_readlane(hi, 63);
     return (long long)hi_t * 65536ll + (long long)lo_t;
 }
 
