@@ -463,9 +463,10 @@ __device__ __forceinline__ void setup_hg_row(const int* V, int* H, int* G4, int 
     }
 }
 // vmask: 0xffffffff for a strip inside the window, 0 for a strip of the last run that hangs below it (stored as zeros)
-template <bool FULL01>  // FULL01: every strip holds at least 2 samples (window width % 4 != 1): the first pair needs no mask
-__device__ __forceinline__ void setup_from_hg(const int* H0, const int* H1, const int* H2, const int* G0, const int* G2, const int* Vmid, int cnt,
-                                              uint2* tI, uint2* tX, uint2* tY, int slot, int& a11, int& a12, int& a22, unsigned vmask = 0xffffffffu)
+// sel01 / sel23: the v_perm selectors that pack the two sample pairs -- 0x07060302 keeps both upper halves, 0x0c0c0302 zeroes the second sample,
+// 0x0c0c0c0c both: samples beyond the window edge and strips below the window cost no masking instruction
+__device__ __forceinline__ void setup_from_hg(const int* H0, const int* H1, const int* H2, const int* G0, const int* G2, const int* Vmid, unsigned sel01,
+                                              unsigned sel23, uint2* tI, uint2* tX, uint2* tY, int slot, int& a11, int& a12, int& a22)
 {
     int iv[4], ix[4], iy[4];  // the wanted int16 in the upper half of each
 #pragma unroll
@@ -474,10 +475,9 @@ __device__ __forceinline__ void setup_from_hg(const int* H0, const int* H1, cons
         ix[c] = mad24_v<40>(H1[c], mad24_s<12>(H0[c] + H2[c], 4 << (W_BITS - 1)));
         iy[c] = G2[c] - G0[c];
     }
-    const unsigned m01 = ((FULL01 || cnt >= 2) ? 0xffffffffu : 0x0000ffffu) & vmask, m23 = (cnt >= 4 ? 0xffffffffu : (cnt == 3 ? 0x0000ffffu : 0u)) & vmask;
-    const uint2 vI = make_uint2(pack_hi16(iv[0], iv[1]) & m01, pack_hi16(iv[2], iv[3]) & m23);
-    const uint2 vX = make_uint2(pack_hi16(ix[0], ix[1]) & m01, pack_hi16(ix[2], ix[3]) & m23);
-    const uint2 vY = make_uint2(pack_hi16(iy[0], iy[1]) & m01, pack_hi16(iy[2], iy[3]) & m23);
+    const uint2 vI = make_uint2(pack_hi16(iv[0], iv[1]), pack_hi16(iv[2], iv[3]));  // enters only through products with the (masked) gradients
+    const uint2 vX = make_uint2(__builtin_amdgcn_perm((unsigned)ix[1], (unsigned)ix[0], sel01), __builtin_amdgcn_perm((unsigned)ix[3], (unsigned)ix[2], sel23));
+    const uint2 vY = make_uint2(__builtin_amdgcn_perm((unsigned)iy[1], (unsigned)iy[0], sel01), __builtin_amdgcn_perm((unsigned)iy[3], (unsigned)iy[2], sel23));
     tI[slot] = vI; tX[slot] = vX; tY[slot] = vY;
     a11 = dot2(vX.y, vX.y, dot2(vX.x, vX.x, a11));
     a12 = dot2(vX.y, vY.y, dot2(vX.x, vY.x, a12));
@@ -997,6 +997,7 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
 #pragma unroll
             for (int c = 0; c < 4; c++) Vm[c] = V1[c + 1];
         }
+        const unsigned sel01 = cnt >= 2 ? 0x07060302u : 0x0c0c0302u, sel23 = cnt >= 4 ? 0x07060302u : (cnt == 3 ? 0x0c0c0302u : 0x0c0c0c0cu);
         // One patch row is read one strip ahead of its use and a scheduling barrier closes every strip: left alone, hipcc hoists the LDS reads of all
         // K strips to the top of the unrolled loop and interleaves the strips (248 VGPRs for K = 13)
         unsigned nlo, nhi;
@@ -1018,8 +1019,10 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
                 setup_row_pairs(clo, chi, prN);
                 setup_v_row(prB, prN, wt, wb, V2);
                 setup_hg_row(V2, H2, G2, k + 2);
-                setup_from_hg<(WIN % 4) != 1>(H0, H1, H2, G0, G2, Vm, cnt, tI, tX, tY, slot_base + k * slot_stride, part[0], part[1], part[2],
-                                              (C::PAD_ROWS > 0 && y >= WIN) ? 0u : 0xffffffffu);
+                // only the last PAD_ROWS strips of a run can hang below the window: the selector is a per-level lane constant everywhere else
+                const bool below = k >= C::K - C::PAD_ROWS && y >= WIN;
+                setup_from_hg(H0, H1, H2, G0, G2, Vm, below ? 0x0c0c0c0cu : sel01, below ? 0x0c0c0c0cu : sel23, tI, tX, tY, slot_base + k * slot_stride,
+                              part[0], part[1], part[2]);
                 cI[0] = dot2(tI[k].y, tX[k].y, dot2(tI[k].x, tX[k].x, cI[0]));
                 cI[1] = dot2(tI[k].y, tY[k].y, dot2(tI[k].x, tY[k].x, cI[1]));
 #pragma unroll
@@ -1388,7 +1391,6 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
             dV[c] = v2 - v0;
         };
         column(0); column(1);
-        const unsigned vmask = r < WIN ? 0xffffffffu : 0u;
 #pragma unroll
         for (int j = 0; j < NS; j++) {
             // strip j needs columns 4j .. 4j+5: four new ones per strip, and a scheduling barrier per strip keeps the column window short
@@ -1405,10 +1407,12 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
                 ix[c] = S4[col + 2] - S4[col];
                 iy[c] = mad24_v<40>(dV[col + 1], mad24_s<12>(dV[col] + dV[col + 2], 4 << (W_BITS - 1)));
             }
-            const unsigned m01 = (cnt >= 2 ? 0xffffffffu : 0x0000ffffu) & vmask, m23 = (cnt >= 4 ? 0xffffffffu : (cnt == 3 ? 0x0000ffffu : 0u)) & vmask;
+            // masking by selector (see setup_from_hg): cnt is a compile-time constant here, only the row mask is per lane
+            const unsigned sel01 = r < WIN ? (cnt >= 2 ? 0x07060302u : 0x0c0c0302u) : 0x0c0c0c0cu;
+            const unsigned sel23 = r < WIN ? (cnt >= 4 ? 0x07060302u : (cnt == 3 ? 0x0c0c0302u : 0x0c0c0c0cu)) : 0x0c0c0c0cu;
             const uint2 vI = make_uint2(pack_hi16(iv[0], iv[1]), pack_hi16(iv[2], iv[3]));
-            const uint2 vX = make_uint2(pack_hi16(ix[0], ix[1]) & m01, pack_hi16(ix[2], ix[3]) & m23);
-            const uint2 vY = make_uint2(pack_hi16(iy[0], iy[1]) & m01, pack_hi16(iy[2], iy[3]) & m23);
+            const uint2 vX = make_uint2(__builtin_amdgcn_perm((unsigned)ix[1], (unsigned)ix[0], sel01), __builtin_amdgcn_perm((unsigned)ix[3], (unsigned)ix[2], sel23));
+            const uint2 vY = make_uint2(__builtin_amdgcn_perm((unsigned)iy[1], (unsigned)iy[0], sel01), __builtin_amdgcn_perm((unsigned)iy[3], (unsigned)iy[2], sel23));
             tX[j] = vX; tY[j] = vY;
             a11 = dot2(vX.y, vX.y, dot2(vX.x, vX.x, a11));
             a12 = dot2(vX.y, vY.y, dot2(vX.x, vY.x, a12));
