@@ -1369,7 +1369,11 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
     int cI[2] = {0, 0};
 #pragma unroll
     for (int j = 0; j < NS; j++) { tX[j] = make_uint2(0, 0); tY[j] = make_uint2(0, 0); }
-    const bool fast_I = ipx >= 4 && ipy >= 1 && ipx + WIN + 12 <= I.w && ipy + WIN + 2 <= I.h;
+    // interior window: the (WIN+3)^2 patch [ipx-1, ipx+WIN+1] x [ipy-1, ipy+WIN+1] lies inside the level, so the V identity holds.  The aligned
+    // 24-byte row reads may run a few bytes past either end of a row: harmless inside the level, excluded where that would leave it (first row to
+    // the left, last row to the right)
+    const bool fast_I = ipx >= 1 && ipy >= 1 && ipx + WIN + 3 <= I.w && ipy + WIN + 2 <= I.h && !(ipy == 1 && ipx < 4) &&
+                        !(ipy + WIN + 2 == I.h && ipx + WIN + 8 > I.w);
     const unsigned w0t = pack16(w0.w00, w0.w01), w0b = pack16(w0.w10, w0.w11);
     if (fast_I) {
         // Interior window, all 16 lanes of the track (lane WIN feeds lane WIN-1).  Lane r reads patch rows r .. r+2 and builds V rows r and r+1 over
@@ -1476,7 +1480,8 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
             break;
         }
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny)));
-        const bool fast = inx >= 3 && iny >= 0 && inx + WIN + 12 <= J.w && iny + WIN + 1 <= J.h;
+        const bool fast = inx >= 0 && iny >= 0 && inx + WIN + 2 <= J.w && iny + WIN + 1 <= J.h && !(iny == 0 && inx < 3) &&
+                          !(iny + WIN + 1 == J.h && inx + WIN + 9 > J.w);  // rows inside the level; same exclusions as fast_I
         n_iter++;
         unsigned p01[NS], p23[NS];
         lkq_sample_row<NS>(J, inx, iny, r, fast, w.wt, w.wb, p01, p23);  // lane r = row r (lane WIN holds the last bottom row)
@@ -1507,7 +1512,8 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
         if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) { status = 0; return; }
         if (!want_err) return;
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny)));
-        const bool fast = inx >= 3 && iny >= 0 && inx + WIN + 12 <= J.w && iny + WIN + 1 <= J.h;
+        const bool fast = inx >= 0 && iny >= 0 && inx + WIN + 2 <= J.w && iny + WIN + 1 <= J.h && !(iny == 0 && inx < 3) &&
+                          !(iny + WIN + 1 == J.h && inx + WIN + 9 > J.w);  // rows inside the level; same exclusions as fast_I
         unsigned p01[NS], p23[NS], i01[NS], i23[NS];
         lkq_sample_row<NS>(J, inx, iny, r, fast, w.wt, w.wb, p01, p23);
         // the template samples again (not kept by the set-up): the same bilinear sampling of I at the template origin
