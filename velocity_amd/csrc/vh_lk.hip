@@ -578,8 +578,11 @@ __device__ void lk_level_strip(const ImgDesc I, const ImgDesc J, int win_rt, int
 
     int a11 = 0, a12 = 0, a22 = 0;
     {
-        // fast path needs the 4x8-byte block [ipx-1 .. ipx+win+5] x [ipy-1 .. ipy+win+1] (+ dword slack) inside the level
-        const bool fast = ipx >= 4 && ipy >= 1 && ipx + win + 12 <= I.w && ipy + win + 2 <= I.h;
+        // interior window: the patch [ipx-1, ipx+win+1] x [ipy-1, ipy+win+1] lies inside the level (V identity).  The aligned 12-byte row reads of a
+        // strip (and the padding samples of the last strip) may run past either end of a row: harmless inside the level, excluded where they would
+        // leave it (first row to the left, last row to the right)
+        const bool fast = ipx >= 1 && ipy >= 1 && ipx + win + 3 <= I.w && ipy + win + 2 <= I.h && !(ipy == 1 && ipx < 4) &&
+                          !(ipy + win + 2 == I.h && ipx + 4 * spr + 7 > I.w);
         if constexpr (WIN_T != 0 && ((((WIN_T + 3) >> 2) * WIN_T + 63) / 64) <= 2) {
             constexpr int SPR = (WIN_T + 3) >> 2, NS = SPR * WIN_T, KMAX = (NS + 63) / 64, G = KMAX < 3 ? KMAX : 3;
 #pragma unroll
@@ -645,7 +648,8 @@ __device__ void lk_level_strip(const ImgDesc I, const ImgDesc J, int win_rt, int
             break;
         }
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny)));
-        const bool fast = inx >= 3 && iny >= 0 && inx + win + 12 <= J.w && iny + win + 1 <= J.h;
+        const bool fast = inx >= 0 && iny >= 0 && inx + win + 2 <= J.w && iny + win + 1 <= J.h && !(iny == 0 && inx < 3) &&
+                          !(iny + win + 1 == J.h && inx + 4 * spr + 8 > J.w);  // see the set-up
         n_iter++;
         int b1 = 0, b2 = 0;
         if constexpr (WIN_T != 0 && ((((WIN_T + 3) >> 2) * WIN_T + 63) / 64) <= 2) {
@@ -718,7 +722,8 @@ __device__ void lk_level_strip(const ImgDesc I, const ImgDesc J, int win_rt, int
         if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) { status = 0; return; }
         if (!want_err) return;  // err is discarded by the caller (KLT.py:83 `pa, v, _`): only the bounds rule matters
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny)));
-        const bool fast = inx >= 3 && iny >= 0 && inx + win + 12 <= J.w && iny + win + 1 <= J.h;
+        const bool fast = inx >= 0 && iny >= 0 && inx + win + 2 <= J.w && iny + win + 1 <= J.h && !(iny == 0 && inx < 3) &&
+                          !(iny + win + 1 == J.h && inx + 4 * spr + 8 > J.w);  // see the set-up
         int se = 0;
         int j = j_first, y = y_first, k = 0;
         for (int s = lane; s < nstrips; s += 64, k++) {
