@@ -425,24 +425,25 @@ __device__ __forceinline__ void setup_v_row(const unsigned* top, const unsigned*
 __device__ __forceinline__ void setup_from_v(const int* V0, const int* V1, const int* V2, int cnt, uint2* tI, uint2* tX, uint2* tY, int slot,
                                              int& a11, int& a12, int& a22)
 {
-    int S[6], D[6];
+    // gradients x4 with the rounding folded in (column c of S carries 2^14 c, so S[c+2] - S[c] brings 4 * 2^13), descale + int16 packing by
+    // v_perm of the upper halves, zeroing of the samples beyond the window edge by the selector (see setup_from_hg)
+    int S4[6], D[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) {
-        S[c] = __mul24(V0[c] + V2[c], 3) + __mul24(V1[c], 10);  // every V fits 23 bits
+        S4[c] = mad24_v<40>(V1[c], mad24_s<12>(V0[c] + V2[c], c << W_BITS));  // every V fits 23 bits
         D[c] = V2[c] - V0[c];
     }
     int iv[4], ix[4], iy[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        iv[c] = vh_descale(V1[c + 1], W_BITS - 5);
-        ix[c] = vh_descale(S[c + 2] - S[c], W_BITS);
-        iy[c] = vh_descale((D[c] + D[c + 2]) * 3 + D[c + 1] * 10, W_BITS);
+        iv[c] = (V1[c + 1] << (16 - (W_BITS - 5))) + (1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5)));
+        ix[c] = S4[c + 2] - S4[c];
+        iy[c] = mad24_v<40>(D[c + 1], mad24_s<12>(D[c] + D[c + 2], 4 << (W_BITS - 1)));
     }
-    // samples beyond the window edge (last strip of a row) are zero
-    const unsigned m01 = cnt >= 2 ? 0xffffffffu : 0x0000ffffu, m23 = cnt >= 4 ? 0xffffffffu : (cnt == 3 ? 0x0000ffffu : 0u);
-    const uint2 vI = make_uint2(pack16(iv[0], iv[1]) & m01, pack16(iv[2], iv[3]) & m23);
-    const uint2 vX = make_uint2(pack16(ix[0], ix[1]) & m01, pack16(ix[2], ix[3]) & m23);
-    const uint2 vY = make_uint2(pack16(iy[0], iy[1]) & m01, pack16(iy[2], iy[3]) & m23);
+    const unsigned sel01 = cnt >= 2 ? 0x07060302u : 0x0c0c0302u, sel23 = cnt >= 4 ? 0x07060302u : (cnt == 3 ? 0x0c0c0302u : 0x0c0c0c0cu);
+    const uint2 vI = make_uint2(__builtin_amdgcn_perm((unsigned)iv[1], (unsigned)iv[0], sel01), __builtin_amdgcn_perm((unsigned)iv[3], (unsigned)iv[2], sel23));
+    const uint2 vX = make_uint2(__builtin_amdgcn_perm((unsigned)ix[1], (unsigned)ix[0], sel01), __builtin_amdgcn_perm((unsigned)ix[3], (unsigned)ix[2], sel23));
+    const uint2 vY = make_uint2(__builtin_amdgcn_perm((unsigned)iy[1], (unsigned)iy[0], sel01), __builtin_amdgcn_perm((unsigned)iy[3], (unsigned)iy[2], sel23));
     tI[slot] = vI; tX[slot] = vX; tY[slot] = vY;
     a11 = dot2(vX.y, vX.y, dot2(vX.x, vX.x, a11));
     a12 = dot2(vX.y, vY.y, dot2(vX.x, vY.x, a12));
