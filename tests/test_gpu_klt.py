@@ -176,6 +176,35 @@ def test_strip_and_per_sample_lk_kernels_agree(seq):
                 assert np.array_equal(x, y), (lk, mode)
 
 
+def test_pyr_lk_interior_border_transition_matches_oracle():
+    """Windows sliding across the line where the interior (V-identity, aligned dword loads) path hands over to the border path: a dense set of
+    15x15 and 51x51 track positions within 30 px of every side of a small frame (half-pixel steps near the corners), 3 levels, forward +
+    backward.  Every kernel route must equal the oracle bit for bit."""
+    from velocity_amd import _lib as L
+    from velocity_amd.KLT import cv2calcOpticalFlowPyrLK
+
+    W, H = 160, 112
+    m = synth.AffineMotion(W, H, s=1.004, theta_deg=0.2, tx=1.3, ty=-0.9)
+    f0 = synth.render_frame(W, H, m, 0, seed=41).numpy()
+    f1 = synth.render_frame(W, H, m, 1, seed=41).numpy()
+    xs = np.concatenate([np.arange(0.0, 31.0, 0.5), np.arange(W - 31.0, W, 0.5)])
+    ys = np.concatenate([np.arange(0.0, 31.0, 2.5), np.arange(H - 31.0, H, 2.5), [H / 2.0]])
+    gx, gy = np.meshgrid(xs, ys)
+    pts = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
+    pts = np.concatenate([pts, pts[:, ::-1] * np.float32([W / H, H / W])]).astype(np.float32)  # the same density along the top / bottom edges
+    for win, lvl, modes in ((15, 2, (0, 2, 3, 4)), (51, 1, (0, 2, 5, 6, 7))):
+        exp = KO.lk_fb(f0, f1, pts, fbt=1.0, win=win, max_level=lvl, max_count=10, eps=0.03)
+        for mode in modes:
+            L.load().vh_debug_force_generic_lk(mode)
+            try:
+                got = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=1.0, winSize=(win, win), maxLevel=lvl, criteria=(3, 10, 0.03))
+            finally:
+                L.load().vh_debug_force_generic_lk(0)
+            assert np.array_equal(got[1], exp[1]), (win, mode)
+            assert np.array_equal(got[0], exp[0]), (win, mode)
+            assert np.array_equal(got[2].ravel(), exp[2]), (win, mode)
+
+
 def test_pyr_lk_large_motion_restages_search_region():
     """Displacements far beyond the staged search margin (coarse 6 px, fine 4 px) must still match the oracle."""
     from velocity_amd import _lib as L
