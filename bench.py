@@ -603,7 +603,7 @@ def main():
             legs = dict(single_stream=extra_leg(a, a.config, a.params, a.scene, 1, 200, 20, dev))
             legs["single_stream"]["latency_ms"] = legs["single_stream"].get("ms_per_step")
             legs["ref_params"] = extra_leg(a, a.config, "ref" if a.params == "baseline" else "baseline", a.scene, S, 60, 10, dev)
-            legs["other_config"] = extra_leg(a, "c3" if c2 else "c2", a.params, a.scene, 32 if c2 else 128, 30 if c2 else 60, 6, dev)
+            legs["other_config"] = extra_leg(a, "c3" if c2 else "c2", a.params, a.scene, 64 if c2 else 128, 24 if c2 else 60, 6, dev)  # 64 4K streams = 320 000 tracks in flight
             legs["roll_scene"] = extra_leg(a, a.config, a.params, "roll" if a.scene == "plane" else "plane", S, 60, 10, dev)
             out["extras"] = legs
         if not a.no_ba and world == 1:
