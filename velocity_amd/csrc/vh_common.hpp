@@ -63,6 +63,19 @@ __device__ __forceinline__ int vh_reflect101(int i, int n)
     while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
     return i;
 }
+// REFLECT_101 for |i| <= 4 (n - 1), branch free: the reflection has period P = 2 (n - 1) and on [0, P] it is min(a, P - a); one round of
+// r = min(|i|, P - |i|) lands in range for |i| <= P, a second one for |i| <= 2 P.  The LK windows stay within a level's width plus one window
+// (and a level is wider than the window), so their columns / rows satisfy the bound.  The looped form above costs a divergent loop PER BYTE in a
+// border load, i.e. one memory round trip per byte instead of one per row.
+__device__ __forceinline__ int vh_reflect101_near(int i, int n)
+{
+    const int P = 2 * (n - 1);
+    int a = max(i, -i);
+    int r = min(a, P - a);
+    a = max(r, -r);
+    r = min(a, P - a);
+    return n == 1 ? 0 : r;
+}
 // correctly rounded float32 sqrt (HIP's __fsqrt_rn is the approximate native instruction; sqrtf is IEEE under the
 // default -fhip-fp32-correctly-rounded-divide-sqrt)
 __device__ __forceinline__ float vh_sqrtf(float v) { return __builtin_sqrtf(v); }

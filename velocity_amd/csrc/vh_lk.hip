@@ -41,7 +41,7 @@ __device__ __forceinline__ Win bilinear_weights(float a, float b)
 // REFLECT_101 sample (image border of the pyramid levels)
 __device__ __forceinline__ int pix_r(const ImgDesc& im, int x, int y)
 {
-    return im.p[(size_t)vh_reflect101(y, im.h) * im.stride + vh_reflect101(x, im.w)];
+    return im.p[(size_t)vh_reflect101_near(y, im.h) * im.stride + vh_reflect101_near(x, im.w)];  // (|x|, |y| within a window of the level)
 }
 
 // template window sample: I (x32), Ix, Iy at the bilinear cell whose top-left pixel is (gx, gy)
@@ -1335,14 +1335,13 @@ __device__ __forceinline__ void load_row_words(const ImgDesc& im, int gx, int gy
 #pragma unroll
         for (int i = 0; i < NWORDS; i++) a[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
     } else {
-        const uint8_t* row = im.p + (size_t)vh_reflect101(gy, im.h) * im.stride;
+        const uint8_t* row = im.p + (size_t)vh_reflect101_near(gy, im.h) * im.stride;
+        // all column indices first (branch free), then all byte loads: one memory round trip per row
+        unsigned b[4 * NWORDS];
 #pragma unroll
-        for (int i = 0; i < NWORDS; i++) {
-            unsigned v = 0;
+        for (int k = 0; k < 4 * NWORDS; k++) b[k] = row[vh_reflect101_near(gx + k, im.w)];
 #pragma unroll
-            for (int c = 0; c < 4; c++) v |= (unsigned)row[vh_reflect101(gx + 4 * i + c, im.w)] << (8 * c);
-            a[i] = v;
-        }
+        for (int i = 0; i < NWORDS; i++) a[i] = b[4 * i] | (b[4 * i + 1] << 8) | (b[4 * i + 2] << 16) | (b[4 * i + 3] << 24);
     }
 }
 
