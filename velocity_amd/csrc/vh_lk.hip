@@ -1431,37 +1431,58 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
             __builtin_amdgcn_sched_barrier(0);
         }
     } else {
-        // Window at the image border (a quarter of the tracks on the coarsest level): gradients of integer pixels, zero outside the image, then
-        // interpolated (strip_setup<false>).  One strip at a time in a ROLLED loop, the lane's patch words and results staged through its private
-        // LDS column: unrolled, this path alone needs 152 VGPRs (3 wavefronts per SIMD for the whole kernel instead of 5).
-        extern __shared__ unsigned lkq_lds[];  // [4 * (NS + 1)][64]
-        unsigned* mine = lkq_lds + (threadIdx.x & 63);
-        if (r < WIN) {
+        // Window at the image border (most tracks on the tiny top levels of a 5-level pyramid).  The derivative image is 0 OUTSIDE the level, so the V
+        // identity does not hold: the Scharr gradients of the integer pixels are built, zeroed outside, then interpolated like any other image.
+        // Everything stays packed int16 (S = 3 (P_up + P_down) + 10 P <= 4080, D = P_down - P_up, Gx = S[k+1] - S[k-1], Gy = 3 (D[k-1] + D[k+1]) + 10 D[k]):
+        // lane r holds pixel rows r-1 .. r+1 and gradient row r of the window as byte / int16 PAIRS (k, k+1), so a sample is two v_dot2 -- the
+        // second one reading the pair of gradient row r+1 straight from lane r+1 (DPP) -- exactly like the search-image sampling.  All 16 lanes
+        // take part (lane WIN feeds lane WIN-1).  REFLECT_101 is in the row loads; same integers as strip_setup<false>.
+        unsigned a[3][NS + 1];
 #pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                unsigned a[NS + 1];
-                load_row_words<NS + 1>(I, ipx - 1, ipy + r - 1 + rr, false, a);
+        for (int rr = 0; rr < 3; rr++) load_row_words<NS + 1>(I, ipx - 1, ipy + r - 1 + rr, false, a[rr]);
+        // bit c of M: gradient pixel (ipx + c, ipy + r) lies inside the level
+        const int ay = ipy + r, cs = max(0, -ipx), ce = min(4 * NS, I.w - 1 - ipx);
+        const unsigned M = (ay >= 0 && ay < I.h && ce >= cs) ? (((2u << ce) - 1u) & ~((1u << cs) - 1u)) : 0u;
+        short2v Sp[4 * NS + 2], Dp[4 * NS + 2];
+        unsigned Pm[4 * NS + 2];
+        auto colb = [&](int k) {
+            const unsigned pt = row_pair(a[0], k), pb = row_pair(a[2], k);
+            Pm[k] = row_pair(a[1], k);
+            const short2v k3 = {3, 3}, k10 = {10, 10};
+            Sp[k] = (as_s2(pt) + as_s2(pb)) * k3 + as_s2(Pm[k]) * k10;
+            Dp[k] = as_s2(pb) - as_s2(pt);
+        };
+        colb(0); colb(1);
 #pragma unroll
-                for (int i = 0; i <= NS; i++) mine[(4 * i + rr) * 64] = a[i];
+        for (int j = 0; j < NS; j++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) colb(4 * j + 2 + c);
+            const int cnt = WIN - 4 * j < 4 ? WIN - 4 * j : 4;
+            int iv[4], ix[4], iy[4];  // the wanted int16 in the upper half of each
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int col = 4 * j + c;
+                const short2v k3 = {3, 3}, k10 = {10, 10};
+                // (pixel col, col + 1) of the gradient row: Gx = S[k+1] - S[k-1] with k = col + 1 in patch columns
+                const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)M, col, 1) & 0xffffu | ((unsigned)__builtin_amdgcn_sbfe((int)M, col + 1, 1) << 16);
+                const unsigned gx = __builtin_bit_cast(unsigned, Sp[col + 2] - Sp[col]) & m;
+                const unsigned gy = __builtin_bit_cast(unsigned, (Dp[col] + Dp[col + 2]) * k3 + Dp[col + 1] * k10) & m;
+                ix[c] = (dot2c_next_lane(dot2_first(gx, w0t), gx, w0b) << 2) + (4 << (W_BITS - 1));
+                iy[c] = (dot2c_next_lane(dot2_first(gy, w0t), gy, w0b) << 2) + (4 << (W_BITS - 1));
+                iv[c] = (dot2c_next_lane(dot2_first(Pm[col + 1], w0t), Pm[col + 1], w0b) << (16 - (W_BITS - 5))) + (1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5)));
             }
-#pragma unroll 1
-            for (int j = 0; j < NS; j++) {
-                unsigned lo[4], hi[4];
-#pragma unroll
-                for (int rr = 0; rr < 4; rr++) { lo[rr] = mine[(4 * j + rr) * 64]; hi[rr] = mine[(4 * j + 4 + rr) * 64]; }
-                const int cnt = WIN - 4 * j < 4 ? WIN - 4 * j : 4;
-                uint2 sI[1], sX[1], sY[1];
-                strip_setup<false>(lo, hi, w0, I, ipx, ipy, 4 * j, r, cnt, sI, sX, sY, 0, a11, a12, a22);
-                cI[0] = dot2(sI[0].y, sX[0].y, dot2(sI[0].x, sX[0].x, cI[0]));
-                cI[1] = dot2(sI[0].y, sY[0].y, dot2(sI[0].x, sY[0].x, cI[1]));
-                mine[(4 * j + 0) * 64] = sX[0].x; mine[(4 * j + 1) * 64] = sX[0].y;  // word j of the four rows is dead now
-                mine[(4 * j + 2) * 64] = sY[0].x; mine[(4 * j + 3) * 64] = sY[0].y;
-            }
-#pragma unroll
-            for (int j = 0; j < NS; j++) {
-                tX[j] = make_uint2(mine[(4 * j + 0) * 64], mine[(4 * j + 1) * 64]);
-                tY[j] = make_uint2(mine[(4 * j + 2) * 64], mine[(4 * j + 3) * 64]);
-            }
+            const unsigned sel01 = r < WIN ? (cnt >= 2 ? 0x07060302u : 0x0c0c0302u) : 0x0c0c0c0cu;
+            const unsigned sel23 = r < WIN ? (cnt >= 4 ? 0x07060302u : (cnt == 3 ? 0x0c0c0302u : 0x0c0c0c0cu)) : 0x0c0c0c0cu;
+            const uint2 vI = make_uint2(pack_hi16(iv[0], iv[1]), pack_hi16(iv[2], iv[3]));
+            const uint2 vX = make_uint2(__builtin_amdgcn_perm((unsigned)ix[1], (unsigned)ix[0], sel01), __builtin_amdgcn_perm((unsigned)ix[3], (unsigned)ix[2], sel23));
+            const uint2 vY = make_uint2(__builtin_amdgcn_perm((unsigned)iy[1], (unsigned)iy[0], sel01), __builtin_amdgcn_perm((unsigned)iy[3], (unsigned)iy[2], sel23));
+            tX[j] = vX; tY[j] = vY;
+            a11 = dot2(vX.y, vX.y, dot2(vX.x, vX.x, a11));
+            a12 = dot2(vX.y, vY.y, dot2(vX.x, vY.x, a12));
+            a22 = dot2(vY.y, vY.y, dot2(vY.x, vY.x, a22));
+            cI[0] = dot2(vI.y, vX.y, dot2(vI.x, vX.x, cI[0]));
+            cI[1] = dot2(vI.y, vY.y, dot2(vI.x, vY.x, cI[1]));
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     const float A11 = __fmul_rn(i64_to_f32(row16_sum_wide(a11)), LK_FLT_SCALE), A12 = __fmul_rn(i64_to_f32(row16_sum_wide(a12)), LK_FLT_SCALE),
@@ -1605,8 +1626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
 template <int WIN>
 static int launch_lkq(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
-    constexpr int lds = 4 * (((WIN + 3) >> 2) + 1) * 64 * 4;  // the border set-up's lane-private staging
-    hipLaunchKernelGGL(k_lk_q<WIN>, dim3((max_n + 3) / 4, batch), dim3(64), lds, s, job_tab, tab_stride);
+    hipLaunchKernelGGL(k_lk_q<WIN>, dim3((max_n + 3) / 4, batch), dim3(64), 0, s, job_tab, tab_stride);
     return 0;
 }
 
