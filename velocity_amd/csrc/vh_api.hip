@@ -53,6 +53,8 @@ extern "C" VH_API int vh_ctx_create(vh_ctx** out, int batch, int max_w, int max_
     StreamBufs* hb = new StreamBufs[batch];
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    // a level buffer holds either layout of any level up to w x h: dense, or bordered (small levels, see VH_LV_PAD)
+    auto lv_bytes = [](int w, int h) { return (size_t)VH_LV_STRIDE(w) * (size_t)(h + 2 * VH_LV_PAD); };
     size_t ws_off = carve(sizeof(StreamWS) * batch);
     size_t small_off = carve(sizeof(double) * 64);
     for (int pass = 0; pass < 2; pass++) {
@@ -74,13 +76,13 @@ extern "C" VH_API int vh_ctx_create(vh_ctx** out, int batch, int max_w, int max_
                 int w = c->sw, h = c->sh;
                 for (int l = 1; l < VH_MAX_LEVELS; l++) {
                     w = (w + 1) / 2; h = (h + 1) / 2;
-                    B.small_lv[k][l] = (uint8_t*)(base + carve((size_t)w * h));
+                    B.small_lv[k][l] = (uint8_t*)(base + carve(lv_bytes(w, h)));
                 }
                 B.small_lv[k][0] = nullptr;
                 w = max_w; h = max_h;
                 for (int l = 1; l < VH_MAX_LEVELS; l++) {
                     w = (w + 1) / 2; h = (h + 1) / 2;
-                    B.roi_lv[k][l] = (uint8_t*)(base + carve((size_t)w * h));
+                    B.roi_lv[k][l] = (uint8_t*)(base + carve(lv_bytes(w, h)));
                 }
                 B.roi_lv[k][0] = nullptr;
             }
@@ -129,8 +131,9 @@ __device__ void fill_pyramid(PyrDesc& P, const uint8_t* lv0, int w, int h, int s
     int n = 0;
     for (int level = 0; level <= max_level && level < VH_MAX_LEVELS; level++) {
         ImgDesc& d = P.lv[level];
-        if (level == 0) { d.p = lv0; d.w = w; d.h = h; d.stride = stride; }
-        else { d.p = lvbuf[level]; d.w = w; d.h = h; d.stride = w; }
+        if (level == 0) { d.p = lv0; d.w = w; d.h = h; d.stride = stride; d.pad = 0; }
+        else if (VH_LV_PADDED(w, h)) { d.stride = VH_LV_STRIDE(w); d.p = lvbuf[level] + (size_t)VH_LV_PAD * d.stride + VH_LV_PAD; d.w = w; d.h = h; d.pad = VH_LV_PAD; }
+        else { d.p = lvbuf[level]; d.w = w; d.h = h; d.stride = w; d.pad = 0; }
         n = level + 1;
         w = (w + 1) / 2; h = (h + 1) / 2;
         if (w <= win || h <= win) break;
@@ -589,9 +592,9 @@ static void host_fill_pyramid(PyrDesc& P, const uint8_t* lv0, int w, int h, int 
     int n = 0;
     for (int level = 0; level <= max_level && level < VH_MAX_LEVELS; level++) {
         ImgDesc& d = P.lv[level];
-        if (level == 0) { d.p = lv0; d.w = w; d.h = h; d.stride = stride; }
-        else { d.p = lvbuf[level]; d.w = w; d.h = h; d.stride = w; }
-        d.pad = 0;
+        if (level == 0) { d.p = lv0; d.w = w; d.h = h; d.stride = stride; d.pad = 0; }
+        else if (VH_LV_PADDED(w, h)) { d.stride = VH_LV_STRIDE(w); d.p = lvbuf[level] + (size_t)VH_LV_PAD * d.stride + VH_LV_PAD; d.w = w; d.h = h; d.pad = VH_LV_PAD; }
+        else { d.p = lvbuf[level]; d.w = w; d.h = h; d.stride = w; d.pad = 0; }
         n = level + 1;
         w = (w + 1) / 2; h = (h + 1) / 2;
         if (w <= win || h <= win) break;

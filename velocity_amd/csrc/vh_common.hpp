@@ -18,10 +18,19 @@
 void vh_set_error(const char* what, hipError_t e, const char* file, int line);
 
 // ---- image / pyramid descriptors (device resident; dims may be data dependent) -------------------------------
+// SMALL pyramid levels >= 1 that the library allocates itself (w * h <= VH_LV_PAD_MAX_PIXELS: there a large share of the windows touches the
+// border) carry a REFLECT_101 border of VH_LV_PAD pixels on every side (rows VH_LV_STRIDE(w) bytes apart, >= 4 spare bytes per row), filled by
+// k_pyr_pad right after the level is built: the row loads of windows at the border of such a level are then plain dword loads.  On large levels
+// border windows are rare and a border ring would cost more to write than it saves.
+#define VH_LV_PAD 24
+#define VH_LV_PAD_MAX_PIXELS 65536
+#define VH_LV_STRIDE(w) (((((w) + 2 * VH_LV_PAD) + 3) & ~3) + 4)
+#define VH_LV_PADDED(w, h) ((long long)(w) * (h) <= VH_LV_PAD_MAX_PIXELS)
+
 struct ImgDesc {
     const uint8_t* p;  // pixel (x,y) at p[y*stride + x]
     int w, h, stride;
-    int pad;
+    int pad;  // pixels of valid REFLECT_101 border around the w x h image (0: none)
 };
 
 struct PyrDesc {

@@ -1,6 +1,7 @@
 // Image-stage kernels of the KLT path: quarter-scale nearest decimation (K1), pyrDown (K2), shifted crop (K8) and
 // affine remap (K9).  All are HBM-bound byte kernels; descriptors are read from device memory because ROI sizes are
 // data dependent (bounding box of the tracks) and the whole frame pipeline runs without a host round trip.
+#include <algorithm>
 #include "vh_kernels.hpp"
 #include "vh_valu.hpp"
 
@@ -367,6 +368,41 @@ void vh_launch_resize_quarter(const void* src_tab, const void* dst_tab, size_t t
     hipLaunchKernelGGL(k_resize_quarter, grd, blk, 0, s, src_tab, dst_tab, tab_stride, per_stream);
 }
 
+// REFLECT_101 border ring of a freshly built small level (see VH_LV_PAD): one thread per dword of 4 ring pixels (the interior origin and the row
+// pitch are dword aligned; a dword that straddles the image edge re-writes interior pixels with themselves).  Same build table as k_pyr_down;
+// levels without a border (large levels, user buffers) and missing levels exit at once.
+__global__ __launch_bounds__(256) void k_pyr_pad(const void* pb_tab, size_t ws_stride, int lvl)
+{
+    const PyrBuild& pb = reinterpret_cast<const PyrBuild*>(reinterpret_cast<const char*>(pb_tab) + (size_t)(blockIdx.z >> 1) * ws_stride)[blockIdx.z & 1];
+    if (!pb.enable || pb.pyr == nullptr) return;
+    const PyrDesc& P = *pb.pyr;
+    if (lvl + 1 >= P.nlevels) return;
+    const ImgDesc d = P.lv[lvl + 1];
+    const int B = d.pad;
+    if (B <= 0) return;
+    const int wq = (d.w + 2 * B + 3) >> 2;        // dwords of a full-width ring row (columns -B .. w+B-1, rounded up: the pitch has 4 spare bytes)
+    const int rq = ((d.w & 3) + B + 3) >> 2;       // dwords of the right band of an image row, starting at column w & ~3
+    const int band = wq * 2 * B, side = (B / 4) + rq;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    int x, y;
+    if (t < band) {  // the 2 B full-width rows above and below
+        const int q = t / wq;
+        x = 4 * (t - q * wq) - B;
+        y = q < B ? q - B : d.h + q - B;
+    } else {         // left (B / 4 dwords) and right (rq dwords) of the image rows
+        const int u = t - band;
+        if (u >= d.h * side) return;
+        y = u / side;
+        const int q = u - y * side;
+        x = q < B / 4 ? 4 * q - B : (d.w & ~3) + 4 * (q - B / 4);
+    }
+    const uint8_t* srow = d.p + (ptrdiff_t)vh_reflect101(y, d.h) * d.stride;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v |= (uint32_t)srow[vh_reflect101(x + k, d.w)] << (8 * k);
+    *reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(d.p) + (ptrdiff_t)y * d.stride + x) = v;
+}
+
 void vh_launch_pyr_down_ws(const void* pb_tab, size_t ws_stride, int batch, int lvl, int max_w0, int max_h0, hipStream_t s)
 {
     // dims of level lvl+1 when level 0 is max_w0 x max_h0
@@ -380,6 +416,13 @@ void vh_launch_pyr_down_ws(const void* pb_tab, size_t ws_stride, int batch, int 
     } else {
         dim3 grd((w + 255) / 256, (h + 7) / 8, batch * 2);
         hipLaunchKernelGGL(k_pyr_down<2>, grd, blk, 0, s, pb_tab, ws_stride, lvl);
+    }
+    // border ring of the new level when it is a small one (decided per image on the device; the launch covers the largest small level: a level of
+    // at most VH_LV_PAD_MAX_PIXELS pixels inside w x h has no more ring dwords than this)
+    {
+        const int ws_ = std::min(w, VH_LV_PAD_MAX_PIXELS / 16), hs_ = std::min(h, VH_LV_PAD_MAX_PIXELS / 16);
+        const int ring = ((ws_ + 2 * VH_LV_PAD + 3) / 4) * 2 * VH_LV_PAD + hs_ * (VH_LV_PAD / 4 + (VH_LV_PAD + 6) / 4);
+        hipLaunchKernelGGL(k_pyr_pad, dim3((ring + 255) / 256, 1, batch * 2), dim3(256), 0, s, pb_tab, ws_stride, lvl);
     }
 }
 

@@ -1439,7 +1439,7 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
         // take part (lane WIN feeds lane WIN-1).  REFLECT_101 is in the row loads; same integers as strip_setup<false>.
         unsigned a[3][NS + 1];
 #pragma unroll
-        for (int rr = 0; rr < 3; rr++) load_row_words<NS + 1>(I, ipx - 1, ipy + r - 1 + rr, false, a[rr]);
+        for (int rr = 0; rr < 3; rr++) load_row_words<NS + 1>(I, ipx - 1, ipy + r - 1 + rr, I.pad >= VH_LV_PAD, a[rr]);  // bordered level: plain dword loads
         // bit c of M: gradient pixel (ipx + c, ipy + r) lies inside the level
         const int ay = ipy + r, cs = max(0, -ipx), ce = min(4 * NS, I.w - 1 - ipx);
         const unsigned M = (ay >= 0 && ay < I.h && ce >= cs) ? (((2u << ce) - 1u) & ~((1u << cs) - 1u)) : 0u;
@@ -1506,8 +1506,8 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
             break;
         }
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny)));
-        const bool fast = inx >= 0 && iny >= 0 && inx + WIN + 2 <= J.w && iny + WIN + 1 <= J.h && !(iny == 0 && inx < 3) &&
-                          !(iny + WIN + 1 == J.h && inx + WIN + 9 > J.w);  // rows inside the level; same exclusions as fast_I
+        const bool fast = J.pad >= VH_LV_PAD || (inx >= 0 && iny >= 0 && inx + WIN + 2 <= J.w && iny + WIN + 1 <= J.h && !(iny == 0 && inx < 3) &&
+                                                 !(iny + WIN + 1 == J.h && inx + WIN + 9 > J.w));  // bordered level, or rows inside the level (exclusions as fast_I)
         n_iter++;
         unsigned p01[NS], p23[NS];
         lkq_sample_row<NS>(J, inx, iny, r, fast, w.wt, w.wb, p01, p23);  // lane r = row r (lane WIN holds the last bottom row)
@@ -1538,12 +1538,12 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
         if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) { status = 0; return; }
         if (!want_err) return;
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny)));
-        const bool fast = inx >= 0 && iny >= 0 && inx + WIN + 2 <= J.w && iny + WIN + 1 <= J.h && !(iny == 0 && inx < 3) &&
-                          !(iny + WIN + 1 == J.h && inx + WIN + 9 > J.w);  // rows inside the level; same exclusions as fast_I
+        const bool fast = J.pad >= VH_LV_PAD || (inx >= 0 && iny >= 0 && inx + WIN + 2 <= J.w && iny + WIN + 1 <= J.h && !(iny == 0 && inx < 3) &&
+                                                 !(iny + WIN + 1 == J.h && inx + WIN + 9 > J.w));  // bordered level, or rows inside the level (exclusions as fast_I)
         unsigned p01[NS], p23[NS], i01[NS], i23[NS];
         lkq_sample_row<NS>(J, inx, iny, r, fast, w.wt, w.wb, p01, p23);
         // the template samples again (not kept by the set-up): the same bilinear sampling of I at the template origin
-        lkq_sample_row<NS>(I, ipx, ipy, r, fast_I, w0t, w0b, i01, i23);
+        lkq_sample_row<NS>(I, ipx, ipy, r, fast_I || I.pad >= VH_LV_PAD, w0t, w0b, i01, i23);
         int se = 0;
 #pragma unroll
         for (int j = 0; j < NS; j++) {
