@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): bench line, stream sweep, rocprofv3 kernel stats, the HBM-traffic PMC passes, the SQ passes of the LK and BA
 # kernels, the single-stream launch timeline, the PCIe-inclusive rates and the VALU issue-rate micro-benchmark.
 # Usage: bash tools/collect_profiles.sh <streams> ; results under gpurun_out/prof/ ; then: python tools/summarize_profiles.py r02
-S=${1:-128}
+S=${1:-256}
 R=/root/repo
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
