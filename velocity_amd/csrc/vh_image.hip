@@ -29,7 +29,14 @@ __global__ __launch_bounds__(256) void k_resize_quarter(const void* src_tab, con
     uint8_t* drow = const_cast<uint8_t*>(d.p) + (size_t)y * d.stride;
     uint32_t pack = 0;
     int cnt = min(4, d.w - x4);
-    for (int k = 0; k < cnt; k++) pack |= (uint32_t)srow[min(4 * (x4 + k), s.w - 1)] << (8 * k);
+    const uint8_t* sp = srow + 4 * (size_t)x4;
+    if (cnt == 4 && 4 * (x4 + 3) <= s.w - 1 && (reinterpret_cast<uintptr_t>(sp) & 3) == 0) {
+        // the four samples are byte 0 of four consecutive dwords: one 16-byte load and two v_perm instead of four dependent byte loads
+        const uint4 q = *reinterpret_cast<const uint4*>(sp);
+        pack = __builtin_amdgcn_perm(q.y, q.x, 0x0c0c0400u) | __builtin_amdgcn_perm(q.w, q.z, 0x04000c0cu);
+    } else {
+        for (int k = 0; k < cnt; k++) pack |= (uint32_t)srow[min(4 * (x4 + k), s.w - 1)] << (8 * k);
+    }
     if (cnt == 4 && ((reinterpret_cast<uintptr_t>(drow + x4) & 3) == 0)) {
         *reinterpret_cast<uint32_t*>(drow + x4) = pack;
     } else {
