@@ -93,6 +93,9 @@ def parse():
                          "then corroborate the run); 0 = exactly --steps steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each cpu_baseline leg (0 disables)")
     ap.add_argument("--exchange-every", type=int, default=30)
+    ap.add_argument("--verify-frames", type=int, default=4,
+                    help="after the timed region, replay this many further frames of two resident streams through the CPU oracle and report "
+                         "`verified` (0 disables)")
     ap.add_argument("--no-ba", action="store_true", help="skip the BA (config 5) leg")
     ap.add_argument("--only-ba", action="store_true", help="run only the BA (config 5) leg and print its object (profiling aid)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (single stream, reference parameters, C3, roll scene)")
@@ -189,7 +192,7 @@ def bench_ba(nt=5000, nf=20, repeats=3, cpu_seconds=12.0, windows=(1, 8, 64)):
 
     K = synth.K_1080P
     ws = L.workspace()
-    K32 = np.ascontiguousarray(K.reshape(9))
+    K64 = L.host_K(K)
     nc = nf - 1
     nx, nz = 3 * nt + 6 * nc, 2 * nt * nf
     out = dict(workload=f"C5 BA: {nf} keyframes x {nt} tracks (nx={nx}, nz={nz}), 10 LM iterations per window",
@@ -220,10 +223,10 @@ def bench_ba(nt=5000, nf=20, repeats=3, cpu_seconds=12.0, windows=(1, 8, 64)):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if nw == 1:
-                L.check(ws.lib.vh_nls_batch(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, 10, L.dptr(trace), L.dptr(info),
+                L.check(ws.lib.vh_nls_batch(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, 10, L.dptr(trace), L.dptr(info),
                                             L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch")
             else:
-                L.check(ws.lib.vh_nls_batch_multi(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, nw, 10, L.dptr(trace),
+                L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, nw, 10, L.dptr(trace),
                                                   L.dptr(info), L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
@@ -277,7 +280,7 @@ def bench_ba_multi_gpu(rank, world, barrier, reduce_max, nt=5000, nf=20, windows
 
     K = synth.K_1080P
     ws = L.workspace()
-    K32 = np.ascontiguousarray(K.reshape(9))
+    K64 = L.host_K(K)
     nc, nw = nf - 1, windows_per_gpu
     packs = [synth.ba_pack(*synth.ba_scene(nt, nf, seed=5 + rank * nw + w)) for w in range(nw)]
     zd = L.to_dev(np.stack([p[0] for p in packs]), torch.float64)
@@ -291,7 +294,7 @@ def bench_ba_multi_gpu(rank, world, barrier, reduce_max, nt=5000, nf=20, windows
         xd = x0d.clone()
         barrier()
         t0 = time.perf_counter()
-        L.check(ws.lib.vh_nls_batch_multi(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, nw, 10, L.dptr(trace), L.dptr(info),
+        L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, nw, 10, L.dptr(trace), L.dptr(info),
                                           L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
         barrier()
         dt = reduce_max(time.perf_counter() - t0)
@@ -302,14 +305,14 @@ def bench_ba_multi_gpu(rank, world, barrier, reduce_max, nt=5000, nf=20, windows
     best = None
     for _ in range(3):
         barrier()
-        t0 = time.perf_counter()
-        _cw, _pw, tr = vdist.fcnNLS_batch_sharded(K, P, pw0, cw0)
-        barrier()
-        dt = reduce_max(time.perf_counter() - t0)
+        tm = {}
+        _cw, _pw, tr = vdist.fcnNLS_batch_sharded(K, P, pw0, cw0, timing=tm)
+        dt = reduce_max(tm["loop_ms"] * 1e-3)  # HIP events around the LM loop of every rank (phases + all-reduces), max over ranks
         best = dt if best is None else min(best, dt)
     out["point_sharded"] = dict(n_gpus=world, iters_per_s=round(len(tr) / best, 1), ms_per_iter=round(1e3 * best / len(tr), 4),
                                 collective="2 all-reduces per LM iteration (104 KB + 8 B)", rms_residual_last=round(float(tr[-1, 0]), 4),
-                                note="includes the host-side packing of fcnNLS_batch_sharded; Amdahl-limited by the replicated reduced-system solve")
+                                timing="HIP events around the LM iterations (host-side packing and the final point gather excluded)",
+                                note="Amdahl-limited by the replicated reduced-system solve")
     return out
 
 
@@ -342,6 +345,7 @@ class Workload:
         # streams of one texture set share its ring but run at different phases, so every launch sees S different frame pairs
         self.phase = [(7 * b) % a.ring for b in range(S)]
         fset = [0 if host_frames else b // a.ring for b in range(S)]
+        self.fset = fset
         if host_frames:
             self.phase = [b % a.ring for b in range(S)]  # consecutive phases: one step's batch is a contiguous slice of the extended host ring
         base_ptr, fbytes = self.frames.data_ptr(), W * H
@@ -380,13 +384,14 @@ class Workload:
                 with torch.cuda.stream(self.hip_streams[g]):
                     self.sessions[g].step(frames_table=row[g * SG:(g + 1) * SG], time_s=i / 30.0, frame_no=i)
             if ex is not None and ex.due(i):
-                ex.wait()
+                ex.wait()  # stream ordered under RCCL: the previous gather has read `local` before the packs below overwrite it
                 for g in range(G):
                     with torch.cuda.stream(self.hip_streams[g]):
                         L.check(self.sessions[g].lib.vh_session_pack_state(self.sessions[g].handle, L.dptr(ex.local[g * SG:(g + 1) * SG]), L.stream_ptr()),
                                 "vh_session_pack_state")
-                torch.cuda.synchronize()
-                ex.start()
+                for g in range(1, G):  # side streams: the collective is issued from the current stream, which must see their packs
+                    self.hip_streams[0].wait_stream(self.hip_streams[g])
+                ex.start()  # no host synchronisation: the collective waits for the current stream itself (dist.TrackStateExchange.start)
 
     def measure(self, steps, warmup, min_seconds, barrier, reduce_max, ex=None):
         """W warm-up steps, then EXACTLY `steps` timed steps between barrier + synchronize; if that took less than min_seconds, further
@@ -420,8 +425,52 @@ class Workload:
             blocks += more
         st = ses.state(0)
         done = warmup + timed
+        self.done_steps = done
         truth = self.motion.t((self.phase[0] + done) % self.ring) - self.motion.t(self.phase[0])
         return dict(elapsed=elapsed, timed_steps=timed, blocks=blocks, prof=prof, st=st, alive=st["n_cur"] / self.N, truth=truth)
+
+    def verify(self, first, nframes=4, which=None):
+        """Parity attestation of the run that was just timed (OUTSIDE the timed region): the state of a few resident streams is handed to the
+        CPU oracle (oracle/session_oracle.py -- the checker, never the product), the whole session advances `nframes` more frames through the very
+        launch sequence that was timed (all streams, same kernel routes), and the chosen streams are compared frame by frame: track positions,
+        validity masks and track ids bit for bit, pose and residual to 1e-5."""
+        from oracle.session_oracle import SessionOracle
+
+        if self.feeder is not None:
+            return dict(skipped="host-frames mode")
+        which = sorted(set(which if which is not None else [0, self.S - 1]))
+        a, SG = self.a, self.SG
+
+        def frame_of(b, i):
+            return self.frames[self.fset[b] * a.ring + (self.phase[b] + i) % a.ring]
+
+        torch.cuda.synchronize()
+        orcs, ids0 = {}, {}
+        for b in which:
+            st = self.sessions[b // SG].state(b % SG)
+            vg = st["vg"]
+            ids0[b] = np.nonzero(vg)[0]
+            orcs[b] = SessionOracle(self.K, frame_of(b, first - 1).cpu().numpy(), st["p"], st["p3"][vg], st["vp"][vg], st["B"][0, 0:3], nhist=nframes + 2,
+                                    lk_coarse=self.lkc, lk_fine=self.lkf, msv_frame=0)
+        ok, worst_t, worst_res, tracks = True, 0.0, 0.0, {}
+        for k in range(nframes):
+            i = first + k
+            self.run(i, 1)
+            torch.cuda.synchronize()
+            for b in which:
+                o = orcs[b]
+                o.step(frame_of(b, i).cpu().numpy(), np.float32(i / 30.0), i)
+                st = self.sessions[b // SG].state(b % SG)
+                same = (np.array_equal(st["ids"], ids0[b][o.vg]) and np.array_equal(st["p"], o.p) and np.array_equal(st["vp"][ids0[b]], o.vp)
+                        and np.array_equal(st["vg"][ids0[b]], o.vg))
+                ok = ok and bool(same)
+                worst_t = max(worst_t, float(np.max(np.abs(st["t"] - o.t) / np.maximum(np.abs(o.t), 1e-3))))
+                worst_res = max(worst_res, abs(st["res"] - o.residuals) / max(abs(o.residuals), 1e-12))
+                tracks[str(b)] = int(st["n_cur"])
+        return dict(streams=which, frames=nframes, bit_exact=ok, pose_within_1e5=bool(worst_t <= 1e-5 and worst_res <= 1e-5),
+                    max_rel_pose_t=float(f"{worst_t:.3g}"), max_rel_residual=float(f"{worst_res:.3g}"), tracks_compared=tracks,
+                    what="after the timed region: these resident streams vs oracle/session_oracle.py (C KLT + NumPy NLS) over further frames of the same "
+                         "launch sequence (all streams stepping); p / vg / vp / ids bit-exact, pose t and rms residual relative error")
 
     def close(self):
         torch.cuda.synchronize()
@@ -508,8 +557,11 @@ def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev):
         fps = wl.S * m["timed_steps"] / m["elapsed"]
         out = dict(workload=f"{cfg_key} / params {params} / scene {scene}", streams=streams, value=round(fps, 2), unit="frames/s",
                    ms_per_step=round(1e3 * m["elapsed"] / m["timed_steps"], 4), timed_steps=m["timed_steps"], tracks_alive_frac=round(m["alive"], 4),
+                   pose_t=[round(float(x), 5) for x in m["st"]["t"]], pose_t_truth=[round(float(x), 5) for x in m["truth"]],
                    rms_residual_px=round(m["st"]["res"], 5),
                    lk_us_per_launch=[round(1e3 * m["prof"]["ms_sum"][k] / max(m["prof"]["launches"][k], 1), 2) for k in range(3)])
+        if a.verify_frames > 0:
+            out["verified"] = wl.verify(wl.done_steps + 1, nframes=min(a.verify_frames, 2))
         wl.close()
         return out
     except Exception as e:  # an extra leg must never take the headline number down with it
@@ -587,9 +639,18 @@ def main():
                    pose_t=[round(float(x), 5) for x in st["t"]], pose_t_truth=[round(float(x), 5) for x in m["truth"]], rms_residual_px=round(st["res"], 5),
                    roofline=roofline_of(wl, m, world), headline_hbm=headline_hbm(cfg, value / world))
         cpu_args = (cfg, wl.K, wl.frames[: a.ring], wl.p0, wl.p3, wl.vp, wl.lkc, wl.lkf)
-    if use_dist and rank == 0 and ex is not None:
-        g = vdist.unpack_state(ex.wait()[0, 0], N)
-        assert g["n_cur"] == st["n_cur"] or g["frame_i"] <= st["frame_i"], "exchanged track state is inconsistent"
+        if a.verify_frames > 0:
+            out["verified"] = wl.verify(wl.done_steps + 1, nframes=a.verify_frames)
+    if use_dist and ex is not None:
+        desc = ex.describe()  # collective (all_gather_object): every rank calls it
+        if rank == 0:
+            g = vdist.unpack_state(ex.wait()[0, 0], N)
+            assert g["n_cur"] == st["n_cur"] or g["frame_i"] <= st["frame_i"], "exchanged track state is inconsistent"
+            # every rank's last gathered record must be a live tracker state (proof that the collective really carried N ranks' data)
+            seen = [vdist.unpack_state(ex.gathered[r, 0], N) for r in range(world)]
+            desc["ranks_seen_in_last_gather"] = sum(1 for q in seen if q["frame_i"] > 0 and q["n_cur"] > 0)
+            desc["exchange_every_frames"] = a.exchange_every
+            out["dist"] = desc
 
     if rank == 0:
         if a.cpu_seconds > 0 and world == 1:

@@ -108,10 +108,11 @@ VH_API int vh_klt_regional(vh_ctx* ctx, const uint8_t* im0, const uint8_t* im, i
 
 /* ---- NLS pose (K11-K13) ---------------------------------------------------------------------------------------- */
 /* estimateWorldCameraPose(K, p, p3, t, R, findR), utils/NLS.py:9-33 -> fcnNLS_t (:102-129) / fcnNLS_Rt (:133-183).
- * K_host: 9 floats (MATLAB layout), x0_host: 6 doubles [rpy(R), t], R_host: 9 doubles.
+ * K_host: 9 doubles (MATLAB layout; a float32 K widens exactly -- estimateWorldCameraPose does K.astype(float), NLS.py:22-24),
+ * x0_host: 6 doubles [rpy(R), t], R_host: 9 doubles.
  * Outputs: t_out float[3]; R_out double[9] (findR: float32-rounded rpy2dcm, else R); res_out double[1] = rms(p - p_proj);
  * p_proj double[n x 2] (may be NULL); info int[2] = {iterations, converged}. */
-VH_API int vh_pose(vh_ctx* ctx, const float* K_host, const float* p, const double* pw, int n, const double* x0_host,
+VH_API int vh_pose(vh_ctx* ctx, const double* K_host, const float* p, const double* pw, int n, const double* x0_host,
                    const double* R_host, int findR, float* t_out, double* R_out, double* res_out, double* p_proj, int* info,
                    void* stream);
 /* world2image(K, R, t, pw), utils/common.py:58-64.  C_host = [R; t] @ K (4x3 row-major, host).  out n x 2 */
@@ -131,7 +132,7 @@ VH_API int vh_n_view_intercept(vh_ctx* ctx, const double* A, const double* U, in
 /* fcnMSV1_t(K, P, B, vg, ii), utils/MSV.py:8-49.  P float32 [5,N0,nhist], B float32 [nhist,14], ids = nonzero(vg)
  * (int32, ng entries).  f32_rays: K and P were float32 on the caller's side (numpy then builds the rays in float32).
  * Outputs: x_out float[3], b0 double[ng x 3], info int[2]; U_scratch double[3*(ii+1)*ng]. */
-VH_API int vh_msv1_t(vh_ctx* ctx, const float* K_host, const float* P, const float* B, const int* ids, int ng, int N0, int nhist,
+VH_API int vh_msv1_t(vh_ctx* ctx, const double* K_host, const float* P, const float* B, const int* ids, int ng, int N0, int nhist,
                      int ii, int f32_rays, double* U_scratch, float* x_out, double* b0, int* info, void* stream);
 
 
@@ -142,14 +143,14 @@ VH_API int vh_msv1_t(vh_ctx* ctx, const float* K_host, const float* P, const flo
  * x is updated in place.  trace [max_iter][2] = (rms(z - zhat), rms(delta)) per iteration (what NLS.py:238 prints),
  * info int[2] = {iterations, converged}.  workspace: vh_nls_batch_workspace(nt, nc) bytes of device memory. */
 VH_API size_t vh_nls_batch_workspace(int nt, int nc);
-VH_API int vh_nls_batch(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
+VH_API int vh_nls_batch(vh_ctx* ctx, const double* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
                         int* info, void* workspace, size_t workspace_bytes, void* stream);
 
 /* nwin independent fcnNLS_batch problems of the same shape (one sliding window per video stream) solved by ONE launch sequence
  * (grid.y = window): z [nwin][2 nt (nc+1)], x [nwin][3 nt + 6 nc], trace [nwin][max_iter][2], info [nwin][2]; workspace = nwin blocks
  * of workspace_bytes_per_window >= vh_nls_batch_workspace(nt, nc) bytes (a multiple of 256).  Every window takes exactly the steps
  * vh_nls_batch would take on it (its own stop flag included). */
-VH_API int vh_nls_batch_multi(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int nwin, int max_iter,
+VH_API int vh_nls_batch_multi(vh_ctx* ctx, const double* K_host, const double* z, double* x, int nt, int nc, int nwin, int max_iter,
                               double* trace, int* info, void* workspace, size_t workspace_bytes_per_window, void* stream);
 
 /* fcnNLS_batch2(K, P, pw, cw), utils/NLS.py:253-328: the constrained sibling -- tie points, ONE joint rotation applied to the
@@ -157,14 +158,14 @@ VH_API int vh_nls_batch_multi(vh_ctx* ctx, const float* K_host, const double* z,
  * Same z packing, damping (+I), step (0.9) and stop rule (rms(delta) < 1e-7); the reference runs at most 20 iterations.
  *   x [3 nt + 5 + nc] float64 = points | joint rpy (3) | el, az | ranges (nc)   (NLS.py:274), updated in place.
  * trace / info / workspace as vh_nls_batch (the same workspace size serves both). */
-VH_API int vh_nls_batch2(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
+VH_API int vh_nls_batch2(vh_ctx* ctx, const double* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
                          int* info, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One phase of a point-sharded BA iteration (multi-GPU fcnNLS_batch): this rank owns nt of the nt_total
  * tie points, the nc free cameras are replicated.  phase 0: init; 1: local normal equations -> [S | rhs | sums] span inside
  * the workspace (the caller all-reduces span_doubles float64 at span_offset bytes); 2: solve + update (the caller
  * then all-reduces ONLY sum delta^2 = the span's third-from-last double; sum r^2 was final after phase 1); 3: iteration record (trace, info, stop flag).  rank0 != 0 on one rank. */
-VH_API int vh_nls_batch_phase(vh_ctx* ctx, const float* K_host, const double* z, double* x, int nt, int nc, int nt_total, int rank0,
+VH_API int vh_nls_batch_phase(vh_ctx* ctx, const double* K_host, const double* z, double* x, int nt, int nc, int nt_total, int rank0,
                               int phase, int it, double* trace, int* info, void* workspace, size_t workspace_bytes,
                               size_t* span_offset, size_t* span_doubles, void* stream);
 
@@ -199,10 +200,11 @@ typedef struct {
     const double* p_proj;   /* n_pose x 2                                                      */
 } vh_session_view;
 
-/* K_host: 9 floats.  n0 = number of initial tracks, nhist = number of frames of history (P, B, S rows),
+/* K_host: 9 doubles; k_is_float32 != 0: the caller's K array is float32 (vidExample.py:29-33), so fcnMSV1_t builds its rays in
+ * float32 like numpy does.  n0 = number of initial tracks, nhist = number of frames of history (P, B, S rows),
  * msv_frame = frame index at which fcnMSV1_t re-triangulates (vidExample.py:155; <= 0 disables). */
-VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, int nhist, int w, int h, const float* K_host,
-                             const vh_lk_params* coarse_host, const vh_lk_params* fine_host, int msv_frame);
+VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, int nhist, int w, int h, const double* K_host,
+                             int k_is_float32, const vh_lk_params* coarse_host, const vh_lk_params* fine_host, int msv_frame);
 VH_API void vh_session_destroy(vh_session* s);
 /* frame-0 state of stream `slot` (vidExample.py:116-131): p n0 x 2, p3 n0 x 3, vp n0 (device); t0_host = plate pose t */
 VH_API int vh_session_init(vh_session* s, int slot, const uint8_t* frame0, int stride, const float* p, const double* p3,

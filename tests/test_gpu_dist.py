@@ -116,6 +116,11 @@ def test_bench_self_launches_two_ranks_on_one_device():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["streams_per_gpu"] == 2 and out["scaling"] == "weak"
     assert out["tracks_alive_frac"] > 0.9
+    # the record itself says what the process group was: backend, world size, one device entry per rank, exchanges done and seen
+    d = out["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and len(d["devices"]) == 2 and [q["rank"] for q in d["devices"]] == [0, 1]
+    assert d["exchanges"] >= 2 and d["ranks_seen_in_last_gather"] == 2 and d["exchange_host_ms_total"] >= 0
+    assert out["verified"]["bit_exact"] is True and out["verified"]["pose_within_1e5"] is True
     assert abs(out["value"] - 2 * 2 * out["steps"] / (out["ms_per_step"] * out["steps"] / 1e3)) < 1e-6 * out["value"] + 1.0
 
 

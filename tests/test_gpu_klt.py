@@ -245,6 +245,29 @@ def test_pyr_lk_textureless_and_small_images():
     assert np.array_equal(v, ev) and np.array_equal(p2, e2) and np.array_equal(err.ravel(), eerr)
 
 
+def test_pyr_lk_images_much_smaller_than_the_window():
+    """Level 0 of an image far smaller than the window (OpenCV's level truncation never drops level 0): window columns reach |i| > 4 (n - 1),
+    beyond the two-fold branch-free REFLECT_101 -- the looped reflection must take over (an out-of-bounds read otherwise).  Every kernel route."""
+    from velocity_amd import _lib as L
+    from velocity_amd.KLT import cv2calcOpticalFlowPyrLK
+
+    rng = np.random.default_rng(11)
+    for (h, w), win in (((4, 4), 51), ((5, 9), 51), ((12, 20), 51), ((6, 5), 15), ((4, 30), 15), ((23, 23), 51)):
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        b = np.roll(a, 1, axis=1)
+        pts = np.concatenate([rng.uniform([-2, -2], [w + 2, h + 2], (24, 2)), [[w / 2.0, h / 2.0]]]).astype(np.float32)
+        exp = KO.lk_fb(a, b, pts, fbt=1.0, win=win, max_level=2, max_count=10, eps=0.03)
+        for mode in ((0, 1, 2, 3, 4) if win == 15 else (0, 1, 2, 5, 6, 7)):
+            L.load().vh_debug_force_generic_lk(mode)
+            try:
+                got = cv2calcOpticalFlowPyrLK(a, b, pts, None, fbt=1.0, winSize=(win, win), maxLevel=2, criteria=(3, 10, 0.03))
+            finally:
+                L.load().vh_debug_force_generic_lk(0)
+            assert np.array_equal(got[1], exp[1]), ((h, w), win, mode)
+            assert np.array_equal(got[0], exp[0]), ((h, w), win, mode)
+            assert np.array_equal(got[2].ravel(), exp[2]), ((h, w), win, mode)
+
+
 @pytest.mark.parametrize("path", [1, 2])
 def test_ransac_affine_bit_exact(path):
     """path 1: compaction / scoring / selection as three launches (hypotheses spread over the chip); path 2: the fused one-workgroup kernel

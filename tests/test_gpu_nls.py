@@ -81,6 +81,68 @@ def test_pose_random_vs_oracle():
         close(proj, eproj, 1e-8)
 
 
+def test_float64_intrinsics_are_not_rounded_to_float32():
+    """estimateWorldCameraPose does K.astype(float) (utils/NLS.py:22-24) and fcnNLS_batch K = K.astype(float) (:196): a float64 K keeps all its
+    digits.  K here differs from its float32 rounding by ~1e-4 px in the focal length: the projections must follow the float64 values."""
+    from velocity_amd.NLS import estimateWorldCameraPose, fcnNLS_batch
+    from velocity_amd import synth
+
+    K64 = np.array([[3000.0 + 1.1e-4, 0, 0], [0, 3000.0 - 1.1e-4, 0], [960.5 + 2.5e-5, 540.5 - 2.5e-5, 1]])
+    K32 = K64.astype(np.float32)
+    assert np.abs(K32.astype(float) - K64).max() > 2e-5
+    rng = np.random.default_rng(8)
+    n = 500
+    pw = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1, 1, n), rng.uniform(-0.1, 0.1, n)], 1)
+    tt = np.array([0.3, -0.2, 4.0])
+    p = (O.project_cam(pw + tt, K64) + rng.normal(0, 0.2, (n, 2))).astype(np.float32)
+    for findR in (False, True):
+        t, R, res, proj = estimateWorldCameraPose(K64, p, pw, findR=findR)
+        et, eR, eres, eproj = O.estimate_world_camera_pose(K64, p, pw, findR=findR)
+        close(t, et, 2e-6)
+        mine = O.world_to_image(K64, np.asarray(R, float), t, pw)    # the float64 formula on the device's own (float32) pose
+        rounded = O.world_to_image(K32, np.asarray(R, float), t, pw)  # what a float32 K in the ABI would have produced
+        assert np.abs(proj - mine).max() < 1e-8
+        assert np.abs(rounded.astype(float) - mine).max() > 1e-5
+        close(res, eres, 1e-7)
+    P, pw0, cw0 = synth.ba_scene(120, 5, seed=12, K=K64)
+    cw, pwo, x, tr = fcnNLS_batch(K64, P.copy(), pw0, cw0, return_info=True)
+    ecw, epw, ex, etr = O.nls_batch_schur(K64, P.copy(), pw0, cw0, return_info=True)
+    close(tr[:, 0], etr[:, 0], 1e-8)
+    close(x, ex, 1e-6, 1e-8)
+
+
+def test_triangulation_with_more_than_16_frames(golden):
+    """fcn2vintercept / fcnMSV1_t over 20 frames (190 ray pairs): the reference has no frame limit (utils/MSV.py:98-142, 8-49)."""
+    from velocity_amd.MSV import fcn2vintercept, fcnMSV1_t
+
+    rng = np.random.default_rng(21)
+    nf, nv = 20, 300
+    X = np.stack([rng.uniform(-3, 3, nv), rng.uniform(-1.5, 1.5, nv), rng.uniform(8, 14, nv)], 1)
+    A = np.stack([[0.05 * k, 0.01 * k, 0.3 * k] for k in range(nf)])
+    U = np.ascontiguousarray(np.transpose(np.stack([(X - A[j]) / np.linalg.norm(X - A[j], axis=1, keepdims=True) for j in range(nf)]), (2, 0, 1)))  # [3, nf, nv]
+    out = fcn2vintercept(A, U)
+    close(out, O.two_view_intercept(A, U), 1e-10)
+    close(out, X, 0, 1e-7)  # exact rays meet in the points
+    # fcnMSV1_t at frame 19 of a synthetic history: camera k sits at -k * step (scene-relative translation k * step), float32 records
+    K32 = golden["K32"]
+    N0, nh, ii = 260, 24, 19
+    Xw = np.stack([rng.uniform(-1, 1, N0), rng.uniform(-0.5, 0.5, N0), rng.uniform(3.2, 4.0, N0)], 1)
+    step = np.array([0.02, 0.004, 0.06])
+    P = np.full((5, N0, nh), np.nan, np.float32)
+    B = np.zeros((nh, 14), np.float32)
+    for k in range(ii + 1):
+        q = O.project_cam(Xw + k * step, K32.astype(float)) + rng.normal(0, 0.05, (N0, 2))
+        P[0:2, :, k] = q.T.astype(np.float32)
+        P[4, :, k] = k
+        B[k, 0:3] = (k * step + rng.normal(0, 1e-3, 3)).astype(np.float32)
+    vg = np.ones(N0, bool)
+    vg[::9] = False
+    x, b0 = fcnMSV1_t(K32, P, B, vg, ii)
+    ex, eb0 = O.msv1_t(K32, P, B, vg, ii)
+    close(x, ex, 5e-6)
+    close(b0, eb0, 1e-5, 1e-6)
+
+
 def test_triangulation_and_msv(golden):
     from velocity_amd.MSV import fcn2vintercept, fcnMSV1_t, fcnNvintercept
 
@@ -171,6 +233,31 @@ def test_nls_batch_many_cameras_vs_oracle(golden, nt, nf):
     close(tr[:, 0], etr[:, 0], 1e-6)       # rms residual per iteration
     close(cw, ecw, 1e-4, 1e-6)
     close(pw, epw, 1e-4, 1e-6)
+
+
+@pytest.mark.parametrize("nt,nf", [(260, 2), (517, 3), (200, 3)])
+def test_nls_batch_two_and_three_frame_windows(golden, nt, nf, capsys):
+    """2- and 3-frame windows: a k_ba_jac block owns 256 / nf = 128 / 85 whole points, more than the 64 point quads of its preparation tail
+    (tp, L of (U+I)^-1) -- every point must still get its record (poisoned workspace: a missed one is NaN).  Matrix cores vs VALU vs oracle."""
+    from velocity_amd import _lib as L
+    from velocity_amd import synth
+    from velocity_amd.NLS import fcnNLS_batch
+
+    P, pw0, cw0 = synth.ba_scene(nt, nf, seed=40 + nf)
+    ecw, epw, ex, etr = O.nls_batch_schur(golden["K32"], P.copy(), pw0, cw0, return_info=True)
+    outs = []
+    for force_valu in (0, 1):
+        L.load().vh_debug_ba_force_valu(force_valu)
+        try:
+            cw, pw, x, tr = fcnNLS_batch(golden["K32"], P.copy(), pw0, cw0, return_info=True)
+        finally:
+            L.load().vh_debug_ba_force_valu(0)
+        assert np.all(np.isfinite(x)) and len(tr) == len(etr)
+        close(tr[:, 0], etr[:, 0], 1e-7)
+        close(x, ex, 1e-6, 1e-8)
+        outs.append(x)
+    close(outs[0], outs[1], 1e-7, 1e-9)
+    capsys.readouterr()
 
 
 @pytest.mark.parametrize("nt,nf", [(20, 5), (40, 7)])

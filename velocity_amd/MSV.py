@@ -32,7 +32,7 @@ def fcnMSV1_t(K, P, B, vg, ii):
     """LM over the last camera translation with re-triangulation inside (utils/MSV.py:8-49) -> (x f32[3], b0 f64[ng,3])."""
     torch = L.torch_cuda()
     f32_rays = int(np.asarray(K).dtype == np.float32 and np.asarray(P).dtype == np.float32)
-    K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+    K64 = L.host_K(K)
     Pd = L.to_dev(np.asarray(P, np.float32), torch.float32)
     Bd = L.to_dev(np.asarray(B, np.float32), torch.float32)
     _, N0, nhist = Pd.shape
@@ -45,7 +45,7 @@ def fcnMSV1_t(K, P, B, vg, ii):
     b0 = torch.zeros((ng, 3), dtype=torch.float64, device="cuda")
     info = torch.zeros(2, dtype=torch.int32, device="cuda")
     ws = L.workspace()
-    L.check(ws.lib.vh_msv1_t(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(Pd), L.dptr(Bd), L.dptr(idd), ng, N0, nhist, int(ii), f32_rays,
+    L.check(ws.lib.vh_msv1_t(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(Pd), L.dptr(Bd), L.dptr(idd), ng, N0, nhist, int(ii), f32_rays,
                              L.dptr(U), L.dptr(x), L.dptr(b0), L.dptr(info), L.stream_ptr()), "vh_msv1_t")
     info = info.cpu().numpy()
     if info[0] >= 1000:  # MSV.py:43 warns whenever the last allowed iteration ran

@@ -19,7 +19,7 @@ def _scratch(torch, shape):
 
 def _pose(K, p, pw, x0, R, findR, want_proj=True):
     torch = L.torch_cuda()
-    K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+    K64 = L.host_K(K)
     pd = L.to_dev(np.asarray(p, np.float32) if not hasattr(p, "is_cuda") else p, torch.float32).reshape(-1, 2)
     pwd = L.to_dev(np.asarray(pw, np.float64) if not hasattr(pw, "is_cuda") else pw, torch.float64).reshape(-1, 3)
     n = pd.shape[0]
@@ -33,7 +33,7 @@ def _pose(K, p, pw, x0, R, findR, want_proj=True):
     proj = torch.zeros((n, 2), dtype=torch.float64, device="cuda") if want_proj else None
     info = torch.zeros(2, dtype=torch.int32, device="cuda")
     ws = L.workspace()
-    L.check(ws.lib.vh_pose(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(pd), L.dptr(pwd), n, x0.ctypes.data_as(L.f64p),
+    L.check(ws.lib.vh_pose(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(pd), L.dptr(pwd), n, x0.ctypes.data_as(L.f64p),
                            R.ctypes.data_as(L.f64p), int(bool(findR)), L.dptr(t), L.dptr(Rout), L.dptr(res), L.dptr(proj), L.dptr(info),
                            L.stream_ptr()), "vh_pose")
     info = info.cpu().numpy()
@@ -90,7 +90,7 @@ def fcnNLS_batch(K, P, pw, cw, max_iter=10, return_info=False):
     nc = nf - 1
     z = np.concatenate([P[0].T.reshape(-1), P[1].T.reshape(-1)]).astype(np.float64)  # NLS.py:198-199
     x0 = np.concatenate((pw, cw[1:], np.zeros((nc, 3)))).reshape(-1)  # NLS.py:202-203
-    K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+    K64 = L.host_K(K)
     zd = L.to_dev(z, torch.float64)
     xd = L.to_dev(x0, torch.float64).clone()
     trace = torch.zeros((max_iter, 2), dtype=torch.float64, device="cuda")
@@ -98,7 +98,7 @@ def fcnNLS_batch(K, P, pw, cw, max_iter=10, return_info=False):
     ws = L.workspace()
     nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
     scratch = _scratch(torch, nbytes)
-    L.check(ws.lib.vh_nls_batch(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, int(max_iter), L.dptr(trace), L.dptr(info),
+    L.check(ws.lib.vh_nls_batch(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, int(max_iter), L.dptr(trace), L.dptr(info),
                                 L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch")
     info = info.cpu().numpy()
     x = xd.cpu().numpy()
@@ -135,7 +135,7 @@ def fcnNLS_batch_windows(K, Ps, pws, cws, max_iter=10, return_info=False):
         xs.append(np.concatenate((pw, cw[1:], np.zeros((nf - 1, 3)))).reshape(-1))  # NLS.py:202-203
     nt, nf = shape
     nc, nw = nf - 1, len(zs)
-    K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+    K64 = L.host_K(K)
     zd = L.to_dev(np.stack(zs), torch.float64)
     xd = L.to_dev(np.stack(xs), torch.float64).clone()
     trace = torch.zeros((nw, max_iter, 2), dtype=torch.float64, device="cuda")
@@ -143,7 +143,7 @@ def fcnNLS_batch_windows(K, Ps, pws, cws, max_iter=10, return_info=False):
     ws = L.workspace()
     nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
     scratch = _scratch(torch, (nw, nbytes))
-    L.check(ws.lib.vh_nls_batch_multi(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, nw, int(max_iter), L.dptr(trace),
+    L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, nw, int(max_iter), L.dptr(trace),
                                       L.dptr(info), L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
     info, x, tr = info.cpu().numpy(), xd.cpu().numpy(), trace.cpu().numpy()
     out = []
@@ -184,7 +184,7 @@ def fcnNLS_batch2(K, P, pw, cw, max_iter=20, return_info=False):
     el, az = np.arcsin(-d[2] / r), np.arctan2(d[1], d[0])
     ranges = np.arange(1, nc + 1) * r
     x0 = np.concatenate((pw.ravel(), np.zeros(3), [el, az], ranges))  # NLS.py:274
-    K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+    K64 = L.host_K(K)
     zd = L.to_dev(z, torch.float64)
     xd = L.to_dev(x0, torch.float64).clone()
     trace = torch.zeros((max_iter, 2), dtype=torch.float64, device="cuda")
@@ -192,7 +192,7 @@ def fcnNLS_batch2(K, P, pw, cw, max_iter=20, return_info=False):
     ws = L.workspace()
     nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
     scratch = _scratch(torch, nbytes)
-    L.check(ws.lib.vh_nls_batch2(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, int(max_iter), L.dptr(trace), L.dptr(info),
+    L.check(ws.lib.vh_nls_batch2(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, int(max_iter), L.dptr(trace), L.dptr(info),
                                  L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch2")
     info = info.cpu().numpy()
     x = xd.cpu().numpy()

@@ -55,7 +55,7 @@ _SIGS = {
     "vh_klt_stage_ptrs": (C.c_int, [vp, C.c_int, C.POINTER(KltStages)]),
     "vh_klt_regional": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, f32p, C.POINTER(LKParams), C.c_float, C.c_int,
                                   vp, vp, vp, vp]),
-    "vh_pose": (C.c_int, [vp, f32p, vp, vp, C.c_int, f64p, f64p, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "vh_pose": (C.c_int, [vp, f64p, vp, vp, C.c_int, f64p, f64p, C.c_int, vp, vp, vp, vp, vp, vp]),
     "vh_world2image": (C.c_int, [vp, f64p, vp, C.c_int, vp, vp]),
     "vh_image2world": (C.c_int, [vp, f64p, vp, C.c_int, vp, vp]),
     "vh_pixel2uvec": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, vp, C.c_int, vp, vp]),
@@ -63,14 +63,14 @@ _SIGS = {
     "vh_two_view_intercept": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "vh_n_view_intercept": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "vh_nls_batch_workspace": (C.c_size_t, [C.c_int, C.c_int]),
-    "vh_nls_batch": (C.c_int, [vp, f32p, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
-    "vh_nls_batch_multi": (C.c_int, [vp, f32p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
-    "vh_nls_batch2": (C.c_int, [vp, f32p, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
+    "vh_nls_batch": (C.c_int, [vp, f64p, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
+    "vh_nls_batch_multi": (C.c_int, [vp, f64p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
+    "vh_nls_batch2": (C.c_int, [vp, f64p, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     "vh_good_features": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, vp, vp, vp]),
     "vh_corner_subpix": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_double, vp]),
-    "vh_nls_batch_phase": (C.c_int, [vp, f32p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t,
+    "vh_nls_batch_phase": (C.c_int, [vp, f64p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t,
                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), vp]),
-    "vh_session_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(LKParams), C.POINTER(LKParams), C.c_int]),
+    "vh_session_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, f64p, C.c_int, C.POINTER(LKParams), C.POINTER(LKParams), C.c_int]),
     "vh_session_destroy": (None, [vp]),
     "vh_session_init": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, f32p, C.c_float, C.c_float, C.c_float, vp]),
     "vh_session_step": (C.c_int, [vp, vp, C.c_float, C.c_float, vp]),
@@ -82,7 +82,7 @@ _SIGS = {
     "vh_debug_ba_force_valu": (None, [C.c_int]),
     "vh_profile_begin": (C.c_int, [vp, C.c_int]),
     "vh_profile_end": (C.c_int, [vp, f64p, i32p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
-    "vh_msv1_t": (C.c_int, [vp, f32p, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "vh_msv1_t": (C.c_int, [vp, f64p, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
 }
 
 
@@ -207,6 +207,11 @@ def workspace(w=0, h=0, n=0):
                 torch.cuda.current_stream().synchronize()  # kernels of earlier calls may still read the old arena
             _default_ws[key] = Workspace(1, mw, mh, mp)
         return _default_ws[key]
+
+
+def host_K(K):
+    """The intrinsics as the C ABI takes them: 9 contiguous float64 (K.astype(float), utils/NLS.py:22-24,196 -- a float32 K widens exactly)."""
+    return np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
 
 
 def lk_params(d):

@@ -26,7 +26,7 @@ int vh_fail(int code, const char* msg)
 }
 #define VH_LAUNCH_CHECK() VH_CHECK(hipGetLastError())
 
-extern "C" VH_API int vh_version(void) { return 102; }
+extern "C" VH_API int vh_version(void) { return 103; }
 void vh_lk_force_generic(int on);
 extern "C" VH_API void vh_debug_force_generic_lk(int on) { vh_lk_force_generic(on); }
 void vh_ransac_force_path(int mode);
@@ -757,7 +757,7 @@ struct PoseSlot {  // lives in the workspace arena right behind d_small (one per
     PoseJob job;
 };
 
-extern "C" VH_API int vh_pose(vh_ctx* c, const float* K, const float* p, const double* pw, int n, const double* x0, const double* R,
+extern "C" VH_API int vh_pose(vh_ctx* c, const double* K, const float* p, const double* pw, int n, const double* x0, const double* R,
                               int findR, float* t_out, double* R_out, double* res_out, double* p_proj, int* info, void* stream)
 {
     if (!c || !K || !x0 || !R || n < 0) return vh_fail(-1, "vh_pose: bad arguments");
@@ -817,7 +817,7 @@ extern "C" VH_API int vh_pixel2uvec_f32(vh_ctx* c, float cx, float cy, float f, 
 
 extern "C" VH_API int vh_two_view_intercept(vh_ctx* c, const double* A, const double* U, int nf, int nv, double* out, void* stream)
 {
-    if (!c || nf < 2 || nf > 16) return vh_fail(-1, "vh_two_view_intercept: nf must be in [2,16]");
+    if (!c || nf < 2) return vh_fail(-1, "vh_two_view_intercept: nf must be >= 2");
     vh_launch_two_view(A, U, nf, nv, out, (hipStream_t)stream);
     VH_LAUNCH_CHECK();
     return 0;
@@ -831,10 +831,10 @@ extern "C" VH_API int vh_n_view_intercept(vh_ctx* c, const double* A, const doub
     return 0;
 }
 
-extern "C" VH_API int vh_msv1_t(vh_ctx* c, const float* K, const float* P, const float* B, const int* ids, int ng, int N0, int nhist, int ii,
+extern "C" VH_API int vh_msv1_t(vh_ctx* c, const double* K, const float* P, const float* B, const int* ids, int ng, int N0, int nhist, int ii,
                                 int f32_rays, double* U_scratch, float* x_out, double* b0, int* info, void* stream)
 {
-    if (!c || !K || ii < 1 || ii + 1 > 16 || ii + 1 > nhist) return vh_fail(-1, "vh_msv1_t: need 2 <= ii+1 <= min(16, nhist)");
+    if (!c || !K || ii < 1 || ii + 1 > nhist || ii + 1 > 2048) return vh_fail(-1, "vh_msv1_t: need 2 <= ii+1 <= min(nhist, 2048)");
     MsvJob J;
     memset(&J, 0, sizeof(J));
     for (int k = 0; k < 9; k++) J.K[k] = (double)K[k];
@@ -855,7 +855,7 @@ extern "C" VH_API void vh_debug_ba_force_valu(int on) { g_ba_force_valu = on; }
 
 extern "C" VH_API size_t vh_nls_batch_workspace(int nt, int nc) { return vh_ba_workspace_bytes(nt, nc, ba_parts(nt)); }
 
-extern "C" VH_API int vh_nls_batch(vh_ctx* c, const float* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
+extern "C" VH_API int vh_nls_batch(vh_ctx* c, const double* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
                                    int* info, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!c || !K_host || nt < 1 || nc < 1 || max_iter < 1) return vh_fail(-1, "vh_nls_batch: bad arguments");
@@ -874,7 +874,7 @@ extern "C" VH_API int vh_nls_batch(vh_ctx* c, const float* K_host, const double*
 
 // nwin independent windows of the same shape through ONE launch sequence (grid.y = window): a sliding-window tracker has one window per
 // video stream, and a single C5 window leaves the chip idle (its solve is one workgroup, its MFMA contraction is latency bound)
-extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const float* K_host, const double* z, double* x, int nt, int nc, int nwin, int max_iter,
+extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const double* K_host, const double* z, double* x, int nt, int nc, int nwin, int max_iter,
                                          double* trace, int* info, void* workspace, size_t workspace_bytes_per_window, void* stream)
 {
     if (!c || !K_host || nt < 1 || nc < 1 || max_iter < 1 || nwin < 1 || nwin > 65535) return vh_fail(-1, "vh_nls_batch_multi: bad arguments");
@@ -897,7 +897,7 @@ extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const float* K_host, const d
 }
 
 // fcnNLS_batch2 (NLS.py:253-328): tie points + ONE joint rotation + a straight-line camera trajectory (el, az, one range per camera)
-extern "C" VH_API int vh_nls_batch2(vh_ctx* c, const float* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
+extern "C" VH_API int vh_nls_batch2(vh_ctx* c, const double* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
                                     int* info, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!c || !K_host || nt < 1 || nc < 1 || max_iter < 1) return vh_fail(-1, "vh_nls_batch2: bad arguments");
@@ -919,7 +919,7 @@ extern "C" VH_API int vh_nls_batch2(vh_ctx* c, const float* K_host, const double
 // all-reduces acc again); 3: iteration record.  rank0 != 0 on exactly one rank (it adds the +I damping and counts the
 // camera part of rms(delta)).  nt_total: points over all ranks.  span_offset / span_doubles (host, may be NULL) return
 // where the all-reduce span lives inside the workspace.
-extern "C" VH_API int vh_nls_batch_phase(vh_ctx* c, const float* K_host, const double* z, double* x, int nt, int nc, int nt_total, int rank0,
+extern "C" VH_API int vh_nls_batch_phase(vh_ctx* c, const double* K_host, const double* z, double* x, int nt, int nc, int nt_total, int rank0,
                                          int phase, int it, double* trace, int* info, void* workspace, size_t workspace_bytes,
                                          size_t* span_offset, size_t* span_doubles, void* stream)
 {

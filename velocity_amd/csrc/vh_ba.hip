@@ -234,8 +234,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
     }
     if (!PREP) return;
     // per point (4 lanes each, measurements c = q, q+4, ...): U_i = I + sum Jp^T Jp, g_i = sum Jp^T r  ->  tp_i = U^-1 g, U^-1 = L L^T
-    const int pl = tid >> 2, q = tid & 3;
-    if (pl >= npts) return;  // whole quads leave together
+    // a block owns ppb = 256 / (nc+1) points but only 64 quads: 2- and 3-frame windows (ppb = 128, 85) take two rounds
+    const int q = tid & 3;
+    for (int pl = tid >> 2; pl < npts; pl += BA_THREADS / 4) {  // whole quads stay together
     double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0, u4 = 0.0, u5 = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
     for (int c = q; c < nf; c += 4) {
         const int t = pl * nf + c;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
         acc[k] += __shfl_xor(acc[k], 1);
         acc[k] += __shfl_xor(acc[k], 2);
     }
-    if (q != 0) return;
+    if (q != 0) continue;
     const int i = i0 + pl;
     const double U[9] = {acc[0] + 1.0, acc[1], acc[2], acc[1], acc[3] + 1.0, acc[4], acc[2], acc[4], acc[5] + 1.0};  // +I damping (NLS.py:220)
     double Ui[9];
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
     const double l22 = sqrt(Ui[8] - l20 * l20 - l21 * l21);
     double* Lo = J.Lc + 6 * (size_t)i;
     Lo[0] = l00; Lo[1] = l10; Lo[2] = l11; Lo[3] = l20; Lo[4] = l21; Lo[5] = l22;
+    }
 }
 
 __device__ void inv3_sym(const double* U, double* Ui)

@@ -72,14 +72,17 @@ __device__ __forceinline__ int vh_reflect101(int i, int n)
     while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
     return i;
 }
-// REFLECT_101 for |i| <= 4 (n - 1), branch free: the reflection has period P = 2 (n - 1) and on [0, P] it is min(a, P - a); one round of
-// r = min(|i|, P - |i|) lands in range for |i| <= P, a second one for |i| <= 2 P.  The LK windows stay within a level's width plus one window
-// (and a level is wider than the window), so their columns / rows satisfy the bound.  The looped form above costs a divergent loop PER BYTE in a
-// border load, i.e. one memory round trip per byte instead of one per row.
+// REFLECT_101, branch free for |i| <= 4 (n - 1): the reflection has period P = 2 (n - 1) and on [0, P] it is min(a, P - a); one round of
+// r = min(|i|, P - |i|) lands in range for |i| <= P, a second one for |i| <= 2 P.  The LK windows stay within a level's width plus one and a
+// half windows, so on every level wider than ~ win / 2 their columns / rows satisfy the bound and the (never taken, wave-uniform) branch below
+// costs two instructions.  Level 0 of an image or ROI SMALLER than that (the API only asks for 4 x 4; OpenCV's level-truncation rule does not
+// apply to level 0) takes the looped form.  Using the looped form everywhere cost a divergent loop PER BYTE in a border load, i.e. one memory
+// round trip per byte instead of one per row.
 __device__ __forceinline__ int vh_reflect101_near(int i, int n)
 {
     const int P = 2 * (n - 1);
     int a = max(i, -i);
+    if (__builtin_expect(a > 2 * P, 0)) return vh_reflect101(i, n);
     int r = min(a, P - a);
     a = max(r, -r);
     r = min(a, P - a);

@@ -424,11 +424,14 @@ void vh_launch_pyr_down_ws(const void* pb_tab, size_t ws_stride, int batch, int 
         dim3 grd((w + 255) / 256, (h + 7) / 8, batch * 2);
         hipLaunchKernelGGL(k_pyr_down<2>, grd, blk, 0, s, pb_tab, ws_stride, lvl);
     }
-    // border ring of the new level when it is a small one (decided per image on the device; the launch covers the largest small level: a level of
-    // at most VH_LV_PAD_MAX_PIXELS pixels inside w x h has no more ring dwords than this)
+    // border ring of the new level when it is a small one (decided per image on the device).  The launch covers the worst small level inside w x h:
+    // the ring dword count grows linearly with each dimension, so over {w' <= w, h' <= h, w' h' <= VH_LV_PAD_MAX_PIXELS} it peaks in a corner --
+    // the widest level with the rows that still fit (e.g. 8192 x 8) or the tallest one
     {
-        const int ws_ = std::min(w, VH_LV_PAD_MAX_PIXELS / 16), hs_ = std::min(h, VH_LV_PAD_MAX_PIXELS / 16);
-        const int ring = ((ws_ + 2 * VH_LV_PAD + 3) / 4) * 2 * VH_LV_PAD + hs_ * (VH_LV_PAD / 4 + (VH_LV_PAD + 6) / 4);
+        auto ring_dwords = [](int ww, int hh) { return ((ww + 2 * VH_LV_PAD + 3) / 4) * 2 * VH_LV_PAD + hh * (VH_LV_PAD / 4 + (VH_LV_PAD + 6) / 4); };
+        const int wa = std::min(w, VH_LV_PAD_MAX_PIXELS), ha = std::min(h, std::max(1, VH_LV_PAD_MAX_PIXELS / wa));
+        const int hb = std::min(h, VH_LV_PAD_MAX_PIXELS), wb = std::min(w, std::max(1, VH_LV_PAD_MAX_PIXELS / hb));
+        const int ring = std::max(ring_dwords(wa, ha), ring_dwords(wb, hb));
         hipLaunchKernelGGL(k_pyr_pad, dim3((ring + 255) / 256, 1, batch * 2), dim3(256), 0, s, pb_tab, ws_stride, lvl);
     }
 }

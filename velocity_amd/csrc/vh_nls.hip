@@ -139,7 +139,8 @@ __global__ __launch_bounds__(MSV_THREADS) void k_msv1(MsvJob J)
     const int ng = J.ng_ptr ? *J.ng_ptr : J.ng;
     const int nf = J.nf;
     __shared__ double sh[9 * NLS_WAVES];
-    __shared__ double s_x[3], s_A[3 * 16];
+    __shared__ double s_x[3];
+    extern __shared__ double s_A[];  // [nf][3] ray origins; row nf-1 is rewritten every iteration (any number of frames: 24 B of LDS each)
     __shared__ int s_stop, s_iters;
     double K[9];
     for (int k = 0; k < 9; k++) K[k] = J.K[k];
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(MSV_THREADS) void k_msv1(MsvJob J)
             for (int c = 0; c < 3; c++) s_A[3 * j + c] = (double)(float)(J.B[c] - J.B[14 * j + c]);
         const double e[3] = {0, 0, 1};
         for (int c = 0; c < 3; c++) s_x[c] = e[c] - s_A[3 * (nf - 2) + c];
+        for (int c = 0; c < 3; c++) s_A[3 * (nf - 1) + c] = -s_x[c];  // vstack(u0[:-1], -x)  (MSV.py:29); u0's own last row is never used
         s_stop = 0;
         s_iters = 0;
     }
@@ -171,10 +173,7 @@ __global__ __launch_bounds__(MSV_THREADS) void k_msv1(MsvJob J)
     int converged = 0;
     for (int it = 0; it < J.max_iter && ng > 0; it++) {
         const double x0 = s_x[0], x1 = s_x[1], x2 = s_x[2];
-        double A[3 * 16];
-        for (int j = 0; j < nf - 1; j++)
-            for (int c = 0; c < 3; c++) A[3 * j + c] = s_A[3 * j + c];
-        A[3 * (nf - 1)] = -x0; A[3 * (nf - 1) + 1] = -x1; A[3 * (nf - 1) + 2] = -x2;  // vstack(u0[:-1], -x)  (MSV.py:29)
+        const double* A = s_A;  // wave-uniform LDS reads (broadcast)
         double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int g = tid; g < ng; g += NLS_THREADS) {
             const int id = J.ids ? J.ids[g] : g;
@@ -193,6 +192,7 @@ __global__ __launch_bounds__(MSV_THREADS) void k_msv1(MsvJob J)
             double x[3] = {x0, x1, x2};
             const double r = lm_update<3>(acc, 1.0, x);  // no step ramp (MSV.py:36)
             s_x[0] = x[0]; s_x[1] = x[1]; s_x[2] = x[2];
+            s_A[3 * (nf - 1)] = -x[0]; s_A[3 * (nf - 1) + 1] = -x[1]; s_A[3 * (nf - 1) + 2] = -x[2];
             s_iters = it + 1;
             if (r < 1e-8) s_stop = 1;
         }
@@ -241,4 +241,7 @@ void vh_launch_n_view(const double* A, const double* U, int nf, int nv, double* 
 {
     if (nv > 0) hipLaunchKernelGGL(k_n_view, dim3((nv + 255) / 256), dim3(256), 0, s, A, U, nf, nv, out);
 }
-void vh_launch_msv1(const MsvJob& job, hipStream_t s) { hipLaunchKernelGGL(k_msv1, dim3(1), dim3(MSV_THREADS), 0, s, job); }
+void vh_launch_msv1(const MsvJob& job, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_msv1, dim3(1), dim3(MSV_THREADS), sizeof(double) * 3 * (size_t)job.nf, s, job);
+}

@@ -4,6 +4,7 @@
 // wavefront each) and a single thread then replays OpenCV's sequential "best so far + adaptive iteration count" rule
 // over the scores, which gives exactly the result of the sequential algorithm.  The refit sums are exact int64
 // fixed-point sums, so the result does not depend on reduction order.
+#include <atomic>
 #include "vh_kernels.hpp"
 
 #define RANSAC_THRESH2 9.0f
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void k_ransac_select(const void* tab, size_t s
 // list -> sample -> pairs -> scores -> ...), about 1 us each, for a few microseconds of arithmetic.  Here the compacted (from, to) pairs and
 // the scores live in LDS, so after the first read of the points nothing waits on global memory.  Same arithmetic, same integers: bit-identical
 // to the three-kernel path (tests/test_gpu_klt.py runs both).  512 threads: a 1024-thread version is capped at 128 VGPRs and spills 516 B / lane.
-#define RANSAC_FUSED_MAX 3072  // pairs held in LDS (48 KB)
+#define RANSAC_FUSED_MAX 3072  // pairs held in LDS: 3072 x (16 + 4) B + 2000 x 4 B of counts = 69 440 B dynamic (+ ~100 B static)
 __device__ bool ransac_hypothesis_lds(const float4* pairs, int m, uint32_t hyp, double* M)
 {
     int id[3];
@@ -538,13 +539,21 @@ void vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max
     // launches at every stream count, 1 .. 256: 4.53 -> 4.48 ms per step at 128 streams); more pairs: hypotheses spread over the chip
     if (max_n <= RANSAC_FUSED_MAX && (g_ransac_force == 2 || g_ransac_force == 0)) {
         const size_t lds = (size_t)RANSAC_FUSED_MAX * (16 + 4) + (size_t)VH_RANSAC_ITERS * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ransac_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
+        // 69 KB of dynamic LDS (> the 64 KB default limit): the attribute is per device; 0 = not tried, 1 = granted, -1 = refused (three-kernel path)
+        static std::atomic<signed char> attr_state[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev = dev < 0 || dev >= 64 ? 0 : dev;
+        signed char st = attr_state[dev].load(std::memory_order_acquire);
+        if (st == 0) {
+            st = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ransac_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
+            if (st < 0) (void)hipGetLastError();  // refused: forget the error, the three launches below serve every size
+            attr_state[dev].store(st, std::memory_order_release);
         }
-        hipLaunchKernelGGL(k_ransac_fused, dim3(batch), dim3(512), lds, s, job_tab, tab_stride);
-        return;
+        if (st > 0) {
+            hipLaunchKernelGGL(k_ransac_fused, dim3(batch), dim3(512), lds, s, job_tab, tab_stride);
+            return;
+        }
     }
     hipLaunchKernelGGL(k_ransac_compact, dim3(batch), dim3(1024), 0, s, job_tab, tab_stride);
     hipLaunchKernelGGL(k_ransac_score, dim3((VH_RANSAC_ITERS + 3) / 4, batch), dim3(256), 0, s, job_tab, tab_stride);

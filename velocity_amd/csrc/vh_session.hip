@@ -12,7 +12,7 @@
 
 struct vh_session {
     vh_ctx* ctx;
-    int batch, N0, nhist, w, h, msv_frame;
+    int batch, N0, nhist, w, h, msv_frame, k_is_f32;
     vh_lk_params coarse, fine;
     char* arena;
     SessStream* d_ss;
@@ -219,14 +219,14 @@ __global__ __launch_bounds__(256) void k_sess_init(SessStream* ss, const float* 
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, int nhist, int w, int h, const float* K_host,
-                                        const vh_lk_params* coarse, const vh_lk_params* fine, int msv_frame)
+extern "C" VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, int nhist, int w, int h, const double* K_host,
+                                        int k_is_float32, const vh_lk_params* coarse, const vh_lk_params* fine, int msv_frame)
 {
     if (!out || !ctx || !K_host || !coarse || !fine || n0 < 1 || nhist < 2) return vh_fail(-1, "vh_session_create: bad arguments");
     if (n0 > ctx->max_pts || w > ctx->max_w || h > ctx->max_h) return vh_fail(-1, "vh_session_create: exceeds the workspace");
     vh_session* s = new (std::nothrow) vh_session();
     if (!s) return vh_fail(-1, "out of host memory");
-    s->ctx = ctx; s->batch = ctx->batch; s->N0 = n0; s->nhist = nhist; s->w = w; s->h = h; s->msv_frame = msv_frame;
+    s->ctx = ctx; s->batch = ctx->batch; s->N0 = n0; s->nhist = nhist; s->w = w; s->h = h; s->msv_frame = msv_frame; s->k_is_f32 = k_is_float32 ? 1 : 0;
     s->coarse = *coarse; s->fine = *fine;
     const int dw = (int)lrint(w * 0.25), dh = (int)lrint(h * 0.25);
     s->h_ss = new SessStream[s->batch];
@@ -253,14 +253,14 @@ extern "C" VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, i
             S.p_all = (float*)(base + carve(sizeof(float) * 2 * n0)); S.v = (uint8_t*)(base + carve(n0));
             S.sel_p = (int*)(base + carve(sizeof(int) * n0)); S.sel_pw = (int*)(base + carve(sizeof(int) * n0));
             S.p_proj = (double*)(base + carve(sizeof(double) * 2 * n0));
-            S.msv_U = (double*)(base + carve(sizeof(double) * 3 * 16 * n0)); S.msv_b0 = (double*)(base + carve(sizeof(double) * 3 * n0));
+            S.msv_U = (double*)(base + carve(sizeof(double) * 3 * (size_t)(msv_frame >= 1 ? msv_frame + 1 : 1) * n0)); S.msv_b0 = (double*)(base + carve(sizeof(double) * 3 * n0));
             S.small[0] = (uint8_t*)(base + carve((size_t)dw * dh)); S.small[1] = (uint8_t*)(base + carve((size_t)dw * dh));
         }
     }
     for (int b = 0; b < s->batch; b++) {
         SessStream& S = s->h_ss[b];
         SessStream* d = s->d_ss + b;
-        for (int k = 0; k < 9; k++) S.K[k] = (double)K_host[k];
+        for (int k = 0; k < 9; k++) S.K[k] = K_host[k];
         S.N0 = n0; S.nhist = nhist; S.w = w; S.h = h; S.stride = w;
         PoseJob& J = S.pose;
         for (int k = 0; k < 9; k++) { J.K[k] = S.K[k]; J.R[k] = (k % 4 == 0) ? 1.0 : 0.0; }
@@ -316,7 +316,7 @@ static int session_step(vh_session* s, const uint8_t* const* frames_dev, float t
         hipLaunchKernelGGL(k_sess_book_b, dim3(nb), dim3(256), 0, st, s->d_ss, frames_dev, time_s, frame_no, times_dev, frame_nos_dev);
     }
     // fcnMSV1_t fires when a stream reaches ITS frame msv_frame (vidExample.py:155), whenever that stream was initialised
-    const bool msv_ok = s->msv_frame >= 1 && s->msv_frame + 1 <= 16 && s->msv_frame < s->nhist;
+    const bool msv_ok = s->msv_frame >= 1 && s->msv_frame + 1 <= 2048 && s->msv_frame < s->nhist;
     bool any = false;
     for (int b = 0; b < nb; b++) {
         const int fi = ++s->h_frame[b];
@@ -327,7 +327,7 @@ static int session_step(vh_session* s, const uint8_t* const* frames_dev, float t
         memset(&J, 0, sizeof(J));
         for (int k = 0; k < 9; k++) J.K[k] = H.K[k];
         J.P = H.P; J.B = H.B; J.ids = H.ids; J.ng_ptr = &s->d_ss[b].n_cur; J.ng = 0; J.N0 = s->N0; J.nhist = s->nhist;
-        J.nf = s->msv_frame + 1; J.max_iter = 1000; J.f32_rays = 1;
+        J.nf = s->msv_frame + 1; J.max_iter = 1000; J.f32_rays = s->k_is_f32;  // P is float32 always; K as the caller holds it
         J.U = H.msv_U; J.b0 = H.msv_b0; J.x_out = s->d_ss[b].msv_x; J.info_out = s->d_ss[b].msv_info;
         vh_launch_msv1(J, st);
     }

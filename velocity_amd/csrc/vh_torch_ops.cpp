@@ -68,11 +68,11 @@ Tensor as_points(const Tensor& p, const char* name)
     return p.to(at::kFloat).contiguous();
 }
 
-void host_K(const Tensor& K, float out[9])
+void host_K(const Tensor& K, double out[9])
 {
     TORCH_CHECK(K.numel() == 9, "K must hold 9 values (MATLAB row-vector layout [[fx,0,0],[s,fy,0],[cx,cy,1]])");
-    Tensor k = K.detach().to(at::kCPU, at::kFloat).contiguous();  // a 36-byte host constant, like the reference's K
-    for (int i = 0; i < 9; i++) out[i] = k.data_ptr<float>()[i];
+    Tensor k = K.detach().to(at::kCPU, at::kDouble).contiguous();  // a 72-byte host constant: K.astype(float), utils/NLS.py:22-24,196 (float32 widens exactly)
+    for (int i = 0; i < 9; i++) out[i] = k.data_ptr<double>()[i];
 }
 
 // ---- KLTmain(im, im0, im0_small, p0) -> (p_all [N,2] f32, v [N] u8, im_small) ; the caller takes p_all[v] (utils/KLT.py:134) -------------------
@@ -137,7 +137,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> pose(const Tensor& K, const T
                 "pose: p [n,2] and pw [n,3] must be CUDA tensors with the same number of rows");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(p.device());
     void* s = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
-    float Kh[9];
+    double Kh[9];
     host_K(K, Kh);
     Tensor pf = p.to(at::kFloat).contiguous(), pwd = pw.to(at::kDouble).contiguous();
     Tensor x0h = x0.detach().to(at::kCPU, at::kDouble).contiguous(), Rh = R.detach().to(at::kCPU, at::kDouble).contiguous();
@@ -209,14 +209,14 @@ std::tuple<Tensor, Tensor, Tensor> msv1_t(const Tensor& K, const Tensor& P, cons
                 "msv1_t: P [5,N0,nhist], B [nhist,14], ids [ng] on the GPU");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(P.device());
     void* s = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
-    float Kh[9];
+    double Kh[9];
     host_K(K, Kh);
     Tensor Pf = P.to(at::kFloat).contiguous(), Bf = B.to(at::kFloat).contiguous(), id = ids.to(at::kInt).contiguous();
     const int ng = (int)id.numel(), N0 = (int)Pf.size(1), nh = (int)Pf.size(2);
     auto opt = P.options();
     Tensor U = at::empty({3 * (ii + 1) * std::max(ng, 1)}, opt.dtype(at::kDouble)), x = at::zeros({3}, opt.dtype(at::kFloat)),
            b0 = at::zeros({ng, 3}, opt.dtype(at::kDouble)), info = at::zeros({2}, opt.dtype(at::kInt));
-    vh_check(vh_msv1_t(workspace(P, 0, 0, 0, s), Kh, Pf.data_ptr<float>(), Bf.data_ptr<float>(), id.data_ptr<int>(), ng, N0, nh, (int)ii, 1, U.data_ptr<double>(),
+    vh_check(vh_msv1_t(workspace(P, 0, 0, 0, s), Kh, Pf.data_ptr<float>(), Bf.data_ptr<float>(), id.data_ptr<int>(), ng, N0, nh, (int)ii, (K.scalar_type() == at::kFloat && P.scalar_type() == at::kFloat) ? 1 : 0, U.data_ptr<double>(),
                        x.data_ptr<float>(), b0.data_ptr<double>(), info.data_ptr<int>(), s),
              "vh_msv1_t");
     return {x, b0, info};
@@ -231,7 +231,7 @@ std::tuple<Tensor, Tensor, Tensor> ba_solve(const Tensor& K, const Tensor& z, co
     TORCH_CHECK(z.size(-1) == nz && x0.size(-1) == nx, "ba_solve: z must hold 2 nt (nc+1) and x0 3 nt + 6 nc values");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(z.device());
     void* s = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
-    float Kh[9];
+    double Kh[9];
     host_K(K, Kh);
     const bool multi = z.dim() == 2;
     const int64_t nw = multi ? z.size(0) : 1;

@@ -44,6 +44,7 @@ class TrackStateExchange:
         self.gathered = torch.zeros((self.world, streams_per_rank, record_words(n0)), dtype=torch.float32, device=dev)
         self._work = None
         self.count = 0
+        self.host_seconds = 0.0  # host time spent inside start() / wait() (under RCCL: enqueue cost only, the collective is stream ordered)
         # gloo (tests only) has no device all-gather: stage through host buffers there; RCCL gathers device to device
         self._host = dist.is_initialized() and dist.get_backend(group) == "gloo" and self.local.is_cuda
         if self._host:
@@ -54,7 +55,15 @@ class TrackStateExchange:
         return self.every > 0 and frame_index % self.every == 0
 
     def start(self):
-        """Begin the all-gather of `self.local` (non-blocking)."""
+        """Begin the all-gather of `self.local` (non-blocking).  Stream ordered: whatever wrote `local` on the CURRENT stream (vh_session_pack_state)
+        is waited for by the collective itself (RCCL: event on the current stream; gloo: the staging copy runs on it) -- no host synchronisation."""
+        import time
+
+        t0 = time.perf_counter()
+        self._start()
+        self.host_seconds += time.perf_counter() - t0
+
+    def _start(self):
         if self.world == 1 and not dist.is_initialized():
             self.gathered[0].copy_(self.local)
             self._work = None
@@ -66,12 +75,30 @@ class TrackStateExchange:
         self.count += 1
 
     def wait(self):
+        import time
+
+        t0 = time.perf_counter()
         if self._work is not None:
             self._work.wait()
             self._work = None
             if self._host:
                 self.gathered.copy_(self._h_gathered)
+        self.host_seconds += time.perf_counter() - t0
         return self.gathered
+
+    def describe(self):
+        """What the process group really is, for the bench record: backend, world size and every rank's device (all-gathered)."""
+        if not dist.is_initialized():
+            return dict(backend=None, world_size=1, devices=[], exchanges=self.count, exchange_host_ms_total=round(1e3 * self.host_seconds, 3))
+        me = dict(rank=dist.get_rank(self.group))
+        if torch.cuda.is_available():
+            d = torch.cuda.current_device()
+            pr = torch.cuda.get_device_properties(d)
+            me.update(device=d, name=pr.name, pci_bus_id=getattr(pr, "pci_bus_id", None), gcn_arch=getattr(pr, "gcnArchName", None))
+        devs = [None] * self.world
+        dist.all_gather_object(devs, me, group=self.group)
+        return dict(backend=dist.get_backend(self.group), world_size=self.world, devices=devs, exchanges=self.count,
+                    exchange_host_ms_total=round(1e3 * self.host_seconds, 3), bytes_per_rank_per_exchange=int(self.local.numel() * 4))
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -85,12 +112,14 @@ def shard_tracks(nt, world_size, rank):
     return ids[0] if ids else 0, (ids[-1] + 1) if ids else 0
 
 
-def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None):
+def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None, timing=None):
     """fcnNLS_batch (utils/NLS.py:186-250) with the tie points sharded over the ranks of `group`.
 
     Every rank passes the FULL P / pw / cw (like the reference call) and gets the full (cw, pw) back; internally it
     packs and solves only its own block of tracks.  Works with any world size, including an uninitialised
     process group (single rank).  Returns (cw, pw, trace) with trace = [(rms residual, rms delta)] per iteration.
+    `timing` (a dict) receives "loop_ms": the device time of the LM iterations alone (HIP events around the loop: phases + all-reduces,
+    without the host-side packing before and the gather after).
     """
     import ctypes as C
 
@@ -114,7 +143,7 @@ def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None):
     Pl = P[:, lo:hi]
     z = np.concatenate([Pl[0].T.reshape(-1), Pl[1].T.reshape(-1)]).astype(np.float64)  # NLS.py:198-199 on the local tracks
     x0 = np.concatenate((pw[lo:hi], cw[1:], np.zeros((nc, 3)))).reshape(-1)
-    K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+    K64 = L.host_K(K)
     zd = L.to_dev(z, tc.float64)
     xd = L.to_dev(x0, tc.float64).clone()
     trace = tc.zeros((max_iter, 2), dtype=tc.float64, device="cuda")
@@ -129,7 +158,7 @@ def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None):
     off, cnt = C.c_size_t(), C.c_size_t()
 
     def phase(ph, it=0):
-        L.check(ws.lib.vh_nls_batch_phase(ws.handle, K32.ctypes.data_as(L.f32p), L.dptr(zd), L.dptr(xd), nt, nc, nt_total, int(rank == 0), ph, it,
+        L.check(ws.lib.vh_nls_batch_phase(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, nt_total, int(rank == 0), ph, it,
                                           L.dptr(trace), L.dptr(info), L.dptr(scratch), nbytes, C.byref(off), C.byref(cnt), L.stream_ptr()),
                 "vh_nls_batch_phase")
 
@@ -139,6 +168,9 @@ def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None):
     # the span ends with the 4 accumulators [sum r^2, sum delta^2, -, -]: sum r^2 travels with the first all-reduce (it is final
     # after phase 1), so the second one carries ONLY sum delta^2 -- reducing the whole tail again would count sum r^2 world times
     sum_delta = span[-3:-2]
+    if timing is not None:
+        ev0, ev1 = tc.cuda.Event(enable_timing=True), tc.cuda.Event(enable_timing=True)
+        ev0.record()
     for it in range(max_iter):
         phase(1, it)
         if collective:
@@ -147,6 +179,10 @@ def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None):
         if collective:
             dist.all_reduce(sum_delta, group=group)
         phase(3, it)
+    if timing is not None:
+        ev1.record()
+        ev1.synchronize()
+        timing["loop_ms"] = ev0.elapsed_time(ev1)
     info_h = info.cpu().numpy()
     x = xd.cpu().numpy()
     # gather the point blocks (cameras are identical on every rank)

@@ -15,11 +15,12 @@ class TrackerSession:
         self.batch, self.w, self.h, self.n0, self.nhist = batch, width, height, n0, nhist
         self.ws = L.Workspace(batch, width, height, n0)
         self.lib = self.ws.lib
-        self.K32 = np.ascontiguousarray(np.asarray(K, np.float32).reshape(9))
+        self.K64 = L.host_K(K)
+        k_is_f32 = int(getattr(K, "dtype", None) == np.float32)  # numpy builds fcnMSV1_t's rays in float32 then (utils/MSV.py:15-17)
         self.lkc = L.lk_params(dict(L.LK_COARSE, **(lk_coarse or {})))
         self.lkf = L.lk_params(dict(L.LK_FINE, **(lk_fine or {})))
         h = C.c_void_p()
-        L.check(self.lib.vh_session_create(C.byref(h), self.ws.handle, n0, nhist, width, height, self.K32.ctypes.data_as(L.f32p),
+        L.check(self.lib.vh_session_create(C.byref(h), self.ws.handle, n0, nhist, width, height, self.K64.ctypes.data_as(L.f64p), k_is_f32,
                                            C.byref(self.lkc), C.byref(self.lkf), int(msv_frame)), "vh_session_create")
         self.handle = h
         self._frames = torch.zeros(batch, dtype=torch.int64, device="cuda")  # device table of frame pointers
@@ -62,12 +63,19 @@ class TrackerSession:
         if frames is not None:
             self.set_frames(frames)
         tab = self._frames if frames_table is None else frames_table
-        if np.ndim(time_s) == 0 and np.ndim(frame_no) == 0 and not hasattr(time_s, "is_cuda"):
+        is_t = [hasattr(x, "is_cuda") for x in (time_s, frame_no)]  # torch tensors first: numpy must never see a CUDA tensor
+        if not any(is_t) and np.ndim(time_s) == 0 and np.ndim(frame_no) == 0:
             L.check(self.lib.vh_session_step(self.handle, L.dptr(tab), float(time_s), float(frame_no), L.stream_ptr()), "vh_session_step")
             return
         torch = self.torch
-        tv = L.to_dev(time_s if hasattr(time_s, "is_cuda") else np.array(np.broadcast_to(np.asarray(time_s, np.float32), (self.batch,))), torch.float32)
-        fv = L.to_dev(frame_no if hasattr(frame_no, "is_cuda") else np.array(np.broadcast_to(np.asarray(frame_no, np.float32), (self.batch,))), torch.float32)
+
+        def clock(x, tensor):  # scalar / 0-dim / length-batch, host or device -> float32 CUDA vector of `batch` values
+            if tensor:
+                t = L.to_dev(x, torch.float32).reshape(-1)
+                return t.expand(self.batch).contiguous() if t.numel() == 1 else t
+            return L.to_dev(np.array(np.broadcast_to(np.asarray(x, np.float32), (self.batch,))), torch.float32)
+
+        tv, fv = clock(time_s, is_t[0]), clock(frame_no, is_t[1])
         assert tv.numel() == self.batch and fv.numel() == self.batch
         self._clock_keep = (tv, fv)
         L.check(self.lib.vh_session_step_v(self.handle, L.dptr(tab), L.dptr(tv), L.dptr(fv), L.stream_ptr()), "vh_session_step_v")
