@@ -184,7 +184,7 @@ def cpu_baseline(cfg, K, frames, p0, p3, vp, lkc, lkf, budget_s, threads):
 # ----------------------------------------------------------------------------------------------------------------------------------
 # config 5: bundle adjustment
 # ----------------------------------------------------------------------------------------------------------------------------------
-def bench_ba(nt=5000, nf=20, repeats=3, cpu_seconds=12.0, windows=(1, 8, 64)):
+def bench_ba(nt=5000, nf=20, repeats=3, cpu_seconds=12.0, windows=(1, 8, 64), min_seconds=0.4):
     """BASELINE config 5: sliding-window BA, 20 keyframes x 5000 full-length tracks, 10 LM iterations (fcnNLS_batch): one window, and
     `windows` independent windows batched into the same launches (vh_nls_batch_multi) -- the mode that fills the chip."""
     from velocity_amd import _lib as L
@@ -197,7 +197,9 @@ def bench_ba(nt=5000, nf=20, repeats=3, cpu_seconds=12.0, windows=(1, 8, 64)):
     nx, nz = 3 * nt + 6 * nc, 2 * nt * nf
     out = dict(workload=f"C5 BA: {nf} keyframes x {nt} tracks (nx={nx}, nz={nz}), 10 LM iterations per window",
                method="compact FD Jacobian; point-block Schur complement with the reduced camera system on v_mfma_f64_16x16x4_f64; "
-                      "register-resident Gauss-Jordan (SPD, pivot-free)",
+                      "block Gauss-Jordan (4x4 pivot blocks, SPD, pivot-free) in the MFMA accumulators",
+               timing="HIP events around each 10-iteration solve on the launch stream; median of the second half of the repetitions "
+                      "(iters_per_s), best (iters_per_s_best) and host wall incl. enqueue + synchronize (iters_per_s_host_wall)",
                dense_equivalent_flop_per_iter=2.0 * nx ** 2 * nz, by_windows={})
     first = None
     for nw in windows:
@@ -217,23 +219,32 @@ def bench_ba(nt=5000, nf=20, repeats=3, cpu_seconds=12.0, windows=(1, 8, 64)):
         scratch = torch.empty((nw, nbytes), dtype=torch.uint8, device="cuda")
         trace = torch.zeros((nw, 10, 2), dtype=torch.float64, device="cuda")
         info = torch.zeros((nw, 2), dtype=torch.int32, device="cuda")
-        best = None
-        for _ in range(repeats + 1):
+        # timed with HIP events on the launch stream (the device time of the whole 10-iteration solve, first kernel to last); repeated until
+        # `min_seconds` of solves have run (the first ones also bring the clocks up after the CPU legs): median AND best are reported, the
+        # headline figure is the median.  The host wall time of the same solves (enqueue + synchronize) is kept next to it.
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dev_ms, wall_ms, t_begin = [], [], time.perf_counter()
+        while len(dev_ms) < repeats + 1 or (time.perf_counter() - t_begin < min_seconds and len(dev_ms) < 400):
             xd = x0d.clone()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+            ev0.record()
             if nw == 1:
                 L.check(ws.lib.vh_nls_batch(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, 10, L.dptr(trace), L.dptr(info),
                                             L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch")
             else:
                 L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, nw, 10, L.dptr(trace),
                                                   L.dptr(info), L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
+            ev1.record()
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
+            wall_ms.append(1e3 * (time.perf_counter() - t0))
+            dev_ms.append(ev0.elapsed_time(ev1))
         its = int(info.cpu()[:, 0].sum())
         tr = trace.cpu().numpy()
-        out["by_windows"][str(nw)] = dict(iters_per_s=round(its / best, 1), ms_per_window_iter=round(1e3 * best / its, 4),
+        half = len(dev_ms) // 2  # the first half is warm-up (clock ramp after the idle CPU legs)
+        med, best, wmed = float(np.median(dev_ms[half:])), float(min(dev_ms)), float(np.median(wall_ms[half:]))
+        out["by_windows"][str(nw)] = dict(iters_per_s=round(1e3 * its / med, 1), ms_per_window_iter=round(med / its, 5), solves_timed=len(dev_ms),
+                                          iters_per_s_best=round(1e3 * its / best, 1), iters_per_s_host_wall=round(1e3 * its / wmed, 1),
                                           rms_residual_first=round(float(tr[0, 0, 0]), 4), rms_residual_last=round(float(tr[0, -1, 0]), 4))
         del scratch, zd, x0d
     one = out["by_windows"]["1"]

@@ -114,6 +114,7 @@ extern "C" VH_API int vh_ctx_create(vh_ctx** out, int batch, int max_w, int max_
 extern "C" VH_API void vh_ctx_destroy(vh_ctx* c)
 {
     if (!c) return;
+    vh_ba_graph_cache_free(c->ba_graphs);
     (void)hipFree(c->arena);
     for (int k = 0; k < 2 * c->prof_cap; k++) (void)hipEventDestroy(c->prof_ev[k]);
     delete[] c->prof_ev;
@@ -862,6 +863,7 @@ extern "C" VH_API int vh_nls_batch(vh_ctx* c, const double* K_host, const double
     if (6 * nc > 256) return vh_fail(-1, "vh_nls_batch: at most 42 free cameras");
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch: workspace too small");
     BaProblem P;
+    P.graph_cache = &c->ba_graphs;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt); P.force_valu = g_ba_force_valu;
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 0;
@@ -882,6 +884,7 @@ extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const double* K_host, const 
     if (workspace_bytes_per_window < vh_ba_workspace_bytes(nt, nc, ba_parts(nt)) || workspace_bytes_per_window % 256)
         return vh_fail(-1, "vh_nls_batch_multi: per-window workspace too small or not a multiple of 256 bytes");
     BaProblem P;
+    P.graph_cache = &c->ba_graphs;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.force_valu = g_ba_force_valu;
     // fewer partial systems per window when many windows fill the chip anyway (the partials are reduced through HBM)
@@ -904,6 +907,7 @@ extern "C" VH_API int vh_nls_batch2(vh_ctx* c, const double* K_host, const doubl
     if (6 * nc > 256) return vh_fail(-1, "vh_nls_batch2: at most 42 free cameras");
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch2: workspace too small");
     BaProblem P;
+    P.graph_cache = &c->ba_graphs;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt); P.force_valu = 1;
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 1;
@@ -927,6 +931,7 @@ extern "C" VH_API int vh_nls_batch_phase(vh_ctx* c, const double* K_host, const 
     if (6 * nc > 256) return vh_fail(-1, "vh_nls_batch_phase: at most 42 free cameras");
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch_phase: workspace too small");
     BaProblem P;
+    P.graph_cache = &c->ba_graphs;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = 1; P.nparts = ba_parts(nt);
     P.force_valu = g_ba_force_valu;

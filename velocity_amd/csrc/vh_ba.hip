@@ -10,6 +10,8 @@
 #include "vh_ba.hpp"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <new>
 
 #define BA_FD 1e-6
 #define BA_THREADS 256
@@ -854,6 +856,151 @@ __global__ __launch_bounds__(G * G) void k_ba_solve(BaJob J, int nparts)
     }
 }
 
+// Schur stage 2b on the matrix cores (nq <= 124): BLOCK Gauss-Jordan with 4 x 4 pivot blocks, the augmented system resident in the accumulator
+// registers of v_mfma_f64_16x16x4_f64.  The 128 x 128 padded matrix M = [S | 0 | rhs] (rhs in column 127, identity on the padded diagonal) is an
+// 8 x 8 grid of 16 x 16 tiles; wavefront w of 4 owns tile rows w and w + 4 (16 tiles = 128 accumulator registers).  Round r eliminates columns
+// c0 = 4r .. 4r+3 from every row but the pivot rows:  M -= F R  with R = the 4 pivot rows (4 x 128) and F = M[:, c0:c0+4] P^-1 (128 x 4, zero in
+// the pivot rows) -- exactly the rank-4 update the instruction performs per tile (A = -F tile rows, B = R tile columns).  Tile columns left of
+// the pivot are finished (their pivot-row entries are zero) and are skipped statically.  Per round: one barrier, the pivot rows / columns
+// travel through double-buffered LDS vectors, every lane inverts the 4 x 4 pivot block itself (two dependent reciprocals), 2 x (8 - r/4) MFMAs.
+// 29 rounds at nq = 114 instead of the 57 rank-2 rounds of the VALU kernel below, and the 16 K multiply-adds of a round are 16 instructions
+// per wavefront instead of 128 v_fma_f64: 64 us -> see DESIGN.md section 6.  S is SPD, so no pivoting is needed (every leading block is SPD).
+__device__ __forceinline__ void ba_inv4(const double (&P)[4][4], double (&Q)[4][4])
+{
+    // block LU on 2 x 2 blocks: P = [[A B],[C D]], T = A^-1 B, Sc = D - C T; P^-1 = [[A^-1 + T Sc^-1 C A^-1, -T Sc^-1],[-Sc^-1 C A^-1, Sc^-1]]
+    const double ia = 1.0 / (P[0][0] * P[1][1] - P[0][1] * P[1][0]);
+    const double a00 = P[1][1] * ia, a01 = -P[0][1] * ia, a10 = -P[1][0] * ia, a11 = P[0][0] * ia;
+    const double t00 = a00 * P[0][2] + a01 * P[1][2], t01 = a00 * P[0][3] + a01 * P[1][3];
+    const double t10 = a10 * P[0][2] + a11 * P[1][2], t11 = a10 * P[0][3] + a11 * P[1][3];
+    const double s00 = P[2][2] - (P[2][0] * t00 + P[2][1] * t10), s01 = P[2][3] - (P[2][0] * t01 + P[2][1] * t11);
+    const double s10 = P[3][2] - (P[3][0] * t00 + P[3][1] * t10), s11 = P[3][3] - (P[3][0] * t01 + P[3][1] * t11);
+    const double is = 1.0 / (s00 * s11 - s01 * s10);
+    const double d00 = s11 * is, d01 = -s01 * is, d10 = -s10 * is, d11 = s00 * is;  // Sc^-1
+    // U = C A^-1 (2 x 2), V = Sc^-1 U
+    const double u00 = P[2][0] * a00 + P[2][1] * a10, u01 = P[2][0] * a01 + P[2][1] * a11;
+    const double u10 = P[3][0] * a00 + P[3][1] * a10, u11 = P[3][0] * a01 + P[3][1] * a11;
+    const double v00 = d00 * u00 + d01 * u10, v01 = d00 * u01 + d01 * u11, v10 = d10 * u00 + d11 * u10, v11 = d10 * u01 + d11 * u11;
+    Q[2][0] = -v00; Q[2][1] = -v01; Q[3][0] = -v10; Q[3][1] = -v11;
+    Q[2][2] = d00; Q[2][3] = d01; Q[3][2] = d10; Q[3][3] = d11;
+    Q[0][2] = -(t00 * d00 + t01 * d10); Q[0][3] = -(t00 * d01 + t01 * d11);
+    Q[1][2] = -(t10 * d00 + t11 * d10); Q[1][3] = -(t10 * d01 + t11 * d11);
+    Q[0][0] = a00 + (t00 * v00 + t01 * v10); Q[0][1] = a01 + (t00 * v01 + t01 * v11);
+    Q[1][0] = a10 + (t10 * v00 + t11 * v10); Q[1][1] = a11 + (t10 * v01 + t11 * v11);
+}
+
+#define BA_GJ_N 128
+#define BA_GJ_MAXQ 124  // the last pivot block must end before the rhs column (127)
+__global__ __launch_bounds__(256) void k_ba_solve_mfma(BaJob J)
+{
+    ba_select_window(J, blockIdx.y);
+    if (*J.done) return;
+    const int nq = J.nq, ld = nq + 1, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane >> 4, lc = lane & 15;
+    __shared__ double s_R[2][4][BA_GJ_N];       // pivot rows of the coming round
+    __shared__ double s_C[2][4][BA_GJ_N];       // pivot columns of the coming round
+    __shared__ double s_pinv[BA_GJ_N / 4][16];  // inverse pivot blocks
+    __shared__ double s_rhs[BA_GJ_N];
+    double4v acc[2][8];
+#pragma unroll
+    for (int il = 0; il < 2; il++)
+#pragma unroll
+        for (int Jt = 0; Jt < 8; Jt++)
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+                const int row = 16 * (w + 4 * il) + lr + 4 * rg, col = 16 * Jt + lc;
+                double v;
+                if (row < nq) v = col < nq ? J.Sfull[(size_t)row * ld + col] : (col == BA_GJ_N - 1 ? J.Sfull[(size_t)row * ld + nq] : 0.0);
+                else v = (row == col && col != BA_GJ_N - 1) ? 1.0 : 0.0;
+                acc[il][Jt][rg] = v;
+            }
+    // publish the pivot rows / columns of round 0
+    if (w == 0) {
+#pragma unroll
+        for (int Jt = 0; Jt < 8; Jt++) s_R[0][lr][16 * Jt + lc] = acc[0][Jt][0];
+    }
+    if (lc < 4) {
+#pragma unroll
+        for (int il = 0; il < 2; il++)
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) s_C[0][lc][16 * (w + 4 * il) + lr + 4 * rg] = acc[il][0][rg];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < BA_GJ_MAXQ / 4; r++) {
+        const int c0 = 4 * r;
+        if (c0 >= nq) break;
+        const int buf = r & 1, J0 = r >> 2;
+        double P[4][4], Q[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) P[m][k] = s_R[buf][m][c0 + k];
+        // operands that do not depend on the inverse: pivot columns of my rows, pivot rows of my tile columns
+        double cv[2][4], b[8];
+#pragma unroll
+        for (int il = 0; il < 2; il++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) cv[il][m] = s_C[buf][m][16 * (w + 4 * il) + lc];
+#pragma unroll
+        for (int Jt = 0; Jt < 8; Jt++)
+            if (Jt >= J0) b[Jt] = s_R[buf][lr][16 * Jt + lc];
+        ba_inv4(P, Q);
+        if (tid == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) s_pinv[r][4 * m + k] = Q[m][k];
+        }
+        // my column lr of P^-1
+        double pk[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) pk[m] = lr == 0 ? Q[m][0] : (lr == 1 ? Q[m][1] : (lr == 2 ? Q[m][2] : Q[m][3]));
+        double f[2];
+#pragma unroll
+        for (int il = 0; il < 2; il++) {
+            const int i = 16 * (w + 4 * il) + lc;
+            const double v = cv[il][0] * pk[0] + cv[il][1] * pk[1] + cv[il][2] * pk[2] + cv[il][3] * pk[3];
+            f[il] = (i >= c0 && i < c0 + 4) ? 0.0 : -v;  // the pivot rows stay
+        }
+#pragma unroll
+        for (int Jt = 0; Jt < 8; Jt++)
+            if (Jt >= J0) {
+                acc[0][Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[0], b[Jt], acc[0][Jt], 0, 0, 0);
+                acc[1][Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[1], b[Jt], acc[1][Jt], 0, 0, 0);
+            }
+        // publish the next pivot rows / columns (the other buffer: slow wavefronts may still read this one)
+        if (c0 + 4 < nq) {
+            const int rn = r + 1, In = rn >> 2, rgn = rn & 3, Jn = rn >> 2, cmn = 4 * (rn & 3);
+            if (w == (In & 3)) {
+#pragma unroll
+                for (int Jt = 0; Jt < 8; Jt++)
+                    if (Jt >= Jn) s_R[buf ^ 1][lr][16 * Jt + lc] = acc[In >> 2][Jt][rgn];
+            }
+            if (lc >= cmn && lc < cmn + 4) {
+#pragma unroll
+                for (int il = 0; il < 2; il++)
+#pragma unroll
+                    for (int rg = 0; rg < 4; rg++) s_C[buf ^ 1][lc - cmn][16 * (w + 4 * il) + lr + 4 * rg] = acc[il][Jn][rg];
+            }
+        }
+        __syncthreads();
+    }
+    // the right-hand side column (127 = tile column 7, local column 15), then dc = P_r^-1 rhs_r per pivot block
+    if (lc == 15) {
+#pragma unroll
+        for (int il = 0; il < 2; il++)
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) s_rhs[16 * (w + 4 * il) + lr + 4 * rg] = acc[il][7][rg];
+    }
+    __syncthreads();
+    if (tid < nq) {
+        const int r = tid >> 2, k = tid & 3;
+        const double* Qr = s_pinv[r];
+        J.dc[tid] = Qr[4 * k] * s_rhs[4 * r] + Qr[4 * k + 1] * s_rhs[4 * r + 1] + Qr[4 * k + 2] * s_rhs[4 * r + 2] + Qr[4 * k + 3] * s_rhs[4 * r + 3];
+    }
+}
+
 // back-substitution dp = tp - Y dc, update x += 0.9 delta, rms(delta) and the stop flag (NLS.py:235-240)
 __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
 {
@@ -987,6 +1134,66 @@ __global__ void k_ba_init(BaJob J, double* flags0)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// replayable launch sequences (hipGraph) of whole solves, owned by the vh_ctx that issues them
+struct BaGraphKey {
+    BaJob J;
+    double* flags0;
+    int max_iter, nparts, use_mfma, pad_;
+};
+struct BaGraphEntry {
+    BaGraphKey key;
+    hipGraphExec_t exec;
+    int seen;
+    unsigned long long stamp;
+};
+struct BaGraphCache {
+    static constexpr int CAP = 8;
+    BaGraphEntry e[CAP];
+    int n = 0;
+    unsigned long long clock = 0;
+    bool disabled = false;
+    hipStream_t capture_stream = nullptr;
+    BaGraphEntry* find(const BaGraphKey& k, hipStream_t s)
+    {
+        for (int i = 0; i < n; i++)
+            if (memcmp(&e[i].key, &k, sizeof(k)) == 0) { e[i].stamp = ++clock; return &e[i]; }
+        BaGraphEntry* slot = nullptr;
+        if (n < CAP) slot = &e[n++];
+        else {
+            slot = &e[0];
+            for (int i = 1; i < CAP; i++)
+                if (e[i].stamp < slot->stamp) slot = &e[i];
+            if (slot->exec) {
+                (void)hipStreamSynchronize(s);  // the evicted sequence may still be running
+                (void)hipGraphExecDestroy(slot->exec);
+            }
+        }
+        memcpy(&slot->key, &k, sizeof(k)); slot->exec = nullptr; slot->seen = 0; slot->stamp = ++clock;
+        return slot;
+    }
+};
+static BaGraphCache* ba_graph_cache(void** where)
+{
+    static const bool off = [] { const char* v = getenv("VH_BA_GRAPH"); return v && v[0] == '0'; }();
+    if (!where || off) return nullptr;
+    if (!*where) {
+        BaGraphCache* c = new (std::nothrow) BaGraphCache();
+        if (!c) return nullptr;
+        if (hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); delete c; return nullptr; }
+        *where = c;
+    }
+    return static_cast<BaGraphCache*>(*where);
+}
+void vh_ba_graph_cache_free(void* cache)
+{
+    BaGraphCache* c = static_cast<BaGraphCache*>(cache);
+    if (!c) return;
+    for (int i = 0; i < c->n; i++)
+        if (c->e[i].exec) (void)hipGraphExecDestroy(c->e[i].exec);
+    if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream);
+    delete c;
+}
+
 size_t vh_ba_workspace_bytes(int nt, int nc, int nparts)
 {
     const size_t nf = nc + 1, nq = 6 * (size_t)nc, m = (size_t)nt * nf;
@@ -1040,6 +1247,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     if (6 * nc > BA_THREADS) return -3;  // reduced rhs ownership (one thread per entry) needs 6 nc <= 256
     const int nparts = P.nparts;
     BaJob J;
+    memset(&J, 0, sizeof(J));  // padding included: whole solves are recognised by the bytes of their descriptor (graph replay below)
     double* flags;
     ba_layout(P, J, flags);
     const long long nent = (long long)nq * nq;
@@ -1072,13 +1280,46 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     };
     auto solve_update = [&](int it) {
         // up to 127 unknowns: 256 threads x 64 doubles (same speed as 1024 x 16: the step is a latency chain, not work)
-        if (nq + 1 <= 128) hipLaunchKernelGGL((k_ba_solve<8, 8, 16>), dim3(1, nw), dim3(256), 0, s, J, nparts);
+        if (nq <= BA_GJ_MAXQ && !(J.dbg & 64)) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1, nw), dim3(256), 0, s, J);  // block Gauss-Jordan on the matrix cores
+        else if (nq + 1 <= 128) hipLaunchKernelGGL((k_ba_solve<8, 8, 16>), dim3(1, nw), dim3(256), 0, s, J, nparts);
         else if (nq <= 192) hipLaunchKernelGGL((k_ba_solve<6, 7, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
         else hipLaunchKernelGGL((k_ba_solve<8, 9, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
         hipLaunchKernelGGL(k_ba_update, dim3(upd_blocks, nw), dim3(BA_THREADS), 0, s, J, it);
     };
     switch (P.phase) {
     case -1: {
+        // whole solve: 2 + 5 max_iter dependent launches.  A sequence seen before (same job descriptor -- pointers, sizes, intrinsics -- and launch
+        // shape) is replayed as ONE hipGraph launch: the device then runs its kernels back to back whatever the host's launch rate is (a busy or
+        // throttled host otherwise shows up as idle gaps between the 10-60 us kernels of a single window).  The second sighting builds the graph.
+        BaGraphKey key;
+        memset(&key, 0, sizeof(key));
+        memcpy(&key.J, &J, sizeof(J)); key.flags0 = flags; key.max_iter = P.max_iter; key.nparts = nparts; key.use_mfma = use_mfma ? 1 : 0;
+        BaGraphCache* gc = ba_graph_cache(P.graph_cache);
+        BaGraphEntry* e = gc ? gc->find(key, s) : nullptr;
+        if (e && e->exec) {
+            if (hipGraphLaunch(e->exec, s) == hipSuccess) break;
+            (void)hipGetLastError();
+            gc->disabled = true;  // fall through to plain launches, now and from here on
+        }
+        if (e && !e->exec && !gc->disabled && e->seen >= 1) {
+            hipStream_t cs = s;
+            s = gc->capture_stream;
+            hipGraph_t g = nullptr;
+            bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                ok = init() == 0;
+                for (int it = 0; ok && it < P.max_iter; it++) { normal_equations(it); solve_update(it); }
+                ok = (hipStreamEndCapture(s, &g) == hipSuccess) && ok && g;
+            }
+            s = cs;
+            if (ok) ok = hipGraphInstantiate(&e->exec, g, nullptr, nullptr, 0) == hipSuccess;
+            if (g) (void)hipGraphDestroy(g);
+            if (ok && hipGraphLaunch(e->exec, s) == hipSuccess) break;
+            (void)hipGetLastError();
+            if (e->exec) { (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+            gc->disabled = true;
+        }
+        if (e) e->seen++;
         int r = init();
         if (r) return r;
         for (int it = 0; it < P.max_iter; it++) { normal_equations(it); solve_update(it); }

@@ -30,7 +30,7 @@ struct BaJob {  // passed by value to every BA kernel
     int nq;     // reduced unknowns: 6 nc (model 0) or nc + 5 (model 1)
     int model;  // 0: fcnNLS_batch (free cameras, NLS.py:186-250); 1: fcnNLS_batch2 (joint rotation + straight-line trajectory, NLS.py:253-328)
     int add_identity, count_cams, defer_finalize;
-    int dbg;    // experiment switches (VH_BA_DBG): 1 skip MFMA, 2 skip Z / diag VALU, 4 skip global fetch, 8 skip barrier
+    int dbg;    // experiment switches (VH_BA_DBG): 1 skip MFMA, 2 skip Z / diag VALU, 4 skip global fetch, 8 skip barrier, 64 VALU Gauss-Jordan solve
     int zmode;  // 1: Y holds Z = L^T W and Spart holds only the upper-triangle 16x16 tiles (k_ba_schur_mfma); 0: Y = (U+I)^-1 W, full Spart
     // batched independent windows (vh_nls_batch_multi): blockIdx.y selects the window; every pointer above is window 0's
     int nwin;
@@ -55,7 +55,9 @@ struct BaProblem {
     int force_valu;  // test hook: 1 = accumulate the reduced camera system on the VALU instead of the matrix cores
     int nwin;        // independent windows solved by the same launches (>= 1); z, x, trace, info and workspace are arrays of nwin
     size_t ws_stride, z_stride, x_stride, trace_stride, info_stride;  // see BaJob (ignored when nwin == 1)
+    void** graph_cache;  // may be null: where the owner (vh_ctx) keeps the replayable launch sequences of whole solves (vh_ba_graph_cache_free)
 };
+void vh_ba_graph_cache_free(void* cache);
 
 size_t vh_ba_workspace_bytes(int nt, int nc, int nparts);
 int vh_ba_run(const BaProblem& P, hipStream_t s);

@@ -66,6 +66,7 @@ struct vh_ctx {
     hipEvent_t* prof_ev;  // 2 * prof_cap events: start/stop pairs
     int* prof_stage;
     double* d_small;     // 64 doubles of scratch for host-provided small matrices
+    void* ba_graphs;     // replayable launch sequences of whole BA solves (vh_ba.hip), created on demand
 };
 
 
