@@ -93,6 +93,7 @@ def parse():
                          "then corroborate the run); 0 = exactly --steps steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each cpu_baseline leg (0 disables)")
     ap.add_argument("--exchange-every", type=int, default=30)
+    ap.add_argument("--fine-max-count", type=int, default=0, help="calibration aid (tools/pmc_lk_calib.sh): cap the Newton iterations of the fine LK stage")
     ap.add_argument("--verify-frames", type=int, default=4,
                     help="after the timed region, replay this many further frames of two resident streams through the CPU oracle and report "
                          "`verified` (0 disables)")
@@ -247,6 +248,73 @@ def bench_ba(nt=5000, nf=20, repeats=3, cpu_seconds=12.0, windows=(1, 8, 64), mi
                                           iters_per_s_best=round(1e3 * its / best, 1), iters_per_s_host_wall=round(1e3 * its / wmed, 1),
                                           rms_residual_first=round(float(tr[0, 0, 0]), 4), rms_residual_last=round(float(tr[0, -1, 0]), 4))
         del scratch, zd, x0d
+    # ---- roofline of the BA kernels: one PROFILED solve per window count (HIP events around every kernel inside the library; the solve is then
+    # launched plainly, not replayed from its graph) ----
+    def profiled(nw):
+        zs, xs = zip(*[synth.ba_pack(*synth.ba_scene(nt, nf, seed=5 + w))[:2] for w in range(nw)])
+        zd, xd = L.to_dev(np.stack(zs), torch.float64), L.to_dev(np.stack(xs), torch.float64)
+        nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+        scratch = torch.empty((nw, nbytes), dtype=torch.uint8, device="cuda")
+        trace = torch.zeros((nw, 10, 2), dtype=torch.float64, device="cuda")
+        info = torch.zeros((nw, 2), dtype=torch.int32, device="cuda")
+        res = None
+        for rep in range(3):  # the last repetition counts (warm caches / clocks)
+            x = xd.clone()
+            L.check(ws.lib.vh_profile_begin(ws.handle, 80), "vh_profile_begin")
+            L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(x), nt, nc, nw, 10, L.dptr(trace), L.dptr(info),
+                                              L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
+            ms, n = (C.c_double * 16)(), (C.c_int * 16)()
+            L.check(ws.lib.vh_profile_end_stages(ws.handle, 16, ms, n), "vh_profile_end_stages")
+            res = {k: 1e3 * ms[i] / max(n[i], 1) for k, i in (("k_ba_jac", 8), ("k_ba_schur_mfma", 9), ("k_ba_reduce", 10), ("k_ba_solve_mfma", 11), ("k_ba_update", 12))}
+        return res
+
+    try:
+        nwr = max(w for w in windows)
+        kus = profiled(nwr)
+        # launch shape of k_ba_schur_mfma (velocity_amd/csrc/vh_api.hip::vh_nls_batch_multi): nparts workgroups per window, each walks its chunk of tie
+        # points in groups of 4; a group = 27 v_mfma_f64_16x16x4_f64 (2048 flop each) on each of the 4 consumer wavefronts
+        parts = max(1, min(256, nt // 16))
+        cap = max(16, 512 // nwr)
+        nparts = cap if (nwr > 1 and parts > cap) else parts
+        chunk = -(-nt // nparts)
+        groups = sum(-(-max(0, min(nt, (b + 1) * chunk) - b * chunk) // 4) for b in range(nparts))
+        mfma = nwr * groups * 4 * 27
+        flop = mfma * 2048.0
+        t = kus["k_ba_schur_mfma"] * 1e-6
+        tf = flop / t / 1e12
+        m_meas = nt * nf
+        rows = [dict(kernel="k_ba_jac<true>", us=round(kus["k_ba_jac"], 2), alg_bytes=int(nwr * (m_meas * 20 * 8 + 2 * m_meas * 8 + 3 * nt * 8 + 9 * nt * 8)),
+                     note="writes the 20 Jacobian / residual planes (160 B per measurement), reads z and x"),
+                dict(kernel="k_ba_schur_mfma", us=round(kus["k_ba_schur_mfma"], 2), alg_bytes=int(nwr * (m_meas * 20 * 8 + 9 * nt * 8)),
+                     note="reads the planes + L, tp once"),
+                dict(kernel="k_ba_reduce", us=round(kus["k_ba_reduce"], 2), alg_bytes=int(nwr * nparts * (6 * nc) ** 2 * 8 * 0.56), note="upper-triangle tiles of the partial systems"),
+                dict(kernel="k_ba_solve_mfma", us=round(kus["k_ba_solve_mfma"], 2), alg_bytes=int(nwr * (6 * nc) * (6 * nc + 1) * 8),
+                     note="one workgroup per window: latency bound (29 dependent block-elimination rounds)"),
+                dict(kernel="k_ba_update", us=round(kus["k_ba_update"], 2), alg_bytes=int(nwr * (m_meas * 18 * 8 + 12 * nt * 8)), note="reads 18 of the 20 planes again, updates x")]
+        for r in rows:
+            r["hbm_gbs"] = round(r["alg_bytes"] / (r["us"] * 1e-6) / 1e9, 1) if r["us"] > 0 else None
+            r["hbm_frac"] = round(r["hbm_gbs"] / HBM_PEAK_GBS, 4) if r["hbm_gbs"] else None
+        busy, bsrc = None, None
+        for name in ("r03_ba_pmc.json", "r02_ba_pmc.json"):
+            bp = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(bp):
+                try:
+                    bj = json.load(open(bp))
+                    busy = bj.get("mfma_busy_frac", bj.get("k_ba_schur_mfma", {}).get("mfma_busy_frac"))
+                    bsrc = f"profiles/{name} (SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 2.4 GHz x 1024 SIMDs) of a rocprofv3 --pmc pass; not measured in this run)"
+                except Exception:
+                    pass
+                break
+        out["roofline"] = dict(bound="mfma", kernel=f"k_ba_schur_mfma ({nwr} windows per launch)", achieved=round(tf, 2), peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s",
+                               frac=round(tf / MFMA_F64_PEAK_TFLOPS, 4), us_per_launch=round(kus["k_ba_schur_mfma"], 2), mfma_instr_per_launch=int(mfma),
+                               flop_per_launch=flop, mfma_busy_frac_pmc=busy, mfma_busy_source=bsrc, windows=nwr, nparts_per_window=nparts,
+                               note="issued v_mfma_f64_16x16x4_f64 x 2048 flop / kernel time (HIP events inside the library) against the dense f64 matrix peak; f64 MFMA and "
+                                    "VALU instructions of co-resident wavefronts do not overlap on gfx950 (profiles/r02_mfma_overlap.json), so the producers' VALU time adds",
+                               kernels=rows, us_per_iteration_all_windows=round(sum(r["us"] for r in rows), 1))
+        k1 = profiled(1)
+        out["single_window_kernels_us"] = {k: round(v, 2) for k, v in k1.items()}
+    except Exception as e:  # the roofline leg must never take the BA numbers down with it
+        out["roofline"] = dict(error=f"{type(e).__name__}: {e}"[:300])
     one = out["by_windows"]["1"]
     out.update(iters_per_s=one["iters_per_s"], ms_per_iter=one["ms_per_window_iter"], rms_residual_first=one["rms_residual_first"],
                rms_residual_last=one["rms_residual_last"])
@@ -339,7 +407,7 @@ class Workload:
         self.a, self.cfg, self.S, self.N, self.W, self.H = a, cfg, streams, cfg["n"], cfg["w"], cfg["h"]
         S, N, W, H = self.S, self.N, self.W, self.H
         lvl = cfg["levels"] - 1 if params == "baseline" else 4
-        self.lkc, self.lkf = dict(max_level=lvl), dict()
+        self.lkc, self.lkf = dict(max_level=lvl), (dict(max_count=a.fine_max_count) if getattr(a, "fine_max_count", 0) > 0 else dict())
         self.params, self.scene, self.ring = params, scene, a.ring
         nhist = min(warmup + steps + 3, 512)
         # one texture set per `ring` streams, so no two resident streams ever work on the same pixels
@@ -412,7 +480,7 @@ class Workload:
         ses = self.sessions[0]
         self.run(1, warmup, ex)
         barrier()
-        L.check(ses.lib.vh_profile_begin(ses.ws.handle, 3 * steps + 8), "vh_profile_begin")
+        L.check(ses.lib.vh_profile_begin(ses.ws.handle, 16 * steps + 16), "vh_profile_begin")
         barrier()
         t0 = time.perf_counter()
         self.run(1 + warmup, steps, ex)
@@ -422,6 +490,10 @@ class Workload:
         elapsed = reduce_max(time.perf_counter() - t0)
         prof = dict(ms_sum=(C.c_double * 3)(), launches=(C.c_int * 3)(), iters=(C.c_ulonglong * 3)(), setups=(C.c_ulonglong * 3)())
         L.check(ses.lib.vh_profile_end(ses.ws.handle, prof["ms_sum"], prof["launches"], prof["iters"], prof["setups"]), "vh_profile_end")
+        stage_ms, stage_n = (C.c_double * 16)(), (C.c_int * 16)()
+        L.check(ses.lib.vh_profile_end_stages(ses.ws.handle, 16, stage_ms, stage_n), "vh_profile_end_stages")
+        rois = np.zeros((self.SG, 4), np.int32)
+        L.check(ses.lib.vh_klt_rois(ses.ws.handle, rois.ctypes.data_as(L.i32p)), "vh_klt_rois")
         timed, blocks = steps, 1
         if min_seconds > 0 and elapsed < min_seconds:
             more = int(math.ceil((min_seconds - elapsed) / max(elapsed, 1e-6)))
@@ -438,7 +510,8 @@ class Workload:
         done = warmup + timed
         self.done_steps = done
         truth = self.motion.t((self.phase[0] + done) % self.ring) - self.motion.t(self.phase[0])
-        return dict(elapsed=elapsed, timed_steps=timed, blocks=blocks, prof=prof, st=st, alive=st["n_cur"] / self.N, truth=truth)
+        return dict(elapsed=elapsed, timed_steps=timed, blocks=blocks, prof=prof, st=st, alive=st["n_cur"] / self.N, truth=truth,
+                    stage_ms=list(stage_ms), stage_n=list(stage_n), rois=rois)
 
     def verify(self, first, nframes=4, which=None):
         """Parity attestation of the run that was just timed (OUTSIDE the timed region): the state of a few resident streams is handed to the
@@ -489,12 +562,33 @@ class Workload:
         torch.cuda.empty_cache()
 
 
+MFMA_F64_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: dense f64 matrix peak (v_mfma_f64_16x16x4_f64: 2048 flop / 64 cycles / SIMD)
+
+
+def lk_valu_model():
+    """Wave instructions the fine-stage kernel issues as a function of its in-kernel counters (template set-ups, Newton iterations), fitted ONCE
+    against rocprofv3 SQ_INSTS_VALU passes at different iteration counts (tools/pmc_lk_calib.sh -> profiles/r03_lk_valu_model.json, which also holds
+    the check run and the tolerance).  Returns None when the file is missing."""
+    path = os.path.join(ROOT, "profiles", "r03_lk_valu_model.json")
+    try:
+        j = json.load(open(path))
+        return dict(per_setup=float(j["wave_instr_per_setup"]), per_iter=float(j["wave_instr_per_newton_iter"]), tolerance=float(j["tolerance"]),
+                    kernel=j["kernel"], source="profiles/r03_lk_valu_model.json (tools/pmc_lk_calib.sh: SQ_INSTS_VALU fitted over runs with different iteration counts)")
+    except Exception:
+        return None
+
+
 def roofline_of(wl, m, world):
-    """roofline object of the dominant kernel (the fine-stage LK launch) from the in-library HIP-event timing of the first timed block."""
-    N, SG = wl.N, wl.SG
+    """roofline object: the dominant kernel (fine-stage LK launch) priced against the bound that really limits it -- VALU instruction issue -- with its
+    HBM figure next to it, and one row per other kernel family of the step (time from HIP events inside the library, algorithmic bytes, HBM fraction).
+    Everything in it is recomputable from the fields it carries."""
+    from velocity_amd import _lib as L
+
+    N, SG, cfg = wl.N, wl.SG, wl.cfg
     prof = m["prof"]
     ms_sum, launches, iters, setups = prof["ms_sum"], prof["launches"], prof["iters"], prof["setups"]
-    wf = 51
+    st_ms, st_n = m["stage_ms"], m["stage_n"]
+    wf, wc = 51, 15
     us_fine = 1e3 * ms_sum[2] / max(launches[2], 1)
     # algorithmic gather bytes per launch of session group 0 (SG streams): SURVEY §8d, KLT track solve row: 2 N L [(w+2)^2 + (w+1)^2], L = 1
     bytes_fine = 2 * N * SG * 1 * ((wf + 2) ** 2 + (wf + 1) ** 2)
@@ -504,12 +598,12 @@ def roofline_of(wl, m, world):
     ops_fine = wf * wf * (47.0 * su_f + 12.0 * it_f)  # SURVEY §8d op model: 47 op/px set-up, 12 op/px per Newton iteration
     # routing of vh_launch_lk (wavefronts per 51x51 track by the number of tracks in flight)
     fine_kernel = "k_lk3<51, 1, 4>" if N * SG >= 3000 else ("k_lk3<51, 2, 4>" if N * SG >= 1024 else "k_lk3<51, 4, 4>")
-    # HBM bytes and SQ issue utilisation of that kernel are NOT measured by this run: they come from the PMC passes committed under
-    # profiles/ (collected at the stream count stored in the file, scaled linearly); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    # HBM bytes of that kernel are NOT measured by this run: they come from the PMC passes committed under profiles/ (collected at the stream count
+    # stored in the file, scaled linearly); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     traffic, sq_util, tsrc = None, None, None
-    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
-        if wl.cfg is CONFIGS["c2"] and os.path.exists(tpath):
+        if cfg is CONFIGS["c2"] and os.path.exists(tpath):
             tj = json.load(open(tpath))
             k = tj.get(fine_kernel)
             if k is not None:
@@ -519,35 +613,78 @@ def roofline_of(wl, m, world):
             break
     peak_tops, lanes, peak_src = valu_peak()
     model_tops = ops_fine / (us_fine * 1e-6) / 1e12 if us_fine > 0 else 0.0
-    # VALU instructions the kernel really issues per launch: SQ_INSTS_VALU (wavefront instructions) x 64 lanes from the committed PMC pass of the
-    # same workload, scaled to this run's stream count; divided by THIS run's launch time
-    issued, isrc = None, None
-    ppath = os.path.join(ROOT, "profiles", "r02_lk_sq_pmc.json")
-    if wl.cfg is CONFIGS["c2"] and wl.params == "baseline" and os.path.exists(ppath):
-        pj = json.load(open(ppath))
-        k = pj.get("kernels", {}).get(fine_kernel)
-        if k and pj.get("streams"):
-            issued = 64.0 * k["SQ_INSTS_VALU"] * SG / pj["streams"]
-            sq_util = k.get("valu_issue_utilisation", sq_util)
-            isrc = f"profiles/r02_lk_sq_pmc.json (SQ_INSTS_VALU x 64 lanes of a rocprofv3 --pmc pass at {pj['streams']} streams, scaled to {SG})"
+    # VALU instructions issued per launch: LIVE from this run's in-kernel counters through the calibrated per-set-up / per-iteration costs
+    issued, isrc, tol = None, None, None
+    vm = lk_valu_model()
+    if vm is not None and vm["kernel"] == fine_kernel:
+        issued = 64.0 * (vm["per_setup"] * su_f + vm["per_iter"] * it_f)
+        isrc, tol = f"64 lanes x ({vm['per_setup']:.1f} x set-ups + {vm['per_iter']:.1f} x Newton iterations) per launch, counters of THIS run; costs from {vm['source']}", vm["tolerance"]
+    else:
+        ppath = os.path.join(ROOT, "profiles", "r02_lk_sq_pmc.json")
+        if cfg is CONFIGS["c2"] and wl.params == "baseline" and os.path.exists(ppath):
+            pj = json.load(open(ppath))
+            k = pj.get("kernels", {}).get(fine_kernel)
+            if k and pj.get("streams"):
+                issued = 64.0 * k["SQ_INSTS_VALU"] * SG / pj["streams"]
+                sq_util = k.get("valu_issue_utilisation", sq_util)
+                isrc = f"profiles/r02_lk_sq_pmc.json (SQ_INSTS_VALU x 64 lanes of a rocprofv3 --pmc pass at {pj['streams']} streams, scaled to {SG}; not live)"
     issued_tops = issued / (us_fine * 1e-6) / 1e12 if issued and us_fine > 0 else None
-    return dict(bound="hbm", kernel=fine_kernel + " (fine stage: 51x51 window, level 0, fwd+bwd)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
-                unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=tsrc, us_per_launch=round(us_fine, 2),
-                alg_bytes_per_launch=bytes_fine,
-                valu=dict(issued_ginstr_per_launch=round(issued / 1e9, 3) if issued else None, issued_source=isrc,
-                          achieved_tops=round(issued_tops, 3) if issued_tops else None, peak_tops=round(peak_tops, 1),
-                          peak_lanes_per_clk_per_simd=lanes, peak_source=peak_src,
-                          frac=round(issued_tops / peak_tops, 4) if issued_tops else None,
-                          op_model_gops_per_launch=round(ops_fine / 1e9, 4), op_model_tops=round(model_tops, 3),
-                          op_model_note="SURVEY §8d counts 47 op/px per set-up and 12 op/px per Newton iteration for a straightforward kernel; this "
-                                        "kernel issues fewer instructions than that for the same integers (gradients of the interpolated patch, "
-                                        "packed int16 dot products), so op_model_tops may exceed the issue peak -- frac prices issued instructions",
-                          newton_iters_per_track_dir=round(it_f / (2 * N * SG), 2), sq_valu_issue_utilisation=sq_util,
-                          sq_valu_issue_utilisation_source=isrc or tsrc),
-                note="track solve is VALU bound (SURVEY §8d); the HBM figure prices its algorithmic gather bytes",
-                lk_us_per_launch=[round(1e3 * ms_sum[k] / max(launches[k], 1), 2) for k in range(3)],
-                lk_newton_iters_per_setup=[round(iters[k] / max(setups[k], 1), 2) for k in range(3)],
-                lk_setups_per_track=[round(setups[k] / max(launches[k], 1) / (N * SG), 2) for k in range(3)])
+
+    # ---- the other kernel families of a step: live HIP-event time + algorithmic bytes (ROI sizes read back from the device after the run) ----
+    def us(stage):
+        return 1e3 * st_ms[stage] / max(st_n[stage], 1) if st_n[stage] else None
+
+    steps_prof = max(launches[2], 1)
+    roi = m["rois"]  # [SG, 4] x0 x1 y0 y1 of the last frame
+    rw, rh = (roi[:, 1] - roi[:, 0]).astype(float), (roi[:, 3] - roi[:, 2]).astype(float)
+    roi_px = float((rw * rh).sum())
+    lc = cfg["levels"] - 1 if wl.params == "baseline" else 4
+    sw, sh = round(cfg["w"] * 0.25), round(cfg["h"] * 0.25)
+    rows = []
+
+    def row(kernel, stage, alg_bytes, per_step_launches, note):
+        t = us(stage)
+        if t is None:
+            return
+        t_step = t * st_n[stage] / steps_prof  # stage time per step (a stage can launch more than once per step)
+        gbs = alg_bytes / (t_step * 1e-6) / 1e9 if t_step > 0 else 0.0
+        rows.append(dict(kernel=kernel, us_per_step=round(t_step, 2), launches_per_step=round(st_n[stage] / steps_prof, 2), alg_bytes_per_step=int(alg_bytes),
+                         hbm_gbs=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4), bytes=note))
+
+    gather_c = 2 * N * SG * (lc + 1) * ((wc + 2) ** 2 + (wc + 1) ** 2)
+    for stg, nm in ((0, "k_lk_q<15> (stage 1: quarter-scale image)"), (1, "k_lk_q<15> (stage 2: ROI)")):
+        t = 1e3 * ms_sum[stg] / max(launches[stg], 1)
+        rows.append(dict(kernel=nm if N * SG >= 3000 else nm.replace("k_lk_q<15>", "k_lk_strip<15>"), us_per_step=round(t, 2), launches_per_step=1.0, alg_bytes_per_step=int(gather_c),
+                         hbm_gbs=round(gather_c / (t * 1e-6) / 1e9, 1) if t > 0 else None, hbm_frac=round(gather_c / (t * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None,
+                         bytes="2 N L [(w+2)^2 + (w+1)^2] gather bytes, w = 15, L = pyramid levels; VALU bound like the fine stage"))
+    row("k_roi_warp (stage 3: float32 affine map + 5-bit bilinear remap of the ROI)", 3, 2.0 * roi_px, 1, "ROI read + ROI written (sum over the streams' ROIs of the last frame)")
+    pyr_bytes = SG * sw * sh * sum(4.0 ** -l * 1.25 for l in range(lc)) + 2.0 * roi_px * sum(4.0 ** -l * 1.25 for l in range(lc))
+    row("k_pyr_down + k_pyr_pad (quarter-scale pyramid of the new frame; ROI pyramids of both frames)", 4, pyr_bytes, 2 * lc,
+        "level l reads 4^-l and writes 4^-(l+1) of its image: new quarter-scale frame + the two ROI crops")
+    row("k_ransac_fused (2 x estimateAffine2D)", 5, 2 * 2 * 16.0 * N * SG, 2, "pairs read once per call (16 B each): latency / VALU bound, the byte figure is nominal")
+    row("k_resize_quarter", 6, SG * (cfg["w"] * cfg["h"] / 16.0) * 2, 1, "1/16 of the pixels read, as many written")
+    row("k_sess_frame (bookkeeping + fused LM pose + records)", 7, SG * N * (8 + 24 + 2 + 4) * 1.0, 1, "track state read (p, p3, masks, ids): latency bound (all LM iterations in one workgroup)")
+    accounted = us_fine + sum(r["us_per_step"] for r in rows)
+    hbm = dict(achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), alg_bytes_per_launch=bytes_fine,
+               traffic=traffic, traffic_source=tsrc, note="algorithmic gather bytes 2 N [(51+2)^2 + (51+1)^2] per stream over the launch time: far below the HBM roof, the kernel is not memory bound")
+    out = dict(bound="valu", kernel=fine_kernel + " (fine stage: 51x51 window, level 0, fwd+bwd)",
+               achieved=round(issued_tops, 3) if issued_tops else None, peak=round(peak_tops, 1), unit="T lane-instr/s",
+               frac=round(issued_tops / peak_tops, 4) if issued_tops else None, us_per_launch=round(us_fine, 2),
+               issued_ginstr_per_launch=round(issued / 1e9, 3) if issued else None, issued_source=isrc, issued_model_tolerance=tol,
+               setups_per_launch=int(su_f), newton_iters_per_launch=int(it_f),
+               peak_lanes_per_clk_per_simd=lanes, peak_source=peak_src, simds=N_SIMD, clock_ghz=CLOCK_GHZ,
+               note="track solve is VALU-issue bound (SURVEY §8d): frac = issued lane-instructions / launch time / (1024 SIMDs x 16 lanes x 2.4 GHz)",
+               # the contract's HBM view of the same kernel (secondary: achieved GB/s of its algorithmic bytes, PMC traffic)
+               hbm=hbm, traffic=traffic,
+               op_model=dict(gops_per_launch=round(ops_fine / 1e9, 4), tops=round(model_tops, 3),
+                             note="SURVEY §8d counts 47 op/px per set-up and 12 op/px per Newton iteration for a straightforward kernel; this kernel issues fewer "
+                                  "instructions for the same integers (packed int16 dot products), so the op model may exceed the issue peak -- frac prices issued instructions"),
+               newton_iters_per_track_dir=round(it_f / (2 * N * SG), 2), sq_valu_issue_utilisation=sq_util,
+               lk_us_per_launch=[round(1e3 * ms_sum[k] / max(launches[k], 1), 2) for k in range(3)],
+               lk_newton_iters_per_setup=[round(iters[k] / max(setups[k], 1), 2) for k in range(3)],
+               lk_setups_per_track=[round(setups[k] / max(launches[k], 1) / (N * SG), 2) for k in range(3)],
+               kernels=rows, step_us_accounted=round(accounted, 1), roi_mean_px=[round(float(rw.mean()), 1), round(float(rh.mean()), 1)])
+    return out
 
 
 def headline_hbm(cfg, fps):

@@ -366,15 +366,17 @@ __global__ void k_klt_glue2(StreamWS* ws_all)
 
 static int launch_lk_profiled(vh_ctx* c, int stage, const void* tab, size_t st, int count, int win, hipStream_t s, int mn)
 {
-    const bool on = c->prof_on && c->prof_n < c->prof_cap;
-    if (on) (void)hipEventRecord(c->prof_ev[2 * c->prof_n], s);
+    const int rec = vh_prof_start(c, s);
     const int r = vh_launch_lk(tab, st, count, mn, win, s);
-    if (on) {
-        (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], s);
-        c->prof_stage[c->prof_n++] = stage;
-    }
+    vh_prof_stop(c, rec, stage, s);
     return r;
 }
+#define VH_PROFILED(c, stage, s, ...)                 \
+    do {                                              \
+        const int rec_ = vh_prof_start((c), (s));     \
+        __VA_ARGS__;                                  \
+        vh_prof_stop((c), rec_, (stage), (s));        \
+    } while (0)
 
 int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine, const SessStream* sess,
                     const uint8_t* const* frames, int n_max)
@@ -384,19 +386,19 @@ int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_p
     const size_t st = sizeof(StreamWS);
     const int lvl_c = min(coarse.max_level, VH_MAX_LEVELS - 1), lvl_f = min(fine.max_level, VH_MAX_LEVELS - 1);
     hipLaunchKernelGGL(k_klt_setup, dim3(count), dim3(64), 0, s, ws, sess ? sess + slot : nullptr, frames, coarse, fine);
-    vh_launch_resize_quarter(&ws->rs_src[0], &ws->rs_dst[0], st, 2, count, c->sw, c->sh, s);
-    for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->sw, c->sh, s);
+    VH_PROFILED(c, VH_PROF_RESIZE, s, vh_launch_resize_quarter(&ws->rs_src[0], &ws->rs_dst[0], st, 2, count, c->sw, c->sh, s));
+    VH_PROFILED(c, VH_PROF_PYR, s, for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->sw, c->sh, s));
     int r = launch_lk_profiled(c, 0, &ws->lk, st, count, coarse.win, s, mn);
     if (r) return vh_fail(r, "vh_launch_lk failed (window too large for LDS?)");
-    vh_launch_ransac(&ws->ransac, st, count, mn, s);
+    VH_PROFILED(c, VH_PROF_RANSAC, s, vh_launch_ransac(&ws->ransac, st, count, mn, s));
     hipLaunchKernelGGL(k_klt_glue1, dim3(count), dim3(256), 0, s, ws);  // (does the zero-padded shifted crop itself when one is needed)
-    for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->max_w, c->max_h, s);
+    VH_PROFILED(c, VH_PROF_PYR, s, for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->max_w, c->max_h, s));
     r = launch_lk_profiled(c, 1, &ws->lk, st, count, coarse.win, s, mn);
     if (r) return vh_fail(r, "vh_launch_lk failed");
-    vh_launch_ransac(&ws->ransac, st, count, mn, s);
+    VH_PROFILED(c, VH_PROF_RANSAC, s, vh_launch_ransac(&ws->ransac, st, count, mn, s));
     hipLaunchKernelGGL(k_klt_glue2, dim3(count), dim3(64), 0, s, ws);
-    vh_launch_roi_warp(&ws->warp, st, count, c->max_w, c->max_h, s);
-    for (int l = 0; l < lvl_f; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->max_w, c->max_h, s);
+    VH_PROFILED(c, VH_PROF_WARP, s, vh_launch_roi_warp(&ws->warp, st, count, c->max_w, c->max_h, s));
+    if (lvl_f > 0) VH_PROFILED(c, VH_PROF_PYR, s, for (int l = 0; l < lvl_f; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->max_w, c->max_h, s));
     r = launch_lk_profiled(c, 2, &ws->lk, st, count, fine.win, s, mn);
     if (r) return vh_fail(r, "vh_launch_lk failed");
     VH_LAUNCH_CHECK();
@@ -433,6 +435,7 @@ extern "C" VH_API int vh_profile_end(vh_ctx* c, double* ms_sum, int* launches, u
     for (int k = 0; k < c->prof_n; k++) {
         float ms = 0.f;
         VH_CHECK(hipEventElapsedTime(&ms, c->prof_ev[2 * k], c->prof_ev[2 * k + 1]));
+        if (c->prof_stage[k] > 2) continue;  // the other stages: vh_profile_end_stages
         ms_sum[c->prof_stage[k]] += ms;
         launches[c->prof_stage[k]]++;
     }
@@ -441,6 +444,31 @@ extern "C" VH_API int vh_profile_end(vh_ctx* c, double* ms_sum, int* launches, u
         VH_CHECK(hipMemcpy(st, c->d_ws[b].lk_stats, sizeof(st), hipMemcpyDeviceToHost));
         for (int k = 0; k < 3; k++) { iters[k] += st[k][0]; setups[k] += st[k][1]; }
     }
+    return 0;
+}
+
+// every profiled stage (VH_PROF_* in vh_ws.hpp): ms_sum[nstages], launches[nstages]; call after (or instead of) vh_profile_end
+extern "C" VH_API int vh_profile_end_stages(vh_ctx* c, int nstages, double* ms_sum, int* launches)
+{
+    if (!c || nstages < 1 || !ms_sum || !launches) return vh_fail(-1, "vh_profile_end_stages: bad arguments");
+    c->prof_on = 0;
+    VH_CHECK(hipDeviceSynchronize());
+    for (int k = 0; k < nstages; k++) { ms_sum[k] = 0; launches[k] = 0; }
+    for (int k = 0; k < c->prof_n; k++) {
+        float ms = 0.f;
+        VH_CHECK(hipEventElapsedTime(&ms, c->prof_ev[2 * k], c->prof_ev[2 * k + 1]));
+        const int st = c->prof_stage[k];
+        if (st >= 0 && st < nstages) { ms_sum[st] += ms; launches[st]++; }
+    }
+    return 0;
+}
+
+// ROI of the last KLTmain call of every stream (x0, x1, y0, y1), host copy: the algorithmic bytes of the ROI-sized stages (bench.py's per-kernel rows)
+extern "C" VH_API int vh_klt_rois(vh_ctx* c, int* roi_host)
+{
+    if (!c || !roi_host) return vh_fail(-1, "vh_klt_rois: bad arguments");
+    VH_CHECK(hipDeviceSynchronize());
+    for (int b = 0; b < c->batch; b++) VH_CHECK(hipMemcpy(roi_host + 4 * b, c->d_ws[b].roi, 4 * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -864,6 +892,7 @@ extern "C" VH_API int vh_nls_batch(vh_ctx* c, const double* K_host, const double
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch: workspace too small");
     BaProblem P;
     P.graph_cache = &c->ba_graphs;
+    P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt); P.force_valu = g_ba_force_valu;
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 0;
@@ -885,6 +914,7 @@ extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const double* K_host, const 
         return vh_fail(-1, "vh_nls_batch_multi: per-window workspace too small or not a multiple of 256 bytes");
     BaProblem P;
     P.graph_cache = &c->ba_graphs;
+    P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.force_valu = g_ba_force_valu;
     // fewer partial systems per window when many windows fill the chip anyway (the partials are reduced through HBM)
@@ -908,6 +938,7 @@ extern "C" VH_API int vh_nls_batch2(vh_ctx* c, const double* K_host, const doubl
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch2: workspace too small");
     BaProblem P;
     P.graph_cache = &c->ba_graphs;
+    P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt); P.force_valu = 1;
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 1;
@@ -932,6 +963,7 @@ extern "C" VH_API int vh_nls_batch_phase(vh_ctx* c, const double* K_host, const 
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch_phase: workspace too small");
     BaProblem P;
     P.graph_cache = &c->ba_graphs;
+    P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = 1; P.nparts = ba_parts(nt);
     P.force_valu = g_ba_force_valu;

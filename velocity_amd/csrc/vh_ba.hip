@@ -8,6 +8,7 @@
 //     H = [[U  W],[W^T V]] + I,   S = V + I - W^T (U+I)^-1 W,   S dc = gc - W^T (U+I)^-1 gp,   dp = (U+I)^-1 (gp - W dc)
 // Everything stays on the device for all iterations (the convergence test only sets a device flag).
 #include "vh_ba.hpp"
+#include "vh_ws.hpp"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -865,27 +866,41 @@ __global__ __launch_bounds__(G * G) void k_ba_solve(BaJob J, int nparts)
 // travel through double-buffered LDS vectors, every lane inverts the 4 x 4 pivot block itself (two dependent reciprocals), 2 x (8 - r/4) MFMAs.
 // 29 rounds at nq = 114 instead of the 57 rank-2 rounds of the VALU kernel below, and the 16 K multiply-adds of a round are 16 instructions
 // per wavefront instead of 128 v_fma_f64: 64 us -> see DESIGN.md section 6.  S is SPD, so no pivoting is needed (every leading block is SPD).
-__device__ __forceinline__ void ba_inv4(const double (&P)[4][4], double (&Q)[4][4])
+// 1 / x from v_rcp_f64 + two Newton steps (relative error ~1e-16; the IEEE division sequence is 11 dependent instructions, this is 5)
+__device__ __forceinline__ double ba_rcp(double x)
 {
-    // block LU on 2 x 2 blocks: P = [[A B],[C D]], T = A^-1 B, Sc = D - C T; P^-1 = [[A^-1 + T Sc^-1 C A^-1, -T Sc^-1],[-Sc^-1 C A^-1, Sc^-1]]
-    const double ia = 1.0 / (P[0][0] * P[1][1] - P[0][1] * P[1][0]);
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return y;
+}
+
+// column `col` (0..3, per lane) of the inverse of the 4 x 4 pivot block P, through block LU on 2 x 2 blocks:
+//   P = [[A B],[C D]], T = A^-1 B, Sc = D - C T, V = Sc^-1 C A^-1;  P^-1 = [[A^-1 + T V, -T Sc^-1],[-V, Sc^-1]]
+// Two dependent reciprocals; the shared intermediates are the same in every lane, only the last four products depend on the column.
+__device__ __forceinline__ void ba_inv4_col(const double (&P)[4][4], int col, double (&q)[4])
+{
+    const double ia = ba_rcp(__builtin_fma(P[0][0], P[1][1], -(P[0][1] * P[1][0])));
     const double a00 = P[1][1] * ia, a01 = -P[0][1] * ia, a10 = -P[1][0] * ia, a11 = P[0][0] * ia;
-    const double t00 = a00 * P[0][2] + a01 * P[1][2], t01 = a00 * P[0][3] + a01 * P[1][3];
-    const double t10 = a10 * P[0][2] + a11 * P[1][2], t11 = a10 * P[0][3] + a11 * P[1][3];
-    const double s00 = P[2][2] - (P[2][0] * t00 + P[2][1] * t10), s01 = P[2][3] - (P[2][0] * t01 + P[2][1] * t11);
-    const double s10 = P[3][2] - (P[3][0] * t00 + P[3][1] * t10), s11 = P[3][3] - (P[3][0] * t01 + P[3][1] * t11);
-    const double is = 1.0 / (s00 * s11 - s01 * s10);
+    const double t00 = __builtin_fma(a00, P[0][2], a01 * P[1][2]), t01 = __builtin_fma(a00, P[0][3], a01 * P[1][3]);
+    const double t10 = __builtin_fma(a10, P[0][2], a11 * P[1][2]), t11 = __builtin_fma(a10, P[0][3], a11 * P[1][3]);
+    const double s00 = __builtin_fma(-P[2][1], t10, __builtin_fma(-P[2][0], t00, P[2][2])), s01 = __builtin_fma(-P[2][1], t11, __builtin_fma(-P[2][0], t01, P[2][3]));
+    const double s10 = __builtin_fma(-P[3][1], t10, __builtin_fma(-P[3][0], t00, P[3][2])), s11 = __builtin_fma(-P[3][1], t11, __builtin_fma(-P[3][0], t01, P[3][3]));
+    const double is = ba_rcp(__builtin_fma(s00, s11, -(s01 * s10)));
     const double d00 = s11 * is, d01 = -s01 * is, d10 = -s10 * is, d11 = s00 * is;  // Sc^-1
-    // U = C A^-1 (2 x 2), V = Sc^-1 U
-    const double u00 = P[2][0] * a00 + P[2][1] * a10, u01 = P[2][0] * a01 + P[2][1] * a11;
-    const double u10 = P[3][0] * a00 + P[3][1] * a10, u11 = P[3][0] * a01 + P[3][1] * a11;
-    const double v00 = d00 * u00 + d01 * u10, v01 = d00 * u01 + d01 * u11, v10 = d10 * u00 + d11 * u10, v11 = d10 * u01 + d11 * u11;
-    Q[2][0] = -v00; Q[2][1] = -v01; Q[3][0] = -v10; Q[3][1] = -v11;
-    Q[2][2] = d00; Q[2][3] = d01; Q[3][2] = d10; Q[3][3] = d11;
-    Q[0][2] = -(t00 * d00 + t01 * d10); Q[0][3] = -(t00 * d01 + t01 * d11);
-    Q[1][2] = -(t10 * d00 + t11 * d10); Q[1][3] = -(t10 * d01 + t11 * d11);
-    Q[0][0] = a00 + (t00 * v00 + t01 * v10); Q[0][1] = a01 + (t00 * v01 + t01 * v11);
-    Q[1][0] = a10 + (t10 * v00 + t11 * v10); Q[1][1] = a11 + (t10 * v01 + t11 * v11);
+    const double u00 = __builtin_fma(P[2][0], a00, P[2][1] * a10), u01 = __builtin_fma(P[2][0], a01, P[2][1] * a11);  // U = C A^-1
+    const double u10 = __builtin_fma(P[3][0], a00, P[3][1] * a10), u11 = __builtin_fma(P[3][0], a01, P[3][1] * a11);
+    const double v00 = __builtin_fma(d00, u00, d01 * u10), v01 = __builtin_fma(d00, u01, d01 * u11);                  // V = Sc^-1 U
+    const double v10 = __builtin_fma(d10, u00, d11 * u10), v11 = __builtin_fma(d10, u01, d11 * u11);
+    // column c < 2: (a_.c + T V_.c ; -V_.c)      column c >= 2: (-T D_.c' ; D_.c')  with c' = c - 2
+    const bool left = col < 2, odd = (col & 1) != 0;
+    const double g0 = left ? (odd ? v01 : v00) : (odd ? d01 : d00), g1 = left ? (odd ? v11 : v10) : (odd ? d11 : d10);
+    const double h0 = left ? (odd ? a01 : a00) : 0.0, h1 = left ? (odd ? a11 : a10) : 0.0;
+    const double e0 = __builtin_fma(t00, g0, t01 * g1), e1 = __builtin_fma(t10, g0, t11 * g1);
+    q[0] = left ? h0 + e0 : -e0;
+    q[1] = left ? h1 + e1 : -e1;
+    q[2] = left ? -g0 : g0;
+    q[3] = left ? -g1 : g1;
 }
 
 #define BA_GJ_N 128
@@ -931,7 +946,7 @@ __global__ __launch_bounds__(256) void k_ba_solve_mfma(BaJob J)
         const int c0 = 4 * r;
         if (c0 >= nq) break;
         const int buf = r & 1, J0 = r >> 2;
-        double P[4][4], Q[4][4];
+        double P[4][4];
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
@@ -945,17 +960,13 @@ __global__ __launch_bounds__(256) void k_ba_solve_mfma(BaJob J)
 #pragma unroll
         for (int Jt = 0; Jt < 8; Jt++)
             if (Jt >= J0) b[Jt] = s_R[buf][lr][16 * Jt + lc];
-        ba_inv4(P, Q);
-        if (tid == 0) {
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) s_pinv[r][4 * m + k] = Q[m][k];
-        }
-        // my column lr of P^-1
+        // my column lr of P^-1 (the A operand of lane l is F[16 I + (l & 15)][l >> 4] = sum_m C[.][m] Pinv[m][l >> 4])
         double pk[4];
+        ba_inv4_col(P, lr, pk);
+        if (w == 0 && lc == 0) {
 #pragma unroll
-        for (int m = 0; m < 4; m++) pk[m] = lr == 0 ? Q[m][0] : (lr == 1 ? Q[m][1] : (lr == 2 ? Q[m][2] : Q[m][3]));
+            for (int m = 0; m < 4; m++) s_pinv[r][4 * m + lr] = pk[m];
+        }
         double f[2];
 #pragma unroll
         for (int il = 0; il < 2; il++) {
@@ -1265,26 +1276,42 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         hipLaunchKernelGGL(k_ba_init, dim3(1, nw), dim3(64), 0, s, J, flags);
         return (int)hipGetLastError();
     };
+    vh_ctx* pc = P.ctx;  // per-kernel event timing (bench.py's ba.roofline); profiled solves are launched plainly, never replayed
+    const bool profiling = pc && pc->prof_on;
     auto normal_equations = [&](int it) {
         if (it == 0) hipLaunchKernelGGL(k_ba_cams, dim3((nc + 1 + 63) / 64, nw), dim3(64), 0, s, J);
         const int ppb = BA_THREADS / (nc + 1);  // k_ba_jac: whole points per block
         if (use_mfma) {
+            int rec = vh_prof_start(pc, s);
             hipLaunchKernelGGL(k_ba_jac<true>, dim3((nt + ppb - 1) / ppb, nw), dim3(BA_THREADS), 0, s, J);
+            vh_prof_stop(pc, rec, VH_PROF_BA_JAC, s);
+            rec = vh_prof_start(pc, s);
             hipLaunchKernelGGL(k_ba_schur_mfma, dim3(nparts, nw), dim3(BA_SCHUR_THREADS), lds_mfma, s, J);
+            vh_prof_stop(pc, rec, VH_PROF_BA_SCHUR, s);
         } else {
+            int rec = vh_prof_start(pc, s);
             hipLaunchKernelGGL(k_ba_jac<false>, dim3((nt + ppb - 1) / ppb, nw), dim3(BA_THREADS), 0, s, J);
+            vh_prof_stop(pc, rec, VH_PROF_BA_JAC, s);
+            rec = vh_prof_start(pc, s);
             for (int pass = 0; pass < npass; pass++)  // later passes overwrite Spart entries of their own range only
                 hipLaunchKernelGGL(k_ba_points, dim3(nparts, nw), dim3(BA_THREADS), lds, s, J, pass);
+            vh_prof_stop(pc, rec, VH_PROF_BA_SCHUR, s);
         }
+        const int rec = vh_prof_start(pc, s);
         hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((nent + nq + 63) / 64), nw), dim3(BA_THREADS), 0, s, J, nparts);
+        vh_prof_stop(pc, rec, VH_PROF_BA_REDUCE, s);
     };
     auto solve_update = [&](int it) {
-        // up to 127 unknowns: 256 threads x 64 doubles (same speed as 1024 x 16: the step is a latency chain, not work)
-        if (nq <= BA_GJ_MAXQ && !(J.dbg & 64)) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1, nw), dim3(256), 0, s, J);  // block Gauss-Jordan on the matrix cores
+        int rec = vh_prof_start(pc, s);
+        // up to 124 unknowns: block Gauss-Jordan on the matrix cores; above: register-resident VALU Gauss-Jordan (256 threads x 64 doubles, then 1024 threads)
+        if (nq <= BA_GJ_MAXQ && !(J.dbg & 64)) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1, nw), dim3(256), 0, s, J);
         else if (nq + 1 <= 128) hipLaunchKernelGGL((k_ba_solve<8, 8, 16>), dim3(1, nw), dim3(256), 0, s, J, nparts);
         else if (nq <= 192) hipLaunchKernelGGL((k_ba_solve<6, 7, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
         else hipLaunchKernelGGL((k_ba_solve<8, 9, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
+        vh_prof_stop(pc, rec, VH_PROF_BA_SOLVE, s);
+        rec = vh_prof_start(pc, s);
         hipLaunchKernelGGL(k_ba_update, dim3(upd_blocks, nw), dim3(BA_THREADS), 0, s, J, it);
+        vh_prof_stop(pc, rec, VH_PROF_BA_UPDATE, s);
     };
     switch (P.phase) {
     case -1: {
@@ -1294,7 +1321,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         BaGraphKey key;
         memset(&key, 0, sizeof(key));
         memcpy(&key.J, &J, sizeof(J)); key.flags0 = flags; key.max_iter = P.max_iter; key.nparts = nparts; key.use_mfma = use_mfma ? 1 : 0;
-        BaGraphCache* gc = ba_graph_cache(P.graph_cache);
+        BaGraphCache* gc = profiling ? nullptr : ba_graph_cache(P.graph_cache);
         BaGraphEntry* e = gc ? gc->find(key, s) : nullptr;
         if (e && e->exec) {
             if (hipGraphLaunch(e->exec, s) == hipSuccess) break;

@@ -55,6 +55,7 @@ struct BaProblem {
     int force_valu;  // test hook: 1 = accumulate the reduced camera system on the VALU instead of the matrix cores
     int nwin;        // independent windows solved by the same launches (>= 1); z, x, trace, info and workspace are arrays of nwin
     size_t ws_stride, z_stride, x_stride, trace_stride, info_stride;  // see BaJob (ignored when nwin == 1)
+    struct vh_ctx* ctx;  // may be null: per-kernel HIP-event timing when its profiling is on (vh_profile_begin)
     void** graph_cache;  // may be null: where the owner (vh_ctx) keeps the replayable launch sequences of whole solves (vh_ba_graph_cache_free)
 };
 void vh_ba_graph_cache_free(void* cache);

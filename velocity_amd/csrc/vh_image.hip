@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void k_pyr_down(const void* pb_tab, size_t ws_
 // (translateFlag branch, SURVEY App. B intent); mode 1: float32 affine map + remap(INTER_LINEAR) with 5-bit
 // fixed-point coordinates and 15-bit weights, constant-0 border.  One thread = 4 consecutive ROI pixels.
 // ---------------------------------------------------------------------------------------------------------------
-#define RW_ROWS 4  // ROI rows per thread: their source loads are all in flight together (one memory round trip per 16 pixels)
+#define RW_ROWS 4  // ROI rows per thread: their source loads are all in flight together
+#define RW_PX 8    // consecutive ROI pixels per thread and row (two packed dword stores)
 
 __device__ __forceinline__ void roi_store4(uint8_t* drow, int x4, int cnt, uint32_t pack)
 {
@@ -206,108 +207,189 @@ __device__ __forceinline__ uint32_t remap_blend(int s00, int s01, int s10, int s
     return (uint32_t)((32 * t + ay * (b - t) + (1 << 9)) >> 10);
 }
 
+// RNE(v) of a float32 |v| < 2^22 as ONE add: v + 1.5 * 2^23 has ulp 1, so the add rounds v to the nearest integer (ties to even, like cvRound),
+// and the result's bit pattern is RW_MAGIC_I + round(v).  RW_MAGIC_I has its low 5 bits clear: (bits & 31) is already the 5-bit fraction.
+#define RW_MAGIC 12582912.f
+#define RW_MAGIC_I 0x4B400000
+#define RW_RANGE 4000000.f
+
+// the blends of one row of RW_PX pixels on the run path: T / B hold the source bytes of the top / bottom row from column c0 = sx0 - 1 on (byte j =
+// column c0 + j).  Pixel k samples columns c0 + k + dk, dk in {0, 1, 2} (a zoom drifts the source column against k), i.e. two of the four bytes of the
+// window starting at byte k: t = (32-ax) s00 + ax s01 is ONE v_dot4_u32_u8 of that window with the byte weights (32 - ax | ax << 8) shifted to byte dk --
+// no byte selection, no widening.  Then (32-ay) t + ay b + 2^9 with the y weights pre-shifted by 6 bits, so that the result byte is byte 2.
+__device__ __forceinline__ void rw_row_blend(const unsigned (&T)[4], const unsigned (&B)[4], const unsigned (&wxb)[RW_PX], const unsigned (&wlo)[RW_PX],
+                                             const unsigned (&whi)[RW_PX], uint32_t& out0, uint32_t& out1)
+{
+    unsigned r[RW_PX];
+#pragma unroll
+    for (int k = 0; k < RW_PX; k++) {
+        const int d = k >> 2, sh = k & 3;
+        const unsigned tw = sh ? __builtin_amdgcn_alignbyte(T[d + 1], T[d], sh) : T[d];
+        const unsigned bw = sh ? __builtin_amdgcn_alignbyte(B[d + 1], B[d], sh) : B[d];
+        const unsigned t = __builtin_amdgcn_udot4(tw, wxb[k], 0u, false), b = __builtin_amdgcn_udot4(bw, wxb[k], 0u, false);
+        r[k] = __umul24(b, whi[k]) + (__umul24(t, wlo[k]) + (1u << 15));  // ((32-ay) t + ay b + 2^9) << 6: the 8-bit result sits in bits 16..23
+    }
+    const unsigned p01 = __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0602u), p23 = __builtin_amdgcn_perm(r[3], r[2], 0x06020c0cu);
+    const unsigned p45 = __builtin_amdgcn_perm(r[5], r[4], 0x0c0c0602u), p67 = __builtin_amdgcn_perm(r[7], r[6], 0x06020c0cu);
+    out0 = p01 | p23;
+    out1 = p45 | p67;
+}
+
+typedef uint32_t rw_u32x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) rw_store8 { rw_u32x2 v; };
+struct rw_load16 { unsigned a, b, c, d; };
+
 __global__ __launch_bounds__(256) void k_roi_warp(const void* job_tab, size_t tab_stride)
 {
     const WarpJob J = *reinterpret_cast<const WarpJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.z * tab_stride);
     if (J.mode < 0) return;
     const int rw = J.x1 - J.x0, rh = J.y1 - J.y0;
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int x8 = (blockIdx.x * blockDim.x + threadIdx.x) * RW_PX;
     const int ry0 = (blockIdx.y * blockDim.y + threadIdx.y) * RW_ROWS;
-    if (ry0 >= rh || x4 >= rw) return;
+    if (ry0 >= rh || x8 >= rw) return;
     const ImgDesc s = J.src;
-    const int cnt = min(4, rw - x4);
+    const int cnt = min(RW_PX, rw - x8);
     if (J.mode == 0) {
         for (int r = 0; r < RW_ROWS && ry0 + r < rh; r++) {
             const int sy = J.y0 + ry0 + r + J.dy;
             const bool yin = sy >= 0 && sy < s.h;
-            uint32_t pack = 0;
-            for (int k = 0; k < cnt; k++) {
-                int sx = J.x0 + x4 + k + J.dx;
-                uint32_t v = (yin && sx >= 0 && sx < s.w) ? s.p[(size_t)sy * s.stride + sx] : 0u;
-                pack |= v << (8 * k);
+            for (int g = 0; g < cnt; g += 4) {
+                const int c4 = min(4, cnt - g);
+                uint32_t pack = 0;
+                for (int k = 0; k < c4; k++) {
+                    int sx = J.x0 + x8 + g + k + J.dx;
+                    uint32_t v = (yin && sx >= 0 && sx < s.w) ? s.p[(size_t)sy * s.stride + sx] : 0u;
+                    pack |= v << (8 * k);
+                }
+                roi_store4(J.dst + (size_t)(ry0 + r) * J.dst_stride, x8 + g, c4, pack);
             }
-            roi_store4(J.dst + (size_t)(ry0 + r) * J.dst_stride, x4, cnt, pack);
         }
         return;
     }
-    // affine remap: coordinates of RW_ROWS x 4 pixels, then every row's source loads, then the blends
-    float xa[4], xb[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float x = (float)(J.x0 + x4 + k);
-        xa[k] = __fmul_rn(x, J.T[0]);
-        xb[k] = __fmul_rn(x, J.T[1]);
-    }
-    int fx[RW_ROWS][4], fy[RW_ROWS][4];
-    unsigned t0[RW_ROWS], t1[RW_ROWS], b0[RW_ROWS], b1[RW_ROWS], sh0[RW_ROWS], sh1[RW_ROWS];
-    // near-identity maps (the tracker's case): the 4 pixels of a row sample one source row pair at consecutive columns, so the 2 x 5 source
-    // bytes come from two aligned dword pairs instead of 16 byte gathers.  The whole thread (4 rows) takes that path or none of it does:
-    // one branch per thread, straight-line code inside (per-row branches cost a third of the kernel's instructions in exec juggling).
-    unsigned bad = (cnt != 4 || ry0 + RW_ROWS > rh) ? ~0u : 0u;
+    // affine remap (numpy: x*T00 + y*T10 + T20 in float32, one rounding per operation, no fma; then cvRound(32 m)).  The map is evaluated 32 x
+    // scaled: a power-of-two factor commutes with every float32 rounding, so fl(fl(32 x T00 + 32 y T10) + 32 T20) == 32 m bit for bit, and the
+    // rounding to an integer is the single add of RW_MAGIC (see above) -- 3 adds per coordinate instead of 2 adds + mul + rndne + cvt.
+    //
+    // Near-identity maps (the tracker's case: translation + zoom + a little rotation): the RW_PX pixels of a row sample ONE source row pair, at
+    // columns that run with k up to a drift of one column either way -- so the 2 x 11 source bytes come from two aligned 16-byte loads instead of 32
+    // byte gathers ("run path").  Order of work: (A) the FIRST pixel of every row gives the load addresses (clamped into the frame, so the loads are
+    // unconditional and leave at once), (B) the other coordinates, the run-path test and the weights are computed while the loads fly, (C) the
+    // blends, (D) the stores -- or, for a thread whose rows do not qualify (ROI edge, strong rotation / zoom, map outside the frame), the general
+    // per-pixel path.  No branch before (D): the straight-line part is what every interior thread runs.
+    const float T0 = __fmul_rn(J.T[0], 32.f), T1 = __fmul_rn(J.T[1], 32.f), T2 = __fmul_rn(J.T[2], 32.f), T3 = __fmul_rn(J.T[3], 32.f),
+                T4 = __fmul_rn(J.T[4], 32.f), T5 = __fmul_rn(J.T[5], 32.f);
+    const float xbase = (float)(J.x0 + x8);
+    float xa[RW_PX], xb[RW_PX];
+    xa[0] = __fmul_rn(xbase, T0); xb[0] = __fmul_rn(xbase, T1);
+    int fb[RW_ROWS][RW_PX], fyb[RW_ROWS][RW_PX];  // RW_MAGIC_I + fx, RW_MAGIC_I + fy
+    int cb[RW_ROWS];                               // RW_MAGIC_I + 32 c0: fx[k] - 32 (c0 + k) = fb[k] - cb - 32 k
+    float yx[RW_ROWS], yy[RW_ROWS];
+    rw_load16 tq[RW_ROWS], bq[RW_ROWS];
+    unsigned sh0[RW_ROWS], sh1[RW_ROWS];
+    unsigned bad = (cnt != RW_PX || ry0 + RW_ROWS > rh || s.w < 20 || s.h < 2) ? ~0u : 0u;
+    if (((reinterpret_cast<uintptr_t>(J.dst) | (uintptr_t)J.dst_stride) & 3) != 0) bad = ~0u;  // packed dword stores need dword rows (x8 is a multiple of 8)
     const unsigned bsh = (unsigned)(reinterpret_cast<uintptr_t>(s.p) & 3);
     const uint8_t* bp = s.p - bsh;  // dword aligned, wave uniform
+    // (A)
 #pragma unroll
     for (int r = 0; r < RW_ROWS; r++) {
         const float y = (float)(J.y0 + ry0 + r);
-        const float yx = __fmul_rn(y, J.T[2]), yy = __fmul_rn(y, J.T[3]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            // float32, one rounding per operation, no fma (numpy: x*T00 + y*T10 + T20)
-            const float mx = __fadd_rn(__fadd_rn(xa[k], yx), J.T[4]);
-            const float my = __fadd_rn(__fadd_rn(xb[k], yy), J.T[5]);
-            fx[r][k] = vh_round(__fmul_rn(mx, 32.f));
-            fy[r][k] = vh_round(__fmul_rn(my, 32.f));
-        }
-        const int sx0 = fx[r][0] >> 5, sy0 = fy[r][0] >> 5;
-        // (fx[k] >> 5) == sx0 + k  <=>  0 <= fx[k] - 32 (sx0 + k) < 32;  (fy[k] >> 5) == sy0  <=>  (fy[k] ^ fy[0]) < 32: one unsigned compare of the OR;
-        // source window inside the frame: sx0 >= 3, sx0 + 8 <= w, 0 <= sy0 < h - 1 as unsigned range tests
-        const int bx = fx[r][0] & ~31;
-        const unsigned spread = (unsigned)(fx[r][1] - bx - 32) | (unsigned)(fx[r][2] - bx - 64) | (unsigned)(fx[r][3] - bx - 96) |
-                                (unsigned)(fy[r][1] ^ fy[r][0]) | (unsigned)(fy[r][2] ^ fy[r][0]) | (unsigned)(fy[r][3] ^ fy[r][0]);
-        const bool ok = spread < 32u && (unsigned)(sx0 - 3) <= (unsigned)(s.w - 11) && (unsigned)sy0 < (unsigned)(s.h - 1) && s.w >= 11;
-        bad |= ok ? 0u : ~0u;
-        // unconditional loads (a branch around a load makes the compiler wait per row): rows that do not qualify read the first bytes of the frame
-        const unsigned o0 = (ok ? (unsigned)(__mul24(sy0, s.stride) + sx0) : 0u) + bsh, o1 = o0 + (ok ? (unsigned)s.stride : 0u);
+        yx[r] = __fmul_rn(y, T2); yy[r] = __fmul_rn(y, T3);
+        const float mx = __fadd_rn(__fadd_rn(xa[0], yx[r]), T4), my = __fadd_rn(__fadd_rn(xb[0], yy[r]), T5);
+        // the magic add needs |32 m| < 2^22: checked on the first and (below) the last pixel of the row -- every operation of the map is monotone in x
+        bad |= (fabsf(mx) < RW_RANGE && fabsf(my) < RW_RANGE) ? 0u : ~0u;
+        fb[r][0] = __float_as_int(__fadd_rn(mx, RW_MAGIC));
+        fyb[r][0] = __float_as_int(__fadd_rn(my, RW_MAGIC));
+        const int c0 = ((fb[r][0] - RW_MAGIC_I) >> 5) - 1, sy0 = (fyb[r][0] - RW_MAGIC_I) >> 5;
+        // source window inside the frame: the aligned 16-byte loads cover columns c0 - 3 .. c0 + 15
+        const int cx = min(max(c0, 3), s.w - 16), cy = min(max(sy0, 0), s.h - 2);
+        bad |= (cx != c0 || cy != sy0) ? ~0u : 0u;
+        cb[r] = (fb[r][0] & ~31) - 32;
+        const unsigned o0 = (unsigned)(__mul24(cy, s.stride) + cx) + bsh, o1 = o0 + (unsigned)s.stride;
         sh0[r] = o0 & 3u; sh1[r] = o1 & 3u;
         pd_gptr p0 = (pd_gptr)(bp + (o0 & ~3u)), p1 = (pd_gptr)(bp + (o1 & ~3u));
-        t0[r] = p0[0]; t1[r] = p0[1]; b0[r] = p1[0]; b1[r] = p1[1];
+        tq[r].a = p0[0]; tq[r].b = p0[1]; tq[r].c = p0[2]; tq[r].d = p0[3];
+        bq[r].a = p1[0]; bq[r].b = p1[1]; bq[r].c = p1[2]; bq[r].d = p1[3];
     }
-    if (((reinterpret_cast<uintptr_t>(J.dst) | (uintptr_t)J.dst_stride) & 3) != 0) bad = ~0u;  // packed dword stores need dword rows (x4 is a multiple of 4)
+    __builtin_amdgcn_sched_barrier(0);  // all 8 loads leave here: the scheduler otherwise sinks each row's pair next to its blend (4 serial round trips)
+    // (B)
+#pragma unroll
+    for (int k = 1; k < RW_PX; k++) {
+        const float x = xbase + (float)k;  // exact (integers below 2^24)
+        xa[k] = __fmul_rn(x, T0); xb[k] = __fmul_rn(x, T1);
+    }
+    unsigned wxb[RW_ROWS][RW_PX];
+#pragma unroll
+    for (int r = 0; r < RW_ROWS; r++) {
+        float mx7 = 0.f, my7 = 0.f;
+#pragma unroll
+        for (int k = 1; k < RW_PX; k++) {
+            const float mx = __fadd_rn(__fadd_rn(xa[k], yx[r]), T4), my = __fadd_rn(__fadd_rn(xb[k], yy[r]), T5);
+            fb[r][k] = __float_as_int(__fadd_rn(mx, RW_MAGIC));
+            fyb[r][k] = __float_as_int(__fadd_rn(my, RW_MAGIC));
+            if (k == RW_PX - 1) { mx7 = mx; my7 = my; }
+        }
+        // e_k = fx[k] - 32 (c0 + k) must lie in [0, 96): source column c0 + k + dk with dk = e_k >> 5 in {0, 1, 2} (e_0 is in [32, 64) by construction);
+        // (fy[k] >> 5) == sy0 for every k  <=>  for k = 7 (monotone)
+        unsigned over = (unsigned)(fyb[r][RW_PX - 1] ^ fyb[r][0]) >> 5;
+#pragma unroll
+        for (int k = 0; k < RW_PX; k++) {
+            const unsigned e = (unsigned)(fb[r][k] - cb[r] - 32 * k);
+            over |= (e >= 96u) ? 1u : 0u;
+            // byte weights (32 - ax | ax << 8) = 255 ax + 32, moved to byte dk of the window that starts at byte k
+            wxb[r][k] = (__umul24((unsigned)(fb[r][k] & 31), 255u) + 32u) << ((e >> 2) & 0x18u);
+        }
+        bad |= (over == 0u && fabsf(mx7) < RW_RANGE && fabsf(my7) < RW_RANGE) ? 0u : ~0u;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (C)
+    uint32_t res[RW_ROWS][2];
+#pragma unroll
+    for (int r = 0; r < RW_ROWS; r++) {
+        unsigned T[4], B[4], wlo[RW_PX], whi[RW_PX];
+        T[0] = __builtin_amdgcn_alignbyte(tq[r].b, tq[r].a, sh0[r]); T[1] = __builtin_amdgcn_alignbyte(tq[r].c, tq[r].b, sh0[r]);
+        T[2] = __builtin_amdgcn_alignbyte(tq[r].d, tq[r].c, sh0[r]); T[3] = tq[r].d >> (8 * sh0[r]);
+        B[0] = __builtin_amdgcn_alignbyte(bq[r].b, bq[r].a, sh1[r]); B[1] = __builtin_amdgcn_alignbyte(bq[r].c, bq[r].b, sh1[r]);
+        B[2] = __builtin_amdgcn_alignbyte(bq[r].d, bq[r].c, sh1[r]); B[3] = bq[r].d >> (8 * sh1[r]);
+#pragma unroll
+        for (int k = 0; k < RW_PX; k++) {
+            const unsigned ay64 = (unsigned)(fyb[r][k] & 31) << 6;
+            wlo[k] = 2048u - ay64; whi[k] = ay64;
+        }
+        rw_row_blend(T, B, wxb[r], wlo, whi, res[r][0], res[r][1]);
+    }
+    // (D)
     if (bad == 0u) {
 #pragma unroll
         for (int r = 0; r < RW_ROWS; r++) {
-            // remap_blend on packed int16 pairs: t = (32-ax) s00 + ax s01 and b likewise are two v_dot2 of the byte pairs (k, k+1) with
-            // (32-ax | ax << 16) = 65535 ax + 32; the result (32-ay) t + ay b + 2^9 is a third one (t, b <= 8160).  Same integers.
-            const unsigned tl = __builtin_amdgcn_alignbyte(t1[r], t0[r], sh0[r]), th = t1[r] >> (8 * sh0[r]);
-            const unsigned bl = __builtin_amdgcn_alignbyte(b1[r], b0[r], sh1[r]), bh = b1[r] >> (8 * sh1[r]);
-            unsigned tp[4], bq[4];
-            tp[0] = __builtin_amdgcn_perm(0u, tl, 0x0c010c00u); bq[0] = __builtin_amdgcn_perm(0u, bl, 0x0c010c00u);
-            tp[1] = __builtin_amdgcn_perm(0u, tl, 0x0c020c01u); bq[1] = __builtin_amdgcn_perm(0u, bl, 0x0c020c01u);
-            tp[2] = __builtin_amdgcn_perm(0u, tl, 0x0c030c02u); bq[2] = __builtin_amdgcn_perm(0u, bl, 0x0c030c02u);
-            tp[3] = __builtin_amdgcn_perm(th, tl, 0x0c040c03u); bq[3] = __builtin_amdgcn_perm(bh, bl, 0x0c040c03u);
-            uint32_t pack = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const unsigned wx = __umul24((unsigned)(fx[r][k] & 31), 65535u) + 32u, wy = __umul24((unsigned)(fy[r][k] & 31), 65535u) + 32u;
-                const unsigned tb = (unsigned)dot2_first(tp[k], wx) | ((unsigned)dot2_first(bq[k], wx) << 16);
-                pack |= (uint32_t)(dot2_s(tb, wy, 1 << 9) >> 10) << (8 * k);
-            }
-            *reinterpret_cast<uint32_t*>(J.dst + (size_t)(ry0 + r) * J.dst_stride + x4) = pack;
+            rw_store8 o;
+            o.v = rw_u32x2{res[r][0], res[r][1]};
+            *reinterpret_cast<rw_store8*>(J.dst + (size_t)(ry0 + r) * J.dst_stride + x8) = o;
         }
         return;
     }
+    // general path (ROI edge columns / rows, strong rotations, maps far outside the frame): per-pixel gathers, coordinates exactly as numpy + cvRound
     for (int r = 0; r < RW_ROWS && ry0 + r < rh; r++) {
-        uint32_t pack = 0;
-        for (int k = 0; k < cnt; k++) {
-            const int sx = fx[r][k] >> 5, sy = fy[r][k] >> 5;
-            const bool x0in = sx >= 0 && sx < s.w, x1in = sx + 1 >= 0 && sx + 1 < s.w;
-            const bool y0in = sy >= 0 && sy < s.h, y1in = sy + 1 >= 0 && sy + 1 < s.h;
-            const uint8_t* r0 = s.p + (ptrdiff_t)sy * s.stride + sx;
-            const int s00 = (y0in && x0in) ? r0[0] : 0, s01 = (y0in && x1in) ? r0[1] : 0;
-            const int s10 = (y1in && x0in) ? r0[s.stride] : 0, s11 = (y1in && x1in) ? r0[s.stride + 1] : 0;
-            pack |= remap_blend(s00, s01, s10, s11, fx[r][k] & 31, fy[r][k] & 31) << (8 * k);
+        const float y = (float)(J.y0 + ry0 + r);
+        const float yx = __fmul_rn(y, J.T[2]), yy = __fmul_rn(y, J.T[3]);
+        for (int g = 0; g < cnt; g += 4) {
+            const int c4 = min(4, cnt - g);
+            uint32_t pack = 0;
+            for (int k = 0; k < c4; k++) {
+                const float x = (float)(J.x0 + x8 + g + k);
+                const float mx = __fadd_rn(__fadd_rn(__fmul_rn(x, J.T[0]), yx), J.T[4]);
+                const float my = __fadd_rn(__fadd_rn(__fmul_rn(x, J.T[1]), yy), J.T[5]);
+                const int fx = vh_round(__fmul_rn(mx, 32.f)), fy = vh_round(__fmul_rn(my, 32.f));
+                const int sx = fx >> 5, sy = fy >> 5;
+                const bool x0in = sx >= 0 && sx < s.w, x1in = sx + 1 >= 0 && sx + 1 < s.w;
+                const bool y0in = sy >= 0 && sy < s.h, y1in = sy + 1 >= 0 && sy + 1 < s.h;
+                const uint8_t* r0 = s.p + (ptrdiff_t)sy * s.stride + sx;
+                const int s00 = (y0in && x0in) ? r0[0] : 0, s01 = (y0in && x1in) ? r0[1] : 0;
+                const int s10 = (y1in && x0in) ? r0[s.stride] : 0, s11 = (y1in && x1in) ? r0[s.stride + 1] : 0;
+                pack |= remap_blend(s00, s01, s10, s11, fx & 31, fy & 31) << (8 * k);
+            }
+            roi_store4(J.dst + (size_t)(ry0 + r) * J.dst_stride, x8 + g, c4, pack);
         }
-        roi_store4(J.dst + (size_t)(ry0 + r) * J.dst_stride, x4, cnt, pack);
     }
 }
 
@@ -438,6 +520,6 @@ void vh_launch_pyr_down_ws(const void* pb_tab, size_t ws_stride, int batch, int 
 
 void vh_launch_roi_warp(const void* job_tab, size_t tab_stride, int batch, int max_w, int max_h, hipStream_t s)
 {
-    dim3 blk(64, 4), grd((max_w + 255) / 256, (max_h + 4 * RW_ROWS - 1) / (4 * RW_ROWS), batch);
+    dim3 blk(64, 4), grd((max_w + 64 * RW_PX - 1) / (64 * RW_PX), (max_h + 4 * RW_ROWS - 1) / (4 * RW_ROWS), batch);
     hipLaunchKernelGGL(k_roi_warp, grd, blk, 0, s, job_tab, tab_stride);
 }

@@ -309,7 +309,9 @@ static int session_step(vh_session* s, const uint8_t* const* frames_dev, float t
     int r = vh_run_klt_main(c, 0, nb, st, s->coarse, s->fine, s->d_ss, frames_dev, s->N0);  // the set-up kernel also fetches this frame's KltIO from the session
     if (r) return r;
     if (s->N0 <= 4096) {
+        const int rec = vh_prof_start(s->ctx, st);
         hipLaunchKernelGGL(k_sess_frame, dim3(nb), dim3(256), 0, st, s->d_ss, frames_dev, time_s, frame_no, times_dev, frame_nos_dev);
+        vh_prof_stop(s->ctx, rec, VH_PROF_SESSION, st);
     } else {  // more pose tracks than 256 threads keep in registers: the 1024-thread pose kernel between the two bookkeeping halves
         hipLaunchKernelGGL(k_sess_book_a, dim3(nb), dim3(256), 0, st, s->d_ss);
         vh_launch_pose(&s->d_ss[0].pose, sizeof(SessStream), nb, 0, s->N0, st);

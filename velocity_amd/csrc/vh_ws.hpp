@@ -107,3 +107,21 @@ struct SessStream {  // device resident, one per video stream
 int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine,
                     const SessStream* sess = nullptr, const uint8_t* const* frames = nullptr, int n_max = 0);
 int vh_fail(int code, const char* msg);
+
+// optional HIP-event timing of individual launches (vh_profile_begin / vh_profile_end_stages): stage ids
+enum { VH_PROF_LK0 = 0, VH_PROF_LK1 = 1, VH_PROF_LK2 = 2, VH_PROF_WARP = 3, VH_PROF_PYR = 4, VH_PROF_RANSAC = 5, VH_PROF_RESIZE = 6, VH_PROF_SESSION = 7,
+       VH_PROF_BA_JAC = 8, VH_PROF_BA_SCHUR = 9, VH_PROF_BA_REDUCE = 10, VH_PROF_BA_SOLVE = 11, VH_PROF_BA_UPDATE = 12, VH_PROF_STAGES = 16 };
+// start of a profiled launch: returns the record index (or -1 when profiling is off / the record table is full); vh_prof_stop closes it
+static inline int vh_prof_start(vh_ctx* c, hipStream_t s)
+{
+    if (!c || !c->prof_on || c->prof_n >= c->prof_cap) return -1;
+    (void)hipEventRecord(c->prof_ev[2 * c->prof_n], s);
+    return c->prof_n;
+}
+static inline void vh_prof_stop(vh_ctx* c, int rec, int stage, hipStream_t s)
+{
+    if (rec < 0) return;
+    (void)hipEventRecord(c->prof_ev[2 * rec + 1], s);
+    c->prof_stage[rec] = stage;
+    c->prof_n = rec + 1;
+}
