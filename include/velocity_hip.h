@@ -73,6 +73,9 @@ VH_API int vh_resize_nearest(vh_ctx* ctx, const uint8_t* src, int w, int h, int 
 /* frame ingest, cv2.cvtColor(imbgr, cv2.COLOR_BGR2GRAY), vidExample.py:91.
  * bgr: uint8 [h][w][3] with row stride stride_bytes; gray: uint8 [h][w] with row stride gray_stride */
 VH_API int vh_bgr2gray(vh_ctx* ctx, const uint8_t* bgr, int w, int h, int stride_bytes, uint8_t* gray, int gray_stride, void* stream);
+/* the same pass also writing the quarter-scale image KLTmain starts from (cv2.resize(.25, INTER_NEAREST), KLT.py:111-113): small = round(h/4) x round(w/4),
+ * dense (may be NULL: gray only) */
+VH_API int vh_ingest_bgr(vh_ctx* ctx, const uint8_t* bgr, int w, int h, int stride_bytes, uint8_t* gray, int gray_stride, uint8_t* small, void* stream);
 /* cv2.pyrDown as used inside cv2.calcOpticalFlowPyrLK (KLT.py:45,48).  dst: (h+1)/2 x (w+1)/2, dense */
 VH_API int vh_pyr_down(vh_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream);
 /* meshgrid + affine + cv2.remap(INTER_LINEAR), utils/KLT.py:70-73.  T: host, 3x2 row-major float32.  dst dense ROI */
@@ -219,6 +222,11 @@ VH_API int vh_session_step_v(vh_session* s, const uint8_t* const* frames_dev, co
 VH_API int vh_session_ptrs(vh_session* s, int slot, vh_session_view* out_host);
 /* Packed track state of every stream for the cross-GPU exchange (RCCL all-gather, DESIGN.md "multi-GPU"):
  * out = device float32 [batch][8 + 3*n0]: {n_cur, n_pose, frame_i, klt_flags, t[3], res | p (n0 x 2) | ids (n0, int32 bits)} */
+/* Fused frame ingest for every stream of the session (vidExample.py:91 + KLT.py:111-113 in ONE pass over the BGR frames): bgr_frames_dev / gray_frames_dev =
+ * device arrays of ctx->batch pointers (h x w x 3 with rows bgr_stride bytes apart; dense w x h gray destinations owned by the caller, a null BGR pointer skips
+ * the stream).  Writes the gray frames and, straight into the session, the quarter-scale images the next vh_session_step starts from (that step then
+ * skips its own resize); pass the same gray frames to that step. */
+VH_API int vh_session_ingest_bgr(vh_session* s, const uint8_t* const* bgr_frames_dev, int bgr_stride, uint8_t* const* gray_frames_dev, void* stream);
 VH_API int vh_session_pack_state(vh_session* s, float* out, void* stream);
 
 /* test hook: route every LK window through one implementation -- 1: per-sample kernel, 2: strip kernel, 3: LDS-staged

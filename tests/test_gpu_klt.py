@@ -107,6 +107,22 @@ def test_remap_and_crop_shift_bit_exact():
         out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
         L.check(ws.lib.vh_remap_affine(ws.handle, L.dptr(t), 480, 270, 480, Tf.ctypes.data_as(L.f32p), *r, L.dptr(out), L.stream_ptr()))
         assert np.array_equal(out.cpu().numpy(), exp), (case, r, Tf)
+    # the run path of k_roi_warp (8 pixels x 4 rows per thread, source column drifting by up to one against the pixel index): zooms around its
+    # limits (|s - 1| < 1/8), small rotations (fy changes inside a row segment), full-HD coordinates (float32 roundings at x ~ 1900),
+    # translations that push the source window across the frame edge, and a map far outside the magic-number rounding range
+    big = rng.integers(0, 256, (1080, 1920), dtype=np.uint8)
+    tb = torch.from_numpy(big).cuda()
+    wsb = L.workspace(1920, 1080, 1)
+    maps = [(sc, th, tx, ty) for sc in (0.874, 0.88, 0.95, 0.9953, 1.0, 1.0049, 1.05, 1.12, 1.126) for th, tx, ty in ((0.0, 0.4, -0.3), (0.002, 7.25, -3.6), (-0.01, -40.0, 25.0))]
+    maps += [(1.0, 0.0, 1.5e5, 0.0), (1.0, 0.0, 0.0, -2.0e5), (1.0, 0.0, 1904.03, 0.0), (1.0, 0.0, -1.97, 1070.5)]
+    for case, (sc, th, tx, ty) in enumerate(maps):
+        A = sc * np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]])
+        Tf = np.concatenate([A.reshape(-1), [tx, ty]]).astype(np.float32)
+        r = (int(rng.integers(0, 30)), int(rng.integers(1500, 1921)), int(rng.integers(0, 20)), int(rng.integers(700, 1081))) if case % 3 else (0, 1920, 0, 1080)
+        exp = KO.remap_affine(big, Tf, r)
+        out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
+        L.check(wsb.lib.vh_remap_affine(wsb.handle, L.dptr(tb), 1920, 1080, 1920, Tf.ctypes.data_as(L.f32p), *r, L.dptr(out), L.stream_ptr()))
+        assert np.array_equal(out.cpu().numpy(), exp), (case, r, Tf)
     for dx, dy in ((0, 0), (11, -2), (-30, 40), (500, 0)):
         exp = KO.crop_shift(img, roi, dx, dy)
         out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
@@ -425,6 +441,25 @@ def test_bgr2gray_bit_exact():
     for (h, w) in ((1080, 1920), (37, 53), (5, 3)):
         bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         assert np.array_equal(bgr2gray(bgr), KO.bgr2gray(bgr))
+
+
+def test_fused_ingest_bit_exact():
+    """vh_ingest_bgr: ONE pass over the BGR frame == cvtColor(BGR2GRAY) followed by resize(.25, INTER_NEAREST) (vidExample.py:91, KLT.py:111-113), for
+    sizes whose quarter-scale rounding goes both ways, unaligned row starts (3 w not a multiple of 4) and a torch tensor input."""
+    import torch
+
+    from velocity_amd import images
+
+    rng = np.random.default_rng(17)
+    for h, w in ((270, 480), (1080, 1920), (271, 483), (6, 5), (5, 9), (33, 130), (2, 2)):
+        bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        gray, small = images.ingest_bgr(bgr)
+        eg = KO.bgr2gray(bgr)
+        assert np.array_equal(gray, eg), (h, w)
+        assert np.array_equal(small, KO.resize_quarter(eg)), (h, w)
+    t = torch.from_numpy(bgr).cuda()
+    g2, s2 = images.ingest_bgr(t)
+    assert g2.is_cuda and np.array_equal(g2.cpu().numpy(), eg)
 
 
 def test_frame0_features_bit_exact(seq):

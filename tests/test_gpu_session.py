@@ -334,3 +334,40 @@ def test_session_stays_on_the_reference_loop_for_2000_frames():
     # the pose the drifting tracks give is still the scene's (what the extras legs of bench.py report as pose_t / pose_t_truth)
     truth = m.t(nframes % ring) - m.t(0)
     assert np.abs(st["t"] - truth).max() < 0.05
+
+
+def test_session_step_from_bgr_frames_equals_gray_path():
+    """TrackerSession.step_bgr (fused ingest: gray + quarter-scale image in one pass, the step skips its own resize) == converting every frame with
+    cvtColor first and stepping on the gray frames: identical track state, and both equal the reference loop on the oracle's gray frames."""
+    import torch
+
+    from oracle import klt_oracle as KO
+    from velocity_amd.driver import TrackerSession
+
+    W, H, n0, nframes, B = 482, 270, 180, 6, 2   # W / 4 = 120.5: the quarter-scale width rounds to even
+    rng = np.random.default_rng(5)
+    scenes = [_scene(W, H, n0, nframes, 321 + 11 * b) for b in range(B)]
+    # colour frames whose luma is NOT the synthetic gray frame (random chroma), so the conversion really matters
+    bgr = [[np.clip(np.stack([scenes[b][0][i].astype(int) + rng.integers(-20, 21, (H, W)) * (c - 1) for c in range(3)], -1), 0, 255).astype(np.uint8)
+            for i in range(nframes)] for b in range(B)]
+    gray = [[KO.bgr2gray(bgr[b][i]) for i in range(nframes)] for b in range(B)]
+    t0 = np.float32([1.5, 0.45, 3.6])
+    states = []
+    for mode in ("gray", "bgr"):
+        ses = TrackerSession(scenes[0][4], W, H, n0, nhist=nframes, batch=B, msv_frame=0)
+        for b in range(B):
+            ses.init_stream(b, gray[b][0], scenes[b][1], scenes[b][2], scenes[b][3], t0)
+        for i in range(1, nframes):
+            if mode == "gray":
+                ses.step([torch.from_numpy(gray[b][i]).cuda() for b in range(B)], time_s=i / 30.0, frame_no=i)
+            else:
+                out = ses.step_bgr([torch.from_numpy(bgr[b][i]).cuda() for b in range(B)], time_s=i / 30.0, frame_no=i)
+                assert np.array_equal(out[0].cpu().numpy(), gray[0][i])
+        states.append([ses.state(b) for b in range(B)])
+    for b in range(B):
+        for key in ("vg", "vp", "p", "ids", "t", "res"):
+            assert np.array_equal(states[0][b][key], states[1][b][key]), key
+        orc = SessionOracle(scenes[b][4], gray[b][0], scenes[b][1], scenes[b][2], scenes[b][3], t0, nhist=nframes, msv_frame=0)
+        for i in range(1, nframes):
+            orc.step(gray[b][i], np.float32(i / 30.0), i)
+        assert np.array_equal(states[1][b]["vg"], orc.vg) and np.array_equal(states[1][b]["p"], orc.p)

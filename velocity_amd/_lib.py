@@ -44,6 +44,8 @@ _SIGS = {
     "vh_resize_quarter": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "vh_resize_nearest": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp, C.c_int, vp]),
     "vh_bgr2gray": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "vh_ingest_bgr": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp]),
+    "vh_session_ingest_bgr": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "vh_pyr_down": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "vh_remap_affine": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "vh_crop_shift": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -177,6 +177,7 @@ __global__ void k_klt_setup(StreamWS* ws_all, const SessStream* ss_all, const ui
         o.flags = const_cast<int*>(&S.klt_flags);
         o.w = S.w; o.h = S.h; o.stride = S.stride; o.stride0 = S.stride;
         o.reuse_prev_small = S.frame_i >= 1 ? 1 : 0;  // the previous step built the pyramid of what is now im0_small
+        o.have_small = S.small_ready == S.frame_i + 1 ? 1 : 0;  // vh_session_ingest_bgr wrote this frame's quarter-scale image already
         o.coarse = coarse; o.fine = fine;
         o.fbt_coarse = 1.0f; o.fbt_fine = 0.3f;
         ws.pp = S.pp;
@@ -192,7 +193,8 @@ __global__ void k_klt_setup(StreamWS* ws_all, const SessStream* ss_all, const ui
     const uint8_t* small_prev = io.im0_small ? io.im0_small : B.small0[prev];
     // resize table
     ws.rs_src[0] = ImgDesc{io.im, io.w, io.h, io.stride, 0};
-    ws.rs_dst[0] = ImgDesc{small_cur, dw, dh, dw, 0};
+    const bool have_small = ss_all != nullptr && io.have_small != 0;
+    ws.rs_dst[0] = ImgDesc{small_cur, have_small ? 0 : dw, have_small ? 0 : dh, dw, 0};
     const bool need_prev = io.im0_small == nullptr;
     ws.rs_src[1] = ImgDesc{io.im0, io.w, io.h, io.stride0, 0};
     ws.rs_dst[1] = ImgDesc{B.small0[prev], need_prev ? dw : 0, need_prev ? dh : 0, dw, 0};
@@ -532,6 +534,22 @@ extern "C" VH_API int vh_bgr2gray(vh_ctx* c, const uint8_t* bgr, int w, int h, i
 {
     if (!c || w < 1 || h < 1) return vh_fail(-1, "vh_bgr2gray: bad arguments");
     vh_launch_bgr2gray(bgr, w, h, (size_t)stride_bytes, gray, (size_t)gray_stride, (hipStream_t)stream);
+    VH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" VH_API int vh_ingest_bgr(vh_ctx* c, const uint8_t* bgr, int w, int h, int stride_bytes, uint8_t* gray, int gray_stride, uint8_t* small, void* stream)
+{
+    if (!c || !bgr || !gray || w < 1 || h < 1 || stride_bytes < 3 * w || gray_stride < w) return vh_fail(-1, "vh_ingest_bgr: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    IngestJob J;
+    memset(&J, 0, sizeof(J));
+    J.bgr = bgr; J.gray = gray; J.small = small; J.w = w; J.h = h; J.bgr_stride = stride_bytes; J.gray_stride = gray_stride;
+    J.dw = (int)lrint(w * 0.25); J.dh = (int)lrint(h * 0.25); J.small_stride = J.dw;
+    static_assert(sizeof(IngestJob) <= sizeof(LKJob), "IngestJob must fit in the LKJob slot");
+    IngestJob* d = reinterpret_cast<IngestJob*>(&c->d_ws[0].lk);  // parked like every stateless call's descriptor
+    VH_CHECK(vh_store(d, J, s));
+    vh_launch_ingest_bgr(d, 1, w, h, s);
     VH_LAUNCH_CHECK();
     return 0;
 }
@@ -877,24 +895,32 @@ extern "C" VH_API int vh_msv1_t(vh_ctx* c, const double* K, const float* P, cons
 // ---------------------------------------------------------------------------------------------------------------
 // bundle adjustment entry points
 // ---------------------------------------------------------------------------------------------------------------
-// partials of the reduced system: one workgroup per ~16 points, at most 256 (512 / 1024 measured 20 % slower at C5: the reduction grows)
-static int ba_parts(int nt) { int p = nt / 16; return p < 1 ? 1 : (p > 256 ? 256 : p); }
+// partials of the reduced system: one workgroup per ~16 points, at most 256 (512 / 1024 measured 20 % slower at C5: the reduction grows); with many
+// cameras fewer, so that the partial systems of one window stay below 256 MB
+static int ba_parts(int nt, int nc)
+{
+    int p = nt / 16;
+    p = p < 1 ? 1 : (p > 256 ? 256 : p);
+    const long long per = 8ll * (6ll * nc) * (6ll * nc), cap = per > 0 ? (256ll << 20) / per : 256;
+    if (cap < p) p = cap < 1 ? 1 : (int)cap;
+    return p;
+}
 static int g_ba_force_valu = 0;
 extern "C" VH_API void vh_debug_ba_force_valu(int on) { g_ba_force_valu = on; }
 
-extern "C" VH_API size_t vh_nls_batch_workspace(int nt, int nc) { return vh_ba_workspace_bytes(nt, nc, ba_parts(nt)); }
+extern "C" VH_API size_t vh_nls_batch_workspace(int nt, int nc) { return vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc)); }
 
 extern "C" VH_API int vh_nls_batch(vh_ctx* c, const double* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
                                    int* info, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!c || !K_host || nt < 1 || nc < 1 || max_iter < 1) return vh_fail(-1, "vh_nls_batch: bad arguments");
-    if (6 * nc > 256) return vh_fail(-1, "vh_nls_batch: at most 42 free cameras");
-    if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch: workspace too small");
+    if (nc > 128) return vh_fail(-1, "vh_nls_batch: at most 128 free cameras");
+    if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc))) return vh_fail(-1, "vh_nls_batch: workspace too small");
     BaProblem P;
     P.graph_cache = &c->ba_graphs;
     P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
-    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt); P.force_valu = g_ba_force_valu;
+    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt, nc); P.force_valu = g_ba_force_valu;
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 0;
     P.nwin = 1; P.ws_stride = P.z_stride = P.x_stride = P.trace_stride = P.info_stride = 0;
     P.nx_total = 3.0 * nt + 6.0 * nc; P.nz_total = 2.0 * nt * (nc + 1);
@@ -909,8 +935,8 @@ extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const double* K_host, const 
                                          double* trace, int* info, void* workspace, size_t workspace_bytes_per_window, void* stream)
 {
     if (!c || !K_host || nt < 1 || nc < 1 || max_iter < 1 || nwin < 1 || nwin > 65535) return vh_fail(-1, "vh_nls_batch_multi: bad arguments");
-    if (6 * nc > 256) return vh_fail(-1, "vh_nls_batch_multi: at most 42 free cameras");
-    if (workspace_bytes_per_window < vh_ba_workspace_bytes(nt, nc, ba_parts(nt)) || workspace_bytes_per_window % 256)
+    if (nc > 128) return vh_fail(-1, "vh_nls_batch_multi: at most 128 free cameras");
+    if (workspace_bytes_per_window < vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc)) || workspace_bytes_per_window % 256)
         return vh_fail(-1, "vh_nls_batch_multi: per-window workspace too small or not a multiple of 256 bytes");
     BaProblem P;
     P.graph_cache = &c->ba_graphs;
@@ -918,7 +944,7 @@ extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const double* K_host, const 
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.force_valu = g_ba_force_valu;
     // fewer partial systems per window when many windows fill the chip anyway (the partials are reduced through HBM)
-    int parts = ba_parts(nt), cap = 512 / nwin < 16 ? 16 : 512 / nwin;
+    int parts = ba_parts(nt, nc), cap = 512 / nwin < 16 ? 16 : 512 / nwin;
     P.nparts = nwin > 1 && parts > cap ? cap : parts;
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 0;
     P.nx_total = 3.0 * nt + 6.0 * nc; P.nz_total = 2.0 * nt * (nc + 1);
@@ -934,13 +960,13 @@ extern "C" VH_API int vh_nls_batch2(vh_ctx* c, const double* K_host, const doubl
                                     int* info, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!c || !K_host || nt < 1 || nc < 1 || max_iter < 1) return vh_fail(-1, "vh_nls_batch2: bad arguments");
-    if (6 * nc > 256) return vh_fail(-1, "vh_nls_batch2: at most 42 free cameras");
-    if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch2: workspace too small");
+    if (nc > 128) return vh_fail(-1, "vh_nls_batch2: at most 128 free cameras");
+    if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc))) return vh_fail(-1, "vh_nls_batch2: workspace too small");
     BaProblem P;
     P.graph_cache = &c->ba_graphs;
     P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
-    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt); P.force_valu = 1;
+    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt, nc); P.force_valu = 1;
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 1;
     P.nwin = 1; P.ws_stride = P.z_stride = P.x_stride = P.trace_stride = P.info_stride = 0;
     P.nx_total = 3.0 * nt + nc + 5.0; P.nz_total = 2.0 * nt * (nc + 1);
@@ -959,13 +985,13 @@ extern "C" VH_API int vh_nls_batch_phase(vh_ctx* c, const double* K_host, const 
                                          size_t* span_offset, size_t* span_doubles, void* stream)
 {
     if (!c || !K_host || nt < 1 || nc < 1 || nt_total < nt) return vh_fail(-1, "vh_nls_batch_phase: bad arguments");
-    if (6 * nc > 256) return vh_fail(-1, "vh_nls_batch_phase: at most 42 free cameras");
-    if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt))) return vh_fail(-1, "vh_nls_batch_phase: workspace too small");
+    if (nc > 128) return vh_fail(-1, "vh_nls_batch_phase: at most 128 free cameras");
+    if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc))) return vh_fail(-1, "vh_nls_batch_phase: workspace too small");
     BaProblem P;
     P.graph_cache = &c->ba_graphs;
     P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
-    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = 1; P.nparts = ba_parts(nt);
+    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = 1; P.nparts = ba_parts(nt, nc);
     P.force_valu = g_ba_force_valu;
     P.phase = phase; P.it = it; P.add_identity = rank0 ? 1 : 0; P.count_cams = rank0 ? 1 : 0; P.defer_finalize = 1; P.model = 0;
     P.nwin = 1; P.ws_stride = P.z_stride = P.x_stride = P.trace_stride = P.info_stride = 0;

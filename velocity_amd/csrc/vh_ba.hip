@@ -17,6 +17,8 @@
 #define BA_FD 1e-6
 #define BA_THREADS 256
 #define BA_EPT 64  // Schur entries owned by one thread per pass
+#define BA_MAX_NC 128                       // free cameras (the reference has no limit; the workspace grows with (6 nc)^2 per partial system)
+#define BA_RQ (6 * BA_MAX_NC / BA_THREADS)  // reduced right-hand-side entries owned by one thread of the VALU Schur kernel
 
 // batched windows: shift every pointer of the job to window w (the job travels by value, so this edits the kernel's own copy)
 __device__ __forceinline__ void ba_select_window(BaJob& J, int w)
@@ -301,7 +303,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
     double accS[BA_EPT];
 #pragma unroll
     for (int e = 0; e < BA_EPT; e++) accS[e] = 0.0;
-    double accR = 0.0;  // reduced rhs entry `tid` (first pass only, tid < nq)
+    double accR[BA_RQ];  // reduced rhs entries tid + 256 j (first pass only)
+#pragma unroll
+    for (int j = 0; j < BA_RQ; j++) accR[j] = 0.0;
 
     for (int i = i0; i < i1; i++) {
         __syncthreads();
@@ -339,7 +343,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
         }
         __syncthreads();
         // W_i [3][nq] and Y_i = U_i^-1 W_i
-        for (int q = tid; q < nq; q += BA_THREADS) {
+#pragma unroll
+        for (int jq = 0; jq < BA_RQ; jq++) {
+            const int q = tid + BA_THREADS * jq;
+            if (q >= nq) break;
             double w0 = 0.0, w1 = 0.0, w2 = 0.0, gq = 0.0;
             if (J.model == 1) {
                 // column q < 5 (joint rpy, el, az) collects every camera, column q >= 5 is the range of camera q - 4
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
                 double* Yg = J.Y + ((size_t)i * nq + q) * 3;
                 Yg[0] = y0; Yg[1] = y1; Yg[2] = y2;
                 // reduced rhs: gc - W^T tp
-                accR += gq - (w0 * sTp[0] + w1 * sTp[1] + w2 * sTp[2]);
+                accR[jq] += gq - (w0 * sTp[0] + w1 * sTp[1] + w2 * sTp[2]);
             }
         }
         __syncthreads();
@@ -404,8 +411,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_points(BaJob J, int pass)
         if (ent < nent) Sp[ent] = accS[e];
     }
     if (pass == 0) {
-        // accR holds the contributions of rhs entries q = tid, tid + 256, ... ; nq <= 256 is required by the launcher
-        if (tid < nq) J.Rpart[(size_t)blockIdx.x * nq + tid] = accR;
+#pragma unroll
+        for (int jq = 0; jq < BA_RQ; jq++)
+            if (tid + BA_THREADS * jq < nq) J.Rpart[(size_t)blockIdx.x * nq + tid + BA_THREADS * jq] = accR[jq];
     }
 }
 
@@ -1012,6 +1020,39 @@ __global__ __launch_bounds__(256) void k_ba_solve_mfma(BaJob J)
     }
 }
 
+// Schur stage 2b for MANY cameras (6 nc > 256: more unknowns than the register-resident kernels hold): Gauss-Jordan without pivoting (S is SPD) on the
+// augmented system in place in global memory -- it stays in L2 (nq = 360: 1 MB) --, one workgroup, scalar pivots; the pivot row and the multipliers
+// of a round travel through LDS.  Columns left of the pivot are already zero in the pivot row and are skipped.  A slow path by design (one CU, L2
+// bandwidth bound: ~5 ms per solve at 60 cameras); windows of up to 42 cameras take the register-resident kernels above.
+__global__ __launch_bounds__(1024) void k_ba_solve_big(BaJob J)
+{
+    ba_select_window(J, blockIdx.y);
+    if (*J.done) return;
+    const int nq = J.nq, ld = nq + 1, tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* s_row = reinterpret_cast<double*>(smem);  // [ld] pivot row
+    double* s_f = s_row + ld;                          // [nq] multipliers a[r][c] / a[c][c] (0 for the pivot row)
+    double* A = J.Sfull;
+    for (int c = 0; c < nq; c++) {
+        __syncthreads();  // the updates of the previous round are complete (same workgroup: global writes are visible after the barrier + fence)
+        const double piv = A[(size_t)c * ld + c];
+        for (int k = c + tid; k < ld; k += 1024) s_row[k] = A[(size_t)c * ld + k];
+        const double ip = 1.0 / piv;
+        for (int r = tid; r < nq; r += 1024) s_f[r] = r == c ? 0.0 : A[(size_t)r * ld + c] * ip;
+        __syncthreads();
+        // columns c+1 .. nq (rhs included); column c itself becomes zero off the pivot and is never read again.  Half-wavefronts walk a row (256-byte segments)
+        for (int r = tid >> 5; r < nq; r += 32) {
+            const double f = s_f[r];
+            if (f == 0.0) continue;
+            double* Ar = A + (size_t)r * ld;
+            for (int k = c + 1 + (tid & 31); k < ld; k += 32) Ar[k] = __builtin_fma(-f, s_row[k], Ar[k]);
+        }
+        __threadfence();  // the round's stores must be visible to the whole workgroup's next loads (L1 is not coherent with its own write-through)
+    }
+    __syncthreads();
+    for (int q = tid; q < nq; q += 1024) J.dc[q] = A[(size_t)q * ld + nq] / A[(size_t)q * ld + q];
+}
+
 // back-substitution dp = tp - Y dc, update x += 0.9 delta, rms(delta) and the stop flag (NLS.py:235-240)
 __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
 {
@@ -1019,7 +1060,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
     if (*J.done) return;
     const int nt = J.nt, nc = J.nc, nq = J.nq, tid = threadIdx.x;
     __shared__ double sh[BA_THREADS / 64];
-    __shared__ double s_par[256];  // new camera-side parameters (block 0)
+    __shared__ double s_par[6 * BA_MAX_NC];  // new camera-side parameters (block 0)
     double ss = 0.0;
     const int lane = tid & 63, wave = tid >> 6;
     if (J.zmode) {
@@ -1255,7 +1296,7 @@ void vh_ba_exchange_span(const BaProblem& P, size_t* offset_bytes, size_t* n_dou
 int vh_ba_run(const BaProblem& P, hipStream_t s)
 {
     const int nt = P.nt, nc = P.nc, nq = P.model == 1 ? nc + 5 : 6 * nc;
-    if (6 * nc > BA_THREADS) return -3;  // reduced rhs ownership (one thread per entry) needs 6 nc <= 256
+    if (nc > BA_MAX_NC) return -3;
     const int nparts = P.nparts;
     BaJob J;
     memset(&J, 0, sizeof(J));  // padding included: whole solves are recognised by the bytes of their descriptor (graph replay below)
@@ -1307,7 +1348,8 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         if (nq <= BA_GJ_MAXQ && !(J.dbg & 64)) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1, nw), dim3(256), 0, s, J);
         else if (nq + 1 <= 128) hipLaunchKernelGGL((k_ba_solve<8, 8, 16>), dim3(1, nw), dim3(256), 0, s, J, nparts);
         else if (nq <= 192) hipLaunchKernelGGL((k_ba_solve<6, 7, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
-        else hipLaunchKernelGGL((k_ba_solve<8, 9, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
+        else if (nq <= 256) hipLaunchKernelGGL((k_ba_solve<8, 9, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
+        else hipLaunchKernelGGL(k_ba_solve_big, dim3(1, nw), dim3(1024), sizeof(double) * (size_t)(2 * nq + 1), s, J);
         vh_prof_stop(pc, rec, VH_PROF_BA_SOLVE, s);
         rec = vh_prof_start(pc, s);
         hipLaunchKernelGGL(k_ba_update, dim3(upd_blocks, nw), dim3(BA_THREADS), 0, s, J, it);

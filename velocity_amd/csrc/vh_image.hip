@@ -414,6 +414,41 @@ __global__ __launch_bounds__(256) void k_bgr2gray(const uint8_t* bgr, int w, int
     else for (int k = 0; k < cnt; k++) d[k] = (uint8_t)(pack >> (8 * k));
 }
 
+// Fused ingest: ONE pass over the BGR frame writes the gray frame (cvtColor, vidExample.py:91) AND the quarter-scale image
+// KLTmain starts from (cv2.resize(im, (0,0), fx=.25, fy=.25, INTER_NEAREST), KLT.py:111-113): small[y][x] = gray[4 y][4 x] (dsize = round(src / 4), so
+// 4 x <= w - 1 always and the min() of the resize never binds).  Same thread layout as k_bgr2gray; the threads of rows 4 y additionally store one
+// quarter-scale pixel each.  `jobs`: one descriptor per frame (blockIdx.z).
+__global__ __launch_bounds__(256) void k_ingest_bgr(const IngestJob* jobs)
+{
+    const IngestJob J = jobs[blockIdx.z];
+    if (J.bgr == nullptr) return;
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (y >= J.h || x4 >= J.w) return;
+    const uint8_t* s = J.bgr + (size_t)y * J.bgr_stride + 3 * (size_t)x4;
+    uint8_t* d = J.gray + (size_t)y * J.gray_stride + x4;
+    const int cnt = min(4, J.w - x4);
+    uint32_t pack = 0;
+    if (cnt == 4 && ((reinterpret_cast<uintptr_t>(s) & 3) == 0)) {  // 12 aligned bytes: three dword loads
+        const uint32_t a = reinterpret_cast<const uint32_t*>(s)[0], b = reinterpret_cast<const uint32_t*>(s)[1], c = reinterpret_cast<const uint32_t*>(s)[2];
+        const uint32_t px[4][3] = {{a & 255u, (a >> 8) & 255u, (a >> 16) & 255u}, {a >> 24, b & 255u, (b >> 8) & 255u},
+                                   {(b >> 16) & 255u, b >> 24, c & 255u}, {(c >> 8) & 255u, (c >> 16) & 255u, c >> 24}};
+#pragma unroll
+        for (int k = 0; k < 4; k++) pack |= ((px[k][0] * 3735u + px[k][1] * 19235u + px[k][2] * 9798u + (1u << 14)) >> 15) << (8 * k);
+    } else {
+        for (int k = 0; k < cnt; k++) pack |= ((s[3 * k] * 3735u + s[3 * k + 1] * 19235u + s[3 * k + 2] * 9798u + (1u << 14)) >> 15) << (8 * k);
+    }
+    if (cnt == 4 && ((reinterpret_cast<uintptr_t>(d) & 3) == 0)) *reinterpret_cast<uint32_t*>(d) = pack;
+    else for (int k = 0; k < cnt; k++) d[k] = (uint8_t)(pack >> (8 * k));
+    if (J.small != nullptr && (y & 3) == 0 && (x4 >> 2) < J.dw && (y >> 2) < J.dh) J.small[(size_t)(y >> 2) * J.small_stride + (x4 >> 2)] = (uint8_t)pack;
+}
+
+void vh_launch_ingest_bgr(const IngestJob* jobs_dev, int count, int max_w, int max_h, hipStream_t s)
+{
+    dim3 blk(64, 4), grd((max_w + 255) / 256, (max_h + 3) / 4, count);
+    hipLaunchKernelGGL(k_ingest_bgr, grd, blk, 0, s, jobs_dev);
+}
+
 void vh_launch_bgr2gray(const uint8_t* bgr, int w, int h, size_t sstride, uint8_t* gray, size_t dstride, hipStream_t s)
 {
     dim3 blk(64, 4), grd((w + 255) / 256, (h + 3) / 4);

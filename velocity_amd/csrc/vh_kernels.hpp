@@ -46,6 +46,14 @@ void vh_launch_pyr_down_ws(const void* pb_tab, size_t ws_stride, int batch, int 
 void vh_launch_resize_nearest(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, int dw, int dh, size_t dstride, double ifx, double ify,
                               hipStream_t s);
 void vh_launch_bgr2gray(const uint8_t* bgr, int w, int h, size_t sstride, uint8_t* gray, size_t dstride, hipStream_t s);
+// fused frame ingest (BGR -> gray + quarter-scale image), one descriptor per frame
+struct IngestJob {
+    const uint8_t* bgr;   // h x w x 3, rows bgr_stride bytes apart (null: skip)
+    uint8_t* gray;        // h x w, rows gray_stride bytes apart
+    uint8_t* small;       // round(h/4) x round(w/4), rows small_stride bytes apart (may be null)
+    int w, h, bgr_stride, gray_stride, dw, dh, small_stride;
+};
+void vh_launch_ingest_bgr(const IngestJob* jobs_dev, int count, int max_w, int max_h, hipStream_t s);
 void vh_launch_roi_warp(const void* job_tab, size_t tab_stride, int batch, int max_w, int max_h, hipStream_t s);
 int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s);
 void vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s);

@@ -17,6 +17,7 @@ struct vh_session {
     char* arena;
     SessStream* d_ss;
     SessStream* h_ss;  // host mirror of the pointer fields
+    IngestJob* d_ingest;  // [batch] descriptors of the fused BGR ingest
     int* h_frame;      // per stream: frames stepped since its vh_session_init (host mirror of SessStream::frame_i; the
                        // reference fires fcnMSV1_t at `i == msvFrame` of EACH video, vidExample.py:155)
 };
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void k_sess_init(SessStream* ss, const float* 
         S.P[((size_t)4 * N0 + g) * nh] = 0.f;
     }
     if (tid == 0) {
-        S.n_cur = N0; S.n_pose = 0; S.frame_i = 0; S.pp = 0; S.klt_flags = 0;
+        S.n_cur = N0; S.n_pose = 0; S.frame_i = 0; S.pp = 0; S.klt_flags = 0; S.small_ready = 0;
         S.B[0] = t0x; S.B[1] = t0y; S.B[2] = t0z; S.B[12] = time0; S.B[13] = frame_no;
         S.t[0] = t0x; S.t[1] = t0y; S.t[2] = t0z;
         S.t0 = time0; S.r_total = 0.f; S.res = (double)res0;
@@ -243,6 +244,7 @@ extern "C" VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, i
         }
         char* base = pass ? s->arena : nullptr;
         s->d_ss = (SessStream*)(base + carve(sizeof(SessStream) * s->batch));
+        s->d_ingest = (IngestJob*)(base + carve(sizeof(IngestJob) * s->batch));
         for (int b = 0; b < s->batch; b++) {
             SessStream& S = s->h_ss[b];
             S.vg = (uint8_t*)(base + carve(n0)); S.vp = (uint8_t*)(base + carve(n0));
@@ -366,6 +368,31 @@ __global__ __launch_bounds__(256) void k_sess_pack(const SessStream* ss_all, flo
         o[8 + 2 * k + 1] = k < n ? S.p_cur[2 * k + 1] : 0.f;
         o[8 + 2 * N0 + k] = __int_as_float(k < n ? S.ids[k] : -1);
     }
+}
+
+// fused frame ingest for every stream: descriptors from the stream state (the quarter-scale image goes straight into
+// the buffer the coming step reads as im_small), then ONE pass over the BGR frames
+__global__ void k_sess_ingest_jobs(SessStream* ss_all, IngestJob* jobs, const uint8_t* const* bgr, int bgr_stride, uint8_t* const* gray, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    SessStream& S = ss_all[b];
+    IngestJob J;
+    J.bgr = bgr[b]; J.gray = gray[b]; J.small = S.small[S.pp];
+    J.w = S.w; J.h = S.h; J.bgr_stride = bgr_stride; J.gray_stride = S.stride;
+    J.dw = __double2int_rn(S.w * 0.25); J.dh = __double2int_rn(S.h * 0.25); J.small_stride = J.dw;
+    jobs[b] = J;
+    if (J.bgr != nullptr) S.small_ready = S.frame_i + 1;
+}
+
+extern "C" VH_API int vh_session_ingest_bgr(vh_session* s, const uint8_t* const* bgr_frames_dev, int bgr_stride, uint8_t* const* gray_frames_dev, void* stream)
+{
+    if (!s || !bgr_frames_dev || !gray_frames_dev || bgr_stride < 3 * s->w) return vh_fail(-1, "vh_session_ingest_bgr: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sess_ingest_jobs, dim3((s->batch + 63) / 64), dim3(64), 0, st, s->d_ss, s->d_ingest, bgr_frames_dev, bgr_stride, gray_frames_dev, s->batch);
+    vh_launch_ingest_bgr(s->d_ingest, s->batch, s->w, s->h, st);
+    SESS_CHECK();
+    return 0;
 }
 
 extern "C" VH_API int vh_session_pack_state(vh_session* s, float* out, void* stream)

@@ -35,6 +35,7 @@ struct KltIO {  // one KLTmain call (KLT.py:99)
     int* flags;                // may be null
     int w, h, stride, stride0, n;
     int reuse_prev_small;      // 1: small_lv[1 - pp] already holds the pyramid of im0_small (session mode)
+    int have_small;            // 1: im_small already holds the quarter-scale image of `im` (fused ingest): no resize
     vh_lk_params coarse, fine;
     float fbt_coarse, fbt_fine;  // 1.0, 0.3 (KLT.py:124,133)
 };
@@ -100,6 +101,7 @@ struct SessStream {  // device resident, one per video stream
     float r_total, t0;
     int pose_info[2], msv_info[2];
     int N0, nhist, n_cur, n_pose, frame_i, pp, klt_flags, w, h, stride;
+    int small_ready;  // frame index whose quarter-scale image vh_session_ingest_bgr has already written into small[pp] (0: none)
 };
 
 

@@ -80,6 +80,28 @@ class TrackerSession:
         self._clock_keep = (tv, fv)
         L.check(self.lib.vh_session_step_v(self.handle, L.dptr(tab), L.dptr(tv), L.dptr(fv), L.stream_ptr()), "vh_session_step_v")
 
+    def step_bgr(self, frames_bgr, time_s=0.0, frame_no=0.0):
+        """One frame for every stream straight from BGR frames (the decoder's output, vidExample.py:89-91): the fused ingest writes the gray frames
+        and the quarter-scale images in one pass (vh_session_ingest_bgr), then the step runs on them.  frames_bgr: list of `batch` CUDA uint8 [H,W,3]
+        tensors.  The session owns two sets of gray buffers (a frame is read by two steps: as `im`, then as `im0`)."""
+        torch = self.torch
+        if getattr(self, "_gray", None) is None:
+            self._gray = [torch.empty((self.batch, self.h, self.w), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            self._gray_tab = [torch.tensor([g[b].data_ptr() for b in range(self.batch)], dtype=torch.int64, device="cuda") for g in self._gray]
+            self._gray_i = 0
+        ptrs = []
+        for f in frames_bgr:
+            assert f.is_cuda and f.dtype == torch.uint8 and f.shape == (self.h, self.w, 3) and f.is_contiguous()
+            ptrs.append(f.data_ptr())
+        self._bgr_keep = list(frames_bgr)
+        bgr_tab = torch.tensor(ptrs, dtype=torch.int64).cuda()
+        self._bgr_tab_keep = bgr_tab
+        k = self._gray_i
+        self._gray_i ^= 1
+        L.check(self.lib.vh_session_ingest_bgr(self.handle, L.dptr(bgr_tab), 3 * self.w, L.dptr(self._gray_tab[k]), L.stream_ptr()), "vh_session_ingest_bgr")
+        self.step(frames_table=self._gray_tab[k], time_s=time_s, frame_no=frame_no)
+        return self._gray[k]
+
     def view(self, slot=0):
         v = L.SessionView()
         L.check(self.lib.vh_session_ptrs(self.handle, slot, C.byref(v)), "vh_session_ptrs")

@@ -49,6 +49,21 @@ def bgr2gray(imbgr):
     return out if keep else out.cpu().numpy()
 
 
+def ingest_bgr(imbgr):
+    """Fused frame ingest: cv2.cvtColor(imbgr, COLOR_BGR2GRAY) (vidExample.py:91) and the quarter-scale image KLTmain starts from
+    (cv2.resize(im, (0,0), fx=.25, fy=.25, INTER_NEAREST), utils/KLT.py:111-113) in ONE pass over the BGR frame -> (gray [H,W], small [round(H/4), round(W/4)])."""
+    torch = L.torch_cuda()
+    keep = isinstance(imbgr, torch.Tensor)
+    t = (imbgr if keep else torch.from_numpy(np.ascontiguousarray(imbgr))).cuda().contiguous()
+    assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3
+    h, w = t.shape[0], t.shape[1]
+    gray = torch.empty((h, w), dtype=torch.uint8, device="cuda")
+    small = torch.empty((int(np.rint(h * 0.25)), int(np.rint(w * 0.25))), dtype=torch.uint8, device="cuda")
+    ws = L.workspace()
+    L.check(ws.lib.vh_ingest_bgr(ws.handle, L.dptr(t), w, h, 3 * w, L.dptr(gray), w, L.dptr(small), L.stream_ptr()), "vh_ingest_bgr")
+    return (gray, small) if keep else (gray.cpu().numpy(), small.cpu().numpy())
+
+
 def resize_nearest(im, fx, fy=None):
     """cv2.resize(im, (0, 0), fx=fx, fy=fy, interpolation=cv2.INTER_NEAREST) -- the `scale != 1` branch of the frame ingest
     (vidExample.py:99-102).  uint8 [H,W] -> uint8 [round(H fy), round(W fx)] (numpy in -> numpy out, tensor in -> tensor out)."""
