@@ -300,7 +300,7 @@ def bench_ba(nt=5000, nf=20, repeats=3, cpu_seconds=12.0, windows=(1, 8, 64), mi
             if os.path.exists(bp):
                 try:
                     bj = json.load(open(bp))
-                    busy = bj.get("mfma_busy_frac", bj.get("k_ba_schur_mfma", {}).get("mfma_busy_frac"))
+                    busy = bj.get("kernels", bj).get("k_ba_schur_mfma", {}).get("mfma_busy_frac")
                     bsrc = f"profiles/{name} (SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 2.4 GHz x 1024 SIMDs) of a rocprofv3 --pmc pass; not measured in this run)"
                 except Exception:
                     pass

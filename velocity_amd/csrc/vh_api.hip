@@ -134,7 +134,7 @@ __device__ void fill_pyramid(PyrDesc& P, const uint8_t* lv0, int w, int h, int s
         ImgDesc& d = P.lv[level];
         if (level == 0) { d.p = lv0; d.w = w; d.h = h; d.stride = stride; d.pad = 0; }
         else if (VH_LV_PADDED(w, h)) { d.stride = VH_LV_STRIDE(w); d.p = lvbuf[level] + (size_t)VH_LV_PAD * d.stride + VH_LV_PAD; d.w = w; d.h = h; d.pad = VH_LV_PAD; }
-        else { d.p = lvbuf[level]; d.w = w; d.h = h; d.stride = w; d.pad = 0; }
+        else { d.p = lvbuf[level]; d.w = w; d.h = h; d.stride = (w + 3) & ~3; d.pad = 0; }  // dword rows: k_pyr_down stores packed dwords (byte stores on a 766-pixel pitch cost it 2x)
         n = level + 1;
         w = (w + 1) / 2; h = (h + 1) / 2;
         if (w <= win || h <= win) break;
@@ -641,7 +641,7 @@ static void host_fill_pyramid(PyrDesc& P, const uint8_t* lv0, int w, int h, int 
         ImgDesc& d = P.lv[level];
         if (level == 0) { d.p = lv0; d.w = w; d.h = h; d.stride = stride; d.pad = 0; }
         else if (VH_LV_PADDED(w, h)) { d.stride = VH_LV_STRIDE(w); d.p = lvbuf[level] + (size_t)VH_LV_PAD * d.stride + VH_LV_PAD; d.w = w; d.h = h; d.pad = VH_LV_PAD; }
-        else { d.p = lvbuf[level]; d.w = w; d.h = h; d.stride = w; d.pad = 0; }
+        else { d.p = lvbuf[level]; d.w = w; d.h = h; d.stride = (w + 3) & ~3; d.pad = 0; }  // dword rows: k_pyr_down stores packed dwords (byte stores on a 766-pixel pitch cost it 2x)
         n = level + 1;
         w = (w + 1) / 2; h = (h + 1) / 2;
         if (w <= win || h <= win) break;

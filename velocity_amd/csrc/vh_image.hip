@@ -104,13 +104,14 @@ __device__ __forceinline__ unsigned pd_vert(unsigned a, unsigned b, unsigned c, 
 template <int RB>
 __global__ __launch_bounds__(256) void k_pyr_down(const void* pb_tab, size_t ws_stride, int lvl)
 {
-    const PyrBuild& pb = reinterpret_cast<const PyrBuild*>(reinterpret_cast<const char*>(pb_tab) + (size_t)(blockIdx.z >> 1) * ws_stride)[blockIdx.z & 1];
+    const unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const PyrBuild& pb = reinterpret_cast<const PyrBuild*>(reinterpret_cast<const char*>(pb_tab) + (size_t)(bz >> 1) * ws_stride)[bz & 1];
     if (!pb.enable || pb.pyr == nullptr) return;
     const PyrDesc& P = *pb.pyr;
     if (lvl + 1 >= P.nlevels) return;
     const ImgDesc s = P.lv[lvl];
     const ImgDesc d = P.lv[lvl + 1];
-    const int ox0 = (blockIdx.x * 64 + threadIdx.x) * 4, oy0 = (blockIdx.y * 4 + threadIdx.y) * RB;
+    const int ox0 = (int)(bx * 64 + threadIdx.x) * 4, oy0 = (int)(by * 4 + threadIdx.y) * RB;
     if (oy0 >= d.h) return;            // wave-uniform
     const bool live = ox0 < d.w;       // dead lanes stay for the DPP exchange, they load and store nothing
     const int sx0 = 2 * ox0 - 2, cnt = min(4, d.w - ox0);
@@ -136,6 +137,46 @@ __global__ __launch_bounds__(256) void k_pyr_down(const void* pb_tab, size_t ws_
     }
 
     constexpr int NR = 2 * RB + 3;
+    // ROW-INTERIOR WAVEFRONT (all but the first and last row blocks of a level): none of the 2 RB + 3 source rows is mirrored or is the first / last
+    // row of the image, so no lane ever needs the byte path -- the left / right edge lanes are fixed by their byte selectors alone, lanes right of
+    // the image load a clamped (in-row) address and store nothing.  A wave-uniform test sends the wavefront down a path WITHOUT per-lane branches:
+    // every lane loads its own 16 aligned bytes per row (the second half overlaps the right neighbour's: served by the cache), 3 v_alignbyte +
+    // 3 v_perm + 4 v_dot4 per row.  The general path below spends most of its instructions on exec-mask bookkeeping around byte paths it never takes.
+    if (wide && 2 * oy0 - 2 >= 1 && 2 * oy0 - 2 + NR <= s.h - 1 && oy0 + RB <= d.h) {
+        const int sxl = live ? sx0 : 0;  // dead lanes: any in-row address
+        uint4 q[NR];
+        unsigned shq[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(s.p + (size_t)(2 * oy0 - 2 + k) * s.stride + sxl);
+            pd_gptr ap = (pd_gptr)(a - (a & 3));
+            shq[k] = (unsigned)(a & 3);
+            q[k] = make_uint4(ap[0], ap[1], ap[2], ap[3]);
+        }
+        uint2 hq[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const unsigned t0 = __builtin_amdgcn_alignbyte(q[k].y, q[k].x, shq[k]), t1 = __builtin_amdgcn_alignbyte(q[k].z, q[k].y, shq[k]),
+                           t2 = __builtin_amdgcn_alignbyte(q[k].w, q[k].z, shq[k]);
+            PdRow r;
+            r.s0 = __builtin_amdgcn_perm(t1, t0, sel0);
+            r.s1 = __builtin_amdgcn_perm(t1, t0, sel1);
+            r.s2 = __builtin_amdgcn_perm(t2, t1, sel2);
+            hq[k] = pd_hsum(r);
+        }
+        if (!live) return;
+        const bool dw_ok = cnt == 4 && ((reinterpret_cast<uintptr_t>(d.p) | (uintptr_t)d.stride) & 3) == 0;  // ox0 is a multiple of 4: dword stores on dword rows
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            const unsigned o01 = pd_vert(hq[2 * r].x, hq[2 * r + 1].x, hq[2 * r + 2].x, hq[2 * r + 3].x, hq[2 * r + 4].x);
+            const unsigned o23 = pd_vert(hq[2 * r].y, hq[2 * r + 1].y, hq[2 * r + 2].y, hq[2 * r + 3].y, hq[2 * r + 4].y);
+            const unsigned pack = __builtin_amdgcn_perm(o23, o01, 0x06040200u);
+            uint8_t* dp = const_cast<uint8_t*>(d.p) + (size_t)(oy0 + r) * d.stride + ox0;
+            if (dw_ok) *reinterpret_cast<uint32_t*>(dp) = pack;
+            else for (int k = 0; k < cnt; k++) dp[k] = (uint8_t)(pack >> (8 * k));
+        }
+        return;
+    }
     uint2 own[NR], ext[NR];
 #pragma unroll
     for (int k = 0; k < NR; k++) {
@@ -187,7 +228,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(const void* pb_tab, size_t ws_
 // (translateFlag branch, SURVEY App. B intent); mode 1: float32 affine map + remap(INTER_LINEAR) with 5-bit
 // fixed-point coordinates and 15-bit weights, constant-0 border.  One thread = 4 consecutive ROI pixels.
 // ---------------------------------------------------------------------------------------------------------------
-#define RW_ROWS 4  // ROI rows per thread: their source loads are all in flight together
+#define RW_ROWS 1  // ROI rows per thread (measured at 256 streams: 4 rows 146 VGPRs / 3 waves per SIMD 630 us; 2 rows 75 VGPRs / 6 waves 499 us; 1 row 478 us)
 #define RW_PX 8    // consecutive ROI pixels per thread and row (two packed dword stores)
 
 __device__ __forceinline__ void roi_store4(uint8_t* drow, int x4, int cnt, uint32_t pack)
@@ -241,11 +282,13 @@ struct rw_load16 { unsigned a, b, c, d; };
 
 __global__ __launch_bounds__(256) void k_roi_warp(const void* job_tab, size_t tab_stride)
 {
-    const WarpJob J = *reinterpret_cast<const WarpJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.z * tab_stride);
+    // (an XCD-contiguous block remap, vh_xcd_remap, measured 478 -> 628 us here: the dispatcher's round robin spreads every ROI over all channels)
+    const unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const WarpJob J = *reinterpret_cast<const WarpJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)bz * tab_stride);
     if (J.mode < 0) return;
     const int rw = J.x1 - J.x0, rh = J.y1 - J.y0;
-    const int x8 = (blockIdx.x * blockDim.x + threadIdx.x) * RW_PX;
-    const int ry0 = (blockIdx.y * blockDim.y + threadIdx.y) * RW_ROWS;
+    const int x8 = (int)(bx * blockDim.x + threadIdx.x) * RW_PX;
+    const int ry0 = (int)(by * blockDim.y + threadIdx.y) * RW_ROWS;
     if (ry0 >= rh || x8 >= rw) return;
     const ImgDesc s = J.src;
     const int cnt = min(RW_PX, rw - x8);
