@@ -439,3 +439,35 @@ def test_bad_arguments_are_rejected():
         rc = ws.lib.vh_pyr_lk(ws.handle, L.dptr(im), L.dptr(im), w, h, s1, 64, L.dptr(p), 4, C.byref(lk), C.c_float(-1.0), L.dptr(out), L.dptr(v), None, None,
                               L.stream_ptr())
         assert rc != 0 and b"vh_pyr_lk" in ws.lib.vh_last_error()
+
+
+def test_one_context_used_from_two_streams_is_serialised_not_raced(golden):
+    """A vh_ctx parks the job descriptor of the call in flight, so it serves one HIP stream at a time; the C entry points enforce it: a call that
+    arrives with another stream first waits for the context's work on the previous one.  Many alternating calls on two streams through ONE context
+    (each overwrites the descriptor slot the previous call's kernel reads) must all give the right pose."""
+    import ctypes as C
+
+    import torch
+
+    from velocity_amd import _lib as L
+
+    ws = L.Workspace(1, 1920, 1080, 4096)
+    K64 = L.host_K(golden["K32"])
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    x0 = np.ascontiguousarray(np.float64([0, 0, 0, 0, 0, 1]))
+    R = np.ascontiguousarray(np.eye(3).reshape(9))
+    jobs = []
+    for rep in range(12):
+        n = (4, 64, 1000, 2000)[rep % 4]
+        p = L.to_dev(golden[f"nlst_{n}_p"], torch.float32)
+        pw = L.to_dev(golden[f"nlst_{n}_pw"], torch.float64)
+        out = dict(t=torch.zeros(3, dtype=torch.float32, device="cuda"), R=torch.zeros(9, dtype=torch.float64, device="cuda"),
+                   res=torch.zeros(1, dtype=torch.float64, device="cuda"), info=torch.zeros(2, dtype=torch.int32, device="cuda"), n=n, keep=(p, pw))
+        st = streams[rep % 2]
+        L.check(ws.lib.vh_pose(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(p), L.dptr(pw), n, x0.ctypes.data_as(L.f64p), R.ctypes.data_as(L.f64p), 0,
+                               L.dptr(out["t"]), L.dptr(out["R"]), L.dptr(out["res"]), None, L.dptr(out["info"]), C.c_void_p(st.cuda_stream)), "vh_pose")
+        jobs.append(out)
+    torch.cuda.synchronize()
+    for out in jobs:
+        close(out["t"].cpu().numpy(), golden[f"pose_{out['n']}_t"], 2e-6)
+        close(out["res"].item(), golden[f"pose_{out['n']}_res"], 1e-7)

@@ -199,14 +199,22 @@ o.append(f"\nLibrary kernel time {lib / 1e6:.1f} ms over {steps} steps = {lib / 
          "step -> launches run back to back.")
 o.append(f"Dominant kernel `{kname}` (fine LK stage): {float(k['AverageNs']) / 1e3:.1f} us average in the trace vs {rf['us_per_launch']} us from the HIP events "
          "inside bench.py (`roofline.us_per_launch`).")
+hb = rf["hbm"]
 o.append(f"HBM traffic of that kernel (`profiles/{tag}_hbm_traffic.json`, separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes at {traffic['streams']} streams, "
          f"FETCH_SIZE doubled per MI355X_MICROARCH.md): {(2 * kk['fetch_kib'] + kk['write_kib']) * 1024 / traffic['streams'] / 1e6:.1f} MB per stream and launch vs "
-         f"22.05 MB algorithmic gather bytes; `roofline.achieved` = {rf['achieved']} GB/s of gather bytes ({100 * rf['frac']:.1f} % of 8 TB/s) - the kernel is VALU "
-         f"bound: {ksq.get('valu_insts_per_wave', 0):.0f} VALU instructions per wavefront (= per track, both directions), "
-         f"{64e-9 * ksq.get('SQ_INSTS_VALU', 0):.1f} G lane-instructions per launch = {64e-12 * ksq.get('SQ_INSTS_VALU', 0) / (1e-6 * rf['us_per_launch']):.1f} T/s of the "
-         f"{rf['valu']['peak_tops']} T lane-instruction/s issue peak of its (half-rate) instruction class; SQ issue utilisation "
-         f"{100 * ksq.get('valu_issue_utilisation', 0):.0f} % (`profiles/{tag}_valu_rate.json` settles the issue rates; SQ counters in `profiles/{tag}_lk_sq_pmc.json`). "
-         f"SURVEY's op model (47 op/px set-up, 12 op/px/iteration) prices the same launch at {rf['valu'].get('op_model_gops_per_launch', rf['valu'].get('model_gops_per_launch'))} G operations.\n")
+         f"22.05 MB algorithmic gather bytes; `roofline.hbm.achieved` = {hb['achieved']} GB/s of gather bytes ({100 * hb['frac']:.1f} % of 8 TB/s) - the kernel is VALU "
+         f"bound (`roofline.bound = valu`): {ksq.get('valu_insts_per_wave', 0):.0f} VALU instructions per wavefront (= per track, both directions) in the PMC pass, "
+         f"{64e-9 * ksq.get('SQ_INSTS_VALU', 0):.1f} G lane-instructions per launch; the bench line derives the same figure LIVE from the kernel's own counters "
+         f"({rf['setups_per_launch']} set-ups, {rf['newton_iters_per_launch']} Newton iterations per launch) through the calibrated costs of "
+         f"`profiles/{tag}_lk_valu_model.json`: {rf['issued_ginstr_per_launch']} G = {rf['achieved']} T/s of the {rf['peak']} T lane-instruction/s issue peak "
+         f"of its (half-rate) instruction class -> frac {rf['frac']}; SQ issue utilisation {100 * ksq.get('valu_issue_utilisation', 0):.0f} % "
+         f"(`profiles/{tag}_valu_rate.json` settles the issue rates; SQ counters in `profiles/{tag}_lk_sq_pmc.json`). "
+         f"SURVEY's op model (47 op/px set-up, 12 op/px/iteration) prices the same launch at {rf['op_model']['gops_per_launch']} G operations.\n")
+o.append("Per-kernel rows of the bench line (`roofline.kernels`: HIP-event time inside the library, algorithmic bytes, HBM fraction):\n")
+o.append("| kernel | us per step | algorithmic MB per step | GB/s | of 8 TB/s |\n|---|---|---|---|---|")
+for r in rf["kernels"]:
+    o.append(f"| {r['kernel'][:90]} | {r['us_per_step']} | {r['alg_bytes_per_step'] / 1e6:.0f} | {r['hbm_gbs']} | {100 * r['hbm_frac']:.1f} % |")
+o.append("")
 o.append(f"Throughput vs resident streams (`profiles/{tag}_stream_sweep.json`, 60 steps each): "
          + ", ".join(f"{s_} -> {v['frames_per_s'] / 1e3:.2f} k" for s_, v in sweep.items()) + " frames/s.\n")
 if host:
@@ -220,6 +228,11 @@ if ba_rows:
     if ba_line.get("by_windows"):
         o.append("Batched windows (`vh_nls_batch_multi`): " + ", ".join(f"{k} windows {v['iters_per_s']:.0f} it/s ({1e3 * v['ms_per_window_iter']:.1f} us per window-iteration)"
                                                                         for k, v in ba_line["by_windows"].items()) + f" (`profiles/{tag}_ba_by_windows.json`).")
+    if bench["ba"].get("roofline", {}).get("achieved"):
+        br = bench["ba"]["roofline"]
+        o.append(f"`ba.roofline` of the bench line: `{br['kernel']}` issues {br['mfma_instr_per_launch']} v_mfma_f64_16x16x4_f64 ({br['flop_per_launch'] / 1e9:.1f} GFLOP) in "
+                 f"{br['us_per_launch']} us = {br['achieved']} TFLOP/s of {br['peak']} ({100 * br['frac']:.0f} %); per LM iteration of all {br['windows']} windows: "
+                 + ", ".join(f"{r['kernel']} {r['us']} us ({r['hbm_gbs']} GB/s)" for r in br["kernels"]) + ".")
     if ba_pmc.get("k_ba_schur_mfma", {}).get("mfma_busy_frac"):
         d = ba_pmc["k_ba_schur_mfma"]
         o.append(f"PMC of `k_ba_schur_mfma` at {d['windows']} windows (`profiles/{tag}_ba_pmc.json`): SQ_VALU_MFMA_BUSY_CYCLES {d['SQ_VALU_MFMA_BUSY_CYCLES'] / 1e6:.1f} M over "

@@ -4,6 +4,7 @@
 // every image / track kernel is launched over the maximum extent and reads its extent from there.  A frame is thus a
 // fixed sequence of launches with no host round trip (hipGraph-capturable), for any number of streams per launch.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -488,7 +489,7 @@ extern "C" VH_API int vh_klt_main(vh_ctx* c, int slot, const uint8_t* im, const 
     io.im = im; io.im0 = im0; io.im0_small = im0_small; io.p0 = p0; io.n_ptr = nullptr; io.p_all = p_all; io.v = v;
     io.im_small = im_small; io.flags = flags; io.w = w; io.h = h; io.stride = stride; io.stride0 = stride0; io.n = n;
     io.reuse_prev_small = 0; io.coarse = *coarse; io.fine = *fine; io.fbt_coarse = 1.0f; io.fbt_fine = 0.3f;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = vh_ctx_bind(c, stream);
     VH_CHECK(vh_store(&c->d_ws[slot].io, io, s));
     return vh_run_klt_main(c, slot, 1, s, *coarse, *fine, nullptr, nullptr, n);
 }
@@ -509,7 +510,7 @@ extern "C" VH_API int vh_klt_stage_ptrs(vh_ctx* c, int slot, vh_klt_stages* out)
 extern "C" VH_API int vh_resize_quarter(vh_ctx* c, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream)
 {
     if (!c) return vh_fail(-1, "null ctx");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = vh_ctx_bind(c, stream);
     const int dw = (int)lrint(w * 0.25), dh = (int)lrint(h * 0.25);
     StreamWS* ws = c->d_ws;
     VH_CHECK(vh_store(&ws->rs_src[0], ImgDesc{src, w, h, stride, 0}, s));
@@ -541,7 +542,7 @@ extern "C" VH_API int vh_bgr2gray(vh_ctx* c, const uint8_t* bgr, int w, int h, i
 extern "C" VH_API int vh_ingest_bgr(vh_ctx* c, const uint8_t* bgr, int w, int h, int stride_bytes, uint8_t* gray, int gray_stride, uint8_t* small, void* stream)
 {
     if (!c || !bgr || !gray || w < 1 || h < 1 || stride_bytes < 3 * w || gray_stride < w) return vh_fail(-1, "vh_ingest_bgr: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = vh_ctx_bind(c, stream);
     IngestJob J;
     memset(&J, 0, sizeof(J));
     J.bgr = bgr; J.gray = gray; J.small = small; J.w = w; J.h = h; J.bgr_stride = stride_bytes; J.gray_stride = gray_stride;
@@ -557,7 +558,7 @@ extern "C" VH_API int vh_ingest_bgr(vh_ctx* c, const uint8_t* bgr, int w, int h,
 extern "C" VH_API int vh_pyr_down(vh_ctx* c, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream)
 {
     if (!c) return vh_fail(-1, "null ctx");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = vh_ctx_bind(c, stream);
     StreamWS* ws = c->d_ws;
     PyrDesc P;
     memset(&P, 0, sizeof(P));
@@ -590,7 +591,7 @@ extern "C" VH_API int vh_remap_affine(vh_ctx* c, const uint8_t* im, int w, int h
     J.src = ImgDesc{im, w, h, stride, 0}; J.dst = dst; J.dst_stride = x1 - x0; J.mode = 1;
     J.x0 = x0; J.x1 = x1; J.y0 = y0; J.y1 = y1;
     for (int k = 0; k < 6; k++) J.T[k] = T[k];
-    return run_warp(c, J, (hipStream_t)stream);
+    return run_warp(c, J, vh_ctx_bind(c, stream));
 }
 
 extern "C" VH_API int vh_crop_shift(vh_ctx* c, const uint8_t* im, int w, int h, int stride, int x0, int x1, int y0, int y1, int dx, int dy,
@@ -601,7 +602,7 @@ extern "C" VH_API int vh_crop_shift(vh_ctx* c, const uint8_t* im, int w, int h, 
     memset(&J, 0, sizeof(J));
     J.src = ImgDesc{im, w, h, stride, 0}; J.dst = dst; J.dst_stride = x1 - x0; J.mode = 0;
     J.x0 = x0; J.x1 = x1; J.y0 = y0; J.y1 = y1; J.dx = dx; J.dy = dy;
-    return run_warp(c, J, (hipStream_t)stream);
+    return run_warp(c, J, vh_ctx_bind(c, stream));
 }
 
 __global__ __launch_bounds__(256) void k_bounding_rect(const float* p, int n, int imw, int imh, int bx, int by, int* roi)
@@ -656,7 +657,7 @@ extern "C" VH_API int vh_pyr_lk(vh_ctx* c, const uint8_t* im1, const uint8_t* im
         return vh_fail(-1, "vh_pyr_lk: bad arguments (need win >= 3, max_level >= 0, w, h >= 4, strides >= w)");
     if (w > c->max_w || h > c->max_h || n > c->max_pts) return vh_fail(-1, "vh_pyr_lk: image or point count exceeds the workspace");
     if (n <= 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = vh_ctx_bind(c, stream);
     const StreamBufs& B = c->h_bufs[0];
     LKJob J;
     memset(&J, 0, sizeof(J));
@@ -685,7 +686,7 @@ extern "C" VH_API int vh_ransac_affine(vh_ctx* c, const float* from, const float
                                        int* status, void* stream)
 {
     if (!c || n < 0 || n > c->max_pts) return vh_fail(-1, "vh_ransac_affine: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = vh_ctx_bind(c, stream);
     const StreamBufs& B = c->h_bufs[0];
     RansacJob R;
     memset(&R, 0, sizeof(R));
@@ -765,7 +766,7 @@ extern "C" VH_API int vh_klt_regional(vh_ctx* c, const uint8_t* im0, const uint8
     if (!c || !lk || !T_host || lk->win < 3 || lk->max_level < 0 || n < 1 || w < 4 || h < 4 || stride0 < w || stride < w)
         return vh_fail(-1, "vh_klt_regional: bad arguments (need win >= 3, max_level >= 0, w, h >= 4, strides >= w)");
     if (w > c->max_w || h > c->max_h || n > c->max_pts) return vh_fail(-1, "vh_klt_regional: image or point count exceeds the workspace");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = vh_ctx_bind(c, stream);
     RegionalIO io;
     memset(&io, 0, sizeof(io));
     io.im0 = im0; io.im = im; io.p0 = p0; io.p_out = p_out; io.v_out = v_out; io.roi_out = roi_out;
@@ -808,7 +809,7 @@ extern "C" VH_API int vh_pose(vh_ctx* c, const double* K, const float* p, const 
                               int findR, float* t_out, double* R_out, double* res_out, double* p_proj, int* info, void* stream)
 {
     if (!c || !K || !x0 || !R || n < 0) return vh_fail(-1, "vh_pose: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = vh_ctx_bind(c, stream);
     PoseJob J;
     memset(&J, 0, sizeof(J));
     for (int k = 0; k < 9; k++) { J.K[k] = (double)K[k]; J.R[k] = R[k]; }
@@ -827,7 +828,7 @@ extern "C" VH_API int vh_pose(vh_ctx* c, const double* K, const float* p, const 
 extern "C" VH_API int vh_world2image(vh_ctx* c, const double* C_host, const double* pw, int n, double* out, void* stream)
 {
     if (!c || !C_host) return vh_fail(-1, "vh_world2image: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = vh_ctx_bind(c, stream);
     int r = store_doubles(c->d_small, C_host, 12, s);
     if (r) return r;
     vh_launch_world2image(c->d_small, pw, n, out, s);
@@ -838,7 +839,7 @@ extern "C" VH_API int vh_world2image(vh_ctx* c, const double* C_host, const doub
 extern "C" VH_API int vh_image2world(vh_ctx* c, const double* Hi_host, const double* p, int n, double* out, void* stream)
 {
     if (!c || !Hi_host) return vh_fail(-1, "vh_image2world: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = vh_ctx_bind(c, stream);
     int r = store_doubles(c->d_small + 16, Hi_host, 9, s);
     if (r) return r;
     vh_launch_image2world(c->d_small + 16, p, n, out, s);
@@ -899,8 +900,10 @@ extern "C" VH_API int vh_msv1_t(vh_ctx* c, const double* K, const float* P, cons
 // cameras fewer, so that the partial systems of one window stay below 256 MB
 static int ba_parts(int nt, int nc)
 {
+    static const int cap_env = [] { const char* e = getenv("VH_BA_PARTS"); return e ? atoi(e) : 0; }();  // experiment switch
+    const int pmax = cap_env > 0 ? cap_env : 256;
     int p = nt / 16;
-    p = p < 1 ? 1 : (p > 256 ? 256 : p);
+    p = p < 1 ? 1 : (p > pmax ? pmax : p);
     const long long per = 8ll * (6ll * nc) * (6ll * nc), cap = per > 0 ? (256ll << 20) / per : 256;
     if (cap < p) p = cap < 1 ? 1 : (int)cap;
     return p;
@@ -924,7 +927,7 @@ extern "C" VH_API int vh_nls_batch(vh_ctx* c, const double* K_host, const double
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 0;
     P.nwin = 1; P.ws_stride = P.z_stride = P.x_stride = P.trace_stride = P.info_stride = 0;
     P.nx_total = 3.0 * nt + 6.0 * nc; P.nz_total = 2.0 * nt * (nc + 1);
-    int r = vh_ba_run(P, (hipStream_t)stream);
+    int r = vh_ba_run(P, vh_ctx_bind(c, stream));
     if (r) return vh_fail(r, "vh_ba_run failed");
     return 0;
 }
@@ -950,7 +953,7 @@ extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const double* K_host, const 
     P.nx_total = 3.0 * nt + 6.0 * nc; P.nz_total = 2.0 * nt * (nc + 1);
     P.nwin = nwin; P.ws_stride = workspace_bytes_per_window; P.z_stride = (size_t)2 * nt * (nc + 1); P.x_stride = (size_t)3 * nt + 6 * (size_t)nc;
     P.trace_stride = (size_t)2 * max_iter; P.info_stride = 2;
-    int r = vh_ba_run(P, (hipStream_t)stream);
+    int r = vh_ba_run(P, vh_ctx_bind(c, stream));
     if (r) return vh_fail(r, "vh_ba_run failed");
     return 0;
 }
@@ -970,7 +973,7 @@ extern "C" VH_API int vh_nls_batch2(vh_ctx* c, const double* K_host, const doubl
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 1;
     P.nwin = 1; P.ws_stride = P.z_stride = P.x_stride = P.trace_stride = P.info_stride = 0;
     P.nx_total = 3.0 * nt + nc + 5.0; P.nz_total = 2.0 * nt * (nc + 1);
-    int r = vh_ba_run(P, (hipStream_t)stream);
+    int r = vh_ba_run(P, vh_ctx_bind(c, stream));
     if (r) return vh_fail(r, "vh_ba_run failed");
     return 0;
 }
@@ -998,7 +1001,7 @@ extern "C" VH_API int vh_nls_batch_phase(vh_ctx* c, const double* K_host, const 
     P.nx_total = 3.0 * nt_total + 6.0 * nc; P.nz_total = 2.0 * nt_total * (nc + 1);
     if (span_offset && span_doubles) vh_ba_exchange_span(P, span_offset, span_doubles);
     if (phase < 0 || phase > 3) return vh_fail(-1, "vh_nls_batch_phase: phase must be 0..3");
-    int r = vh_ba_run(P, (hipStream_t)stream);
+    int r = vh_ba_run(P, vh_ctx_bind(c, stream));
     if (r) return vh_fail(r, "vh_ba_run failed");
     return 0;
 }

@@ -1633,7 +1633,9 @@ static int launch_lkq(const void* job_tab, size_t tab_stride, int batch, int max
 template <int WIN, int NW, int M>
 static int launch_lk3(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
-    constexpr int lds = LK3<WIN, NW, M>::LDS_BYTES;
+    // VH_LK_LDS_PAD (experiments only): extra dynamic LDS per workgroup = fewer resident wavefronts per SIMD (the occupancy sensitivity behind DESIGN.md section 9)
+    static const int pad = [] { const char* e = getenv("VH_LK_LDS_PAD"); return e ? atoi(e) : 0; }();
+    const int lds = LK3<WIN, NW, M>::LDS_BYTES + pad;
     hipLaunchKernelGGL((k_lk3<WIN, NW, M>), dim3(max_n, batch), dim3(64 * NW), lds, s, job_tab, tab_stride);
     return 0;
 }

@@ -290,7 +290,7 @@ extern "C" VH_API int vh_session_init(vh_session* s, int slot, const uint8_t* fr
 {
     if (!s || slot < 0 || slot >= s->batch || !t0_host) return vh_fail(-1, "vh_session_init: bad arguments");
     if (stride != s->w) return vh_fail(-1, "vh_session_init: frames must be dense (stride == width)");
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = vh_ctx_bind(s->ctx, stream);
     hipLaunchKernelGGL(k_sess_init, dim3(1), dim3(256), 0, st, s->d_ss + slot, p, p3, vp, frame0, t0_host[0], t0_host[1], t0_host[2], time0,
                        frame_no, res0);
     // quarter-scale copy of frame 0 = im0_small of the first step (pp starts at 0 -> previous index 1)
@@ -305,7 +305,7 @@ static int session_step(vh_session* s, const uint8_t* const* frames_dev, float t
                         const float* frame_nos_dev, void* stream)
 {
     if (!s || !frames_dev) return vh_fail(-1, "vh_session_step: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = vh_ctx_bind(s->ctx, stream);
     vh_ctx* c = s->ctx;
     const int nb = s->batch;
     int r = vh_run_klt_main(c, 0, nb, st, s->coarse, s->fine, s->d_ss, frames_dev, s->N0);  // the set-up kernel also fetches this frame's KltIO from the session
@@ -388,7 +388,7 @@ __global__ void k_sess_ingest_jobs(SessStream* ss_all, IngestJob* jobs, const ui
 extern "C" VH_API int vh_session_ingest_bgr(vh_session* s, const uint8_t* const* bgr_frames_dev, int bgr_stride, uint8_t* const* gray_frames_dev, void* stream)
 {
     if (!s || !bgr_frames_dev || !gray_frames_dev || bgr_stride < 3 * s->w) return vh_fail(-1, "vh_session_ingest_bgr: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = vh_ctx_bind(s->ctx, stream);
     hipLaunchKernelGGL(k_sess_ingest_jobs, dim3((s->batch + 63) / 64), dim3(64), 0, st, s->d_ss, s->d_ingest, bgr_frames_dev, bgr_stride, gray_frames_dev, s->batch);
     vh_launch_ingest_bgr(s->d_ingest, s->batch, s->w, s->h, st);
     SESS_CHECK();

@@ -68,7 +68,24 @@ struct vh_ctx {
     int* prof_stage;
     double* d_small;     // 64 doubles of scratch for host-provided small matrices
     void* ba_graphs;     // replayable launch sequences of whole BA solves (vh_ba.hip), created on demand
+    hipStream_t bound_stream;  // the stream whose work may still read this context's job descriptors (vh_ctx_bind)
+    int bound;
 };
+
+// A vh_ctx parks the job descriptors of the calls in flight, so it serves ONE HIP stream at a time.  Enforced here: an entry point that arrives with
+// another stream first waits for the work queued through this context on the previous one (a serialisation, never a race), then rebinds.
+static inline hipStream_t vh_ctx_bind(vh_ctx* c, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (c) {
+        if (c->bound && c->bound_stream != s) {
+            if (hipStreamSynchronize(c->bound_stream) != hipSuccess) (void)hipGetLastError();  // e.g. the old stream was destroyed: nothing left to wait for
+        }
+        c->bound_stream = s;
+        c->bound = 1;
+    }
+    return s;
+}
 
 
 // tracker-session state of one video stream (vh_session.hip); declared here because the KLTmain set-up kernel (vh_api.hip) fetches a
