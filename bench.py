@@ -480,6 +480,9 @@ class Workload:
         ses = self.sessions[0]
         self.run(1, warmup, ex)
         barrier()
+        # every stage is timed when the launches are long (many tracks in flight); a latency run (few streams) times its three LK launches only -- an event
+        # record between two 5 us kernels is not free
+        L.check(ses.lib.vh_profile_detail(ses.ws.handle, 1 if self.N * self.SG >= 3000 else 0), "vh_profile_detail")
         L.check(ses.lib.vh_profile_begin(ses.ws.handle, 16 * steps + 16), "vh_profile_begin")
         barrier()
         t0 = time.perf_counter()

@@ -247,6 +247,7 @@ VH_API int vh_profile_begin(vh_ctx* ctx, int max_launches);
 VH_API int vh_profile_end(vh_ctx* ctx, double* ms_sum, int* launches, unsigned long long* iters, unsigned long long* setups);
 /* every profiled stage of the same run: 0-2 the LK launches of KLTmain, 3 ROI warp, 4 pyrDown (+ border ring), 5 RANSAC, 6 quarter-scale resize,
  * 7 session frame kernel, 8-12 bundle adjustment (Jacobian, Schur complement, reduction, solve, update).  ms_sum / launches: nstages entries. */
+VH_API int vh_profile_detail(vh_ctx* ctx, int all_stages);  /* before vh_profile_begin: 1 = every stage (default), 0 = the LK launches only */
 VH_API int vh_profile_end_stages(vh_ctx* ctx, int nstages, double* ms_sum, int* launches);
 /* host copy of every stream's ROI (x0, x1, y0, y1) of the last KLTmain call (images.py:9-19 as KLT.py:121-123 applies it): 4 ints per stream */
 VH_API int vh_klt_rois(vh_ctx* ctx, int* roi_host);

@@ -85,6 +85,7 @@ _SIGS = {
     "vh_profile_begin": (C.c_int, [vp, C.c_int]),
     "vh_profile_end": (C.c_int, [vp, f64p, i32p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "vh_profile_end_stages": (C.c_int, [vp, C.c_int, f64p, i32p]),
+    "vh_profile_detail": (C.c_int, [vp, C.c_int]),
     "vh_klt_rois": (C.c_int, [vp, i32p]),
     "vh_msv1_t": (C.c_int, [vp, f64p, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
 }

@@ -369,7 +369,7 @@ __global__ void k_klt_glue2(StreamWS* ws_all)
 
 static int launch_lk_profiled(vh_ctx* c, int stage, const void* tab, size_t st, int count, int win, hipStream_t s, int mn)
 {
-    const int rec = vh_prof_start(c, s);
+    const int rec = vh_prof_start(c, s, 1);
     const int r = vh_launch_lk(tab, st, count, mn, win, s);
     vh_prof_stop(c, rec, stage, s);
     return r;
@@ -422,7 +422,7 @@ extern "C" VH_API int vh_profile_begin(vh_ctx* c, int max_launches)
         c->prof_cap = max_launches;
     }
     c->prof_n = 0;
-    c->prof_on = 1;
+    c->prof_on = c->prof_light ? 1 : 2;
     VH_CHECK(hipDeviceSynchronize());
     for (int b = 0; b < c->batch; b++) VH_CHECK(hipMemset(c->d_ws[b].lk_stats, 0, sizeof(c->d_ws[b].lk_stats)));
     return 0;
@@ -447,6 +447,15 @@ extern "C" VH_API int vh_profile_end(vh_ctx* c, double* ms_sum, int* launches, u
         VH_CHECK(hipMemcpy(st, c->d_ws[b].lk_stats, sizeof(st), hipMemcpyDeviceToHost));
         for (int k = 0; k < 3; k++) { iters[k] += st[k][0]; setups[k] += st[k][1]; }
     }
+    return 0;
+}
+
+// detail of the NEXT vh_profile_begin: 1 (default) times every stage, 0 only the three LK launches of a step (6 event records per step instead of
+// ~22: the choice for single-stream latency runs, where an event record between two 5 us kernels is not free)
+extern "C" VH_API int vh_profile_detail(vh_ctx* c, int all_stages)
+{
+    if (!c) return vh_fail(-1, "null ctx");
+    c->prof_light = all_stages ? 0 : 1;
     return 0;
 }
 

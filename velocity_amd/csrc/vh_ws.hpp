@@ -63,7 +63,8 @@ struct vh_ctx {
     StreamWS* d_ws;
     StreamBufs* h_bufs;  // host copy of every stream's buffer table
     // optional per-stage HIP-event timing of the LK launches (bench.py roofline leg)
-    int prof_on, prof_n, prof_cap;
+    int prof_on, prof_n, prof_cap;  // prof_on: 0 off, 1 LK launches only, 2 every stage
+    int prof_light;                  // vh_profile_detail(ctx, 0): the next vh_profile_begin times the LK launches only
     hipEvent_t* prof_ev;  // 2 * prof_cap events: start/stop pairs
     int* prof_stage;
     double* d_small;     // 64 doubles of scratch for host-provided small matrices
@@ -131,9 +132,10 @@ int vh_fail(int code, const char* msg);
 enum { VH_PROF_LK0 = 0, VH_PROF_LK1 = 1, VH_PROF_LK2 = 2, VH_PROF_WARP = 3, VH_PROF_PYR = 4, VH_PROF_RANSAC = 5, VH_PROF_RESIZE = 6, VH_PROF_SESSION = 7,
        VH_PROF_BA_JAC = 8, VH_PROF_BA_SCHUR = 9, VH_PROF_BA_REDUCE = 10, VH_PROF_BA_SOLVE = 11, VH_PROF_BA_UPDATE = 12, VH_PROF_STAGES = 16 };
 // start of a profiled launch: returns the record index (or -1 when profiling is off / the record table is full); vh_prof_stop closes it
-static inline int vh_prof_start(vh_ctx* c, hipStream_t s)
+static inline int vh_prof_start(vh_ctx* c, hipStream_t s, int level = 2)
 {
-    if (!c || !c->prof_on || c->prof_n >= c->prof_cap) return -1;
+    // level 1: the three LK launches of a frame step (always timed while profiling is on); level 2: every other stage (vh_profile_detail)
+    if (!c || c->prof_on < level || c->prof_n >= c->prof_cap) return -1;
     (void)hipEventRecord(c->prof_ev[2 * c->prof_n], s);
     return c->prof_n;
 }
