@@ -471,3 +471,39 @@ def test_one_context_used_from_two_streams_is_serialised_not_raced(golden):
     for out in jobs:
         close(out["t"].cpu().numpy(), golden[f"pose_{out['n']}_t"], 2e-6)
         close(out["res"].item(), golden[f"pose_{out['n']}_res"], 1e-7)
+
+
+def test_nls_batch_replayed_from_its_graph_equals_plain_launches(golden):
+    """A solve whose job descriptor (pointers, sizes, intrinsics) was seen before is replayed as one hipGraph launch (vh_ba.hip::BaGraphCache: the
+    second sighting builds the graph, later ones replay it).  Same buffers five times: every repetition must give the first (plainly launched)
+    result -- the state bit for bit, the trace to the rounding of its atomically accumulated sums -- and the oracle's."""
+    import torch
+
+    from velocity_amd import _lib as L
+    from velocity_amd import synth
+
+    nt, nf = 300, 7
+    nc = nf - 1
+    z, x0, _, _ = synth.ba_pack(*synth.ba_scene(nt, nf, seed=77))
+    K64 = L.host_K(golden["K32"])
+    ws = L.Workspace(1, 64, 64, 64)  # a context of its own: its graph cache starts empty
+    zd, x0d = L.to_dev(z, torch.float64), L.to_dev(x0, torch.float64)
+    xd = torch.empty_like(x0d)
+    nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    trace = torch.zeros((10, 2), dtype=torch.float64, device="cuda")
+    info = torch.zeros(2, dtype=torch.int32, device="cuda")
+    runs = []
+    for rep in range(5):
+        xd.copy_(x0d)
+        scratch.fill_(0xFF)  # poisoned again: a replayed sequence must not depend on what the previous one left behind
+        trace.zero_()
+        L.check(ws.lib.vh_nls_batch(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, 10, L.dptr(trace), L.dptr(info), L.dptr(scratch),
+                                    nbytes, L.stream_ptr()), "vh_nls_batch")
+        runs.append((xd.cpu().numpy().copy(), trace.cpu().numpy().copy(), info.cpu().numpy().copy()))
+    for x, tr, inf in runs[1:]:
+        assert np.array_equal(x, runs[0][0]) and np.array_equal(inf, runs[0][2])
+        close(tr, runs[0][1], 1e-12)
+    ex, etr = O.ba_schur_solve(golden["K32"].astype(float), z, x0.copy(), nt, nc, 10)
+    close(runs[-1][1][:, 0], np.asarray(etr)[:, 0], 1e-8)
+    close(runs[-1][0], ex, 1e-6, 1e-8)
