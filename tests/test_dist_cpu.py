@@ -50,6 +50,10 @@ def _worker(rank, world, port, n0, total_streams, out):
             st = vd.unpack_state(g[r, j], n0)
             ok &= st["n_cur"] == len(p) and np.array_equal(st["p"], p) and np.array_equal(st["ids"], ids)
             ok &= abs(st["res"] - (0.25 + sid)) < 1e-6 and st["frame_i"] == 7
+    # the record the bench line carries under `dist`: what the process group really was, from the group itself
+    d = ex.describe()
+    ok &= d["backend"] == "gloo" and d["world_size"] == world and [q["rank"] for q in d["devices"]] == list(range(world))
+    ok &= d["exchanges"] == 1 and d["exchange_host_ms_total"] >= 0 and d["bytes_per_rank_per_exchange"] == 4 * len(mine) * vd.record_words(n0)
     out[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
@@ -75,6 +79,8 @@ def test_single_process_exchange():
     ex.start()
     st = vd.unpack_state(ex.wait()[0, 1], 16)
     assert st["n_cur"] == 14 and st["frame_i"] == 7
+    d = ex.describe()
+    assert d["backend"] is None and d["world_size"] == 1 and d["exchanges"] == 1
 
 
 def test_shard_tracks_cover_everything():

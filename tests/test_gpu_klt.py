@@ -123,6 +123,17 @@ def test_remap_and_crop_shift_bit_exact():
         out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
         L.check(wsb.lib.vh_remap_affine(wsb.handle, L.dptr(tb), 1920, 1080, 1920, Tf.ctypes.data_as(L.f32p), *r, L.dptr(out), L.stream_ptr()))
         assert np.array_equal(out.cpu().numpy(), exp), (case, r, Tf)
+    # frames narrower than the run path's 16-byte source window (every thread takes the general path; the unconditional loads must stay inside the frame)
+    for (h, w) in ((4, 4), (5, 9), (9, 19), (12, 21), (30, 17)):
+        tiny = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        tt_ = torch.from_numpy(tiny).cuda()
+        wst = L.workspace(w, h, 1)
+        for Tf in (np.float32([1, 0, 0, 1, 0, 0]), np.float32([0.97, 0.01, -0.02, 1.03, 0.6, -0.4]), np.float32([1, 0, 0, 1, 2.5, 1.25])):
+            r = (0, w, 0, h)
+            exp = KO.remap_affine(tiny, Tf, r)
+            out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
+            L.check(wst.lib.vh_remap_affine(wst.handle, L.dptr(tt_), w, h, w, Tf.ctypes.data_as(L.f32p), *r, L.dptr(out), L.stream_ptr()))
+            assert np.array_equal(out.cpu().numpy(), exp), ((h, w), Tf)
     for dx, dy in ((0, 0), (11, -2), (-30, 40), (500, 0)):
         exp = KO.crop_shift(img, roi, dx, dy)
         out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")

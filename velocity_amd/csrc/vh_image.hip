@@ -338,7 +338,7 @@ __device__ __forceinline__ void rw_thread(const WarpJob& J, const ImgDesc& s, in
         fyb[r][0] = __float_as_int(__fadd_rn(my, RW_MAGIC));
         const int c0 = ((fb[r][0] - RW_MAGIC_I) >> 5) - 1, sy0 = (fyb[r][0] - RW_MAGIC_I) >> 5;
         // source window inside the frame: the aligned 16-byte loads cover columns c0 - 3 .. c0 + 15
-        const int cx = min(max(c0, 3), s.w - 16), cy = min(max(sy0, 0), s.h - 2);
+        const int cx = max(min(max(c0, 3), s.w - 16), 0), cy = max(min(max(sy0, 0), s.h - 2), 0);  // (frames narrower than 20 px: the thread is `bad`, the address stays at the row start)
         bad |= (cx != c0 || cy != sy0) ? ~0u : 0u;
         cb[r] = (fb[r][0] & ~31) - 32;
         const unsigned o0 = (unsigned)(__mul24(cy, s.stride) + cx) + bsh, o1 = o0 + (unsigned)s.stride;
