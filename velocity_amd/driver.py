@@ -145,9 +145,16 @@ class HostFrameFeeder:
     stream wait for it and returns the device table of frame pointers for TrackerSession.step(frames_table=...);
     `after_step(slot)` hands the previous frame's buffer back.  depth >= 3 keeps the upload one frame ahead."""
 
-    def __init__(self, batch, height, width, depth=3):
+    def __init__(self, batch, height, width, depth=3, lanes=None):
         torch = L.torch_cuda()
         self.torch, self.batch, self.depth = torch, batch, depth
+        # one upload is split over `lanes` HIP streams (separate DMA engines).  Measured at 64 streams of 1080p (bench.py --host-frames, tools/exp/
+        # host_feed_lanes.sh): 1 lane 21.7 k frames/s, 2 lanes 24.6 k (50.8 GB/s of the x16 Gen5 link), 4 lanes 24.1 k, 8 lanes 18.0 k
+        import os
+
+        self.lanes = max(1, min(batch, int(os.environ.get("VH_FEEDER_LANES", 0)) or (lanes or (2 if batch >= 8 else 1))))
+        self.lane_streams = [torch.cuda.Stream() for _ in range(self.lanes - 1)]
+        self.lane_done = [[torch.cuda.Event() for _ in range(self.lanes - 1)] for _ in range(depth)]
         self.pinned = [torch.empty((batch, height, width), dtype=torch.uint8).pin_memory() for _ in range(depth)]
         self.dev = [torch.empty((batch, height, width), dtype=torch.uint8, device="cuda") for _ in range(depth)]
         self.tables = [torch.tensor([self.dev[k][b].data_ptr() for b in range(batch)], dtype=torch.int64, device="cuda") for k in range(depth)]
@@ -177,7 +184,19 @@ class HostFrameFeeder:
                     src[b].numpy()[...] = f
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(self.free[slot])  # the tracker is done with this device buffer
-            self.dev[slot].copy_(src, non_blocking=True)
+            if self.lanes == 1:
+                self.dev[slot].copy_(src, non_blocking=True)
+            else:
+                bounds = [round(k * self.batch / self.lanes) for k in range(self.lanes + 1)]
+                for k, st in enumerate(self.lane_streams):  # lanes 1.. on their own streams, lane 0 on the copy stream itself
+                    a, b = bounds[k + 1], bounds[k + 2]
+                    st.wait_event(self.free[slot])
+                    with torch.cuda.stream(st):
+                        self.dev[slot][a:b].copy_(src[a:b], non_blocking=True)
+                        self.lane_done[slot][k].record(st)
+                self.dev[slot][: bounds[1]].copy_(src[: bounds[1]], non_blocking=True)
+                for ev in self.lane_done[slot]:
+                    self.copy_stream.wait_event(ev)
             self.ready[slot].record(self.copy_stream)
         return slot
 
