@@ -1,0 +1,78 @@
+"""bench.py host logic without a GPU: the roofline object is recomputable from the fields it carries, the calibrated instruction model is read
+from profiles/, host_cores() honours a cgroup quota."""
+import importlib.util
+import json
+import os
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _fake_measurement(S, N, steps):
+    # stage ids: vh_ws.hpp VH_PROF_* (0-2 LK, 3 warp, 4 pyr, 5 ransac, 6 resize, 7 session)
+    stage_ms, stage_n = [0.0] * 16, [0] * 16
+    for st, (ms, n) in {3: (0.5, 1), 4: (0.25, 2), 5: (0.03, 2), 6: (0.06, 1), 7: (0.14, 1)}.items():
+        stage_ms[st], stage_n[st] = ms * n * steps, n * steps
+    prof = dict(ms_sum=[0.8 * steps, 1.4 * steps, 4.25 * steps], launches=[steps] * 3,
+                iters=[int(2.03 * 3 * N * S) * steps, int(1.6 * 6 * N * S) * steps, int(2.25 * 2 * N * S) * steps],
+                setups=[3 * N * S * steps, 6 * N * S * steps, 2 * N * S * steps])
+    rois = np.tile(np.int32([190, 1722, 90, 992]), (S, 1))
+    return dict(prof=prof, stage_ms=stage_ms, stage_n=stage_n, rois=rois)
+
+
+def test_roofline_object_is_recomputable_from_its_own_fields():
+    b = _bench()
+    S, N, steps = 256, 2000, 20
+    wl = types.SimpleNamespace(N=N, SG=S, cfg=b.CONFIGS["c2"], params="baseline")
+    r = b.roofline_of(wl, _fake_measurement(S, N, steps), 1)
+    assert r["bound"] == "valu" and r["unit"] == "T lane-instr/s" and r["kernel"].startswith("k_lk3<51, 1, 4>")
+    # frac = issued lane-instructions / launch time / (SIMDs x lanes/clk x clock), every factor in the object
+    peak = r["simds"] * r["peak_lanes_per_clk_per_simd"] * r["clock_ghz"] * 1e9 / 1e12
+    assert abs(peak - r["peak"]) < 0.06
+    achieved = r["issued_ginstr_per_launch"] * 1e9 / (r["us_per_launch"] * 1e-6) / 1e12
+    assert abs(achieved - r["achieved"]) < 2e-3 * r["achieved"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # the live instruction count = the calibrated model applied to the run's own counters
+    model = json.load(open(os.path.join(ROOT, "profiles", "r03_lk_valu_model.json")))
+    issued = 64 * (model["wave_instr_per_setup"] * r["setups_per_launch"] + model["wave_instr_per_newton_iter"] * r["newton_iters_per_launch"])
+    assert abs(issued / 1e9 - r["issued_ginstr_per_launch"]) < 1e-3 * r["issued_ginstr_per_launch"] and r["issued_model_tolerance"] == model["tolerance"]
+    # the contract's HBM view of the same kernel
+    h = r["hbm"]
+    assert h["unit"] == "GB/s" and h["peak"] == 8000.0 and h["alg_bytes_per_launch"] == 2 * N * S * (53 ** 2 + 52 ** 2)
+    assert abs(h["achieved"] - h["alg_bytes_per_launch"] / (r["us_per_launch"] * 1e-6) / 1e9) < 0.01 and abs(h["frac"] - h["achieved"] / 8000.0) < 1e-5
+    # one row per other kernel family, each recomputable
+    names = " | ".join(k["kernel"] for k in r["kernels"])
+    for want in ("k_lk_q<15> (stage 1", "k_lk_q<15> (stage 2", "k_roi_warp", "k_pyr_down", "k_ransac_fused", "k_resize_quarter", "k_sess_frame"):
+        assert want in names
+    for k in r["kernels"]:
+        assert abs(k["hbm_gbs"] - k["alg_bytes_per_step"] / (k["us_per_step"] * 1e-6) / 1e9) <= 0.06 + 1e-3 * k["hbm_gbs"]
+        assert abs(k["hbm_frac"] - k["hbm_gbs"] / 8000.0) < 1e-4
+    warp = [k for k in r["kernels"] if k["kernel"].startswith("k_roi_warp")][0]
+    assert warp["alg_bytes_per_step"] == 2 * S * (1722 - 190) * (992 - 90)
+    assert abs(r["step_us_accounted"] - (r["us_per_launch"] + sum(k["us_per_step"] for k in r["kernels"]))) < 0.2
+
+
+def test_latency_legs_carry_the_lk_rows_only():
+    b = _bench()
+    m = _fake_measurement(1, 2000, 200)
+    m["stage_ms"], m["stage_n"] = [0.0] * 16, [0] * 16  # vh_profile_detail(0): only the three LK launches are timed
+    wl = types.SimpleNamespace(N=2000, SG=1, cfg=b.CONFIGS["c2"], params="baseline")
+    r = b.roofline_of(wl, m, 1)
+    assert r["kernel"].startswith("k_lk3<51, 2, 4>") and len(r["kernels"]) == 2  # 2000 tracks in flight: two wavefronts per track; the model is for <51,1,4>
+    assert r["kernels"][0]["kernel"].startswith("k_lk_strip<15>")
+
+
+def test_headline_hbm_and_host_cores():
+    b = _bench()
+    h = b.headline_hbm(b.CONFIGS["c2"], 33000.0)
+    per_frame = 1920 * 1080 * (1 + 2 * (1 / 4 + 1 / 16)) + 21 * 2000
+    assert h["bytes_per_frame"] == int(per_frame) and abs(h["achieved_gbs"] - per_frame * 33000 / 1e9) < 0.01
+    assert 1 <= b.host_cores() <= (os.cpu_count() or 1)
