@@ -13,7 +13,10 @@
  *     reference's row-vector layout (uv1 ~ [X Y Z] @ K, X_cam = X_w @ R + t, affine [x y 1] @ T with T 3x2);
  *   - a vh_ctx serves ONE HIP stream at a time: the stateless entry points (vh_pyr_lk, vh_pose, vh_remap_affine, ...) park their small job
  *     descriptors in slot 0 of the workspace they are given, so calls that may overlap on different streams / threads need their own vh_ctx
- *     (both bindings do this: velocity_amd/_lib.py::workspace and vh_torch_ops.cpp keep one per (device, stream));
+ *     (both bindings do this: velocity_amd/_lib.py::workspace and vh_torch_ops.cpp keep one per (device, stream)).  The library enforces the rule:
+ *     an entry point that is handed another stream than the context's previous call first waits for the work queued through the context on that
+ *     previous stream (a serialisation, never a race);
+ *   - camera intrinsics K_host are 9 float64 in the reference's MATLAB layout [[fx,0,0],[s,fy,0],[cx,cy,1]] (a float32 K widens exactly);
  *   - return value 0 = success, otherwise a hipError_t (or a negative vh error); vh_last_error() describes it.
  *     Numerical non-convergence is NOT an error: like the reference (NLS.py:126-127,178-179; KLT.py:129) the call
  *     succeeds and reports it through an info/flags output so the host shim can print the same warning.
