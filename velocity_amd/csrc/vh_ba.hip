@@ -926,40 +926,38 @@ __device__ __forceinline__ void ba_inv4_col(const double (&P)[4][4], int col, do
 
 #define BA_GJ_N 128
 #define BA_GJ_MAXQ 124  // the last pivot block must end before the rhs column (127)
-__global__ __launch_bounds__(256) void k_ba_solve_mfma(BaJob J)
+#define BA_GJ_WAVES 8   // one 16-row tile row per wavefront, two wavefronts per SIMD: the per-round hand-over (accumulator read-back, LDS publish, waits) is
+                        // per-wavefront serial work, so halving each wavefront's share and letting two of them interleave on a SIMD shortens the round
+__global__ __launch_bounds__(64 * BA_GJ_WAVES) void k_ba_solve_mfma(BaJob J)
 {
     ba_select_window(J, blockIdx.y);
     if (*J.done) return;
     const int nq = J.nq, ld = nq + 1, tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // tile row of this wavefront
     const int lr = lane >> 4, lc = lane & 15;
     __shared__ double s_R[2][4][BA_GJ_N];       // pivot rows of the coming round
     __shared__ double s_C[2][4][BA_GJ_N];       // pivot columns of the coming round
     __shared__ double s_pinv[BA_GJ_N / 4][16];  // inverse pivot blocks
     __shared__ double s_rhs[BA_GJ_N];
-    double4v acc[2][8];
+    double4v acc[8];
 #pragma unroll
-    for (int il = 0; il < 2; il++)
+    for (int Jt = 0; Jt < 8; Jt++)
 #pragma unroll
-        for (int Jt = 0; Jt < 8; Jt++)
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++) {
-                const int row = 16 * (w + 4 * il) + lr + 4 * rg, col = 16 * Jt + lc;
-                double v;
-                if (row < nq) v = col < nq ? J.Sfull[(size_t)row * ld + col] : (col == BA_GJ_N - 1 ? J.Sfull[(size_t)row * ld + nq] : 0.0);
-                else v = (row == col && col != BA_GJ_N - 1) ? 1.0 : 0.0;
-                acc[il][Jt][rg] = v;
-            }
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = 16 * w + lr + 4 * rg, col = 16 * Jt + lc;
+            double v;
+            if (row < nq) v = col < nq ? J.Sfull[(size_t)row * ld + col] : (col == BA_GJ_N - 1 ? J.Sfull[(size_t)row * ld + nq] : 0.0);
+            else v = (row == col && col != BA_GJ_N - 1) ? 1.0 : 0.0;
+            acc[Jt][rg] = v;
+        }
     // publish the pivot rows / columns of round 0
     if (w == 0) {
 #pragma unroll
-        for (int Jt = 0; Jt < 8; Jt++) s_R[0][lr][16 * Jt + lc] = acc[0][Jt][0];
+        for (int Jt = 0; Jt < 8; Jt++) s_R[0][lr][16 * Jt + lc] = acc[Jt][0];
     }
     if (lc < 4) {
 #pragma unroll
-        for (int il = 0; il < 2; il++)
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++) s_C[0][lc][16 * (w + 4 * il) + lr + 4 * rg] = acc[il][0][rg];
+        for (int rg = 0; rg < 4; rg++) s_C[0][lc][16 * w + lr + 4 * rg] = acc[0][rg];
     }
     __syncthreads();
 #pragma unroll
@@ -973,11 +971,9 @@ __global__ __launch_bounds__(256) void k_ba_solve_mfma(BaJob J)
 #pragma unroll
             for (int k = 0; k < 4; k++) P[m][k] = s_R[buf][m][c0 + k];
         // operands that do not depend on the inverse: pivot columns of my rows, pivot rows of my tile columns
-        double cv[2][4], b[8];
+        double cv[4], b[8];
 #pragma unroll
-        for (int il = 0; il < 2; il++)
-#pragma unroll
-            for (int m = 0; m < 4; m++) cv[il][m] = s_C[buf][m][16 * (w + 4 * il) + lc];
+        for (int m = 0; m < 4; m++) cv[m] = s_C[buf][m][16 * w + lc];
 #pragma unroll
         for (int Jt = 0; Jt < 8; Jt++)
             if (Jt >= J0) b[Jt] = s_R[buf][lr][16 * Jt + lc];
@@ -988,32 +984,23 @@ __global__ __launch_bounds__(256) void k_ba_solve_mfma(BaJob J)
 #pragma unroll
             for (int m = 0; m < 4; m++) s_pinv[r][4 * m + lr] = pk[m];
         }
-        double f[2];
-#pragma unroll
-        for (int il = 0; il < 2; il++) {
-            const int i = 16 * (w + 4 * il) + lc;
-            const double v = cv[il][0] * pk[0] + cv[il][1] * pk[1] + cv[il][2] * pk[2] + cv[il][3] * pk[3];
-            f[il] = (i >= c0 && i < c0 + 4) ? 0.0 : -v;  // the pivot rows stay
-        }
+        const int i = 16 * w + lc;
+        const double fv = cv[0] * pk[0] + cv[1] * pk[1] + cv[2] * pk[2] + cv[3] * pk[3];
+        const double f = (i >= c0 && i < c0 + 4) ? 0.0 : -fv;  // the pivot rows stay
 #pragma unroll
         for (int Jt = 0; Jt < 8; Jt++)
-            if (Jt >= J0) {
-                acc[0][Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[0], b[Jt], acc[0][Jt], 0, 0, 0);
-                acc[1][Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[1], b[Jt], acc[1][Jt], 0, 0, 0);
-            }
+            if (Jt >= J0) acc[Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f, b[Jt], acc[Jt], 0, 0, 0);
         // publish the next pivot rows / columns (the other buffer: slow wavefronts may still read this one)
         if (c0 + 4 < nq) {
             const int rn = r + 1, In = rn >> 2, rgn = rn & 3, Jn = rn >> 2, cmn = 4 * (rn & 3);
-            if (w == (In & 3)) {
+            if (w == In) {
 #pragma unroll
                 for (int Jt = 0; Jt < 8; Jt++)
-                    if (Jt >= Jn) s_R[buf ^ 1][lr][16 * Jt + lc] = acc[In >> 2][Jt][rgn];
+                    if (Jt >= Jn) s_R[buf ^ 1][lr][16 * Jt + lc] = acc[Jt][rgn];
             }
             if (lc >= cmn && lc < cmn + 4) {
 #pragma unroll
-                for (int il = 0; il < 2; il++)
-#pragma unroll
-                    for (int rg = 0; rg < 4; rg++) s_C[buf ^ 1][lc - cmn][16 * (w + 4 * il) + lr + 4 * rg] = acc[il][Jn][rg];
+                for (int rg = 0; rg < 4; rg++) s_C[buf ^ 1][lc - cmn][16 * w + lr + 4 * rg] = acc[Jn][rg];
             }
         }
         __syncthreads();
@@ -1021,9 +1008,7 @@ __global__ __launch_bounds__(256) void k_ba_solve_mfma(BaJob J)
     // the right-hand side column (127 = tile column 7, local column 15), then dc = P_r^-1 rhs_r per pivot block
     if (lc == 15) {
 #pragma unroll
-        for (int il = 0; il < 2; il++)
-#pragma unroll
-            for (int rg = 0; rg < 4; rg++) s_rhs[16 * (w + 4 * il) + lr + 4 * rg] = acc[il][7][rg];
+        for (int rg = 0; rg < 4; rg++) s_rhs[16 * w + lr + 4 * rg] = acc[7][rg];
     }
     __syncthreads();
     if (tid < nq) {
@@ -1358,7 +1343,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     auto solve_update = [&](int it) {
         int rec = vh_prof_start(pc, s);
         // up to 124 unknowns: block Gauss-Jordan on the matrix cores; above: register-resident VALU Gauss-Jordan (256 threads x 64 doubles, then 1024 threads)
-        if (nq <= BA_GJ_MAXQ && !(J.dbg & 64)) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1, nw), dim3(256), 0, s, J);
+        if (nq <= BA_GJ_MAXQ && !(J.dbg & 64)) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1, nw), dim3(64 * BA_GJ_WAVES), 0, s, J);
         else if (nq + 1 <= 128) hipLaunchKernelGGL((k_ba_solve<8, 8, 16>), dim3(1, nw), dim3(256), 0, s, J, nparts);
         else if (nq <= 192) hipLaunchKernelGGL((k_ba_solve<6, 7, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
         else if (nq <= 256) hipLaunchKernelGGL((k_ba_solve<8, 9, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
