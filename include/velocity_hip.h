@@ -243,6 +243,8 @@ VH_API void vh_debug_ransac_path(int mode);
 
 /* test hook: 1 accumulates the reduced camera system of vh_nls_batch on the VALU instead of the f64 matrix cores */
 VH_API void vh_debug_ba_force_valu(int on);
+/* test hook: pyrDown with 2 / 4 / 8 output rows per thread whatever the launch size (0: chosen by size) */
+VH_API void vh_debug_pyr_rows(int rows);
 
 /* ---- measurement aids (bench.py): HIP-event timing of the LK launches + Newton-iteration statistics ------------- */
 VH_API int vh_profile_begin(vh_ctx* ctx, int max_launches);

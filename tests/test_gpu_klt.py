@@ -46,14 +46,19 @@ def test_resize_quarter_bit_exact():
 def test_pyr_down_bit_exact_incl_views_and_odd_sizes():
     L, C, torch = _lib()
     rng = np.random.default_rng(1)
-    for (h, w) in ((1080, 1920), (135, 241), (17, 30), (68, 120), (33, 1), (5, 7)):
+    for (h, w) in ((1080, 1920), (135, 241), (17, 30), (68, 120), (33, 1), (5, 7), (451, 766), (271, 483)):
         img = rng.integers(0, 256, (h, w), dtype=np.uint8)
         ws = L.workspace(w, h, 1)
         t = torch.from_numpy(img).cuda()
         exp = KO.pyr_down(img)
-        out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
-        L.check(ws.lib.vh_pyr_down(ws.handle, L.dptr(t), w, h, w, L.dptr(out), L.stream_ptr()))
-        assert np.array_equal(out.cpu().numpy(), exp), (h, w)
+        for rows in (0, 2, 4, 8):  # every instantiation (rows per thread; the launcher picks by launch size), incl. their row-interior fast path
+            L.load().vh_debug_pyr_rows(rows)
+            try:
+                out = torch.zeros(exp.shape, dtype=torch.uint8, device="cuda")
+                L.check(ws.lib.vh_pyr_down(ws.handle, L.dptr(t), w, h, w, L.dptr(out), L.stream_ptr()))
+            finally:
+                L.load().vh_debug_pyr_rows(0)
+            assert np.array_equal(out.cpu().numpy(), exp), (h, w, rows)
     # strided view like im0[y0:y1, x0:x1]
     img = rng.integers(0, 256, (300, 400), dtype=np.uint8)
     t = torch.from_numpy(img).cuda()

@@ -919,6 +919,7 @@ static int ba_parts(int nt, int nc)
 }
 static int g_ba_force_valu = 0;
 extern "C" VH_API void vh_debug_ba_force_valu(int on) { g_ba_force_valu = on; }
+extern "C" VH_API void vh_debug_pyr_rows(int rows) { vh_pyr_force_rows(rows == 2 || rows == 4 || rows == 8 ? rows : 0); }
 
 extern "C" VH_API size_t vh_nls_batch_workspace(int nt, int nc) { return vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc)); }
 
