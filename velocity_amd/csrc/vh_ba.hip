@@ -950,10 +950,27 @@ __global__ __launch_bounds__(64 * BA_GJ_WAVES) void k_ba_solve_mfma(BaJob J)
             else v = (row == col && col != BA_GJ_N - 1) ? 1.0 : 0.0;
             acc[Jt][rg] = v;
         }
-    // publish the pivot rows / columns of round 0
+    // The wavefront that holds the coming round's pivot rows publishes them, reads the 4 x 4 pivot block back (its own LDS writes complete in order) and
+    // publishes the block's INVERSE too: the other seven wavefronts then read their column of it (4 doubles) instead of the block (16) and skip the
+    // reciprocal chain -- the round's LDS read phase is throughput bound (8 wavefronts x 14 KB), and the owner's extra work overlaps the others' wait.
+    auto publish_inverse = [&](int buf_, int rn_) {  // owner wavefront only: s_R[buf_][.][4 rn_ ..] was just written by this very wavefront
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double P[4][4], pk[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) P[m][k] = s_R[buf_][m][4 * rn_ + k];
+        ba_inv4_col(P, lr, pk);
+        if (lc == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) s_pinv[rn_][4 * m + lr] = pk[m];
+        }
+    };
+    // publish the pivot rows / columns (and the inverse pivot block) of round 0
     if (w == 0) {
 #pragma unroll
         for (int Jt = 0; Jt < 8; Jt++) s_R[0][lr][16 * Jt + lc] = acc[Jt][0];
+        publish_inverse(0, 0);
     }
     if (lc < 4) {
 #pragma unroll
@@ -965,42 +982,37 @@ __global__ __launch_bounds__(64 * BA_GJ_WAVES) void k_ba_solve_mfma(BaJob J)
         const int c0 = 4 * r;
         if (c0 >= nq) break;
         const int buf = r & 1, J0 = r >> 2;
-        double P[4][4];
+        // my column lr of P^-1 (the A operand of lane l is F[16 I + (l & 15)][l >> 4] = sum_m C[.][m] Pinv[m][l >> 4]), pivot columns of my rows,
+        // pivot rows of my tile columns
+        double pk[4], cv[4], b[8];
 #pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) P[m][k] = s_R[buf][m][c0 + k];
-        // operands that do not depend on the inverse: pivot columns of my rows, pivot rows of my tile columns
-        double cv[4], b[8];
+        for (int m = 0; m < 4; m++) pk[m] = s_pinv[r][4 * m + lr];
 #pragma unroll
         for (int m = 0; m < 4; m++) cv[m] = s_C[buf][m][16 * w + lc];
 #pragma unroll
         for (int Jt = 0; Jt < 8; Jt++)
             if (Jt >= J0) b[Jt] = s_R[buf][lr][16 * Jt + lc];
-        // my column lr of P^-1 (the A operand of lane l is F[16 I + (l & 15)][l >> 4] = sum_m C[.][m] Pinv[m][l >> 4])
-        double pk[4];
-        ba_inv4_col(P, lr, pk);
-        if (w == 0 && lc == 0) {
-#pragma unroll
-            for (int m = 0; m < 4; m++) s_pinv[r][4 * m + lr] = pk[m];
-        }
         const int i = 16 * w + lc;
         const double fv = cv[0] * pk[0] + cv[1] * pk[1] + cv[2] * pk[2] + cv[3] * pk[3];
         const double f = (i >= c0 && i < c0 + 4) ? 0.0 : -fv;  // the pivot rows stay
+        const bool has_next = c0 + 4 < nq;
+        const int rn = r + 1, In = rn >> 2, rgn = rn & 3, Jn = rn >> 2, cmn = 4 * (rn & 3);
+        // the tile column of the next pivot first: its results are published while the other tiles are still in the matrix pipe
+        if (has_next) acc[Jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f, b[Jn], acc[Jn], 0, 0, 0);
 #pragma unroll
         for (int Jt = 0; Jt < 8; Jt++)
-            if (Jt >= J0) acc[Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f, b[Jt], acc[Jt], 0, 0, 0);
+            if (Jt >= J0 && !(has_next && Jt == Jn)) acc[Jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f, b[Jt], acc[Jt], 0, 0, 0);
         // publish the next pivot rows / columns (the other buffer: slow wavefronts may still read this one)
-        if (c0 + 4 < nq) {
-            const int rn = r + 1, In = rn >> 2, rgn = rn & 3, Jn = rn >> 2, cmn = 4 * (rn & 3);
+        if (has_next) {
+            if (lc >= cmn && lc < cmn + 4) {
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) s_C[buf ^ 1][lc - cmn][16 * w + lr + 4 * rg] = acc[Jn][rg];
+            }
             if (w == In) {
 #pragma unroll
                 for (int Jt = 0; Jt < 8; Jt++)
                     if (Jt >= Jn) s_R[buf ^ 1][lr][16 * Jt + lc] = acc[Jt][rgn];
-            }
-            if (lc >= cmn && lc < cmn + 4) {
-#pragma unroll
-                for (int rg = 0; rg < 4; rg++) s_C[buf ^ 1][lc - cmn][16 * w + lr + 4 * rg] = acc[Jn][rg];
+                publish_inverse(buf ^ 1, rn);
             }
         }
         __syncthreads();
