@@ -314,6 +314,33 @@ __device__ __forceinline__ long long wave_sum_i32_wide(int v)
     return (long long)hi_t * 65536ll + (long long)lo_t;
 }
 
+// Two (or three) such sums at once, transposing while folding: v_permlane32_swap puts the upper half-wave of one vector beside the lower half-wave
+// of another, so ONE add folds two vectors 64 -> 32 lanes; v_permlane16_swap does the same for 16-lane rows.  The four 16-bit halves of two values
+// end up in the four rows of one register: 3 swaps + 3 adds + 4 DPP adds + 4 readlanes instead of 24 DPP adds + 6 readlanes (gfx950 only).
+__device__ __forceinline__ int fold32_pair(int a, int b)  // lanes 0..31: a[l] + a[l+32], lanes 32..63: b[l-32] + b[l]
+{
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    return (int)(r[0] + r[1]);
+}
+__device__ __forceinline__ int fold16_pair(int a, int b)  // rows 0/2: a[row] + a[row+1], rows 1/3: b[row-1] + b[row]
+{
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+    return (int)(r[0] + r[1]);
+}
+__device__ __forceinline__ void wave_sum2_i32_wide(int a, int b, long long& sa, long long& sb)
+{
+    const int x = fold32_pair(a & 0xffff, a >> 16), y = fold32_pair(b & 0xffff, b >> 16);
+    const int z = dpp_row_sum(fold16_pair(x, y));  // rows: a.lo, b.lo, a.hi, b.hi
+    sa = (long long)__builtin_amdgcn_readlane(z, 32) * 65536ll + (long long)__builtin_amdgcn_readlane(z, 0);
+    sb = (long long)__builtin_amdgcn_readlane(z, 48) * 65536ll + (long long)__builtin_amdgcn_readlane(z, 16);
+}
+__device__ __forceinline__ long long wave_sum1_i32_wide_swap(int a)
+{
+    const int x = fold32_pair(a & 0xffff, a >> 16);
+    const int z = dpp_row_sum(fold16_pair(x, x));  // rows 0,1: a.lo, rows 2,3: a.hi
+    return (long long)__builtin_amdgcn_readlane(z, 32) * 65536ll + (long long)__builtin_amdgcn_readlane(z, 0);
+}
+
 // wave-wide sum when 16 lanes of partials provably fit int32 (one 4-sample strip per lane: 16 * 4 * 8160 * 4080 < 2^31):
 // one DPP chain per value instead of two
 __device__ __forceinline__ long long wave_sum_i32_rows(int v)
@@ -914,8 +941,13 @@ template <int NW, int NV, bool ROWSAFE>
 __device__ __forceinline__ void block_sum_wide(const int* part, long long* tot, long long* red, int& phase, int wave)
 {
     long long w[NV];
+    if constexpr (!ROWSAFE && NV >= 2) {
+        wave_sum2_i32_wide(part[0], part[1], w[0], w[1]);
+        if constexpr (NV == 3) w[2] = wave_sum1_i32_wide_swap(part[2]);
+    } else {
 #pragma unroll
-    for (int k = 0; k < NV; k++) w[k] = ROWSAFE ? wave_sum_i32_rows(part[k]) : wave_sum_i32_wide(part[k]);
+        for (int k = 0; k < NV; k++) w[k] = ROWSAFE ? wave_sum_i32_rows(part[k]) : wave_sum_i32_wide(part[k]);
+    }
     if (NW == 1) {
 #pragma unroll
         for (int k = 0; k < NV; k++) tot[k] = w[k];
