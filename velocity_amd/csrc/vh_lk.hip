@@ -864,8 +864,16 @@ struct LK3 {
     // lane -> (strip column j, run q): every lane owns K vertically consecutive strips of one column, so consecutive
     // strips share patch rows, byte pairs and V rows in registers (a strip's set-up needs 1 new V row instead of 3, a
     // Newton iteration 1 new search row instead of 2)
-    static constexpr int RUNS = T / SPR;
-    static constexpr int K = (WIN + RUNS - 1) / RUNS;
+    // SPLIT (one wavefront, 51x51): 13 strip columns x 4 runs fill 52 lanes only, and 13 strips per lane cover 52 rows.  Instead every lane owns 11
+    // strips: lanes 0..51 (column, run) as before with runs of 11 rows = rows 0..43; the 7 rows left (44..50) go to lanes 52..63 -- lane 52+c takes
+    // column c < 12 in its first KA = 7 strips; the 7 strips of column 12 go ONE each to the last strip slot of lanes 52..58, whose slots 7..9 walk the
+    // three rows above it so that the rolling state (two V rows in the set-up, one row of byte pairs in an iteration) is valid when slot 10 needs it.
+    // Slots that hold no strip are kept as zeros by their selector (below).  663 strips in 64 x 11 slots instead of 52 x 13: -2 strips per lane.
+    static constexpr bool SPLIT = (NW == 1 && WIN == 51);
+    static constexpr int RUNS = SPLIT ? 4 : T / SPR;
+    static constexpr int K = SPLIT ? 11 : (WIN + RUNS - 1) / RUNS;
+    static constexpr int KA = SPLIT ? WIN - RUNS * K : K;  // strips of a lane's first segment
+    static_assert(!SPLIT || (KA == 7 && SPR == 13 && RUNS * SPR + SPR - 1 <= T && KA <= T - RUNS * SPR && K - KA == 4), "split lane mapping");
     static constexpr int PI_ROWS = WIN + 3;                                   // template patch rows
     static constexpr int PI_PITCH = ((4 * (SPR - 1) + 8 + 3) / 4) * 4;        // bytes read per patch row, dword multiple
     static constexpr int RJ = WIN + 1 + 2 * M;                                // search region rows / cols
@@ -878,8 +886,8 @@ struct LK3 {
     // Every lane runs all K strips of its run with NO per-strip branch: strips below the window (the tail of the last run(s)) are computed from
     // whatever the padded buffers hold and kept as ZEROS, so they add nothing to any window sum in the set-up or in the Newton iterations.
     // (Branching on `y < WIN` per strip split the unrolled K loop into exec-masked blocks joined by register moves.)
-    static constexpr int LANES = RUNS * SPR;                     // active lanes
-    static constexpr int PAD_ROWS = RUNS * K - WIN;              // window rows the last run(s) hang over the bottom edge
+    static constexpr int LANES = SPLIT ? T : RUNS * SPR;         // active lanes
+    static constexpr int PAD_ROWS = SPLIT ? 0 : RUNS * K - WIN;  // window rows the last run(s) hang over the bottom edge
     static constexpr int OFF_PI = 0;
     static constexpr int OFF_PJ = OFF_PI + (PI_ROWS + PAD_ROWS) * PI_PITCH + 8;
     static constexpr int OFF_RED = ((OFF_PJ + (RJ + PAD_ROWS) * PJ_PITCH + 16 + 15) / 16) * 16;
@@ -1009,25 +1017,69 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
     __syncthreads();
 
     const bool inside_I = ipx >= 1 && ipy >= 1 && ipx + WIN + 1 <= I.w - 1 && ipy + WIN + 1 <= I.h - 1;
-    // this lane's strips: column j, window rows y0 .. y0+K-1
-    const int run = tid / C::SPR, j = tid - run * C::SPR, y0 = run * C::K;
-    const bool lane_on = run < C::RUNS;
-    const int cnt = min(4, WIN - 4 * j);
+    // this lane's strips: slots 0..KA-1 = column jA, window rows rA + k; slots KA..K-1 = column jB, rows rB + k (one segment unless C::SPLIT).
+    // selA / selB / selC: the v_perm selectors that pack (and mask) the gradient pairs of slots [0, KA), [KA, K-1) and K-1
+    int jA, rA, jB, rB;
+    bool lane_on;
+    unsigned selA01, selA23, selB01, selB23, selC01, selC23;
+    const auto sel01_of = [](int cnt) { return cnt >= 2 ? 0x07060302u : (cnt == 1 ? 0x0c0c0302u : 0x0c0c0c0cu); };
+    const auto sel23_of = [](int cnt) { return cnt >= 4 ? 0x07060302u : (cnt == 3 ? 0x0c0c0302u : 0x0c0c0c0cu); };
+    if constexpr (C::SPLIT) {
+        constexpr int MAIN = C::RUNS * C::SPR;  // 52
+        const bool main_lane = tid < MAIN;
+        const int run = tid / C::SPR;
+        jA = main_lane ? tid - run * C::SPR : tid - MAIN;
+        rA = main_lane ? run * C::K : C::RUNS * C::K;
+        const bool tail = !main_lane && tid < MAIN + C::KA;  // carries one strip of the last column in its last slot
+        jB = main_lane ? jA : C::SPR - 1;
+        rB = main_lane ? rA : (tail ? C::RUNS * C::K + (tid - MAIN) - (C::K - 1) : 0);
+        lane_on = true;
+        const int cntA = min(4, WIN - 4 * jA), cntL = WIN - 4 * (C::SPR - 1);
+        selA01 = sel01_of(cntA); selA23 = sel23_of(cntA);
+        selB01 = main_lane ? selA01 : 0x0c0c0c0cu; selB23 = main_lane ? selA23 : 0x0c0c0c0cu;
+        selC01 = main_lane ? selA01 : (tail ? sel01_of(cntL) : 0x0c0c0c0cu); selC23 = main_lane ? selA23 : (tail ? sel23_of(cntL) : 0x0c0c0c0cu);
+    } else {
+        const int run = tid / C::SPR;
+        jA = jB = tid - run * C::SPR;
+        rA = rB = run * C::K;
+        lane_on = run < C::RUNS;
+        const int cnt = min(4, WIN - 4 * jA);
+        selA01 = selB01 = selC01 = sel01_of(cnt);
+        selA23 = selB23 = selC23 = sel23_of(cnt);
+    }
+    // (k is a compile-time constant wherever these are used: the strip loops are fully unrolled)
+    const auto slot_col = [&](int k) { return k < C::KA ? jA : jB; };
+    const auto slot_row = [&](int k) { return (k < C::KA ? rA : rB) + k; };
+    const auto slot_sel = [&](int k, unsigned& s01, unsigned& s23) {
+        if (C::SPLIT) {
+            s01 = k < C::KA ? selA01 : (k < C::K - 1 ? selB01 : selC01);
+            s23 = k < C::KA ? selA23 : (k < C::K - 1 ? selB23 : selC23);
+        } else {
+            // only the last PAD_ROWS strips of a run can hang below the window: the selector is a per-level lane constant everywhere else
+            const bool below = k >= C::K - C::PAD_ROWS && rA + k >= WIN;
+            s01 = below ? 0x0c0c0c0cu : selA01;
+            s23 = below ? 0x0c0c0c0cu : selA23;
+        }
+    };
+    const auto slot_live = [&](int k) { unsigned a, b; slot_sel(k, a, b); return a != 0x0c0c0c0cu; };  // the slot holds a strip of the window
     constexpr int slot_base = 0, slot_stride = 1;
+    constexpr int PIP = C::PI_PITCH >> 2;
     int part[3] = {0, 0, 0};
     if (lane_on && inside_I) {
         // interior: rolling V rows (see strip_setup_linear): patch rows y .. y+3 feed strip y; one new row per strip
         const unsigned wt = pack16(w0.w00, w0.w01), wb = pack16(w0.w10, w0.w11);
-        const unsigned* col = pI + j;
+        const unsigned* colA = pI + jA + rA * PIP;
+        const unsigned* colB = pI + jB + rB * PIP;
+        const auto patch_row = [&](int k, int dr) { return (k < C::KA ? colA : colB) + (k + dr) * PIP; };  // patch row slot_row(k) + dr, this lane's 8 bytes
         unsigned prB[6];
         int H0[4], H1[4], G0[4], G1[4], Vm[4];  // of V rows y, y+1 (Vm = the middle row's sample columns, for the template value)
         {
             unsigned pr0[6], prA[6];
             int V0[6], V1[6];
-            const unsigned* r0 = col + y0 * (C::PI_PITCH >> 2);
+            const unsigned* r0 = patch_row(0, 0);
             setup_row_pairs(r0[0], r0[1], pr0);
-            setup_row_pairs(r0[C::PI_PITCH >> 2], r0[(C::PI_PITCH >> 2) + 1], prA);
-            setup_row_pairs(r0[2 * (C::PI_PITCH >> 2)], r0[2 * (C::PI_PITCH >> 2) + 1], prB);
+            setup_row_pairs(r0[PIP], r0[PIP + 1], prA);
+            setup_row_pairs(r0[2 * PIP], r0[2 * PIP + 1], prB);
             setup_v_row(pr0, prA, wt, wb, V0);
             setup_v_row(prA, prB, wt, wb, V1);
             setup_hg_row(V0, H0, G0, 0);
@@ -1035,21 +1087,19 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
 #pragma unroll
             for (int c = 0; c < 4; c++) Vm[c] = V1[c + 1];
         }
-        const unsigned sel01 = cnt >= 2 ? 0x07060302u : 0x0c0c0302u, sel23 = cnt >= 4 ? 0x07060302u : (cnt == 3 ? 0x0c0c0302u : 0x0c0c0c0cu);
         // One patch row is read one strip ahead of its use and a scheduling barrier closes every strip: left alone, hipcc hoists the LDS reads of all
         // K strips to the top of the unrolled loop and interleaves the strips (248 VGPRs for K = 13)
         unsigned nlo, nhi;
         {
-            const unsigned* rn = col + (y0 + 3) * (C::PI_PITCH >> 2);
+            const unsigned* rn = patch_row(0, 3);
             nlo = rn[0]; nhi = rn[1];
         }
 #pragma unroll
         for (int k = 0; k < C::K; k++) {
-            const int y = y0 + k;
-            {   // no branch on y < WIN: see LK3 (rows past the patch read the padding / the next buffer: harmless garbage)
+            {   // no branch per strip: see LK3 (rows past the patch read the padding / the next buffer: harmless garbage, masked by the selector)
                 const unsigned clo = nlo, chi = nhi;
                 if (k + 1 < C::K) {
-                    const unsigned* rn = col + (y + 4) * (C::PI_PITCH >> 2);
+                    const unsigned* rn = patch_row(k + 1, 3);
                     nlo = rn[0]; nhi = rn[1];
                 }
                 unsigned prN[6];
@@ -1057,10 +1107,9 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
                 setup_row_pairs(clo, chi, prN);
                 setup_v_row(prB, prN, wt, wb, V2);
                 setup_hg_row(V2, H2, G2, k + 2);
-                // only the last PAD_ROWS strips of a run can hang below the window: the selector is a per-level lane constant everywhere else
-                const bool below = k >= C::K - C::PAD_ROWS && y >= WIN;
-                setup_from_hg(H0, H1, H2, G0, G2, Vm, below ? 0x0c0c0c0cu : sel01, below ? 0x0c0c0c0cu : sel23, tI, tX, tY, slot_base + k * slot_stride,
-                              part[0], part[1], part[2]);
+                unsigned s01, s23;
+                slot_sel(k, s01, s23);
+                setup_from_hg(H0, H1, H2, G0, G2, Vm, s01, s23, tI, tX, tY, slot_base + k * slot_stride, part[0], part[1], part[2]);
                 cI[0] = dot2(tI[k].y, tX[k].y, dot2(tI[k].x, tX[k].x, cI[0]));
                 cI[1] = dot2(tI[k].y, tY[k].y, dot2(tI[k].x, tY[k].x, cI[1]));
 #pragma unroll
@@ -1073,18 +1122,18 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
     } else if (lane_on) {
 #pragma unroll
         for (int k = 0; k < C::K; k++) {
-            const int y = y0 + k;
-            if (y >= WIN) {  // strips below the window are zeros (the iterations read every slot)
+            const int y = slot_row(k), j = slot_col(k);
+            if (!slot_live(k)) {  // slots without a strip are zeros (the iterations read every slot)
                 const uint2 z = make_uint2(0u, 0u);
                 tI[slot_base + k * slot_stride] = z; tX[slot_base + k * slot_stride] = z; tY[slot_base + k * slot_stride] = z;
             } else {
                 unsigned lo[4], hi[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const unsigned* row = pI + (y + r) * (C::PI_PITCH >> 2) + j;
+                    const unsigned* row = pI + (y + r) * PIP + j;
                     lo[r] = row[0]; hi[r] = row[1];
                 }
-                strip_setup<false>(lo, hi, w0, I, ipx, ipy, 4 * j, y, cnt, tI, tX, tY, slot_base + k * slot_stride, part[0], part[1], part[2]);
+                strip_setup<false>(lo, hi, w0, I, ipx, ipy, 4 * j, y, min(4, WIN - 4 * j), tI, tX, tY, slot_base + k * slot_stride, part[0], part[1], part[2]);
                 cI[0] = dot2(tI[k].y, tX[k].y, dot2(tI[k].x, tX[k].x, cI[0]));
                 cI[1] = dot2(tI[k].y, tY[k].y, dot2(tI[k].x, tY[k].x, cI[1]));
             }
@@ -1107,7 +1156,7 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
     // packed byte pairs of window row y (strip column j) of the staged search region at window origin (inx, iny)
     // The strip starts at byte `off` of the staged row: its 5 bytes lie inside the two dwords at off >> 2, and the byte pair (c, c+1) is ONE
     // v_perm of those two dwords with the selector 0x0c000c00 + (c + sh) * 0x00010001 + 0x00010000, sh = off & 3 (wave uniform: no alignbyte)
-    auto region_row_pairs = [&](int inx, int iny, int y, unsigned* t) {
+    auto region_row_pairs = [&](int inx, int iny, int j, int y, unsigned* t) {
         const int off = (inx - rjx) + 4 * j;
         const unsigned sel0 = 0x0c010c00u + (unsigned)__builtin_amdgcn_readfirstlane((inx - rjx) & 3) * 0x00010001u;
         const unsigned* row = pJ + (iny - rjy + y) * (C::PJ_PITCH >> 2) + (off >> 2);
@@ -1136,23 +1185,26 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
         int b[2] = {-cI[0], -cI[1]};
         if (lane_on) {
             // rows are read one strip ahead of their use, a scheduling barrier closes every strip (see the set-up loop)
-            const int off = (inx - rjx) + 4 * j;
+            constexpr int PJP = C::PJ_PITCH >> 2;
             const unsigned sel0 = 0x0c010c00u + (unsigned)__builtin_amdgcn_readfirstlane((inx - rjx) & 3) * 0x00010001u;
-            const unsigned* row = pJ + (iny - rjy + y0) * (C::PJ_PITCH >> 2) + (off >> 2);
+            const unsigned* rowA = pJ + (iny - rjy + rA) * PJP + (((inx - rjx) + 4 * jA) >> 2);
+            const unsigned* rowB = pJ + (iny - rjy + rB) * PJP + (((inx - rjx) + 4 * jB) >> 2);
+            const auto region_row = [&](int k, int dr) { return (k < C::KA ? rowA : rowB) + (k + dr) * PJP; };  // search row slot_row(k) + dr
             unsigned top[4];
             {
+                const unsigned* row = region_row(0, 0);
                 const unsigned d0 = row[0], d1 = row[1];
 #pragma unroll
                 for (int c = 0; c < 4; c++) top[c] = __builtin_amdgcn_perm(d1, d0, sel0 + (unsigned)c * 0x00010001u);
             }
-            unsigned n0 = row[C::PJ_PITCH >> 2], n1 = row[(C::PJ_PITCH >> 2) + 1];
+            unsigned n0 = region_row(0, 1)[0], n1 = region_row(0, 1)[1];
 #pragma unroll
             for (int k = 0; k < C::K; k++) {
-                {   // every strip of the run, no branch: the gradients of strips below the window are zeros (set-up)
+                {   // every slot, no branch: the gradients of slots without a strip are zeros (set-up)
                     const unsigned c0 = n0, c1 = n1;
                     if (k + 1 < C::K) {
-                        n0 = row[(k + 2) * (C::PJ_PITCH >> 2)];
-                        n1 = row[(k + 2) * (C::PJ_PITCH >> 2) + 1];
+                        n0 = region_row(k + 1, 1)[0];
+                        n1 = region_row(k + 1, 1)[1];
                     }
                     unsigned bot[4], p01, p23;  // the bottom row of strip y is the top row of strip y+1
 #pragma unroll
@@ -1193,14 +1245,13 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny)));
         int se[1] = {0};
         if (lane_on) {
-            unsigned top[4];
-            region_row_pairs(inx, iny, y0, top);
 #pragma unroll
             for (int k = 0; k < C::K; k++) {
-                const int y = y0 + k;
-                if (y < WIN) {
-                    unsigned bot[4], p01, p23;
-                    region_row_pairs(inx, iny, y + 1, bot);
+                if (slot_live(k)) {
+                    const int y = slot_row(k), j = slot_col(k), cnt = min(4, WIN - 4 * j);
+                    unsigned top[4], bot[4], p01, p23;
+                    region_row_pairs(inx, iny, j, y, top);
+                    region_row_pairs(inx, iny, j, y + 1, bot);
                     strip_bilinear_pairs(top, bot, w, p01, p23);
                     // template samples of strip y again from the staged patch (rows y+1, y+2; byte columns 1..5 of the lane's 8 bytes)
                     uint2 vI;
@@ -1216,8 +1267,6 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
                     const int d[4] = {d01.x, d01.y, d23.x, d23.y};
 #pragma unroll
                     for (int c = 0; c < 4; c++) se[0] += c < cnt ? (d[c] < 0 ? -d[c] : d[c]) : 0;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) top[c] = bot[c];
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
