@@ -916,21 +916,23 @@ __device__ __forceinline__ void stage_region(const ImgDesc& im, int rx, int ry, 
         const unsigned bsh = (unsigned)(reinterpret_cast<uintptr_t>(im.p) & 3);
         const uint8_t* bp = im.p - bsh;  // dword aligned, wave uniform
         const unsigned off0 = (unsigned)(__mul24(ry + r0, im.stride) + rx + 4 * d) + bsh;
-        unsigned d0[NIT], d1[NIT], sh[NIT];
+        // A batch steps RPI rows = a multiple of 4 bytes whatever the stride is, so a lane keeps its byte phase and its dword-aligned offset over the
+        // whole staging: one 32-bit add of a wave-uniform step per load pair (was: add + 2 and)
+        static_assert(RPI % 4 == 0, "a batch of rows must keep the byte phase of a lane");
+        const unsigned sh = off0 & 3u, aoff = off0 & ~3u;
+        unsigned d0[NIT], d1[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             // unconditional loads (row clamped in the last batch): a branch around a load makes hipcc wait vmcnt(0) per element
-            unsigned off;
-            if ((it + 1) * RPI <= ROWS) off = off0 + (unsigned)(it * RPI) * (unsigned)im.stride;
-            else off = off0 + (unsigned)__mul24(min(it * RPI, ROWS - 1 - r0), im.stride);
-            sh[it] = off & 3u;
-            gptr_u32 ap = (gptr_u32)(bp + (off & ~3u));
+            gptr_u32 ap;
+            if ((it + 1) * RPI <= ROWS) ap = (gptr_u32)(bp + (aoff + (unsigned)(it * RPI) * (unsigned)im.stride));  // scalar base + 32-bit lane offset
+            else ap = (gptr_u32)(bp + ((off0 + (unsigned)__mul24(min(it * RPI, ROWS - 1 - r0), im.stride)) & ~3u));  // clamped lanes are not stored
             d0[it] = ap[0]; d1[it] = ap[1];
         }
         if (l < DPR) {
 #pragma unroll
             for (int it = 0; it < NIT; it++)
-                if ((it + 1) * RPI <= ROWS || r0 + it * RPI < ROWS) dst[(r0 + it * RPI) * LP + l] = __builtin_amdgcn_alignbyte(d1[it], d0[it], sh[it]);
+                if ((it + 1) * RPI <= ROWS || r0 + it * RPI < ROWS) dst[(r0 + it * RPI) * LP + l] = __builtin_amdgcn_alignbyte(d1[it], d0[it], sh);
         }
     } else {
         constexpr int TOTAL = ROWS * DPR;
