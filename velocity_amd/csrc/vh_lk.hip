@@ -106,7 +106,7 @@ __device__ void lk_level(const ImgDesc I, const ImgDesc J, int win, int level, i
                          int& n_iter, int& n_setup, bool want_err)
 {
     const float half = (float)(win - 1) * 0.5f;
-    const float lscale = (float)(1. / (double)(1 << level));
+    const float lscale = __uint_as_float((unsigned)(127 - level) << 23);  // 2^-level exactly = (float)(1. / (1 << level)), without the f64 division
     float px = __fmul_rn(p0x, lscale), py = __fmul_rn(p0y, lscale);
     float nx, ny;
     if (level == top_level) { nx = px; ny = py; }
@@ -585,7 +585,7 @@ __device__ void lk_level_strip(const ImgDesc I, const ImgDesc J, int win_rt, int
     const int spr = (win + 3) >> 2;   // strips per window row
     const int nstrips = spr * win;
     const float half = (float)(win - 1) * 0.5f;
-    const float lscale = (float)(1. / (double)(1 << level));
+    const float lscale = __uint_as_float((unsigned)(127 - level) << 23);  // 2^-level exactly = (float)(1. / (1 << level)), without the f64 division
     float px = __fmul_rn(p0x, lscale), py = __fmul_rn(p0y, lscale);
     float nx, ny;
     if (level == top_level) { nx = px; ny = py; }
@@ -994,7 +994,7 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
     const int wave = tid >> 6;
 
     const float half = (float)(WIN - 1) * 0.5f;
-    const float lscale = (float)(1. / (double)(1 << level));
+    const float lscale = __uint_as_float((unsigned)(127 - level) << 23);  // 2^-level exactly = (float)(1. / (1 << level)), without the f64 division
     float px = __fmul_rn(p0x, lscale), py = __fmul_rn(p0y, lscale);
     float nx, ny;
     if (level == top_level) { nx = px; ny = py; }
@@ -1435,7 +1435,7 @@ __device__ __forceinline__ void lkq_level(const ImgDesc I, const ImgDesc J, int 
 {
     constexpr int NS = (WIN + 3) >> 2;  // strips per row
     const float half = (float)(WIN - 1) * 0.5f;
-    const float lscale = (float)(1. / (double)(1 << level));
+    const float lscale = __uint_as_float((unsigned)(127 - level) << 23);  // 2^-level exactly = (float)(1. / (1 << level)), without the f64 division
     float px = __fmul_rn(p0x, lscale), py = __fmul_rn(p0y, lscale);
     float nx, ny;
     if (level == top_level) { nx = px; ny = py; }
