@@ -1311,14 +1311,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
     const float px = __fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]);
     const float py = __fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]);
 
-    float fx, fy, err;
-    int st, n_iter = 0, n_setup = 0, phase = 0;
-    lk3_track<WIN, NW, M>(job.I, job.J, max_count, eps2, px, py, fx, fy, st, err, smem, tid, phase, n_iter, n_setup, job.err_out != nullptr);
+    // forward pass, then (fbt >= 0) the backward pass from its result: ONE copy of the track code in a loop over the direction -- two inlined copies
+    // doubled the kernel and recomputed the per-lane mapping / masks of lk3_level in each
+    float fx = 0.f, fy = 0.f, err = 0.f, bx = 0.f, by = 0.f;
+    int st = 0, st2 = 0, n_iter = 0, n_setup = 0, phase = 0;
+    const int ndir = fbt >= 0.f ? 2 : 1;
+    const bool want_err = job.err_out != nullptr;
+#pragma unroll 1
+    for (int dir = 0; dir < ndir; dir++) {
+        const PyrDesc& PA = dir ? job.J : job.I;
+        const PyrDesc& PB = dir ? job.I : job.J;
+        float ox, oy, e;
+        int s;
+        lk3_track<WIN, NW, M>(PA, PB, max_count, eps2, dir ? fx : px, dir ? fy : py, ox, oy, s, e, smem, tid, phase, n_iter, n_setup, want_err && dir == 0);
+        if (dir == 0) { fx = ox; fy = oy; st = s; err = e; }
+        else { bx = ox; by = oy; st2 = s; }
+    }
     float fbe = 0.f;
     if (fbt >= 0.f) {
-        float bx, by, e2;
-        int st2;
-        lk3_track<WIN, NW, M>(job.J, job.I, max_count, eps2, fx, fy, bx, by, st2, e2, smem, tid, phase, n_iter, n_setup, false);
         const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
         fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
         st = st && st2 && (fbe < fbt);
