@@ -660,6 +660,18 @@ def roofline_of(wl, m, world):
         rows.append(dict(kernel=nm if N * SG >= 3000 else nm.replace("k_lk_q<15>", "k_lk_strip<15>"), us_per_step=round(t, 2), launches_per_step=1.0, alg_bytes_per_step=int(gather_c),
                          hbm_gbs=round(gather_c / (t * 1e-6) / 1e9, 1) if t > 0 else None, hbm_frac=round(gather_c / (t * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None,
                          bytes="2 N L [(w+2)^2 + (w+1)^2] gather bytes, w = 15, L = pyramid levels; VALU bound like the fine stage"))
+    # VALU view of the two coarse launches together (committed counter pass, scaled by the stream count: not live, and labelled so)
+    cpath = os.path.join(ROOT, "profiles", "r03_lk_sq_pmc.json")
+    if cfg is CONFIGS["c2"] and wl.params == "baseline" and N * SG >= 3000 and os.path.exists(cpath) and len(rows) == 2:
+        pj = json.load(open(cpath))
+        k = pj.get("kernels", {}).get("k_lk_q<15>")
+        t_both = rows[0]["us_per_step"] + rows[1]["us_per_step"]
+        if k and pj.get("streams") and t_both > 0:
+            lane_instr = 2 * 64.0 * k["SQ_INSTS_VALU"] * SG / pj["streams"]  # the file holds the mean of the two launches of a step
+            for r_ in rows:
+                r_["valu_frac_both_coarse_launches"] = round(lane_instr / (t_both * 1e-6) / 1e12 / peak_tops, 4)
+                r_["valu_source"] = (f"profiles/r03_lk_sq_pmc.json: SQ_INSTS_VALU x 64 lanes of both k_lk_q launches of a step at {pj['streams']} streams (scaled to {SG}) "
+                                     "over THIS run's launch times; not live")
     row("k_roi_warp (stage 3: float32 affine map + 5-bit bilinear remap of the ROI)", 3, 2.0 * roi_px, 1, "ROI read + ROI written (sum over the streams' ROIs of the last frame)")
     pyr_bytes = SG * sw * sh * sum(4.0 ** -l * 1.25 for l in range(lc)) + 2.0 * roi_px * sum(4.0 ** -l * 1.25 for l in range(lc))
     row("k_pyr_down + k_pyr_pad (quarter-scale pyramid of the new frame; ROI pyramids of both frames)", 4, pyr_bytes, 2 * lc,
