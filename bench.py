@@ -569,14 +569,19 @@ MFMA_F64_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: dense f64 matrix peak (v_mfm
 
 
 def lk_valu_model():
-    """Wave instructions the fine-stage kernel issues as a function of its in-kernel counters (template set-ups, Newton iterations), fitted ONCE
-    against rocprofv3 SQ_INSTS_VALU passes at different iteration counts (tools/pmc_lk_calib.sh -> profiles/r03_lk_valu_model.json, which also holds
-    the check run and the tolerance).  Returns None when the file is missing."""
-    path = os.path.join(ROOT, "profiles", "r03_lk_valu_model.json")
+    """Wave instructions the fine-stage kernel issues as a function of its in-kernel counters (template set-ups, Newton iterations), fitted
+    against rocprofv3 SQ_INSTS_VALU passes at different iteration counts (tools/pmc_lk_calib.sh -> profiles/rNN_lk_valu_model.json, which also holds
+    the check run and the tolerance; tools/collect_profiles.sh re-fits it first, so a profile set and its model belong to the same kernel build).
+    The newest round's file is used.  Returns None when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_lk_valu_model.json")))
+    if not files:
+        return None
+    rel = os.path.relpath(files[-1], ROOT)
     try:
-        j = json.load(open(path))
+        j = json.load(open(files[-1]))
         return dict(per_setup=float(j["wave_instr_per_setup"]), per_iter=float(j["wave_instr_per_newton_iter"]), tolerance=float(j["tolerance"]),
-                    kernel=j["kernel"], source="profiles/r03_lk_valu_model.json (tools/pmc_lk_calib.sh: SQ_INSTS_VALU fitted over runs with different iteration counts)")
+                    kernel=j["kernel"], source=f"{rel} (tools/pmc_lk_calib.sh: SQ_INSTS_VALU fitted over runs with different iteration counts)")
     except Exception:
         return None
 

@@ -7,6 +7,11 @@ R=/root/repo
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# first: re-fit the instruction-cost model of the fine LK kernel for THIS build (the bench line prices its live counters with it); the file travels back
+# as gpurun_out/prof/lk_valu_model.json and summarize_profiles.py files it as profiles/rNN_lk_valu_model.json
+bash $R/tools/pmc_lk_calib.sh $S > $OUT/lk_calib.log 2>&1
+M=$(ls $R/profiles/r[0-9][0-9]_lk_valu_model.json 2>/dev/null | tail -1)
+if [ -s $R/gpurun_out/lk_valu_model.json ]; then cp $R/gpurun_out/lk_valu_model.json $OUT/lk_valu_model.json; [ -n "$M" ] && cp $R/gpurun_out/lk_valu_model.json $M; fi
 python $R/bench.py --streams $S > $OUT/bench_default.json 2> $OUT/bench_default.err
 for s in 1 2 4 8 16 32 64 128 256; do
   python $R/bench.py --streams $s --steps 60 --warmup 10 --cpu-seconds 0 --no-ba --no-extras --min-seconds 1 2>/dev/null | tail -1 > $OUT/sweep_$s.json

@@ -151,6 +151,11 @@ if os.path.exists(vr) and os.path.getsize(vr) > 100:
                    % (sum(half.values()) / max(len(half), 1), sum(half.values()) / max(len(half), 1) / 2.4, sum(full.values()) / max(len(full), 1)))
     json.dump(j, open(os.path.join(DST, f"{tag}_valu_rate.json"), "w"), indent=1)
 
+# the instruction-cost model of the fine LK kernel fitted at the start of the collection (tools/pmc_lk_calib.sh)
+lm = os.path.join(SRC, "lk_valu_model.json")
+if os.path.exists(lm) and os.path.getsize(lm) > 100:
+    json.dump(json.load(open(lm)), open(os.path.join(DST, f"{tag}_lk_valu_model.json"), "w"), indent=1)
+
 # BA per-kernel stats + the bench line of the profiled run
 ba_rows, ba_line = [], None
 bas = glob.glob(os.path.join(SRC, "ba", "**", "*kernel_stats.csv"), recursive=True)
