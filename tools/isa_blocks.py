@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Static per-basic-block instruction mix of one kernel in hipcc's -S output (VALU / SALU / LDS / VMEM / branch counts per block).
-usage: isa_blocks.py file.s kernel_symbol [min_valu]"""
+usage: isa_blocks.py file.s kernel_symbol [min_valu]
+Blocks are true basic blocks: a label starts one, a branch ends one ("LABEL+n" = the part of a labelled region n lines below its label)."""
 import re
 import sys
 
@@ -10,12 +11,14 @@ lines = open(path).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith(sym + ":"))
 end = next(i for i in range(start, len(lines)) if lines[i].startswith("\t.end_amdhsa_kernel") or lines[i].startswith(".Lfunc_end"))
 blocks, cur = [], ["entry", start, {}, []]
+base_line = start
 for i in range(start + 1, end):
     l = lines[i]
     m = re.match(r"^(\.LBB\d+_\d+):", l)
     if m:
         blocks.append(cur)
         cur = [m.group(1), i, {}, []]
+        base_line = i
         continue
     t = l.strip().split()
     if not t or t[0].startswith(";") or t[0].startswith("."):
@@ -27,7 +30,11 @@ for i in range(start + 1, end):
     cur[2].setdefault("ops", {})
     cur[2]["ops"][op] = cur[2]["ops"].get(op, 0) + 1
     if "branch" in op:
+        # a branch ends the basic block: what follows it in the same labelled region runs only on fall-through (counting a whole labelled region as
+        # one block once made 342 instructions of a skipped border path look like per-level work of k_lk_q)
         cur[3].append(t[1] if len(t) > 1 else "?")
+        blocks.append(cur)
+        cur = [cur[0].split("+")[0] + "+%d" % (i - (cur[1] if "+" not in cur[0] else base_line)), i, {}, []]
 blocks.append(cur)
 tot = {}
 for b in blocks:
