@@ -806,6 +806,8 @@ def main():
                    per_stream_fps=round(value / (S * world), 2), tracks_alive_frac=round(m["alive"], 4),
                    pose_t=[round(float(x), 5) for x in st["t"]], pose_t_truth=[round(float(x), 5) for x in m["truth"]], rms_residual_px=round(st["res"], 5),
                    roofline=roofline_of(wl, m, world), headline_hbm=headline_hbm(cfg, value / world))
+        out["build"] = L.build_info()  # which binary ran: vh_build_id() of the loaded library vs the hash of the tree's sources
+        out["build_id"] = out["build"]["build_id"]
         cpu_args = (cfg, wl.K, wl.frames[: a.ring], wl.p0, wl.p3, wl.vp, wl.lkc, wl.lkf)
         if a.verify_frames > 0:
             out["verified"] = wl.verify(wl.done_steps + 1, nframes=a.verify_frames)

@@ -58,6 +58,9 @@ typedef struct {
 } vh_klt_stages;
 
 VH_API int vh_version(void);
+/* identity of the sources + compiler this binary was built from: "<sha256(csrc, this header, flags)[:24]>-<sha256(hipcc --version)[:8]>"
+ * (velocity_amd/_build.py::build_id).  The Python loader refuses a library whose id is not the tree's; bench.py and pytest print it. */
+VH_API const char* vh_build_id(void);
 VH_API const char* vh_last_error(void);
 /* utility: synchronous device -> host copy of a raw device pointer (used to read the stage pointers below) */
 VH_API int vh_copy_to_host(void* dst_host, const void* src_dev, size_t bytes, void* stream);

@@ -17,6 +17,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_report_header(config):
+    """Which binary the suite runs: the id compiled into velocity_amd/libvelocity_hip.so and the hash of the tree's sources."""
+    try:
+        from velocity_amd import _build, _lib
+
+        info = _lib.build_info()
+        return (f"velocity_amd build_id: {info['build_id']} (tree sources hash to {info['source_hash']}, torch ops "
+                f"{_build.file_build_id(_build.TORCH_OUT, _build._TMARK)}" + (f", VH_LIB override {info['override']}" if info["override"] else "") + ")")
+    except Exception as e:  # reported, never hidden: test_lib_cpu fails on the same condition
+        return f"velocity_amd build_id: UNAVAILABLE ({e})"
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Repeat the id in the tail of the output (the driver's GPUTEST record keeps the tail)."""
+    try:
+        from velocity_amd import _lib
+
+        terminalreporter.write_line(f"velocity_amd build_id: {_lib.build_info()['build_id']}")
+    except Exception as e:
+        terminalreporter.write_line(f"velocity_amd build_id: UNAVAILABLE ({e})")
+
+
 @pytest.fixture(scope="session")
 def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "nls_golden.npz"))

@@ -82,3 +82,40 @@ def test_every_shim_module_imports_without_a_gpu():
 
     for mod in ("NLS", "KLT", "MSV", "common", "dist", "driver", "images", "transforms", "synth", "torch_ops"):
         importlib.import_module(f"velocity_amd.{mod}")
+
+
+def test_library_is_built_from_the_tree():
+    """The binary that travels to the GPU box IS the source: the id compiled into libvelocity_hip.so (and libvelocity_torch.so) equals
+    sha256(csrc + header + flags)[:24] - sha256(hipcc --version)[:8] of this tree (velocity_amd/_build.py); mtimes play no part."""
+    from velocity_amd import _build
+
+    info = _lib.build_info()
+    assert info["override"] is None, "the suite must not run under a VH_LIB override"
+    assert info["matches_source"] and info["build_id"].split("-")[0] == _build.source_hash()
+    assert info["build_id"] == _build.build_id(), "library built with another hipcc than this box's"
+    assert _build.file_build_id(_build.TORCH_OUT, _build._TMARK) == info["build_id"]
+    assert not _build.needs_build()
+
+
+def test_loader_refuses_a_library_from_other_sources(tmp_path):
+    """A library whose id is not the tree's is refused (the round-3 failure: an A/B restore copied a stale .so back and mtimes said
+    'up to date'); only the explicit VH_LIB override loads it, and says so."""
+    import subprocess
+    import sys
+
+    from velocity_amd import _build
+
+    data = open(_build.OUT, "rb").read()
+    have = _build.file_build_id(_build.OUT).encode()
+    fake = tmp_path / "libvelocity_hip.so"
+    fake.write_bytes(data.replace(b"VH_BUILD_ID=" + have, b"VH_BUILD_ID=" + b"0" * 24 + have[24:]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\nfrom velocity_amd import _lib\n_lib.LIB_PATH = %r\n"
+            "try:\n    _lib.load()\nexcept RuntimeError as e:\n    assert 'was not built from this tree' in str(e), e\n    print('REFUSED')\n") % (root, str(fake))
+    env = {k: v for k, v in os.environ.items() if k != "VH_LIB"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert "REFUSED" in r.stdout, r.stdout + r.stderr
+    code = ("import sys; sys.path.insert(0, %r)\nfrom velocity_amd import _lib\ni = _lib.build_info()\n"
+            "assert i['override'] and not i['matches_source'], i\nprint('OVERRIDE')\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, VH_LIB=str(fake)))
+    assert "OVERRIDE" in r.stdout and "VH_LIB override" in r.stderr, r.stdout + r.stderr

@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvelocity_hip.so")
 _lib = None
+_info = None
 _lock = threading.RLock()
 
 u8p, f32p, f64p, i32p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
@@ -37,6 +38,7 @@ LK_FINE = dict(win=51, max_level=0, max_count=30, eps=0.001)  # utils/KLT.py:107
 
 _SIGS = {
     "vh_version": (C.c_int, []),
+    "vh_build_id": (C.c_char_p, []),
     "vh_last_error": (C.c_char_p, []),
     "vh_copy_to_host": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "vh_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -93,21 +95,49 @@ _SIGS = {
 
 
 def load():
-    """Load the HIP library (no GPU needed for loading).  Raises if it has not been built."""
-    global _lib
+    """Load the HIP library (no GPU needed for loading).  Raises if it has not been built, or if it was built from other sources than
+    the tree's: the id compiled into the library (vh_build_id) must carry _build.source_hash().  The only way around the check is the
+    explicit experiment override VH_LIB=/path/to/other.so (tools/exp/ab_libs.sh), which is announced on stderr and shows up in
+    build_info()["override"] -- and therefore in the bench line and the pytest header."""
+    global _lib, _info
     with _lock:
         if _lib is None:
-            if not os.path.exists(LIB_PATH):
+            from . import _build
+
+            want = _build.source_hash()
+            override = os.environ.get("VH_LIB")
+            path = override or LIB_PATH
+            if not os.path.exists(path):
                 raise RuntimeError(
-                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(hipcc --offload-arch=gfx950). velocity_amd has no CPU fallback."
                 )
-            L = C.CDLL(LIB_PATH)
+            have = _build.file_build_id(path)
+            if override:
+                import sys
+
+                print(f"velocity_amd: VH_LIB override: loading {path} (id {have}; the tree's sources hash to {want})", file=sys.stderr)
+            elif have is None or have.split("-")[0] != want:
+                raise RuntimeError(
+                    f"{path} was not built from this tree: it carries build id {have}, the sources hash to {want}-*. "
+                    "Rebuild with `python -c 'import __graft_entry__ as g; g.build()'`."
+                )
+            L = C.CDLL(path)
             for name, (res, args) in _SIGS.items():
                 fn = getattr(L, name)  # AttributeError here = header/library mismatch
                 fn.restype, fn.argtypes = res, args
+            got = L.vh_build_id().decode()
+            if got != have:
+                raise RuntimeError(f"{path}: vh_build_id() says {got}, the file's marker says {have}")
+            _info = {"build_id": got, "source_hash": want, "matches_source": got.split("-")[0] == want, "override": override or None}
             _lib = L
     return _lib
+
+
+def build_info():
+    """{"build_id", "source_hash", "matches_source", "override"} of the loaded library."""
+    load()
+    return dict(_info)
 
 
 def declared_symbols():

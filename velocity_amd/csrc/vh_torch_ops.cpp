@@ -21,6 +21,12 @@
 
 #include "../../include/velocity_hip.h"
 
+#ifndef VH_TORCH_BUILD_ID
+#error "build through velocity_amd/_build.py::build_torch_ops (it passes the tree's build id)"
+#endif
+static const char vh_torch_id[] = "VH_TORCH_BUILD_ID=" VH_TORCH_BUILD_ID;
+extern "C" __attribute__((visibility("default"))) const char* vh_torch_build_id(void) { return vh_torch_id + 18; }
+
 namespace {
 
 using at::Tensor;

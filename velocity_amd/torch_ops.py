@@ -22,6 +22,9 @@ def load():
         _lib.load()  # libvelocity_hip.so first (clear error message when it has not been built)
         if not os.path.exists(_build.TORCH_OUT):
             raise RuntimeError(f"{_build.TORCH_OUT} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        have, want = _build.file_build_id(_build.TORCH_OUT, _build._TMARK), _lib.build_info()["build_id"]
+        if have != want and not _lib.build_info()["override"]:
+            raise RuntimeError(f"{_build.TORCH_OUT} carries build id {have}, libvelocity_hip.so {want}: rebuild (__graft_entry__.build())")
         torch.ops.load_library(_build.TORCH_OUT)
         _LOADED = True
     return torch.ops.velocity_hip
