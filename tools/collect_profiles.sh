@@ -6,6 +6,24 @@ S=${1:-256}
 R=/root/repo
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
+# gate: nothing is profiled unless the loaded binary IS the tree's source and the whole GPU suite is green on it
+cd $R
+python - > $OUT/gate.json <<PY
+import json, sys
+sys.path.insert(0, "$R")
+from velocity_amd import _build, _lib
+i = _lib.build_info()
+i["tree_build_id"] = _build.build_id()
+i["ok"] = bool(i["matches_source"] and not i["override"] and i["build_id"] == i["tree_build_id"])
+print(json.dumps(i))
+PY
+if ! grep -q '"ok": true' $OUT/gate.json; then echo "collect_profiles: the library is not built from this tree:"; cat $OUT/gate.json; exit 3; fi
+if [ -z "$VH_SKIP_SUITE" ]; then
+  python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1
+  rc=$?
+  tail -3 $OUT/pytest_gpu.log
+  if [ $rc -ne 0 ]; then echo "collect_profiles: pytest -m gpu is RED (rc $rc): no profiles are written"; exit 4; fi
+fi
 cd /tmp && export TMPDIR=/tmp
 # first: re-fit the instruction-cost model of the fine LK kernel for THIS build (the bench line prices its live counters with it); the file travels back
 # as gpurun_out/prof/lk_valu_model.json and summarize_profiles.py files it as profiles/rNN_lk_valu_model.json

@@ -182,7 +182,14 @@ steps = [int(r["Calls"]) for r in keep if "k_lk3" in r["Name"]][0]
 rf, cb = bench["roofline"], bench["cpu_baseline"]
 cb1 = bench.get("cpu_baseline_1core", {})
 kname = rf["kernel"].split(" (")[0]
+gate = json.load(open(os.path.join(SRC, "gate.json")))
+suite = [l for l in open(os.path.join(SRC, "pytest_gpu.log")).read().splitlines() if " passed" in l or " failed" in l] if os.path.exists(os.path.join(SRC, "pytest_gpu.log")) else ["(suite skipped: VH_SKIP_SUITE)"]
+if not gate["ok"] or bench.get("build_id") != gate["build_id"]:
+    raise SystemExit(f"summarize_profiles: the collection's gate record does not match the bench line: {gate} vs {bench.get('build_id')}")
+json.dump(dict(gate, pytest_gpu=suite[-1] if suite else None), open(os.path.join(DST, f"{tag}_gate.json"), "w"), indent=1)
 o = [f"# Round {tag[1:]} profiles (1x MI355X)\n",
+     f"Binary: `vh_build_id()` = **{gate['build_id']}** = the hash of the tree's sources (`velocity_amd/_build.py::build_id`); `pytest tests -m gpu -x -q` on the same "
+     f"box, before anything was profiled: **{suite[-1] if suite else 'n/a'}** (`profiles/{tag}_gate.json`; the collection aborts when either check fails).\n",
      f"Regenerate: `gpurun -- bash tools/collect_profiles.sh {S}` then `python tools/summarize_profiles.py {tag}`.\n",
      f"## Default bench: C2 (1080p, 2000 tracks, 3 pyramid levels), {S} streams resident per GPU\n",
      f"`python bench.py` -> `profiles/{tag}_bench_default.json`: **{bench['value']:.0f} tracked frames/s** ({bench['ms_per_step']} ms per step of {S} "
