@@ -73,6 +73,14 @@ def test_track_state_all_gather_world2():
     assert all(out[r] for r in range(world)), dict(out)
 
 
+def test_track_state_all_gather_world8_one_stream_per_rank():
+    """BASELINE config 4's topology: 8 ranks, one stream each (gloo on CPU tensors here; the GPU suite runs the same world with real sessions)."""
+    world, n0, total = 8, 48, 8
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), n0, total, out), nprocs=world, join=True)
+    assert all(out[r] for r in range(world)), dict(out)
+
+
 def test_single_process_exchange():
     ex = vd.TrackStateExchange(2, 16, every=5, device="cpu")
     ex.local[1] = torch.from_numpy(_fake_record(1, 16)[0])

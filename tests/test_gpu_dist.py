@@ -133,3 +133,70 @@ def test_bench_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "visible MI355X" in (r.stdout + r.stderr) and "n_gpus" not in r.stdout
+
+
+def test_c4_topology_eight_ranks_one_stream_each_exchange_with_live_state(tmp_path):
+    """BASELINE config 4 as specified, as far as one device allows: world = 8 (gloo, all ranks on cuda:0), ONE 1080p-shaped stream per rank
+    (16:9 at reduced size), 31 tracked frames with the all-gather of the packed track state every 30 frames, so a real exchange fires on
+    live state (frame 30).  Every rank checks ALL EIGHT gathered records bit for bit against per-stream SessionOracles (CPU, the checker),
+    and the exchange's own record must say world_size 8 with eight device entries."""
+    body = (
+        "from velocity_amd import synth, _lib as L, dist as vd\n"
+        "from velocity_amd.driver import TrackerSession\n"
+        "from oracle.session_oracle import SessionOracle\n"
+        "W, H, n, NF, EVERY = 480, 270, 160, 32, 30\n"
+        "K = synth.K_1080P.copy(); K[:2, :2] *= W / 1920.0; K[2, 0], K[2, 1] = W / 2 + 0.5, H / 2 + 0.5\n"
+        "def scene(r):\n"
+        "    m = synth.PlaneMotion(K, z0=3.6, traj=synth.oscillating_traj(period=20.0 + r))\n"
+        "    fr = [synth.render_frame(W, H, m, k, seed=0xC0FFEE + r).numpy() for k in range(NF)]\n"
+        "    p0 = m.apply(0, synth.grid_tracks(n, W, H, seed=1 + r).astype(float)).astype(np.float32)\n"
+        "    return fr, p0, synth.plane_pose_scene(p0, K), np.ones(n, bool)\n"
+        "fr, p0, p3, vp = scene(rank)\n"
+        "t0 = np.float32([0, 0, 3.6])\n"
+        "ses = TrackerSession(K, W, H, n, nhist=NF, batch=1, msv_frame=5)\n"
+        "ses.init_stream(0, fr[0], p0, p3, vp, t0)\n"
+        "ex = vd.TrackStateExchange(1, n, every=EVERY, device='cuda')\n"
+        "fired = []\n"
+        "for i in range(1, NF):\n"
+        "    ses.step([torch.from_numpy(fr[i]).cuda()], time_s=float(np.float32(i / 30.0)), frame_no=i)\n"
+        "    if ex.due(i):\n"
+        "        ex.wait()\n"
+        "        L.check(ses.lib.vh_session_pack_state(ses.handle, L.dptr(ex.local), L.stream_ptr()), 'pack')\n"
+        "        ex.start()\n"
+        "        fired.append(i)\n"
+        "g = ex.wait().cpu()\n"
+        "assert fired == [30] and g.shape[0] == world == 8\n"
+        "for r in range(world):\n"
+        "    f2, q0, q3, qv = scene(r)\n"
+        "    orc = SessionOracle(K, f2[0], q0, q3, qv, t0, nhist=NF, msv_frame=5)\n"
+        "    for i in range(1, 31):\n"
+        "        orc.step(f2[i], np.float32(i / 30.0), i)\n"
+        "    rec = vd.unpack_state(g[r, 0], n)\n"
+        "    assert rec['frame_i'] == 30 and rec['n_cur'] == int(orc.vg.sum()) > n // 2, (r, rec['frame_i'], rec['n_cur'])\n"
+        "    assert np.array_equal(rec['ids'], np.nonzero(orc.vg)[0]) and np.array_equal(rec['p'], orc.p), f'rank {rank}: stream {r} differs'\n"
+        "    np.testing.assert_allclose(rec['t'], orc.t, rtol=1e-5)\n"
+        "d = ex.describe()\n"
+        "assert d['backend'] == 'gloo' and d['world_size'] == 8 and len(d['devices']) == 8 and sorted(q['rank'] for q in d['devices']) == list(range(8))\n"
+        "assert d['exchanges'] == 1\n"
+        "if rank == 0: print('C4_DIST', json.dumps(d))\n"
+    )
+    out = _run_ranks(tmp_path, body, world=8, timeout=1500)
+    assert "C4_DIST" in out
+
+
+def test_bench_eight_ranks_oversubscribed_prints_n_gpus_8():
+    """`python bench.py --gpus 8 --oversubscribe --backend gloo`: the driver's 8-GPU launch shape (8 ranks, weak scaling, exchange every 30
+    frames) on one device; the line says n_gpus 8 and its dist record shows 8 ranks seen in the last gather."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--oversubscribe", "--streams", "1", "--steps", "32",
+           "--warmup", "2", "--no-ba", "--cpu-seconds", "0", "--exchange-every", "30", "--min-seconds", "0", "--no-extras", "--verify-frames", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["streams_per_gpu"] == 1 and out["scaling"] == "weak"
+    d = out["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 8 and len(d["devices"]) == 8
+    assert d["exchanges"] >= 1 and d["ranks_seen_in_last_gather"] == 8
+    assert out["verified"]["bit_exact"] is True
+    assert out["build"]["matches_source"] is True
