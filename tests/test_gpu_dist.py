@@ -153,7 +153,7 @@ def test_c4_topology_eight_ranks_one_stream_each_exchange_with_live_state(tmp_pa
         "    return fr, p0, synth.plane_pose_scene(p0, K), np.ones(n, bool)\n"
         "fr, p0, p3, vp = scene(rank)\n"
         "t0 = np.float32([0, 0, 3.6])\n"
-        "ses = TrackerSession(K, W, H, n, nhist=NF, batch=1, msv_frame=5)\n"
+        "ses = TrackerSession(K, W, H, n, nhist=NF, batch=1, msv_frame=0)   # no re-triangulation: this test is about the exchange (MSV parity: test_gpu_session.py)\n"
         "ses.init_stream(0, fr[0], p0, p3, vp, t0)\n"
         "ex = vd.TrackStateExchange(1, n, every=EVERY, device='cuda')\n"
         "fired = []\n"
@@ -168,7 +168,7 @@ def test_c4_topology_eight_ranks_one_stream_each_exchange_with_live_state(tmp_pa
         "assert fired == [30] and g.shape[0] == world == 8\n"
         "for r in range(world):\n"
         "    f2, q0, q3, qv = scene(r)\n"
-        "    orc = SessionOracle(K, f2[0], q0, q3, qv, t0, nhist=NF, msv_frame=5)\n"
+        "    orc = SessionOracle(K, f2[0], q0, q3, qv, t0, nhist=NF, msv_frame=0)\n"
         "    for i in range(1, 31):\n"
         "        orc.step(f2[i], np.float32(i / 30.0), i)\n"
         "    rec = vd.unpack_state(g[r, 0], n)\n"

