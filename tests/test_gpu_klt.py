@@ -178,12 +178,13 @@ def test_pyr_lk_bit_exact(seq, lk, fbt):
     # the 4-tracks-per-wave kernel (default only for large batches) on the same border / REFLECT_101 cases
     from velocity_amd import _lib as L
 
-    L.load().vh_debug_force_generic_lk(4)
-    try:
-        p4, v4, err4 = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=fbt, **lk)
-    finally:
-        L.load().vh_debug_force_generic_lk(0)
-    assert np.array_equal(v4, ev) and np.array_equal(p4, e2) and np.array_equal(err4.ravel(), eerr)
+    for mode in (4, 8):  # (8: the 8-tracks-per-wave kernel, the default route at full load)
+        L.load().vh_debug_force_generic_lk(mode)
+        try:
+            p4, v4, err4 = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=fbt, **lk)
+        finally:
+            L.load().vh_debug_force_generic_lk(0)
+        assert np.array_equal(v4, ev) and np.array_equal(p4, e2) and np.array_equal(err4.ravel(), eerr), mode
     assert v[: len(p0)].mean() > 0.9
 
 
@@ -197,8 +198,8 @@ def test_strip_and_per_sample_lk_kernels_agree(seq):
     pts = np.concatenate([p0, rng.uniform(-20, 30, (60, 2)).astype(np.float32), rng.uniform([W - 30, H - 30], [W + 20, H + 20], (60, 2)).astype(np.float32)])
     for lk in (CV_COARSE, CV_FINE, dict(winSize=(9, 9), maxLevel=3, criteria=(3, 20, 0.03)), dict(winSize=(31, 31), maxLevel=1, criteria=(3, 20, 0.03))):
         a = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=0.5, **lk)
-        # 1: per-sample, 2: strip, 3: LDS-staged, 4: 4-tracks-per-wave (15x15 only), 5 / 6 / 7: LDS-staged 51x51 with 1 / 2 / 4 wavefronts per track; default: routed
-        for mode in (1, 2, 3, 4, 5, 6, 7):
+        # 1: per-sample, 2: strip, 3: LDS-staged, 4 / 8: 4 / 8 tracks per wave (15x15 only), 5 / 6 / 7: LDS-staged 51x51 with 1 / 2 / 4 wavefronts per track; default: routed
+        for mode in (1, 2, 3, 4, 5, 6, 7, 8):
             L.load().vh_debug_force_generic_lk(mode)
             try:
                 b = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=0.5, **lk)
@@ -224,7 +225,7 @@ def test_pyr_lk_interior_border_transition_matches_oracle():
     gx, gy = np.meshgrid(xs, ys)
     pts = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
     pts = np.concatenate([pts, pts[:, ::-1] * np.float32([W / H, H / W])]).astype(np.float32)  # the same density along the top / bottom edges
-    for win, lvl, modes in ((15, 2, (0, 2, 3, 4)), (51, 1, (0, 2, 5, 6, 7))):
+    for win, lvl, modes in ((15, 2, (0, 2, 3, 4, 8)), (51, 1, (0, 2, 5, 6, 7))):
         exp = KO.lk_fb(f0, f1, pts, fbt=1.0, win=win, max_level=lvl, max_count=10, eps=0.03)
         for mode in modes:
             L.load().vh_debug_force_generic_lk(mode)
@@ -251,7 +252,7 @@ def test_pyr_lk_large_motion_restages_search_region():
                    (dict(winSize=(51, 51), maxLevel=0, criteria=(3, 30, 0.001)), dict(win=51, max_level=0, max_count=30, eps=0.001)),
                    (dict(winSize=(15, 15), maxLevel=1, criteria=(3, 10, 0.1)), dict(win=15, max_level=1, max_count=10, eps=0.1))):
         e2, ev, eerr = KO.lk_fb(f0, f1, pts, fbt=2.0, **kw)
-        for mode in (0, 3, 4, 5, 6):  # default routing, the LDS-staged kernel for both windows, 4 tracks per wave for 15x15, 1 / 2 waves per 51x51 track
+        for mode in (0, 3, 4, 5, 6, 8):  # (8: 8 tracks per wave for 15x15) default routing, the LDS-staged kernel for both windows, 4 tracks per wave for 15x15, 1 / 2 waves per 51x51 track
             L.load().vh_debug_force_generic_lk(mode)
             try:
                 p2, v, err = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=2.0, **lk)
@@ -289,7 +290,7 @@ def test_pyr_lk_images_much_smaller_than_the_window():
         b = np.roll(a, 1, axis=1)
         pts = np.concatenate([rng.uniform([-2, -2], [w + 2, h + 2], (24, 2)), [[w / 2.0, h / 2.0]]]).astype(np.float32)
         exp = KO.lk_fb(a, b, pts, fbt=1.0, win=win, max_level=2, max_count=10, eps=0.03)
-        for mode in ((0, 1, 2, 3, 4) if win == 15 else (0, 1, 2, 5, 6, 7)):
+        for mode in ((0, 1, 2, 3, 4, 8) if win == 15 else (0, 1, 2, 5, 6, 7)):
             L.load().vh_debug_force_generic_lk(mode)
             try:
                 got = cv2calcOpticalFlowPyrLK(a, b, pts, None, fbt=1.0, winSize=(win, win), maxLevel=2, criteria=(3, 10, 0.03))
@@ -516,7 +517,7 @@ def test_pyr_lk_fuzz_all_kernels_vs_oracle():
         cnt, eps = int(rng.integers(1, 31)), float(rng.choice([0.1, 0.03, 0.01, 0.001]))
         fbt = [None, 1.0, 0.3][int(rng.integers(0, 3))]
         exp = KO.lk_fb(f0, f1, pts, fbt=fbt, win=win, max_level=lvl, max_count=cnt, eps=eps)
-        for mode in (0, 1, 2, 3, 4, 5, 6, 7):
+        for mode in (0, 1, 2, 3, 4, 5, 6, 7, 8):
             L.load().vh_debug_force_generic_lk(mode)
             try:
                 got = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=fbt, winSize=(win, win), maxLevel=lvl, criteria=(3, cnt, eps))

@@ -1716,6 +1716,366 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     }
 }
 
+// =================================================================================================================
+// v5: eighth-wave kernel for the 15x15 coarse stages at full load.
+// 8 tracks per wavefront: a track owns 8 consecutive lanes (half a DPP row), lane r owns window rows 2r and 2r+1 (row 15 of lane 7 is a
+// dummy that carries zero gradients).  What k_lk_q spends per 4 tracks on the per-track "uniform" work -- weights, the three window sums and
+// minEig, the 2x2 solve, the stop rules, every DPP reduction: ~37 % of its instructions -- serves 8 tracks here, and the template set-up
+// shares V rows inside a lane: a lane builds V rows 2r, 2r+1, 2r+2 from its four patch rows (3 per 2 window rows instead of 2 per row) and
+// takes V row 2r+3 from lane r+1.  In the Newton iterations a lane loads its own two search rows; the row below its second row is the first
+// row of lane r+1 (v_dot2c_i32_i16_dpp).  Window sums are 8-lane DPP reductions (quad_perm, quad_perm, row_half_mirror).  Lane 7 of a track
+// reads lane 0 of the next track through DPP only for its dummy row.  Same integers, same float sequence per track: bit-identical results.
+// =================================================================================================================
+__device__ __forceinline__ int dpp_oct_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror: lane i <-> lane 7 - i of its half row
+    return v;
+}
+__device__ __forceinline__ long long oct_sum_wide(int v)
+{
+    const int lo = dpp_oct_sum(v & 0xffff), hi = dpp_oct_sum(v >> 16);
+    return (long long)hi * 65536ll + (long long)lo;
+}
+// bilinear x32 samples of window rows 2r and 2r+1 (NS strips each) at (x0, y0) of image im: the lane holds image rows y0 + 2r and y0 + 2r + 1,
+// the row below them is the first row of lane r + 1
+template <int NS>
+__device__ __forceinline__ void lko_sample_rows(const ImgDesc& im, int x0, int y0, int r, bool fast, unsigned wt, unsigned wb, unsigned* a01,
+                                                unsigned* a23, unsigned* b01, unsigned* b23)
+{
+    unsigned top[NS + 1], mid[NS + 1];
+    load_row_words<NS + 1>(im, x0, y0 + 2 * r, fast, top);
+    load_row_words<NS + 1>(im, x0, y0 + 2 * r + 1, fast, mid);
+    constexpr int SH = 16 - (W_BITS - 5), RND = 1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5));
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        int va[4], vb[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const unsigned pa = row_pair(top, 4 * j + c), pb = row_pair(mid, 4 * j + c);
+            va[c] = (dot2(pb, wb, dot2_first(pa, wt)) << SH) + RND;
+            vb[c] = (dot2c_next_lane(dot2_first(pb, wt), pa, wb) << SH) + RND;
+        }
+        a01[j] = pack_hi16(va[0], va[1]); a23[j] = pack_hi16(va[2], va[3]);
+        b01[j] = pack_hi16(vb[0], vb[1]); b23[j] = pack_hi16(vb[2], vb[3]);
+    }
+}
+
+template <int WIN>
+__device__ __forceinline__ void lko_level(const ImgDesc I, const ImgDesc J, int level, int top_level, int max_count, double eps2, float p0x,
+                                          float p0y, float& nxo, float& nyo, int& status, float& err, int r, int& n_iter, int& n_setup,
+                                          bool want_err)
+{
+    constexpr int NS = (WIN + 3) >> 2;  // strips per row
+    const float half = (float)(WIN - 1) * 0.5f;
+    const float lscale = __uint_as_float((unsigned)(127 - level) << 23);
+    float px = __fmul_rn(p0x, lscale), py = __fmul_rn(p0y, lscale);
+    float nx, ny;
+    if (level == top_level) { nx = px; ny = py; }
+    else { nx = __fmul_rn(nxo, 2.f); ny = __fmul_rn(nyo, 2.f); }
+    nxo = nx; nyo = ny;
+
+    px = __fsub_rn(px, half); py = __fsub_rn(py, half);
+    const int ipx = vh_floor(px), ipy = vh_floor(py);
+    if (ipx < -WIN || ipx >= I.w || ipy < -WIN || ipy >= I.h) {
+        if (level == 0) { status = 0; err = 0.f; }
+        return;
+    }
+    const Win w0 = bilinear_weights(__fsub_rn(px, (float)ipx), __fsub_rn(py, (float)ipy));
+    n_setup++;
+
+    int a11 = 0, a12 = 0, a22 = 0;
+    uint2 tXa[NS], tYa[NS], tXb[NS], tYb[NS];  // template gradients of window rows 2r (a) and 2r + 1 (b)
+    int cI[2] = {0, 0};
+    const bool fast_I = ipx >= 1 && ipy >= 1 && ipx + WIN + 3 <= I.w && ipy + WIN + 2 <= I.h && !(ipy == 1 && ipx < 4) &&
+                        !(ipy + WIN + 2 == I.h && ipx + WIN + 8 > I.w);
+    const unsigned w0t = pack16(w0.w00, w0.w01), w0b = pack16(w0.w10, w0.w11);
+    const bool rowb = 2 * r + 1 < WIN;  // (row 2r is always a window row)
+    // accumulate one strip of one window row: template samples vI, gradients vX / vY (already masked)
+    auto accumulate = [&](uint2 vI, uint2 vX, uint2 vY) {
+        a11 = dot2(vX.y, vX.y, dot2(vX.x, vX.x, a11));
+        a12 = dot2(vX.y, vY.y, dot2(vX.x, vY.x, a12));
+        a22 = dot2(vY.y, vY.y, dot2(vY.x, vY.x, a22));
+        cI[0] = dot2(vI.y, vX.y, dot2(vI.x, vX.x, cI[0]));
+        cI[1] = dot2(vI.y, vY.y, dot2(vI.x, vY.x, cI[1]));
+    };
+    if (fast_I) {
+        // Lane r reads patch rows 2r .. 2r+3 (patch row 0 = image row ipy - 1) and builds V rows 2r, 2r+1, 2r+2 over the NC columns its strips share
+        // (V = bilinear weights . patch, no rounding); V row 2r+3 is the neighbour's V row 2(r+1)+1 (DPP).  Window row w uses V rows w, w+1, w+2:
+        //   S = 3 (V_w + V_w+2) + 10 V_w+1,  dV = V_w+2 - V_w,  Ix = S[c+2] - S[c],  Iy = 3 (dV[c] + dV[c+2]) + 10 dV[c+1]   (see lkq_level)
+        constexpr int NC = 4 * NS + 2;
+        unsigned a[4][NS + 1];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) load_row_words<NS + 1>(I, ipx - 1, ipy - 1 + 2 * r + rr, true, a[rr]);
+        int SA[NC], SB[NC], dA[NC], dB[NC], CA[NC], CB[NC];
+        auto column = [&](int c) {
+            const unsigned q0 = row_pair(a[0], c), q1 = row_pair(a[1], c), q2 = row_pair(a[2], c), q3 = row_pair(a[3], c);
+            const int va = dot2(q1, w0b, dot2_first(q0, w0t));
+            const int vb = dot2(q2, w0b, dot2_first(q1, w0t));
+            const int vc = dot2(q3, w0b, dot2_first(q2, w0t));
+            const int vd = (int)dpp_from_next_lane((unsigned)vb);
+            CA[c] = vb; CB[c] = vc;
+            SA[c] = mad24_v<40>(vb, mad24_s<12>(va + vc, c << W_BITS));
+            dA[c] = vc - va;
+            SB[c] = mad24_v<40>(vc, mad24_s<12>(vb + vd, c << W_BITS));
+            dB[c] = vd - vb;
+        };
+        column(0); column(1);
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) column(4 * j + 2 + c);
+            const int cnt = WIN - 4 * j < 4 ? WIN - 4 * j : 4;
+            const unsigned s01 = cnt >= 2 ? 0x07060302u : 0x0c0c0302u, s23 = cnt >= 4 ? 0x07060302u : (cnt == 3 ? 0x0c0c0302u : 0x0c0c0c0cu);
+            const unsigned sb01 = rowb ? s01 : 0x0c0c0c0cu, sb23 = rowb ? s23 : 0x0c0c0c0cu;
+            int iv[4], ix[4], iy[4];
+            // window row 2r
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int col = 4 * j + c;
+                iv[c] = (CA[col + 1] << (16 - (W_BITS - 5))) + (1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5)));
+                ix[c] = SA[col + 2] - SA[col];
+                iy[c] = mad24_v<40>(dA[col + 1], mad24_s<12>(dA[col] + dA[col + 2], 4 << (W_BITS - 1)));
+            }
+            {
+                const uint2 vI = make_uint2(pack_hi16(iv[0], iv[1]), pack_hi16(iv[2], iv[3]));
+                const uint2 vX = make_uint2(__builtin_amdgcn_perm((unsigned)ix[1], (unsigned)ix[0], s01), __builtin_amdgcn_perm((unsigned)ix[3], (unsigned)ix[2], s23));
+                const uint2 vY = make_uint2(__builtin_amdgcn_perm((unsigned)iy[1], (unsigned)iy[0], s01), __builtin_amdgcn_perm((unsigned)iy[3], (unsigned)iy[2], s23));
+                tXa[j] = vX; tYa[j] = vY;
+                accumulate(vI, vX, vY);
+            }
+            // window row 2r + 1
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int col = 4 * j + c;
+                iv[c] = (CB[col + 1] << (16 - (W_BITS - 5))) + (1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5)));
+                ix[c] = SB[col + 2] - SB[col];
+                iy[c] = mad24_v<40>(dB[col + 1], mad24_s<12>(dB[col] + dB[col + 2], 4 << (W_BITS - 1)));
+            }
+            {
+                const uint2 vI = make_uint2(pack_hi16(iv[0], iv[1]), pack_hi16(iv[2], iv[3]));
+                const uint2 vX = make_uint2(__builtin_amdgcn_perm((unsigned)ix[1], (unsigned)ix[0], sb01), __builtin_amdgcn_perm((unsigned)ix[3], (unsigned)ix[2], sb23));
+                const uint2 vY = make_uint2(__builtin_amdgcn_perm((unsigned)iy[1], (unsigned)iy[0], sb01), __builtin_amdgcn_perm((unsigned)iy[3], (unsigned)iy[2], sb23));
+                tXb[j] = vX; tYb[j] = vY;
+                accumulate(vI, vX, vY);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // Window at the image border: the derivative image is 0 OUTSIDE the level, so the Scharr gradients of the integer pixels are built (packed
+        // int16 pairs (k, k+1), see lkq_level), zeroed outside, then interpolated like any other image.  Lane r holds pixel rows 2r-1 .. 2r+2 of the
+        // window (image rows ipy + 2r - 1 ..) and gradient rows 2r, 2r+1; gradient / pixel row 2r+2 is lane r+1's first row (DPP).
+        unsigned a[4][NS + 1];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) load_row_words<NS + 1>(I, ipx - 1, ipy - 1 + 2 * r + rr, I.pad >= VH_LV_PAD, a[rr]);
+        const int ay = ipy + 2 * r, cs = max(0, -ipx), ce = min(4 * NS, I.w - 1 - ipx);
+        const unsigned Mc = ce >= cs ? (((2u << ce) - 1u) & ~((1u << cs) - 1u)) : 0u;
+        const unsigned MA = (ay >= 0 && ay < I.h) ? Mc : 0u, MB = (ay + 1 >= 0 && ay + 1 < I.h) ? Mc : 0u;
+        short2v SpA[4 * NS + 2], DpA[4 * NS + 2], SpB[4 * NS + 2], DpB[4 * NS + 2];
+        unsigned PA[4 * NS + 2], PB[4 * NS + 2];
+        const short2v k3 = {3, 3}, k10 = {10, 10};
+        auto colb = [&](int k) {
+            const unsigned p0 = row_pair(a[0], k), p3 = row_pair(a[3], k);
+            PA[k] = row_pair(a[1], k);
+            PB[k] = row_pair(a[2], k);
+            SpA[k] = (as_s2(p0) + as_s2(PB[k])) * k3 + as_s2(PA[k]) * k10;
+            DpA[k] = as_s2(PB[k]) - as_s2(p0);
+            SpB[k] = (as_s2(PA[k]) + as_s2(p3)) * k3 + as_s2(PB[k]) * k10;
+            DpB[k] = as_s2(p3) - as_s2(PA[k]);
+        };
+        colb(0); colb(1);
+        constexpr int SH = 16 - (W_BITS - 5), RND = 1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5));
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) colb(4 * j + 2 + c);
+            const int cnt = WIN - 4 * j < 4 ? WIN - 4 * j : 4;
+            const unsigned s01 = cnt >= 2 ? 0x07060302u : 0x0c0c0302u, s23 = cnt >= 4 ? 0x07060302u : (cnt == 3 ? 0x0c0c0302u : 0x0c0c0c0cu);
+            const unsigned sb01 = rowb ? s01 : 0x0c0c0c0cu, sb23 = rowb ? s23 : 0x0c0c0c0cu;
+            int ivA[4], ixA[4], iyA[4], ivB[4], ixB[4], iyB[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int col = 4 * j + c;
+                const unsigned ma = (unsigned)__builtin_amdgcn_sbfe((int)MA, col, 1) & 0xffffu | ((unsigned)__builtin_amdgcn_sbfe((int)MA, col + 1, 1) << 16);
+                const unsigned mb = (unsigned)__builtin_amdgcn_sbfe((int)MB, col, 1) & 0xffffu | ((unsigned)__builtin_amdgcn_sbfe((int)MB, col + 1, 1) << 16);
+                const unsigned gxa = __builtin_bit_cast(unsigned, SpA[col + 2] - SpA[col]) & ma;
+                const unsigned gya = __builtin_bit_cast(unsigned, (DpA[col] + DpA[col + 2]) * k3 + DpA[col + 1] * k10) & ma;
+                const unsigned gxb = __builtin_bit_cast(unsigned, SpB[col + 2] - SpB[col]) & mb;
+                const unsigned gyb = __builtin_bit_cast(unsigned, (DpB[col] + DpB[col + 2]) * k3 + DpB[col + 1] * k10) & mb;
+                ixA[c] = (dot2(gxb, w0b, dot2_first(gxa, w0t)) << 2) + (4 << (W_BITS - 1));
+                iyA[c] = (dot2(gyb, w0b, dot2_first(gya, w0t)) << 2) + (4 << (W_BITS - 1));
+                ivA[c] = (dot2(PB[col + 1], w0b, dot2_first(PA[col + 1], w0t)) << SH) + RND;
+                ixB[c] = (dot2c_next_lane(dot2_first(gxb, w0t), gxa, w0b) << 2) + (4 << (W_BITS - 1));
+                iyB[c] = (dot2c_next_lane(dot2_first(gyb, w0t), gya, w0b) << 2) + (4 << (W_BITS - 1));
+                ivB[c] = (dot2c_next_lane(dot2_first(PB[col + 1], w0t), PA[col + 1], w0b) << SH) + RND;
+            }
+            {
+                const uint2 vI = make_uint2(pack_hi16(ivA[0], ivA[1]), pack_hi16(ivA[2], ivA[3]));
+                const uint2 vX = make_uint2(__builtin_amdgcn_perm((unsigned)ixA[1], (unsigned)ixA[0], s01), __builtin_amdgcn_perm((unsigned)ixA[3], (unsigned)ixA[2], s23));
+                const uint2 vY = make_uint2(__builtin_amdgcn_perm((unsigned)iyA[1], (unsigned)iyA[0], s01), __builtin_amdgcn_perm((unsigned)iyA[3], (unsigned)iyA[2], s23));
+                tXa[j] = vX; tYa[j] = vY;
+                accumulate(vI, vX, vY);
+            }
+            {
+                const uint2 vI = make_uint2(pack_hi16(ivB[0], ivB[1]), pack_hi16(ivB[2], ivB[3]));
+                const uint2 vX = make_uint2(__builtin_amdgcn_perm((unsigned)ixB[1], (unsigned)ixB[0], sb01), __builtin_amdgcn_perm((unsigned)ixB[3], (unsigned)ixB[2], sb23));
+                const uint2 vY = make_uint2(__builtin_amdgcn_perm((unsigned)iyB[1], (unsigned)iyB[0], sb01), __builtin_amdgcn_perm((unsigned)iyB[3], (unsigned)iyB[2], sb23));
+                tXb[j] = vX; tYb[j] = vY;
+                accumulate(vI, vX, vY);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const float A11 = __fmul_rn(i64_to_f32(oct_sum_wide(a11)), LK_FLT_SCALE), A12 = __fmul_rn(i64_to_f32(oct_sum_wide(a12)), LK_FLT_SCALE),
+                A22 = __fmul_rn(i64_to_f32(oct_sum_wide(a22)), LK_FLT_SCALE);
+    float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
+    const float dAf = __fsub_rn(A11, A22);
+    const float disc = __fadd_rn(__fmul_rn(dAf, dAf), __fmul_rn(__fmul_rn(4.f, A12), A12));
+    const float minEig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11), vh_sqrtf(disc)), (float)(2 * WIN * WIN));
+    if (minEig < 1e-4f || D < 1.1920929e-07f) {
+        if (level == 0) status = 0;
+        return;
+    }
+    D = __fdiv_rn(1.f, D);
+
+    nx = __fsub_rn(nx, half); ny = __fsub_rn(ny, half);
+    float pdx = 0.f, pdy = 0.f;
+    for (int it = 0; it < max_count; it++) {
+        const int inx = vh_floor(nx), iny = vh_floor(ny);
+        if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
+            if (level == 0) status = 0;
+            break;
+        }
+        const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny)));
+        const bool fast = J.pad >= VH_LV_PAD || (inx >= 0 && iny >= 0 && inx + WIN + 2 <= J.w && iny + WIN + 1 <= J.h && !(iny == 0 && inx < 3) &&
+                                                 !(iny + WIN + 1 == J.h && inx + WIN + 9 > J.w));
+        n_iter++;
+        unsigned pa01[NS], pa23[NS], pb01[NS], pb23[NS];
+        lko_sample_rows<NS>(J, inx, iny, r, fast, w.wt, w.wb, pa01, pa23, pb01, pb23);
+        int b1 = -cI[0], b2 = -cI[1];
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            b1 = dot2(pa23[j], tXa[j].y, dot2(pa01[j], tXa[j].x, b1));
+            b2 = dot2(pa23[j], tYa[j].y, dot2(pa01[j], tYa[j].x, b2));
+            b1 = dot2(pb23[j], tXb[j].y, dot2(pb01[j], tXb[j].x, b1));
+            b2 = dot2(pb23[j], tYb[j].y, dot2(pb01[j], tYb[j].x, b2));
+        }
+        const float fb1 = __fmul_rn(i64_to_f32(oct_sum_wide(b1)), LK_FLT_SCALE), fb2 = __fmul_rn(i64_to_f32(oct_sum_wide(b2)), LK_FLT_SCALE);
+        const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
+        const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
+        nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
+        nxo = __fadd_rn(nx, half); nyo = __fadd_rn(ny, half);
+        if (__dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy)) <= eps2) break;
+        if (it > 0 && fabsf(__fadd_rn(dx, pdx)) < 0.01f && fabsf(__fadd_rn(dy, pdy)) < 0.01f) {
+            nxo = __fsub_rn(nxo, __fmul_rn(dx, 0.5f));
+            nyo = __fsub_rn(nyo, __fmul_rn(dy, 0.5f));
+            break;
+        }
+        pdx = dx; pdy = dy;
+    }
+
+    if (status && level == 0) {
+        const float fx = __fsub_rn(nxo, half), fy = __fsub_rn(nyo, half);
+        const int inx = vh_floor(fx), iny = vh_floor(fy);
+        if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) { status = 0; return; }
+        if (!want_err) return;
+        const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(fx, (float)inx), __fsub_rn(fy, (float)iny)));
+        const bool fast = J.pad >= VH_LV_PAD || (inx >= 0 && iny >= 0 && inx + WIN + 2 <= J.w && iny + WIN + 1 <= J.h && !(iny == 0 && inx < 3) &&
+                                                 !(iny + WIN + 1 == J.h && inx + WIN + 9 > J.w));
+        unsigned pa01[NS], pa23[NS], pb01[NS], pb23[NS], ia01[NS], ia23[NS], ib01[NS], ib23[NS];
+        lko_sample_rows<NS>(J, inx, iny, r, fast, w.wt, w.wb, pa01, pa23, pb01, pb23);
+        lko_sample_rows<NS>(I, ipx, ipy, r, fast_I || I.pad >= VH_LV_PAD, w0t, w0b, ia01, ia23, ib01, ib23);
+        int se = 0;
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const short2v da01 = as_s2(pa01[j]) - as_s2(ia01[j]), da23 = as_s2(pa23[j]) - as_s2(ia23[j]);
+            const short2v db01 = as_s2(pb01[j]) - as_s2(ib01[j]), db23 = as_s2(pb23[j]) - as_s2(ib23[j]);
+            const int da[4] = {da01.x, da01.y, da23.x, da23.y}, db[4] = {db01.x, db01.y, db23.x, db23.y};
+            const int cnt = WIN - 4 * j < 4 ? WIN - 4 * j : 4;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                se += c < cnt ? (da[c] < 0 ? -da[c] : da[c]) : 0;
+                se += (c < cnt && rowb) ? (db[c] < 0 ? -db[c] : db[c]) : 0;
+            }
+        }
+        err = __fmul_rn(i64_to_f32(oct_sum_wide(se)), __fdiv_rn(1.f, (float)(32 * WIN * WIN)));
+    }
+}
+
+template <int WIN>
+__device__ __forceinline__ void lko_track(const PyrDesc& PI, const PyrDesc& PJ, int max_count, double eps2, float px, float py, float& ox,
+                                          float& oy, int& status, float& err, int r, int& n_iter, int& n_setup, bool want_err)
+{
+    const int nl = min(PI.nlevels, PJ.nlevels);
+    status = 1;
+    err = 0.f;
+    ox = 0.f; oy = 0.f;
+    for (int level = nl - 1; level >= 0; level--)
+        lko_level<WIN>(PI.lv[level], PJ.lv[level], level, nl - 1, max_count, eps2, px, py, ox, oy, status, err, r, n_iter, n_setup, want_err);
+}
+
+template <int WIN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_lk_o(const void* job_tab, size_t tab_stride)
+{
+    static_assert(WIN == 15, "8 lanes x 2 rows: row 15 is the dummy that feeds nothing");
+    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
+    const int n = job.n_ptr ? *job.n_ptr : job.n;
+    const int pt = blockIdx.x * 8 + (threadIdx.x >> 3);
+    if (pt >= n) return;  // whole 8-lane groups leave together
+    const int r = threadIdx.x & 7;
+
+    const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];
+    const float px = __fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]);
+    const float py = __fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]);
+
+    float fx, fy, err;
+    int st, n_iter = 0, n_setup = 0;
+    lko_track<WIN>(job.I, job.J, job.max_count, job.eps2, px, py, fx, fy, st, err, r, n_iter, n_setup, job.err_out != nullptr);
+    float fbe = 0.f;
+    if (job.fbt >= 0.f) {
+        float bx, by, e2;
+        int st2;
+        lko_track<WIN>(job.J, job.I, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, r, n_iter, n_setup, false);
+        const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
+        fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
+        st = st && st2 && (fbe < job.fbt);
+    }
+    if (r == 0) {
+        float ox, oy;
+        if (job.out_mode == VH_OUT_SCALE) {
+            ox = __fdiv_rn(fx, job.out_scale);
+            oy = __fdiv_rn(fy, job.out_scale);
+        } else {
+            const float ax = __fadd_rn(fx, job.in_off[0]), ay = __fadd_rn(fy, job.in_off[1]);
+            if (job.out_mode == VH_OUT_TRANSLATE) {
+                ox = __fadd_rn(ax, job.out_off[0]);
+                oy = __fadd_rn(ay, job.out_off[1]);
+            } else {
+                ox = __fadd_rn(__fadd_rn(__fmul_rn(ax, job.T[0]), __fmul_rn(ay, job.T[2])), job.T[4]);
+                oy = __fadd_rn(__fadd_rn(__fmul_rn(ax, job.T[1]), __fmul_rn(ay, job.T[3])), job.T[5]);
+            }
+        }
+        job.p_out[2 * pt] = ox;
+        job.p_out[2 * pt + 1] = oy;
+        job.v_out[pt] = (uint8_t)(st != 0);
+        if (job.err_out) job.err_out[pt] = err;
+        if (job.fbe_out) job.fbe_out[pt] = fbe;
+        if (job.praw_out) { job.praw_out[2 * pt] = fx; job.praw_out[2 * pt + 1] = fy; }
+        if (job.stats) {
+            atomicAdd(&job.stats[0], (unsigned long long)n_iter);
+            atomicAdd(&job.stats[1], (unsigned long long)n_setup);
+        }
+    }
+}
+
+template <int WIN>
+static int launch_lko(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lk_o<WIN>, dim3((max_n + 7) / 8, batch), dim3(64), 0, s, job_tab, tab_stride);
+    return 0;
+}
+
 template <int WIN>
 static int launch_lkq(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
@@ -1747,9 +2107,10 @@ static int launch_strip(const void* job_tab, size_t tab_stride, int batch, int m
 }
 
 // test hook: 1 = per-sample kernel, 2 = strip kernel, 3 = LDS-staged kernel, 4 = 4-tracks-per-wave kernel (15x15), 5 / 6 / 7 = LDS-staged 51x51 kernel with
-// 1 / 2 / 4 wavefronts per track, 0 = default routing
+// 1 / 2 / 4 wavefronts per track, 8 = 8-tracks-per-wave kernel (15x15), 0 = default routing
 static int g_lk_force_generic = getenv("VH_LK_FORCE") ? atoi(getenv("VH_LK_FORCE")) : 0;  // (environment: experiments only)
 void vh_lk_force_generic(int on) { g_lk_force_generic = on; }
+static long long g_lko_min_tracks = getenv("VH_LKO_MIN") ? atoll(getenv("VH_LKO_MIN")) : 24000;  // (environment: experiments only)
 
 int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s)
 {
@@ -1775,6 +2136,9 @@ int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, i
     // 15x15: 4 tracks per wavefront from ~3000 tracks in flight (measured: 53 / 89 us vs 55 / 99 us for the two coarse stages at 4000 tracks,
     // 0.43 / 0.81 ms vs 0.9 / 1.7 ms at 256 000); below that the one-wave-per-track strip kernel has the shorter critical path (43 / 73 us vs
     // 51 / 82 us at 2000 tracks).  Mode 4 forces it (tests).
+    // 8 tracks per wavefront (mode 8 forces it) once the launch fills the chip at 8 per wavefront.
+    if (win == 15 && (g_lk_force_generic == 8 || ((g_lk_force_generic == 0 || force_nw) && (long long)max_n * batch >= g_lko_min_tracks)))
+        return launch_lko<15>(job_tab, tab_stride, batch, max_n, s);
     if (win == 15 && (g_lk_force_generic == 4 || ((g_lk_force_generic == 0 || force_nw) && (long long)max_n * batch >= 3000)))
         return launch_lkq<15>(job_tab, tab_stride, batch, max_n, s);
     if (g_lk_force_generic != 1 && win <= 63) {  // (modes 5..7 with another window than 51: default routing)
