@@ -259,6 +259,12 @@ static inline void bilinear_weights(float a, float b, int *w00, int *w01, int *w
     *w11 = (1 << W_BITS) - *w00 - *w01 - *w10;
 }
 
+/* diagnostic hook (tools/exp/lk_bucketing_study.py): Newton iterations of every point on every level of the NEXT lk runs, buf[(run * n + i) * 8 + level] */
+static int *g_iter_trace = 0;
+static int g_iter_run = 0;
+static __thread int t_last_iters;
+KO_API void ko_set_iter_trace(int *buf) { g_iter_trace = buf; g_iter_run = 0; }
+
 /* one point on one level; returns nothing, updates next[2], status, err */
 static void lk_point_level(const level_t *I, const level_t *J, int win, int level, int top_level, int max_count, double eps2,
                            float min_eig_thr, const float prev_pt_full[2], float next[2], uint8_t *status, float *err,
@@ -268,6 +274,7 @@ static void lk_point_level(const level_t *I, const level_t *J, int win, int leve
     const float lscale = (float)(1. / (1 << level));
     float px = prev_pt_full[0] * lscale, py = prev_pt_full[1] * lscale;
     float nx, ny;
+    t_last_iters = 0;
     if (level == top_level) { nx = px; ny = py; }
     else { nx = next[0] * 2.f; ny = next[1] * 2.f; }
     next[0] = nx; next[1] = ny;
@@ -329,6 +336,7 @@ static void lk_point_level(const level_t *I, const level_t *J, int win, int leve
             break;
         }
         bilinear_weights(nx - inx, ny - iny, &w00, &w01, &w10, &w11);
+        t_last_iters++;
         int64_t sb1 = 0, sb2 = 0;
         float fb1 = 0.f, fb2 = 0.f, qb1[4] = {0, 0, 0, 0}, qb2[4] = {0, 0, 0, 0};
         int dbuf[8];
@@ -408,15 +416,18 @@ static void lk_run(const pyramid_t *PI, const pyramid_t *PJ, const float *prev_p
             status[i] = 1;
             err[i] = 0.f;
             float nxt[2] = {0.f, 0.f};
-            for (int level = nl - 1; level >= 0; level--)
+            for (int level = nl - 1; level >= 0; level--) {
                 lk_point_level(&PI->lv[level], &PJ->lv[level], win, level, nl - 1, max_count, eps, 1e-4f, prev_pts + 2 * i, nxt,
                                &status[i], &err[i], Iwin, dIwin);
+                if (g_iter_trace && level < 8) g_iter_trace[((size_t)g_iter_run * n + i) * 8 + level] = t_last_iters;
+            }
             next_pts[2 * i] = nxt[0];
             next_pts[2 * i + 1] = nxt[1];
         }
         free(Iwin);
         free(dIwin);
     }
+    if (g_iter_trace) g_iter_run++;
 }
 
 /* cv2.calcOpticalFlowPyrLK(prev, next, pts, None, winSize=(win,win), maxLevel, criteria=(EPS|COUNT, max_count, eps)) */
