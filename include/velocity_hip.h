@@ -152,6 +152,13 @@ VH_API int vh_msv1_t(vh_ctx* ctx, const double* K_host, const float* P, const fl
  * x is updated in place.  trace [max_iter][2] = (rms(z - zhat), rms(delta)) per iteration (what NLS.py:238 prints),
  * info int[2] = {iterations, converged}.  workspace: vh_nls_batch_workspace(nt, nc) bytes of device memory. */
 VH_API size_t vh_nls_batch_workspace(int nt, int nc);
+/* Opt-in (default OFF): replay a repeated whole solve as ONE hipGraph launch.  A captured sequence bakes the device pointers it was captured with
+ * (z, x, trace, info, workspace), so the caller promises POINTER STABILITY: the same buffers are passed on every call (a sliding-window solver that
+ * owns its arrays; bench.py).  With on = 1 the second call with an identical job descriptor captures (one synchronous instantiate in that call's
+ * latency), later ones replay; any other descriptor is launched plainly; at most 8 sequences are kept (least recently used is dropped after a stream
+ * synchronisation).  Callers whose buffers come from an allocator per call (the torch ops, the numpy shim) leave it off.  on = 0 also stops the
+ * replay of sequences captured earlier. */
+VH_API int vh_ba_graph_replay(vh_ctx* ctx, int on);
 VH_API int vh_nls_batch(vh_ctx* ctx, const double* K_host, const double* z, double* x, int nt, int nc, int max_iter, double* trace,
                         int* info, void* workspace, size_t workspace_bytes, void* stream);
 

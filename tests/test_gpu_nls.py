@@ -487,6 +487,7 @@ def test_nls_batch_replayed_from_its_graph_equals_plain_launches(golden):
     z, x0, _, _ = synth.ba_pack(*synth.ba_scene(nt, nf, seed=77))
     K64 = L.host_K(golden["K32"])
     ws = L.Workspace(1, 64, 64, 64)  # a context of its own: its graph cache starts empty
+    L.check(ws.lib.vh_ba_graph_replay(ws.handle, 1), "vh_ba_graph_replay")  # opt-in: this caller's buffers are pointer stable
     zd, x0d = L.to_dev(z, torch.float64), L.to_dev(x0, torch.float64)
     xd = torch.empty_like(x0d)
     nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))

@@ -371,3 +371,41 @@ def test_session_step_from_bgr_frames_equals_gray_path():
         for i in range(1, nframes):
             orc.step(gray[b][i], np.float32(i / 30.0), i)
         assert np.array_equal(states[1][b]["vg"], orc.vg) and np.array_equal(states[1][b]["p"], orc.p)
+
+
+def test_profile_table_overflow_is_an_error_not_an_undercount():
+    """a record table sized for fewer launches than a step issues used to drop the later launches silently (under-counted ms / launches).
+    Now the dropped records are counted and vh_profile_end / vh_profile_end_stages fail loudly."""
+    import ctypes as C
+
+    import torch
+
+    from velocity_amd import _lib as L
+    from velocity_amd.driver import TrackerSession
+
+    W, H, n0 = 320, 180, 64
+    frames, p, p3, vp, K = _scene(W, H, n0, 3, 5)
+    ses = TrackerSession(K, W, H, n0, nhist=6, batch=1, msv_frame=0)
+    ses.init_stream(0, frames[0], p, p3, vp, np.float32([1.5, 0.45, 3.6]))
+    L.check(ses.lib.vh_profile_detail(ses.ws.handle, 1), "detail")
+    L.check(ses.lib.vh_profile_begin(ses.ws.handle, 3), "begin")  # three records: a step issues ~20
+    ses.step([torch.from_numpy(frames[1]).cuda()], time_s=1 / 30.0, frame_no=1)
+    ms, nl = (C.c_double * 16)(), (C.c_int * 16)()
+    rc = ses.lib.vh_profile_end_stages(ses.ws.handle, 16, ms, nl)
+    assert rc != 0 and b"too small" in ses.lib.vh_last_error()
+    L.check(ses.lib.vh_profile_begin(ses.ws.handle, 64), "begin")  # large enough: fine again
+    ses.step([torch.from_numpy(frames[2]).cuda()], time_s=2 / 30.0, frame_no=2)
+    L.check(ses.lib.vh_profile_end_stages(ses.ws.handle, 16, ms, nl), "end_stages")
+    assert sum(nl) >= 10
+
+
+def test_session_with_a_never_msv_sentinel_allocates_no_msv_history():
+    """msv_frame beyond the history (a 'never' sentinel) must not size the fcnMSV1_t scratch (it used to carve
+    24 B x (msv_frame + 1) x n0 per stream): a huge sentinel creates a session as cheaply as msv_frame = 0."""
+    from velocity_amd.driver import TrackerSession
+
+    W, H, n0 = 320, 180, 512
+    frames, p, p3, vp, K = _scene(W, H, n0, 2, 6)
+    ses = TrackerSession(K, W, H, n0, nhist=6, batch=2, msv_frame=1 << 24)  # 24 B * 2^24 * 512 = 206 GB per stream if it were carved
+    ses.init_stream(0, frames[0], p, p3, vp, np.float32([1.5, 0.45, 3.6]))
+    assert ses.state(0)["n_cur"] == n0

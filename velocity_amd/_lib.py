@@ -67,6 +67,7 @@ _SIGS = {
     "vh_two_view_intercept": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "vh_n_view_intercept": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "vh_nls_batch_workspace": (C.c_size_t, [C.c_int, C.c_int]),
+    "vh_ba_graph_replay": (C.c_int, [vp, C.c_int]),
     "vh_nls_batch": (C.c_int, [vp, f64p, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     "vh_nls_batch_multi": (C.c_int, [vp, f64p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     "vh_nls_batch2": (C.c_int, [vp, f64p, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),

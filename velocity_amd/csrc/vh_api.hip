@@ -117,6 +117,7 @@ extern "C" VH_API void vh_ctx_destroy(vh_ctx* c)
     if (!c) return;
     vh_ba_graph_cache_free(c->ba_graphs);
     (void)hipFree(c->arena);
+    if (c->bound_ev) (void)hipEventDestroy(c->bound_ev);
     for (int k = 0; k < 2 * c->prof_cap; k++) (void)hipEventDestroy(c->prof_ev[k]);
     delete[] c->prof_ev;
     delete[] c->prof_stage;
@@ -422,6 +423,7 @@ extern "C" VH_API int vh_profile_begin(vh_ctx* c, int max_launches)
         c->prof_cap = max_launches;
     }
     c->prof_n = 0;
+    c->prof_dropped = 0;
     c->prof_on = c->prof_light ? 1 : 2;
     VH_CHECK(hipDeviceSynchronize());
     for (int b = 0; b < c->batch; b++) VH_CHECK(hipMemset(c->d_ws[b].lk_stats, 0, sizeof(c->d_ws[b].lk_stats)));
@@ -434,6 +436,7 @@ extern "C" VH_API int vh_profile_end(vh_ctx* c, double* ms_sum, int* launches, u
     if (!c) return vh_fail(-1, "null ctx");
     c->prof_on = 0;
     VH_CHECK(hipDeviceSynchronize());
+    if (c->prof_dropped) return vh_fail(-5, "vh_profile_end: the record table given to vh_profile_begin was too small, launches went unrecorded (size it for ~22 records per frame step + 5 per BA iteration, or call vh_profile_detail(ctx, 0))");
     for (int k = 0; k < 3; k++) { ms_sum[k] = 0; launches[k] = 0; iters[k] = 0; setups[k] = 0; }
     for (int k = 0; k < c->prof_n; k++) {
         float ms = 0.f;
@@ -465,6 +468,7 @@ extern "C" VH_API int vh_profile_end_stages(vh_ctx* c, int nstages, double* ms_s
     if (!c || nstages < 1 || !ms_sum || !launches) return vh_fail(-1, "vh_profile_end_stages: bad arguments");
     c->prof_on = 0;
     VH_CHECK(hipDeviceSynchronize());
+    if (c->prof_dropped) return vh_fail(-5, "vh_profile_end_stages: the record table given to vh_profile_begin was too small, launches went unrecorded");
     for (int k = 0; k < nstages; k++) { ms_sum[k] = 0; launches[k] = 0; }
     for (int k = 0; k < c->prof_n; k++) {
         float ms = 0.f;
@@ -472,6 +476,13 @@ extern "C" VH_API int vh_profile_end_stages(vh_ctx* c, int nstages, double* ms_s
         const int st = c->prof_stage[k];
         if (st >= 0 && st < nstages) { ms_sum[st] += ms; launches[st]++; }
     }
+    return 0;
+}
+
+extern "C" VH_API int vh_ba_graph_replay(vh_ctx* c, int on)
+{
+    if (!c) return vh_fail(-1, "null ctx");
+    c->ba_graph_on = on ? 1 : 0;
     return 0;
 }
 
@@ -498,7 +509,8 @@ extern "C" VH_API int vh_klt_main(vh_ctx* c, int slot, const uint8_t* im, const 
     io.im = im; io.im0 = im0; io.im0_small = im0_small; io.p0 = p0; io.n_ptr = nullptr; io.p_all = p_all; io.v = v;
     io.im_small = im_small; io.flags = flags; io.w = w; io.h = h; io.stride = stride; io.stride0 = stride0; io.n = n;
     io.reuse_prev_small = 0; io.coarse = *coarse; io.fine = *fine; io.fbt_coarse = 1.0f; io.fbt_fine = 0.3f;
-    hipStream_t s = vh_ctx_bind(c, stream);
+    vh_ctx_bind bound_(c, stream);
+    hipStream_t s = bound_.s;
     VH_CHECK(vh_store(&c->d_ws[slot].io, io, s));
     return vh_run_klt_main(c, slot, 1, s, *coarse, *fine, nullptr, nullptr, n);
 }
@@ -519,7 +531,8 @@ extern "C" VH_API int vh_klt_stage_ptrs(vh_ctx* c, int slot, vh_klt_stages* out)
 extern "C" VH_API int vh_resize_quarter(vh_ctx* c, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream)
 {
     if (!c) return vh_fail(-1, "null ctx");
-    hipStream_t s = vh_ctx_bind(c, stream);
+    vh_ctx_bind bound_(c, stream);
+    hipStream_t s = bound_.s;
     const int dw = (int)lrint(w * 0.25), dh = (int)lrint(h * 0.25);
     StreamWS* ws = c->d_ws;
     VH_CHECK(vh_store(&ws->rs_src[0], ImgDesc{src, w, h, stride, 0}, s));
@@ -551,7 +564,8 @@ extern "C" VH_API int vh_bgr2gray(vh_ctx* c, const uint8_t* bgr, int w, int h, i
 extern "C" VH_API int vh_ingest_bgr(vh_ctx* c, const uint8_t* bgr, int w, int h, int stride_bytes, uint8_t* gray, int gray_stride, uint8_t* small, void* stream)
 {
     if (!c || !bgr || !gray || w < 1 || h < 1 || stride_bytes < 3 * w || gray_stride < w) return vh_fail(-1, "vh_ingest_bgr: bad arguments");
-    hipStream_t s = vh_ctx_bind(c, stream);
+    vh_ctx_bind bound_(c, stream);
+    hipStream_t s = bound_.s;
     IngestJob J;
     memset(&J, 0, sizeof(J));
     J.bgr = bgr; J.gray = gray; J.small = small; J.w = w; J.h = h; J.bgr_stride = stride_bytes; J.gray_stride = gray_stride;
@@ -567,7 +581,8 @@ extern "C" VH_API int vh_ingest_bgr(vh_ctx* c, const uint8_t* bgr, int w, int h,
 extern "C" VH_API int vh_pyr_down(vh_ctx* c, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream)
 {
     if (!c) return vh_fail(-1, "null ctx");
-    hipStream_t s = vh_ctx_bind(c, stream);
+    vh_ctx_bind bound_(c, stream);
+    hipStream_t s = bound_.s;
     StreamWS* ws = c->d_ws;
     PyrDesc P;
     memset(&P, 0, sizeof(P));
@@ -666,7 +681,8 @@ extern "C" VH_API int vh_pyr_lk(vh_ctx* c, const uint8_t* im1, const uint8_t* im
         return vh_fail(-1, "vh_pyr_lk: bad arguments (need win >= 3, max_level >= 0, w, h >= 4, strides >= w)");
     if (w > c->max_w || h > c->max_h || n > c->max_pts) return vh_fail(-1, "vh_pyr_lk: image or point count exceeds the workspace");
     if (n <= 0) return 0;
-    hipStream_t s = vh_ctx_bind(c, stream);
+    vh_ctx_bind bound_(c, stream);
+    hipStream_t s = bound_.s;
     const StreamBufs& B = c->h_bufs[0];
     LKJob J;
     memset(&J, 0, sizeof(J));
@@ -695,7 +711,8 @@ extern "C" VH_API int vh_ransac_affine(vh_ctx* c, const float* from, const float
                                        int* status, void* stream)
 {
     if (!c || n < 0 || n > c->max_pts) return vh_fail(-1, "vh_ransac_affine: bad arguments");
-    hipStream_t s = vh_ctx_bind(c, stream);
+    vh_ctx_bind bound_(c, stream);
+    hipStream_t s = bound_.s;
     const StreamBufs& B = c->h_bufs[0];
     RansacJob R;
     memset(&R, 0, sizeof(R));
@@ -775,7 +792,8 @@ extern "C" VH_API int vh_klt_regional(vh_ctx* c, const uint8_t* im0, const uint8
     if (!c || !lk || !T_host || lk->win < 3 || lk->max_level < 0 || n < 1 || w < 4 || h < 4 || stride0 < w || stride < w)
         return vh_fail(-1, "vh_klt_regional: bad arguments (need win >= 3, max_level >= 0, w, h >= 4, strides >= w)");
     if (w > c->max_w || h > c->max_h || n > c->max_pts) return vh_fail(-1, "vh_klt_regional: image or point count exceeds the workspace");
-    hipStream_t s = vh_ctx_bind(c, stream);
+    vh_ctx_bind bound_(c, stream);
+    hipStream_t s = bound_.s;
     RegionalIO io;
     memset(&io, 0, sizeof(io));
     io.im0 = im0; io.im = im; io.p0 = p0; io.p_out = p_out; io.v_out = v_out; io.roi_out = roi_out;
@@ -818,7 +836,8 @@ extern "C" VH_API int vh_pose(vh_ctx* c, const double* K, const float* p, const 
                               int findR, float* t_out, double* R_out, double* res_out, double* p_proj, int* info, void* stream)
 {
     if (!c || !K || !x0 || !R || n < 0) return vh_fail(-1, "vh_pose: bad arguments");
-    hipStream_t s = vh_ctx_bind(c, stream);
+    vh_ctx_bind bound_(c, stream);
+    hipStream_t s = bound_.s;
     PoseJob J;
     memset(&J, 0, sizeof(J));
     for (int k = 0; k < 9; k++) { J.K[k] = (double)K[k]; J.R[k] = R[k]; }
@@ -837,7 +856,8 @@ extern "C" VH_API int vh_pose(vh_ctx* c, const double* K, const float* p, const 
 extern "C" VH_API int vh_world2image(vh_ctx* c, const double* C_host, const double* pw, int n, double* out, void* stream)
 {
     if (!c || !C_host) return vh_fail(-1, "vh_world2image: bad arguments");
-    hipStream_t s = vh_ctx_bind(c, stream);
+    vh_ctx_bind bound_(c, stream);
+    hipStream_t s = bound_.s;
     int r = store_doubles(c->d_small, C_host, 12, s);
     if (r) return r;
     vh_launch_world2image(c->d_small, pw, n, out, s);
@@ -848,7 +868,8 @@ extern "C" VH_API int vh_world2image(vh_ctx* c, const double* C_host, const doub
 extern "C" VH_API int vh_image2world(vh_ctx* c, const double* Hi_host, const double* p, int n, double* out, void* stream)
 {
     if (!c || !Hi_host) return vh_fail(-1, "vh_image2world: bad arguments");
-    hipStream_t s = vh_ctx_bind(c, stream);
+    vh_ctx_bind bound_(c, stream);
+    hipStream_t s = bound_.s;
     int r = store_doubles(c->d_small + 16, Hi_host, 9, s);
     if (r) return r;
     vh_launch_image2world(c->d_small + 16, p, n, out, s);
@@ -930,7 +951,7 @@ extern "C" VH_API int vh_nls_batch(vh_ctx* c, const double* K_host, const double
     if (nc > 128) return vh_fail(-1, "vh_nls_batch: at most 128 free cameras");
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc))) return vh_fail(-1, "vh_nls_batch: workspace too small");
     BaProblem P;
-    P.graph_cache = &c->ba_graphs;
+    P.graph_cache = c->ba_graph_on ? &c->ba_graphs : nullptr;
     P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt, nc); P.force_valu = g_ba_force_valu;
@@ -952,7 +973,7 @@ extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const double* K_host, const 
     if (workspace_bytes_per_window < vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc)) || workspace_bytes_per_window % 256)
         return vh_fail(-1, "vh_nls_batch_multi: per-window workspace too small or not a multiple of 256 bytes");
     BaProblem P;
-    P.graph_cache = &c->ba_graphs;
+    P.graph_cache = c->ba_graph_on ? &c->ba_graphs : nullptr;
     P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.force_valu = g_ba_force_valu;
@@ -976,7 +997,7 @@ extern "C" VH_API int vh_nls_batch2(vh_ctx* c, const double* K_host, const doubl
     if (nc > 128) return vh_fail(-1, "vh_nls_batch2: at most 128 free cameras");
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc))) return vh_fail(-1, "vh_nls_batch2: workspace too small");
     BaProblem P;
-    P.graph_cache = &c->ba_graphs;
+    P.graph_cache = c->ba_graph_on ? &c->ba_graphs : nullptr;
     P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt, nc); P.force_valu = 1;
@@ -1001,7 +1022,7 @@ extern "C" VH_API int vh_nls_batch_phase(vh_ctx* c, const double* K_host, const 
     if (nc > 128) return vh_fail(-1, "vh_nls_batch_phase: at most 128 free cameras");
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc))) return vh_fail(-1, "vh_nls_batch_phase: workspace too small");
     BaProblem P;
-    P.graph_cache = &c->ba_graphs;
+    P.graph_cache = c->ba_graph_on ? &c->ba_graphs : nullptr;
     P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = 1; P.nparts = ba_parts(nt, nc);

@@ -53,6 +53,9 @@ __device__ __forceinline__ void ba_project(const double* K, const double* R, con
     const double uq = q0 * r, vq = q1 * r;
     u = __builtin_fma(__builtin_fma(-uq, q2, q0), r, uq);
     v = __builtin_fma(__builtin_fma(-vq, q2, q1), r, vq);
+    // q2 == 0 (a point on the camera plane) or an overflowing / vanishing reciprocal: the correction would give fma(-inf, 0, q0) = NaN where the
+    // division -- and numpy's pscale -- give +-inf / 0, and the NaN would spread through the whole window's Schur system.  Rare: a branch, not a select.
+    if (__builtin_expect(!(r != 0.0 && __builtin_isfinite(r)), 0)) { u = q0 / q2; v = q1 / q2; }
 }
 
 // x / BA_FD (the reference's forward difference (f(x + dx) - f(x)) / dx, NLS.py:228-233) without the division: RN(1 / 1e-6) is exactly 1e6, and
@@ -1375,7 +1378,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         memcpy(&key.J, &J, sizeof(J)); key.flags0 = flags; key.max_iter = P.max_iter; key.nparts = nparts; key.use_mfma = use_mfma ? 1 : 0;
         BaGraphCache* gc = profiling ? nullptr : ba_graph_cache(P.graph_cache);
         BaGraphEntry* e = gc ? gc->find(key, s) : nullptr;
-        if (e && e->exec) {
+        if (e && e->exec && !gc->disabled) {
             if (hipGraphLaunch(e->exec, s) == hipSuccess) break;
             (void)hipGetLastError();
             gc->disabled = true;  // fall through to plain launches, now and from here on

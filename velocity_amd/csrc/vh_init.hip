@@ -199,7 +199,8 @@ extern "C" VH_API int vh_good_features(vh_ctx* c, const uint8_t* im, int w, int 
                                        double k, float* corners, int* count, void* stream)
 {
     if (!c || w < 3 || h < 3 || max_corners < 1 || block < 1 || block > 15) return vh_fail(-1, "vh_good_features: bad arguments");
-    hipStream_t s = vh_ctx_bind(c, stream);
+    vh_ctx_bind bound_(c, stream);
+    hipStream_t s = bound_.s;
     const size_t pixels = (size_t)w * h;
     int r = init_reserve(pixels);
     if (r) return r;
@@ -225,7 +226,8 @@ extern "C" VH_API int vh_corner_subpix(vh_ctx* c, const uint8_t* im, int w, int 
 {
     if (!c || win < 1 || win > SUBPIX_MAXWIN || n < 0) return vh_fail(-1, "vh_corner_subpix: bad arguments (window half-size 1..7)");
     if (n == 0) return 0;
-    hipStream_t s = vh_ctx_bind(c, stream);
+    vh_ctx_bind bound_(c, stream);
+    hipStream_t s = bound_.s;
     int r = init_reserve(1);
     if (r) return r;
     max_iter = max_iter < 1 ? 1 : (max_iter > 100 ? 100 : max_iter);

@@ -1733,14 +1733,16 @@ __device__ __forceinline__ int dpp_oct_sum(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror: lane i <-> lane 7 - i of its half row
     return v;
 }
-__device__ __forceinline__ long long oct_sum_wide(int v)
+// exact 8-lane sum of int32 partials as the float32 the int64 -> float32 conversion gives: hi * 2^16 + lo is exact in float64 (|hi| < 2^19, lo < 2^19),
+// the final conversion rounds once
+__device__ __forceinline__ float oct_sum_f32(int v)
 {
     const int lo = dpp_oct_sum(v & 0xffff), hi = dpp_oct_sum(v >> 16);
-    return (long long)hi * 65536ll + (long long)lo;
+    return (float)__fma_rn((double)hi, 65536.0, (double)lo);
 }
 // bilinear x32 samples of window rows 2r and 2r+1 (NS strips each) at (x0, y0) of image im: the lane holds image rows y0 + 2r and y0 + 2r + 1,
 // the row below them is the first row of lane r + 1
-template <int NS>
+template <int NS, int WIN>
 __device__ __forceinline__ void lko_sample_rows(const ImgDesc& im, int x0, int y0, int r, bool fast, unsigned wt, unsigned wb, unsigned* a01,
                                                 unsigned* a23, unsigned* b01, unsigned* b23)
 {
@@ -1750,9 +1752,10 @@ __device__ __forceinline__ void lko_sample_rows(const ImgDesc& im, int x0, int y
     constexpr int SH = 16 - (W_BITS - 5), RND = 1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5));
 #pragma unroll
     for (int j = 0; j < NS; j++) {
-        int va[4], vb[4];
+        int va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0};  // columns >= WIN are never used (zero template gradients there): not computed
 #pragma unroll
         for (int c = 0; c < 4; c++) {
+            if (4 * j + c >= WIN) continue;
             const unsigned pa = row_pair(top, 4 * j + c), pb = row_pair(mid, 4 * j + c);
             va[c] = (dot2(pb, wb, dot2_first(pa, wt)) << SH) + RND;
             vb[c] = (dot2c_next_lane(dot2_first(pb, wt), pa, wb) << SH) + RND;
@@ -1824,15 +1827,17 @@ __device__ __forceinline__ void lko_level(const ImgDesc I, const ImgDesc J, int 
         column(0); column(1);
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) column(4 * j + 2 + c);
             const int cnt = WIN - 4 * j < 4 ? WIN - 4 * j : 4;
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (c < cnt) column(4 * j + 2 + c);  // (window column k uses V columns k .. k+2)
             const unsigned s01 = cnt >= 2 ? 0x07060302u : 0x0c0c0302u, s23 = cnt >= 4 ? 0x07060302u : (cnt == 3 ? 0x0c0c0302u : 0x0c0c0c0cu);
             const unsigned sb01 = rowb ? s01 : 0x0c0c0c0cu, sb23 = rowb ? s23 : 0x0c0c0c0cu;
-            int iv[4], ix[4], iy[4];
+            int iv[4] = {0, 0, 0, 0}, ix[4] = {0, 0, 0, 0}, iy[4] = {0, 0, 0, 0};
             // window row 2r
 #pragma unroll
             for (int c = 0; c < 4; c++) {
+                if (c >= cnt) continue;
                 const int col = 4 * j + c;
                 iv[c] = (CA[col + 1] << (16 - (W_BITS - 5))) + (1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5)));
                 ix[c] = SA[col + 2] - SA[col];
@@ -1848,6 +1853,7 @@ __device__ __forceinline__ void lko_level(const ImgDesc I, const ImgDesc J, int 
             // window row 2r + 1
 #pragma unroll
             for (int c = 0; c < 4; c++) {
+                if (c >= cnt) continue;
                 const int col = 4 * j + c;
                 iv[c] = (CB[col + 1] << (16 - (W_BITS - 5))) + (1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5)));
                 ix[c] = SB[col + 2] - SB[col];
@@ -1888,14 +1894,16 @@ __device__ __forceinline__ void lko_level(const ImgDesc I, const ImgDesc J, int 
         constexpr int SH = 16 - (W_BITS - 5), RND = 1 << (W_BITS - 5 - 1 + 16 - (W_BITS - 5));
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) colb(4 * j + 2 + c);
             const int cnt = WIN - 4 * j < 4 ? WIN - 4 * j : 4;
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (c < cnt) colb(4 * j + 2 + c);
             const unsigned s01 = cnt >= 2 ? 0x07060302u : 0x0c0c0302u, s23 = cnt >= 4 ? 0x07060302u : (cnt == 3 ? 0x0c0c0302u : 0x0c0c0c0cu);
             const unsigned sb01 = rowb ? s01 : 0x0c0c0c0cu, sb23 = rowb ? s23 : 0x0c0c0c0cu;
-            int ivA[4], ixA[4], iyA[4], ivB[4], ixB[4], iyB[4];
+            int ivA[4] = {0, 0, 0, 0}, ixA[4] = {0, 0, 0, 0}, iyA[4] = {0, 0, 0, 0}, ivB[4] = {0, 0, 0, 0}, ixB[4] = {0, 0, 0, 0}, iyB[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int c = 0; c < 4; c++) {
+                if (c >= cnt) continue;
                 const int col = 4 * j + c;
                 const unsigned ma = (unsigned)__builtin_amdgcn_sbfe((int)MA, col, 1) & 0xffffu | ((unsigned)__builtin_amdgcn_sbfe((int)MA, col + 1, 1) << 16);
                 const unsigned mb = (unsigned)__builtin_amdgcn_sbfe((int)MB, col, 1) & 0xffffu | ((unsigned)__builtin_amdgcn_sbfe((int)MB, col + 1, 1) << 16);
@@ -1927,8 +1935,8 @@ __device__ __forceinline__ void lko_level(const ImgDesc I, const ImgDesc J, int 
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    const float A11 = __fmul_rn(i64_to_f32(oct_sum_wide(a11)), LK_FLT_SCALE), A12 = __fmul_rn(i64_to_f32(oct_sum_wide(a12)), LK_FLT_SCALE),
-                A22 = __fmul_rn(i64_to_f32(oct_sum_wide(a22)), LK_FLT_SCALE);
+    const float A11 = __fmul_rn(oct_sum_f32(a11), LK_FLT_SCALE), A12 = __fmul_rn(oct_sum_f32(a12), LK_FLT_SCALE),
+                A22 = __fmul_rn(oct_sum_f32(a22), LK_FLT_SCALE);
     float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
     const float dAf = __fsub_rn(A11, A22);
     const float disc = __fadd_rn(__fmul_rn(dAf, dAf), __fmul_rn(__fmul_rn(4.f, A12), A12));
@@ -1952,7 +1960,7 @@ __device__ __forceinline__ void lko_level(const ImgDesc I, const ImgDesc J, int 
                                                  !(iny + WIN + 1 == J.h && inx + WIN + 9 > J.w));
         n_iter++;
         unsigned pa01[NS], pa23[NS], pb01[NS], pb23[NS];
-        lko_sample_rows<NS>(J, inx, iny, r, fast, w.wt, w.wb, pa01, pa23, pb01, pb23);
+        lko_sample_rows<NS, WIN>(J, inx, iny, r, fast, w.wt, w.wb, pa01, pa23, pb01, pb23);
         int b1 = -cI[0], b2 = -cI[1];
 #pragma unroll
         for (int j = 0; j < NS; j++) {
@@ -1961,7 +1969,7 @@ __device__ __forceinline__ void lko_level(const ImgDesc I, const ImgDesc J, int 
             b1 = dot2(pb23[j], tXb[j].y, dot2(pb01[j], tXb[j].x, b1));
             b2 = dot2(pb23[j], tYb[j].y, dot2(pb01[j], tYb[j].x, b2));
         }
-        const float fb1 = __fmul_rn(i64_to_f32(oct_sum_wide(b1)), LK_FLT_SCALE), fb2 = __fmul_rn(i64_to_f32(oct_sum_wide(b2)), LK_FLT_SCALE);
+        const float fb1 = __fmul_rn(oct_sum_f32(b1), LK_FLT_SCALE), fb2 = __fmul_rn(oct_sum_f32(b2), LK_FLT_SCALE);
         const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb2), __fmul_rn(A22, fb1)), D);
         const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, fb1), __fmul_rn(A11, fb2)), D);
         nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
@@ -1984,8 +1992,8 @@ __device__ __forceinline__ void lko_level(const ImgDesc I, const ImgDesc J, int 
         const bool fast = J.pad >= VH_LV_PAD || (inx >= 0 && iny >= 0 && inx + WIN + 2 <= J.w && iny + WIN + 1 <= J.h && !(iny == 0 && inx < 3) &&
                                                  !(iny + WIN + 1 == J.h && inx + WIN + 9 > J.w));
         unsigned pa01[NS], pa23[NS], pb01[NS], pb23[NS], ia01[NS], ia23[NS], ib01[NS], ib23[NS];
-        lko_sample_rows<NS>(J, inx, iny, r, fast, w.wt, w.wb, pa01, pa23, pb01, pb23);
-        lko_sample_rows<NS>(I, ipx, ipy, r, fast_I || I.pad >= VH_LV_PAD, w0t, w0b, ia01, ia23, ib01, ib23);
+        lko_sample_rows<NS, WIN>(J, inx, iny, r, fast, w.wt, w.wb, pa01, pa23, pb01, pb23);
+        lko_sample_rows<NS, WIN>(I, ipx, ipy, r, fast_I || I.pad >= VH_LV_PAD, w0t, w0b, ia01, ia23, ib01, ib23);
         int se = 0;
 #pragma unroll
         for (int j = 0; j < NS; j++) {
@@ -1999,7 +2007,7 @@ __device__ __forceinline__ void lko_level(const ImgDesc I, const ImgDesc J, int 
                 se += (c < cnt && rowb) ? (db[c] < 0 ? -db[c] : db[c]) : 0;
             }
         }
-        err = __fmul_rn(i64_to_f32(oct_sum_wide(se)), __fdiv_rn(1.f, (float)(32 * WIN * WIN)));
+        err = __fmul_rn(oct_sum_f32(se), __fdiv_rn(1.f, (float)(32 * WIN * WIN)));
     }
 }
 

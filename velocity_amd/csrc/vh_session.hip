@@ -220,6 +220,9 @@ __global__ __launch_bounds__(256) void k_sess_init(SessStream* ss, const float* 
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
+// fcnMSV1_t (vidExample.py:155-160) can fire for this session: the predicate that both sizes its scratch and gates its launch
+static inline bool sess_msv_fires(int msv_frame, int nhist) { return msv_frame >= 1 && msv_frame + 1 <= 2048 && msv_frame < nhist; }
+
 extern "C" VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, int nhist, int w, int h, const double* K_host,
                                         int k_is_float32, const vh_lk_params* coarse, const vh_lk_params* fine, int msv_frame)
 {
@@ -255,7 +258,7 @@ extern "C" VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, i
             S.p_all = (float*)(base + carve(sizeof(float) * 2 * n0)); S.v = (uint8_t*)(base + carve(n0));
             S.sel_p = (int*)(base + carve(sizeof(int) * n0)); S.sel_pw = (int*)(base + carve(sizeof(int) * n0));
             S.p_proj = (double*)(base + carve(sizeof(double) * 2 * n0));
-            S.msv_U = (double*)(base + carve(sizeof(double) * 3 * (size_t)(msv_frame >= 1 ? msv_frame + 1 : 1) * n0)); S.msv_b0 = (double*)(base + carve(sizeof(double) * 3 * n0));
+            S.msv_U = (double*)(base + carve(sizeof(double) * 3 * (size_t)(sess_msv_fires(msv_frame, nhist) ? msv_frame + 1 : 1) * n0));  /* one row when fcnMSV1_t can never fire (a 'never' sentinel must not size the buffer) */ S.msv_b0 = (double*)(base + carve(sizeof(double) * 3 * n0));
             S.small[0] = (uint8_t*)(base + carve((size_t)dw * dh)); S.small[1] = (uint8_t*)(base + carve((size_t)dw * dh));
         }
     }
@@ -290,7 +293,8 @@ extern "C" VH_API int vh_session_init(vh_session* s, int slot, const uint8_t* fr
 {
     if (!s || slot < 0 || slot >= s->batch || !t0_host) return vh_fail(-1, "vh_session_init: bad arguments");
     if (stride != s->w) return vh_fail(-1, "vh_session_init: frames must be dense (stride == width)");
-    hipStream_t st = vh_ctx_bind(s->ctx, stream);
+    vh_ctx_bind bound_(s->ctx, stream);
+    hipStream_t st = bound_.s;
     hipLaunchKernelGGL(k_sess_init, dim3(1), dim3(256), 0, st, s->d_ss + slot, p, p3, vp, frame0, t0_host[0], t0_host[1], t0_host[2], time0,
                        frame_no, res0);
     // quarter-scale copy of frame 0 = im0_small of the first step (pp starts at 0 -> previous index 1)
@@ -305,7 +309,8 @@ static int session_step(vh_session* s, const uint8_t* const* frames_dev, float t
                         const float* frame_nos_dev, void* stream)
 {
     if (!s || !frames_dev) return vh_fail(-1, "vh_session_step: bad arguments");
-    hipStream_t st = vh_ctx_bind(s->ctx, stream);
+    vh_ctx_bind bound_(s->ctx, stream);
+    hipStream_t st = bound_.s;
     vh_ctx* c = s->ctx;
     const int nb = s->batch;
     int r = vh_run_klt_main(c, 0, nb, st, s->coarse, s->fine, s->d_ss, frames_dev, s->N0);  // the set-up kernel also fetches this frame's KltIO from the session
@@ -320,7 +325,7 @@ static int session_step(vh_session* s, const uint8_t* const* frames_dev, float t
         hipLaunchKernelGGL(k_sess_book_b, dim3(nb), dim3(256), 0, st, s->d_ss, frames_dev, time_s, frame_no, times_dev, frame_nos_dev);
     }
     // fcnMSV1_t fires when a stream reaches ITS frame msv_frame (vidExample.py:155), whenever that stream was initialised
-    const bool msv_ok = s->msv_frame >= 1 && s->msv_frame + 1 <= 2048 && s->msv_frame < s->nhist;
+    const bool msv_ok = sess_msv_fires(s->msv_frame, s->nhist);
     bool any = false;
     for (int b = 0; b < nb; b++) {
         const int fi = ++s->h_frame[b];
@@ -388,7 +393,8 @@ __global__ void k_sess_ingest_jobs(SessStream* ss_all, IngestJob* jobs, const ui
 extern "C" VH_API int vh_session_ingest_bgr(vh_session* s, const uint8_t* const* bgr_frames_dev, int bgr_stride, uint8_t* const* gray_frames_dev, void* stream)
 {
     if (!s || !bgr_frames_dev || !gray_frames_dev || bgr_stride < 3 * s->w) return vh_fail(-1, "vh_session_ingest_bgr: bad arguments");
-    hipStream_t st = vh_ctx_bind(s->ctx, stream);
+    vh_ctx_bind bound_(s->ctx, stream);
+    hipStream_t st = bound_.s;
     hipLaunchKernelGGL(k_sess_ingest_jobs, dim3((s->batch + 63) / 64), dim3(64), 0, st, s->d_ss, s->d_ingest, bgr_frames_dev, bgr_stride, gray_frames_dev, s->batch);
     vh_launch_ingest_bgr(s->d_ingest, s->batch, s->w, s->h, st);
     SESS_CHECK();

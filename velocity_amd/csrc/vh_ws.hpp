@@ -64,29 +64,56 @@ struct vh_ctx {
     StreamBufs* h_bufs;  // host copy of every stream's buffer table
     // optional per-stage HIP-event timing of the LK launches (bench.py roofline leg)
     int prof_on, prof_n, prof_cap;  // prof_on: 0 off, 1 LK launches only, 2 every stage
+    int prof_dropped;                // launches that found the record table full since vh_profile_begin (vh_profile_end* report them as an error)
     int prof_light;                  // vh_profile_detail(ctx, 0): the next vh_profile_begin times the LK launches only
     hipEvent_t* prof_ev;  // 2 * prof_cap events: start/stop pairs
     int* prof_stage;
     double* d_small;     // 64 doubles of scratch for host-provided small matrices
     void* ba_graphs;     // replayable launch sequences of whole BA solves (vh_ba.hip), created on demand
+    int ba_graph_on;     // vh_ba_graph_replay: the caller promises pointer-stable buffers (default 0: every solve is launched plainly)
     hipStream_t bound_stream;  // the stream whose work may still read this context's job descriptors (vh_ctx_bind)
-    int bound;
+    hipEvent_t bound_ev;       // recorded on bound_stream by vh_ctx_release at the end of every entry point: what a rebind waits for
+    int bound;                 // 0: never used, 1: bound
 };
 
-// A vh_ctx parks the job descriptors of the calls in flight, so it serves ONE HIP stream at a time.  Enforced here: an entry point that arrives with
-// another stream first waits for the work queued through this context on the previous one (a serialisation, never a race), then rebinds.
-static inline hipStream_t vh_ctx_bind(vh_ctx* c, void* stream)
+// A vh_ctx parks the job descriptors of the calls in flight, so it serves ONE HIP stream at a time.  Enforced on the DEVICE: every entry point ends
+// with vh_ctx_release (an event record on its stream); an entry point that arrives with another stream makes that stream wait for the event
+// (hipStreamWaitEvent) before it rebinds.  No host blocking, legal under stream capture, and the previous stream handle is never touched again (it
+// may have been destroyed: only the event is used).
+static inline hipStream_t vh_ctx_bind_raw(vh_ctx* c, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (c) {
-        if (c->bound && c->bound_stream != s) {
-            if (hipStreamSynchronize(c->bound_stream) != hipSuccess) (void)hipGetLastError();  // e.g. the old stream was destroyed: nothing left to wait for
+        if (c->bound && c->bound_stream != s && c->bound_ev) {
+            if (hipStreamWaitEvent(s, c->bound_ev, 0) != hipSuccess) (void)hipGetLastError();
         }
         c->bound_stream = s;
         c->bound = 1;
     }
     return s;
 }
+// end of an entry point: marks how far the bound stream has got with this context's descriptors (one event record, no synchronisation)
+static inline void vh_ctx_release(vh_ctx* c)
+{
+    if (!c || !c->bound) return;
+    if (!c->bound_ev && hipEventCreateWithFlags(&c->bound_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->bound_ev = nullptr; return; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->bound_stream, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (cs != hipStreamCaptureStatusNone) return;  // inside a capture the launches are graph nodes: ordering is the graph's
+    if (hipEventRecord(c->bound_ev, c->bound_stream) != hipSuccess) (void)hipGetLastError();
+}
+
+
+// scope of one entry point: binds on construction, releases (event record) when the entry point returns, whichever return path it takes
+struct vh_ctx_bind {
+    vh_ctx* c;
+    hipStream_t s;
+    vh_ctx_bind(vh_ctx* ctx, void* stream) : c(ctx), s(vh_ctx_bind_raw(ctx, stream)) {}
+    ~vh_ctx_bind() { vh_ctx_release(c); }
+    vh_ctx_bind(const vh_ctx_bind&) = delete;
+    vh_ctx_bind& operator=(const vh_ctx_bind&) = delete;
+    operator hipStream_t() const { return s; }
+};
 
 
 // tracker-session state of one video stream (vh_session.hip); declared here because the KLTmain set-up kernel (vh_api.hip) fetches a
@@ -135,7 +162,11 @@ enum { VH_PROF_LK0 = 0, VH_PROF_LK1 = 1, VH_PROF_LK2 = 2, VH_PROF_WARP = 3, VH_P
 static inline int vh_prof_start(vh_ctx* c, hipStream_t s, int level = 2)
 {
     // level 1: the three LK launches of a frame step (always timed while profiling is on); level 2: every other stage (vh_profile_detail)
-    if (!c || c->prof_on < level || c->prof_n >= c->prof_cap) return -1;
+    if (!c || c->prof_on < level) return -1;
+    if (c->prof_n >= c->prof_cap) {  // table sized for fewer launches than were issued: counted, and vh_profile_end / _end_stages fail loudly
+        c->prof_dropped++;
+        return -1;
+    }
     (void)hipEventRecord(c->prof_ev[2 * c->prof_n], s);
     return c->prof_n;
 }
