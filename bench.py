@@ -94,6 +94,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each cpu_baseline leg (0 disables)")
     ap.add_argument("--exchange-every", type=int, default=30)
     ap.add_argument("--fine-max-count", type=int, default=0, help="calibration aid (tools/pmc_lk_calib.sh): cap the Newton iterations of the fine LK stage")
+    ap.add_argument("--coarse-max-count", type=int, default=0, help="calibration aid (tools/pmc_lk_calib.sh): cap the Newton iterations of the coarse LK stages")
     ap.add_argument("--verify-frames", type=int, default=4,
                     help="after the timed region, replay this many further frames of two resident streams through the CPU oracle and report "
                          "`verified` (0 disables)")
@@ -410,6 +411,8 @@ class Workload:
         S, N, W, H = self.S, self.N, self.W, self.H
         lvl = cfg["levels"] - 1 if params == "baseline" else 4
         self.lkc, self.lkf = dict(max_level=lvl), (dict(max_count=a.fine_max_count) if getattr(a, "fine_max_count", 0) > 0 else dict())
+        if getattr(a, "coarse_max_count", 0) > 0:
+            self.lkc["max_count"] = a.coarse_max_count
         self.params, self.scene, self.ring = params, scene, a.ring
         nhist = min(warmup + steps + 3, 512)
         # one texture set per `ring` streams, so no two resident streams ever work on the same pixels
@@ -583,9 +586,85 @@ def lk_valu_model():
     try:
         j = json.load(open(files[-1]))
         return dict(per_setup=float(j["wave_instr_per_setup"]), per_iter=float(j["wave_instr_per_newton_iter"]), tolerance=float(j["tolerance"]),
-                    kernel=j["kernel"], source=f"{rel} (tools/pmc_lk_calib.sh: SQ_INSTS_VALU fitted over runs with different iteration counts)")
+                    kernel=j["kernel"], source=f"{rel} (tools/pmc_lk_calib.sh: SQ_INSTS_VALU fitted over runs with different iteration counts)",
+                    coarse=j.get("coarse"))
     except Exception:
         return None
+
+
+def coarse_kernel_name(tracks):
+    """routing of vh_launch_lk for the 15x15 window (velocity_amd/csrc/vh_lk.hip)"""
+    return "k_lk_o<15>" if tracks >= 24000 else ("k_lk_q<15>" if tracks >= 3000 else "k_lk_strip<15>")
+
+
+def valu_rates():
+    """opcode -> measured lanes / clk / SIMD (best over 1-4 waves per SIMD, 16 independent chains), from the newest profiles/rNN_valu_rate.json"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_valu_rate.json")))
+    if not files:
+        return {}, None
+    best = {}
+    for r in json.load(open(files[-1]))["results"]:
+        if r["chains"] > 1:
+            k = r["inst"]
+            best[k] = max(best.get(k, 0.0), r["lanes_per_ns_per_simd"] / CLOCK_GHZ)
+    return best, os.path.relpath(files[-1], ROOT)
+
+
+_RATE_ALIAS = {  # ISA spelling (tools/isa_mix.py) -> name in the micro-benchmark
+    "v_dot2c_i32_i16": "v_dot2c_i32_i16 (VOP2)", "v_dot2c_i32_i16_dpp": "v_dot2c_i32_i16 row_shl:1 (DPP)", "v_add_u32_dpp": "v_add_u32 row_shr:1 (DPP)",
+    "v_sub_u32_dpp": "v_add_u32 row_shr:1 (DPP)", "v_mov_b32_dpp": "v_mov_b32 row_shr:1 (DPP)", "v_mul_i32_i24_sdwa": "v_mul_i32_i24 (SDWA)",
+    "v_subrev_u32": "v_sub_u32", "v_cndmask_b32": "v_cmp_lt_i32 + v_cndmask_b32 (pair)", "v_cmp_lt_i32": "v_cmp_lt_i32 + v_cndmask_b32 (pair)",
+    "v_cmp_gt_i32": "v_cmp_lt_i32 + v_cndmask_b32 (pair)", "v_cmp_le_i32": "v_cmp_lt_i32 + v_cndmask_b32 (pair)", "v_cmp_ge_i32": "v_cmp_lt_i32 + v_cndmask_b32 (pair)",
+    "v_readlane_b32": "v_readlane_b32 + v_writelane_b32 (pair)", "v_writelane_b32": "v_readlane_b32 + v_writelane_b32 (pair)", "v_pk_add_u16": "v_pk_add_u16",
+    "v_pk_mad_u16": "v_pk_mad_u16", "v_pk_sub_i16": "v_pk_sub_i16", "v_fmac_f64": "v_fma_f64", "v_pk_mul_f32": "v_pk_fma_f32", "v_pk_add_f32": "v_pk_fma_f32",
+    "v_fmac_f32": "v_fma_f32", "v_mul_lo_u32": "v_mul_lo_u32", "v_min_i32": "v_min_i32", "v_max_i32": "v_max_i32"}
+
+
+def valu_mix(kernel, setups, iters, per_setup=None, per_iter=None):
+    """Instruction mix of one launch of an LK kernel: the static opcode histograms of its set-up and Newton-iteration blocks (profiles/rNN_lk_isa_mix.json,
+    tools/isa_mix.py) weighted by the LIVE set-up / iteration counters (x the fitted wave instructions per set-up / iteration when a PMC fit exists,
+    else the static block sizes), every opcode priced with its measured issue rate (profiles/rNN_valu_rate.json).  Returns None without the files."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_lk_isa_mix.json")))
+    rates, rsrc = valu_rates()
+    if not files or not rates:
+        return None
+    k = json.load(open(files[-1]))["kernels"].get(kernel.replace(" ", ""))
+    if not k:
+        return None
+    hs, hi = k["setup"]["opcodes"], k["iteration"]["opcodes"]
+    ns, ni = float(sum(hs.values())), float(sum(hi.values()))
+    ws = (per_setup if per_setup else ns / (2 if kernel.startswith(("k_lk_o", "k_lk_q")) else 1)) * setups  # (the coarse kernels inline both directions: two static copies)
+    wi = (per_iter if per_iter else ni / (2 if kernel.startswith(("k_lk_o", "k_lk_q")) else 1)) * iters
+    tot = ws + wi
+    if tot <= 0:
+        return None
+    frac = {}
+    for h, n, w in ((hs, ns, ws), (hi, ni, wi)):
+        for op, c in h.items():
+            frac[op] = frac.get(op, 0.0) + (c / n) * (w / tot)
+    cls = dict(full_rate=0.0, half_rate=0.0, slow=0.0, unmeasured=0.0)
+    cyc, per_op = 0.0, []
+    for op, f in frac.items():
+        r = rates.get(_RATE_ALIAS.get(op, op))
+        if r is None:
+            cls["unmeasured"] += f
+            r_eff = 14.5  # priced like the half-rate class
+        else:
+            cls["full_rate" if r >= 20.0 else ("half_rate" if r >= 12.0 else "slow")] += f
+            r_eff = r
+        cyc += f / r_eff
+        per_op.append((f / r_eff, op, f, r))
+    per_op.sort(reverse=True)
+    return dict(full_rate_frac=round(cls["full_rate"], 4), half_rate_frac=round(cls["half_rate"], 4), slow_frac=round(cls["slow"], 4), unmeasured_frac=round(cls["unmeasured"], 4),
+                classes="full: measured >= 20 lanes/clk/SIMD (v_add_u32, v_sub_u32, v_and_b32, v_ashrrev_i32, f32 add / mul / fma ...); half: 12-20 (v_dot2*, v_perm, v_mad_i32_i24, "
+                        "v_lshl_add, v_pk_*, DPP ...); slow: < 12 (f64, v_cndmask pairs, lane moves); unmeasured opcodes are priced like the half-rate class",
+                mix_ceiling_lanes_per_clk_per_simd=round(1.0 / cyc, 2),
+                top5_by_issue_cycles=[dict(opcode=op, share_of_instructions=round(f, 4), share_of_issue_cycles=round(c / cyc, 4), lanes_per_clk=(round(r, 1) if r else None))
+                                      for c, op, f, r in per_op[:5]],
+                setup_share_of_instructions=round(ws / tot, 4),
+                source=f"{os.path.relpath(files[-1], ROOT)} (tools/isa_mix.py: static hot-path opcode histograms) x this run's set-up / iteration counters; rates from {rsrc}")
 
 
 def roofline_of(wl, m, world):
@@ -639,6 +718,8 @@ def roofline_of(wl, m, world):
                 sq_util = k.get("valu_issue_utilisation", sq_util)
                 isrc = f"profiles/r02_lk_sq_pmc.json (SQ_INSTS_VALU x 64 lanes of a rocprofv3 --pmc pass at {pj['streams']} streams, scaled to {SG}; not live)"
     issued_tops = issued / (us_fine * 1e-6) / 1e12 if issued and us_fine > 0 else None
+    abs_peak = N_SIMD * 32 * CLOCK_GHZ * 1e9 / 1e12  # the guide's SIMD-32 figure: 32 lanes / clk / SIMD, the rate only the full-rate opcodes approach
+    mix = valu_mix(fine_kernel, su_f, it_f, vm["per_setup"] if vm and vm["kernel"] == fine_kernel else None, vm["per_iter"] if vm and vm["kernel"] == fine_kernel else None)
 
     # ---- the other kernel families of a step: live HIP-event time + algorithmic bytes (ROI sizes read back from the device after the run) ----
     def us(stage):
@@ -662,23 +743,25 @@ def roofline_of(wl, m, world):
                          hbm_gbs=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4), bytes=note))
 
     gather_c = 2 * N * SG * (lc + 1) * ((wc + 2) ** 2 + (wc + 1) ** 2)
-    for stg, nm in ((0, "k_lk_q<15> (stage 1: quarter-scale image)"), (1, "k_lk_q<15> (stage 2: ROI)")):
+    ck = coarse_kernel_name(N * SG)
+    cm = (vm or {}).get("coarse") if vm else None
+    for stg, nm in ((0, ck + " (stage 1: quarter-scale image)"), (1, ck + " (stage 2: ROI)")):
         t = 1e3 * ms_sum[stg] / max(launches[stg], 1)
-        rows.append(dict(kernel=nm if N * SG >= 3000 else nm.replace("k_lk_q<15>", "k_lk_strip<15>"), us_per_step=round(t, 2), launches_per_step=1.0, alg_bytes_per_step=int(gather_c),
-                         hbm_gbs=round(gather_c / (t * 1e-6) / 1e9, 1) if t > 0 else None, hbm_frac=round(gather_c / (t * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None,
-                         bytes="2 N L [(w+2)^2 + (w+1)^2] gather bytes, w = 15, L = pyramid levels; VALU bound like the fine stage"))
-    # VALU view of the two coarse launches together (committed counter pass, scaled by the stream count: not live, and labelled so)
-    cpath = os.path.join(ROOT, "profiles", "r03_lk_sq_pmc.json")
-    if cfg is CONFIGS["c2"] and wl.params == "baseline" and N * SG >= 3000 and os.path.exists(cpath) and len(rows) == 2:
-        pj = json.load(open(cpath))
-        k = pj.get("kernels", {}).get("k_lk_q<15>")
-        t_both = rows[0]["us_per_step"] + rows[1]["us_per_step"]
-        if k and pj.get("streams") and t_both > 0:
-            lane_instr = 2 * 64.0 * k["SQ_INSTS_VALU"] * SG / pj["streams"]  # the file holds the mean of the two launches of a step
-            for r_ in rows:
-                r_["valu_frac_both_coarse_launches"] = round(lane_instr / (t_both * 1e-6) / 1e12 / peak_tops, 4)
-                r_["valu_source"] = (f"profiles/r03_lk_sq_pmc.json: SQ_INSTS_VALU x 64 lanes of both k_lk_q launches of a step at {pj['streams']} streams (scaled to {SG}) "
-                                     "over THIS run's launch times; not live")
+        r_ = dict(kernel=nm, us_per_step=round(t, 2), launches_per_step=1.0, alg_bytes_per_step=int(gather_c),
+                  hbm_gbs=round(gather_c / (t * 1e-6) / 1e9, 1) if t > 0 else None, hbm_frac=round(gather_c / (t * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None,
+                  bytes="2 N L [(w+2)^2 + (w+1)^2] gather bytes, w = 15, L = pyramid levels; VALU bound like the fine stage")
+        su_c, it_c = setups[stg] / max(launches[stg], 1), iters[stg] / max(launches[stg], 1)
+        r_["setups_per_launch"], r_["newton_iters_per_launch"] = int(su_c), int(it_c)
+        if cm and cm.get("kernel") == ck and t > 0:
+            # LIVE: this run's in-kernel counters through the fitted per-set-up / per-iteration wave-instruction costs (per TRACK counters: the idle lanes of
+            # a wavefront whose tracks need different iteration counts are inside the fitted per-iteration cost)
+            lane_instr = 64.0 * (cm["wave_instr_per_setup"] * su_c + cm["wave_instr_per_newton_iter"] * it_c)
+            r_["valu_frac"] = round(lane_instr / (t * 1e-6) / 1e12 / peak_tops, 4)
+            r_["valu_frac_abs"] = round(lane_instr / (t * 1e-6) / 1e12 / (N_SIMD * 32 * CLOCK_GHZ * 1e9 / 1e12), 4)
+            r_["issued_ginstr_per_launch"] = round(lane_instr / 1e9, 3)
+            r_["valu_source"] = f"64 lanes x ({cm['wave_instr_per_setup']:.1f} x set-ups + {cm['wave_instr_per_newton_iter']:.1f} x Newton iterations), counters of THIS run; costs fitted by tools/pmc_lk_calib.sh (tolerance {cm.get('tolerance')})"
+            r_["mix"] = valu_mix(ck, su_c, it_c, cm["wave_instr_per_setup"], cm["wave_instr_per_newton_iter"])
+        rows.append(r_)
     row("k_roi_warp (stage 3: float32 affine map + 5-bit bilinear remap of the ROI)", 3, 2.0 * roi_px, 1, "ROI read + ROI written (sum over the streams' ROIs of the last frame)")
     pyr_bytes = SG * sw * sh * sum(4.0 ** -l * 1.25 for l in range(lc)) + 2.0 * roi_px * sum(4.0 ** -l * 1.25 for l in range(lc))
     row("k_pyr_down + k_pyr_pad (quarter-scale pyramid of the new frame; ROI pyramids of both frames)", 4, pyr_bytes, 2 * lc,
@@ -691,11 +774,17 @@ def roofline_of(wl, m, world):
                traffic=traffic, traffic_source=tsrc, note="algorithmic gather bytes 2 N [(51+2)^2 + (51+1)^2] per stream over the launch time: far below the HBM roof, the kernel is not memory bound")
     out = dict(bound="valu", kernel=fine_kernel + " (fine stage: 51x51 window, level 0, fwd+bwd)",
                achieved=round(issued_tops, 3) if issued_tops else None, peak=round(peak_tops, 1), unit="T lane-instr/s",
-               frac=round(issued_tops / peak_tops, 4) if issued_tops else None, us_per_launch=round(us_fine, 2),
+               frac=round(issued_tops / peak_tops, 4) if issued_tops else None,
+               frac_abs=round(issued_tops / abs_peak, 4) if issued_tops else None, peak_abs=round(abs_peak, 1),
+               frac_of_mix_ceiling=(round(issued_tops / (N_SIMD * mix["mix_ceiling_lanes_per_clk_per_simd"] * CLOCK_GHZ * 1e9 / 1e12), 4) if issued_tops and mix else None),
+               mix=mix, us_per_launch=round(us_fine, 2),
                issued_ginstr_per_launch=round(issued / 1e9, 3) if issued else None, issued_source=isrc, issued_model_tolerance=tol,
                setups_per_launch=int(su_f), newton_iters_per_launch=int(it_f),
                peak_lanes_per_clk_per_simd=lanes, peak_source=peak_src, simds=N_SIMD, clock_ghz=CLOCK_GHZ,
-               note="track solve is VALU-issue bound (SURVEY §8d): frac = issued lane-instructions / launch time / (1024 SIMDs x 16 lanes x 2.4 GHz)",
+               note="track solve is VALU-issue bound (SURVEY §8d): frac = issued lane-instructions / launch time / (1024 SIMDs x 16 lanes x 2.4 GHz), the issue rate of "
+                    "the half-rate opcode class the kernel is made of (mix.half_rate_frac); frac_abs prices the same lane-instructions against 32 lanes / clk / SIMD "
+                    "(MI355X_MICROARCH.md: SIMD-32, 2-cycle wave64 issue), which only the full-rate class approaches (measured 23-27); frac_of_mix_ceiling against the "
+                    "rate a perfect scheduler would reach with THIS opcode mix at the measured per-opcode rates",
                # the contract's HBM view of the same kernel (secondary: achieved GB/s of its algorithmic bytes, PMC traffic)
                hbm=hbm, traffic=traffic,
                op_model=dict(gops_per_launch=round(ops_fine / 1e9, 4), tops=round(model_tops, 3),

@@ -474,6 +474,10 @@ KO_API void ko_lk_fb(const uint8_t *im1, const uint8_t *im2, int w, int h, int s
 /* ------------------------------------------------------------------------------------------------ */
 KO_API void ko_bounding_rect(const float *p, int n, int imw, int imh, int bx, int by, int roi[4])
 {
+    if (n <= 0) { /* no tracks left (the reference would raise on min() of an empty array; SURVEY App. B: resolve by intent): an empty ROI at the frame origin, as the product's glue */
+        roi[0] = 1; roi[1] = 1; roi[2] = 1; roi[3] = 1;
+        return;
+    }
     float mnx = p[0], mxx = p[0], mny = p[1], mxy = p[1];
     for (int i = 1; i < n; i++) {
         float x = p[2 * i], y = p[2 * i + 1];
@@ -882,6 +886,14 @@ KO_API int ko_klt_main(const uint8_t *im, const uint8_t *im0, const uint8_t *im0
         small0 = (uint8_t *)malloc((size_t)dw * dh);
         ko_resize_quarter(im0, w, h, stride0, small0);
         im0_small = small0;
+    }
+    if (n <= 0) { /* no tracks left: nothing to track, v.sum() > 10 fails (KLT.py:126-130) -> the coarse-affine failure flag; empty ROI like the product's glue */
+        free(small0);
+        if (st && st->T_trans) { st->T_trans[0] = 0; st->T_trans[1] = 0; }
+        if (st && st->roi) { st->roi[0] = 1; st->roi[1] = 1; st->roi[2] = 1; st->roi[3] = 1; }
+        if (st && st->T23) { double I6[6] = {1, 0, 0, 0, 1, 0}; memcpy(st->T23, I6, sizeof(I6)); }
+        if (st && st->flags) *st->flags = 1;
+        return 1;
     }
     float *ps = (float *)malloc(sizeof(float) * 2 * n), *p = (float *)malloc(sizeof(float) * 2 * n);
     float *err = (float *)malloc(sizeof(float) * n);

@@ -41,7 +41,9 @@ def test_roofline_object_is_recomputable_from_its_own_fields():
     achieved = r["issued_ginstr_per_launch"] * 1e9 / (r["us_per_launch"] * 1e-6) / 1e12
     assert abs(achieved - r["achieved"]) < 2e-3 * r["achieved"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # the live instruction count = the calibrated model applied to the run's own counters
-    model = json.load(open(os.path.join(ROOT, "profiles", "r03_lk_valu_model.json")))
+    import glob
+
+    model = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_lk_valu_model.json")))[-1]))  # the newest round's fit, as bench.py
     issued = 64 * (model["wave_instr_per_setup"] * r["setups_per_launch"] + model["wave_instr_per_newton_iter"] * r["newton_iters_per_launch"])
     assert abs(issued / 1e9 - r["issued_ginstr_per_launch"]) < 1e-3 * r["issued_ginstr_per_launch"] and r["issued_model_tolerance"] == model["tolerance"]
     # the contract's HBM view of the same kernel
@@ -50,7 +52,7 @@ def test_roofline_object_is_recomputable_from_its_own_fields():
     assert abs(h["achieved"] - h["alg_bytes_per_launch"] / (r["us_per_launch"] * 1e-6) / 1e9) < 0.01 and abs(h["frac"] - h["achieved"] / 8000.0) < 1e-5
     # one row per other kernel family, each recomputable
     names = " | ".join(k["kernel"] for k in r["kernels"])
-    for want in ("k_lk_q<15> (stage 1", "k_lk_q<15> (stage 2", "k_roi_warp", "k_pyr_down", "k_ransac_fused", "k_resize_quarter", "k_sess_frame"):
+    for want in ("k_lk_o<15> (stage 1", "k_lk_o<15> (stage 2", "k_roi_warp", "k_pyr_down", "k_ransac_fused", "k_resize_quarter", "k_sess_frame"):
         assert want in names
     for k in r["kernels"]:
         assert abs(k["hbm_gbs"] - k["alg_bytes_per_step"] / (k["us_per_step"] * 1e-6) / 1e9) <= 0.06 + 1e-3 * k["hbm_gbs"]
@@ -58,6 +60,14 @@ def test_roofline_object_is_recomputable_from_its_own_fields():
     warp = [k for k in r["kernels"] if k["kernel"].startswith("k_roi_warp")][0]
     assert warp["alg_bytes_per_step"] == 2 * S * (1722 - 190) * (992 - 90)
     assert abs(r["step_us_accounted"] - (r["us_per_launch"] + sum(k["us_per_step"] for k in r["kernels"]))) < 0.2
+    # both fractions of the VALU view are recomputable from the line alone: the class-relative one (16 lanes / clk) and the absolute one (32 lanes / clk)
+    assert abs(r["peak_abs"] - r["simds"] * 32 * r["clock_ghz"] * 1e9 / 1e12) < 0.06 and abs(r["frac_abs"] - r["achieved"] / r["peak_abs"]) < 1e-3
+    mx = r["mix"]
+    if mx is not None:  # (needs profiles/rNN_lk_isa_mix.json + rNN_valu_rate.json)
+        assert abs(mx["full_rate_frac"] + mx["half_rate_frac"] + mx["slow_frac"] + mx["unmeasured_frac"] - 1.0) < 2e-3
+        assert mx["half_rate_frac"] > mx["full_rate_frac"] and len(mx["top5_by_issue_cycles"]) == 5
+        ceil_tops = r["simds"] * mx["mix_ceiling_lanes_per_clk_per_simd"] * r["clock_ghz"] * 1e9 / 1e12
+        assert abs(r["frac_of_mix_ceiling"] - r["achieved"] / ceil_tops) < 2e-3
 
 
 def test_latency_legs_carry_the_lk_rows_only():

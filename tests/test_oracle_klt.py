@@ -202,3 +202,16 @@ def test_harris_corners_and_subpix_on_checkerboard():
     r = KO.harris_response(img)
     vals = r[top[:, 1].astype(int), top[:, 0].astype(int)]
     assert np.all(np.diff(vals) <= 0)
+
+
+def test_klt_main_without_tracks_does_not_touch_memory():
+    """Total track loss (real stills, sequence A): the next frame calls KLTmain with an EMPTY track list.  The oracle used to read p[0] of the
+    empty array in its boundingRect (a heap overflow ASan caught, a segfault on the GPU box); now: quarter-scale image as always, no tracks,
+    the coarse-affine failure flag (v.sum() > 10 fails, KLT.py:126-130) and the empty ROI the product's glue writes."""
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (90, 120), dtype=np.uint8)
+    b = np.roll(a, 2, axis=1)
+    p, v, small, S = KO.klt_main(b, a, None, np.zeros((0, 2), np.float32), stages=True)
+    assert p.shape == (0, 2) and v.shape == (0,) and S["flags"] == 1 and tuple(S["roi"]) == (1, 1, 1, 1)
+    assert np.array_equal(small, KO.resize_quarter(b))
+    assert KO.bounding_rect(np.zeros((0, 2), np.float32), (90, 120), (50, 50)) == (1, 1, 1, 1)

@@ -29,12 +29,14 @@
 
 enum Op { DOT2_I16, PERM, ADD_U32, MAD_I24, FMA_F32, PK_FMA_F32, PK_ADD_U16, ALIGNBYTE, MUL_LO, LSHL_ADD, DPP_ADD,
           AND_B32, LSHLREV, ASHRREV, BFE_U32, ADD3, MAD_U24, MUL_I24, SUB_U32, MAX_I32, CNDMASK, CVT_F32_I32, DOT4_I8, PK_MUL_LO, PK_MAD_I16, AND_OR, MOV_DPP,
-          ADD_F32, MUL_F32, FMA_F64, SAD_U8, LSHL_OR, MAD_U32_U16, N_OPS };
+          ADD_F32, MUL_F32, FMA_F64, SAD_U8, LSHL_OR, MAD_U32_U16,
+          DOT2C, DOT2C_DPP, MUL_I24_SDWA, LSHRREV, MOV, MIN_I32, BFE_I32, BITOP3, PK_SUB_I16, PK_MAD_U16, OR_B32, XOR_B32, SUB_F32, CVT_I32_F32, RNDNE_F32, CMP_CND, ADD_F64, MUL_F64, CVT_F64_I32, LSHL_ADD_U64, MAD_U64_U32, READLANE_W, N_OPS };
 static const char* kNames[] = {"v_dot2_i32_i16", "v_perm_b32",       "v_add_u32",      "v_mad_i32_i24", "v_fma_f32", "v_pk_fma_f32",
                                "v_pk_add_u16",   "v_alignbyte_b32", "v_mul_lo_u32",   "v_lshl_add_u32", "v_add_u32 row_shr:1 (DPP)",
                                "v_and_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_bfe_u32", "v_add3_u32", "v_mad_u32_u24", "v_mul_i32_i24", "v_sub_u32", "v_max_i32",
                                "v_cndmask_b32", "v_cvt_f32_i32", "v_dot4_i32_i8", "v_pk_mul_lo_u16", "v_pk_mad_i16", "v_and_or_b32", "v_mov_b32 row_shr:1 (DPP)",
-                               "v_add_f32", "v_mul_f32", "v_fma_f64", "v_sad_u8", "v_lshl_or_b32", "v_mad_u32_u16"};
+                               "v_add_f32", "v_mul_f32", "v_fma_f64", "v_sad_u8", "v_lshl_or_b32", "v_mad_u32_u16",
+                               "v_dot2c_i32_i16 (VOP2)", "v_dot2c_i32_i16 row_shl:1 (DPP)", "v_mul_i32_i24 (SDWA)", "v_lshrrev_b32", "v_mov_b32", "v_min_i32", "v_bfe_i32", "v_bitop3_b32", "v_pk_sub_i16", "v_pk_mad_u16", "v_or_b32", "v_xor_b32", "v_sub_f32", "v_cvt_i32_f32", "v_rndne_f32", "v_cmp_lt_i32 + v_cndmask_b32 (pair)", "v_add_f64", "v_mul_f64", "v_cvt_f64_i32", "v_lshl_add_u64", "v_mad_u64_u32", "v_readlane_b32 + v_writelane_b32 (pair)"};
 
 template <int OP>
 __device__ __forceinline__ void one(unsigned& a, unsigned b, unsigned c, float& fa, float fb, float fc, float2& pa, float2 pb, float2 pc)
@@ -72,6 +74,28 @@ __device__ __forceinline__ void one(unsigned& a, unsigned b, unsigned c, float& 
     if (OP == SAD_U8) asm volatile("v_sad_u8 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));
     if (OP == LSHL_OR) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a) : "v"(b));
     if (OP == MAD_U32_U16) asm volatile("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));
+    if (OP == DOT2C) asm volatile("v_dot2c_i32_i16 %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (OP == DOT2C_DPP) asm volatile("v_dot2c_i32_i16_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a) : "v"(b), "v"(c));
+    if (OP == MUL_I24_SDWA) asm volatile("v_mul_i32_i24_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_0" : "+v"(a) : "v"(b));
+    if (OP == LSHRREV) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a));
+    if (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "+v"(a) : "v"(b));
+    if (OP == MIN_I32) asm volatile("v_min_i32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (OP == BFE_I32) asm volatile("v_bfe_i32 %0, %0, 3, 17" : "+v"(a));
+    if (OP == BITOP3) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x6c" : "+v"(a) : "v"(b), "v"(c));
+    if (OP == PK_SUB_I16) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (OP == PK_MAD_U16) asm volatile("v_pk_mad_u16 %0, %1, %2, %0" : "+v"(a) : "v"(b), "v"(c));
+    if (OP == OR_B32) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (OP == XOR_B32) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (OP == SUB_F32) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(fa) : "v"(fb));
+    if (OP == CVT_I32_F32) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a));
+    if (OP == RNDNE_F32) asm volatile("v_rndne_f32 %0, %0" : "+v"(fa));
+    if (OP == CMP_CND) asm volatile("v_cmp_lt_i32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(a) : "v"(b), "v"(c) : "vcc");
+    if (OP == ADD_F64) asm volatile("v_add_f64 %0, %0, %1" : "+v"(pa) : "v"(pb));
+    if (OP == MUL_F64) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(pa) : "v"(pb));
+    if (OP == CVT_F64_I32) asm volatile("v_cvt_f64_i32 %0, %1" : "+v"(pa) : "v"(b));
+    if (OP == LSHL_ADD_U64) asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(pa) : "v"(pb));
+    if (OP == MAD_U64_U32) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(pa) : "v"(b), "v"(c) : "vcc");
+    if (OP == READLANE_W) { unsigned t_; asm volatile("v_readlane_b32 %1, %0, 3\n\ts_nop 0\n\tv_writelane_b32 %0, %1, 5" : "+v"(a), "=s"(t_)); }
 }
 
 template <int OP, int CHAINS>
@@ -194,6 +218,28 @@ int main()
     sweep<SAD_U8>(d_out, d_cyc, ncu, 0, first);
     sweep<LSHL_OR>(d_out, d_cyc, ncu, 0, first);
     sweep<MAD_U32_U16>(d_out, d_cyc, ncu, 0, first);
+    sweep<DOT2C>(d_out, d_cyc, ncu, 0, first);
+    sweep<DOT2C_DPP>(d_out, d_cyc, ncu, 0, first);
+    sweep<MUL_I24_SDWA>(d_out, d_cyc, ncu, 0, first);
+    sweep<LSHRREV>(d_out, d_cyc, ncu, 0, first);
+    sweep<MOV>(d_out, d_cyc, ncu, 0, first);
+    sweep<MIN_I32>(d_out, d_cyc, ncu, 0, first);
+    sweep<BFE_I32>(d_out, d_cyc, ncu, 0, first);
+    sweep<BITOP3>(d_out, d_cyc, ncu, 0, first);
+    sweep<PK_SUB_I16>(d_out, d_cyc, ncu, 0, first);
+    sweep<PK_MAD_U16>(d_out, d_cyc, ncu, 0, first);
+    sweep<OR_B32>(d_out, d_cyc, ncu, 0, first);
+    sweep<XOR_B32>(d_out, d_cyc, ncu, 0, first);
+    sweep<SUB_F32>(d_out, d_cyc, ncu, 0, first);
+    sweep<CVT_I32_F32>(d_out, d_cyc, ncu, 0, first);
+    sweep<RNDNE_F32>(d_out, d_cyc, ncu, 0, first);
+    sweep<CMP_CND>(d_out, d_cyc, ncu, 0, first);
+    sweep<ADD_F64>(d_out, d_cyc, ncu, 0, first);
+    sweep<MUL_F64>(d_out, d_cyc, ncu, 0, first);
+    sweep<CVT_F64_I32>(d_out, d_cyc, ncu, 0, first);
+    sweep<LSHL_ADD_U64>(d_out, d_cyc, ncu, 0, first);
+    sweep<MAD_U64_U32>(d_out, d_cyc, ncu, 0, first);
+    sweep<READLANE_W>(d_out, d_cyc, ncu, 0, first);
     printf("\n  ]\n}\n");
     return 0;
 }
