@@ -298,7 +298,8 @@ def bench_ba(nt=5000, nf=20, repeats=3, cpu_seconds=12.0, windows=(1, 8, 64), mi
             r["hbm_gbs"] = round(r["alg_bytes"] / (r["us"] * 1e-6) / 1e9, 1) if r["us"] > 0 else None
             r["hbm_frac"] = round(r["hbm_gbs"] / HBM_PEAK_GBS, 4) if r["hbm_gbs"] else None
         busy, bsrc = None, None
-        for name in ("r03_ba_pmc.json", "r02_ba_pmc.json"):
+        import glob as _glob
+        for name in [os.path.basename(f) for f in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_ba_pmc.json")), reverse=True)]:
             bp = os.path.join(ROOT, "profiles", name)
             if os.path.exists(bp):
                 try:
@@ -690,7 +691,8 @@ def roofline_of(wl, m, world):
     # HBM bytes of that kernel are NOT measured by this run: they come from the PMC passes committed under profiles/ (collected at the stream count
     # stored in the file, scaled linearly); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     traffic, sq_util, tsrc = None, None, None
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+    import glob as _glob
+    for name in [os.path.basename(f) for f in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")), reverse=True)]:
         tpath = os.path.join(ROOT, "profiles", name)
         if cfg is CONFIGS["c2"] and os.path.exists(tpath):
             tj = json.load(open(tpath))

@@ -37,7 +37,7 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --streams $S --steps 40 --warmup 5 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/stats.log 2>&1
 find $OUT/stats -name "*kernel_trace.csv" -delete   # tens of MB; the per-kernel summary is what is kept
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_q|k_lk_strip|k_pyr_down|k_roi_warp' --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --streams $S --steps 6 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_o|k_lk_q|k_lk_strip|k_pyr_down|k_roi_warp' --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --streams $S --steps 6 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/pmc_$c.log 2>&1
   find $OUT/pmc_$c -name "*kernel_trace.csv" -delete
 done
 # SQ counters of the LK kernels (two passes of <= 8 counters)
@@ -46,7 +46,7 @@ P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_I
 i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_q' --pmc $P --output-format csv -d $OUT/sq_lk$i -- python $R/bench.py --streams $S --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/sq_lk$i.log 2>&1
+  rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_o|k_lk_q' --pmc $P --output-format csv -d $OUT/sq_lk$i -- python $R/bench.py --streams $S --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/sq_lk$i.log 2>&1
   find $OUT/sq_lk$i -name "*kernel_trace.csv" -delete
 done
 # BA (C5): per-kernel stats of bench.bench_ba() (1, 8 and 64 windows) + SQ / MFMA counters of its kernels
