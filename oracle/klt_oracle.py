@@ -52,7 +52,8 @@ def _host_signature():
 def lib(native=False):
     global _LIB
     if _LIB is None or native:
-        path = build(native=native)
+        # KO_LIB: load another build of the same source (e.g. gcc -fsanitize=address, tests/README in oracle/Makefile): checker-of-the-checker runs
+        path = os.environ.get("KO_LIB") or build(native=native)
         L = C.CDLL(path)
         L.ko_det_log.restype = C.c_double
         L.ko_det_log.argtypes = [C.c_double]
