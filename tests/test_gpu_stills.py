@@ -119,3 +119,31 @@ def test_real_stills_fast_close_motion_kills_every_track_like_the_oracle(stills)
     print("frame, alive, pose tracks, klt flags:", log)
     assert log[0][1] == 0 and (log[0][3] & 1), "expected total loss with the coarse-affine failure flag at frame 1"
     assert st["n_cur"] == 0 and np.all(np.isfinite(st["t"])) and np.isfinite(st["res"])
+
+
+def test_real_stills_through_the_drop_in_functions_and_the_torch_op(stills):
+    """The stateless boundary on real pixels: KLTmain (utils/KLT.py:99-134) as the ctypes shim and as torch.ops.velocity_hip.klt_main, frame 0 -> 1 of
+    both sequences (B: 278 -> 112 tracks through every status gate; A: total loss with the coarse-affine failure message), bit-exact against the oracle
+    incl. the quarter-scale image; then cv2calcOpticalFlowPyrLK alone (forward-backward, both parameter sets) on the same frames."""
+    import torch
+
+    import velocity_amd.torch_ops  # noqa: F401
+    from velocity_amd import KLT
+
+    for tag, border in (("b", (180, 140)), ("a", (233, 167))):
+        fr, q = stills[f"{tag}_frames"], stills[f"{tag}_q"]
+        H, W = fr[0].shape
+        boxb = KO.bounding_rect(q, (H, W), border)
+        roi = fr[0][boxb[2]:boxb[3], boxb[0]:boxb[1]]
+        p0 = KO.corner_subpix(fr[0], KO.good_features(roi, 1000, 0.01, 5, 0.04) + np.float32([boxb[0], boxb[2]]), 5, 100, 0.001)
+        ep, ev, esmall, S = KO.klt_main(fr[1], fr[0], None, p0, stages=True)
+        p, v, small = KLT.KLTmain(fr[1], fr[0], None, p0)
+        assert np.array_equal(v, ev) and np.array_equal(p, ep) and np.array_equal(small, esmall), tag
+        pa, va, sa = torch.ops.velocity_hip.klt_main(torch.from_numpy(fr[1]).cuda(), torch.from_numpy(fr[0]).cuda(), None, torch.from_numpy(p0).cuda())
+        assert np.array_equal(va.cpu().numpy().astype(bool), ev) and np.array_equal(pa.cpu().numpy()[ev], ep) and np.array_equal(sa.cpu().numpy(), esmall)
+        assert (ev.sum() == 0) == (tag == "a")
+        for lk, kw, fbt in ((dict(winSize=(15, 15), maxLevel=4, criteria=(3, 10, 0.1)), dict(win=15, max_level=4, max_count=10, eps=0.1), 1.0),
+                            (dict(winSize=(51, 51), maxLevel=0, criteria=(3, 30, 0.001)), dict(win=51, max_level=0, max_count=30, eps=0.001), 0.3)):
+            e2, ev2, eerr = KO.lk_fb(fr[0], fr[1], p0, fbt=fbt, **kw)
+            p2, v2, err = KLT.cv2calcOpticalFlowPyrLK(fr[0], fr[1], p0, None, fbt=fbt, **lk)
+            assert np.array_equal(v2, ev2) and np.array_equal(p2, e2) and np.array_equal(err.ravel(), eerr), (tag, kw)
