@@ -381,6 +381,31 @@ def test_klt_main_bit_exact_all_stages(seq, coarse_levels):
     assert np.array_equal(p_b, p) and np.array_equal(v_b, v)
 
 
+@pytest.mark.parametrize("coarse_levels", [4, 2])
+def test_klt_main_on_the_scene_that_fires_every_status_gate(coarse_levels):
+    """synth.gate_scene: independent foreground motion, a textureless band, a saturated patch, tracks across the frame border.  Unlike the plain scenes
+    (no gate ever fires there) this one kills tracks on EVERY gate of KLTmain, like the reference's real stills do (profiles/r04_gate_census.json): the
+    census (tests/klt_gate_census.py, oracle side) must show each gate firing, and every stage of the HIP path must equal the oracle bit for bit."""
+    from klt_gate_census import census
+
+    from velocity_amd import KLT
+
+    f0, f1, p0 = synth.gate_scene()
+    lkc = dict(max_level=coarse_levels)
+    c = census(f1, f0, p0, lk_coarse=lkc)
+    s1, s2, s3 = c["stage1_quarter_scale_lk"], c["stage2_roi_translation_lk_fb1"], c["stage3_affine_warp_lk_fb03"]
+    assert s1["fwd_status"] > 0 and s1["ransac_outliers"] > 20 and s2["fwd_status"] > 10 and s2["bwd_status"] > 0 and s2["fb"] > 20
+    assert s3["fwd_status"] > 0 and s3["bwd_status"] > 0 and s3["fb"] > 50 and 0.5 < c["survive"] / c["tracks"] < 0.85
+    p, v, small, p_all, flags = KLT.KLTmain(f1, f0, None, p0, lk_coarse=lkc, return_all=True)
+    ep, ev, esmall, S = KO.klt_main(f1, f0, None, p0, lk_coarse=lkc, stages=True)
+    G = KLT.klt_stages(len(p0))
+    assert np.array_equal(small, esmall)
+    for k in ("p_small", "v_small", "T_trans", "roi", "p_coarse", "v_coarse", "T23", "warped"):
+        assert np.array_equal(G[k], S[k]), k
+    assert flags == S["flags"] and np.array_equal(v, ev) and np.array_equal(p_all, S["p_all"]) and np.array_equal(p, ep)
+    assert int(ev.sum()) == c["survive"]
+
+
 def test_klt_main_failure_path_matches(seq):
     """Unrelated frames: few survivors -> 'coarse-affine failure' branch (KLT.py:126-130) must agree with the oracle."""
     from velocity_amd import KLT

@@ -215,3 +215,16 @@ def test_klt_main_without_tracks_does_not_touch_memory():
     assert p.shape == (0, 2) and v.shape == (0,) and S["flags"] == 1 and tuple(S["roi"]) == (1, 1, 1, 1)
     assert np.array_equal(small, KO.resize_quarter(b))
     assert KO.bounding_rect(np.zeros((0, 2), np.float32), (90, 120), (50, 50)) == (1, 1, 1, 1)
+
+
+def test_gate_scene_fires_every_status_gate_in_the_oracle():
+    """The synthetic counterpart of the real stills' gate census (CPU half of tests/test_gpu_klt.py::test_klt_main_on_the_scene_that_fires_every_status_gate)."""
+    from klt_gate_census import census
+
+    from velocity_amd import synth
+
+    f0, f1, p0 = synth.gate_scene()
+    c = census(f1, f0, p0)
+    s1, s2, s3 = c["stage1_quarter_scale_lk"], c["stage2_roi_translation_lk_fb1"], c["stage3_affine_warp_lk_fb03"]
+    assert min(s1["fwd_status"], s2["fwd_status"], s2["bwd_status"], s3["fwd_status"], s3["bwd_status"]) > 0
+    assert s1["ransac_outliers"] > 20 and s2["fb"] > 20 and s3["fb"] > 50 and 0.5 < c["survive"] / c["tracks"] < 0.85

@@ -186,3 +186,27 @@ def ba_pack(P, pw, cw):
     z = np.concatenate([P[0].T.reshape(-1), P[1].T.reshape(-1)]).astype(np.float64)
     x0 = np.concatenate((pw, np.asarray(cw, float)[1:], np.zeros((nf - 1, 3)))).reshape(-1)
     return z, x0, nt, nf - 1
+
+
+def gate_scene(width=960, height=540, n=600, seed=21):
+    """Two consecutive frames that make every status gate of KLTmain fire (the plain synthetic scenes fire none, the reference's real stills fire all:
+    profiles/r04_gate_census.json): a textured background under a small affine motion, an independently moving foreground rectangle (its tracks fail the
+    RANSAC / forward-backward gates, tracks on its edge see two motions), a textureless band (min-eigenvalue gate), a saturated patch, and tracks that
+    run up to and beyond the frame border.  Returns (frame0, frame1, p0 float32 [n,2])."""
+    bg = AffineMotion(width, height, s=1.006, theta_deg=0.25, tx=6.5, ty=-3.0)
+    fg = AffineMotion(width, height, s=0.97, theta_deg=-1.2, tx=-19.0, ty=11.0)
+    f0 = render_frame(width, height, bg, 0, seed=seed).numpy().copy()
+    f1 = render_frame(width, height, bg, 1, seed=seed).numpy().copy()
+    g0 = render_frame(width, height, fg, 0, seed=seed + 1).numpy()
+    g1 = render_frame(width, height, fg, 1, seed=seed + 1).numpy()
+    x0, x1, y0, y1 = int(0.55 * width), int(0.85 * width), int(0.25 * height), int(0.7 * height)
+    f0[y0:y1, x0:x1] = g0[y0:y1, x0:x1]  # the foreground object: own texture, own motion (its outline moves with it by the mean shift of fg)
+    sx, sy = int(round(fg.t[0])), int(round(fg.t[1]))
+    f1[y0 + sy:y1 + sy, x0 + sx:x1 + sx] = g1[y0 + sy:y1 + sy, x0 + sx:x1 + sx]
+    for f in (f0, f1):
+        f[int(0.80 * height):int(0.88 * height), :] = 117  # textureless band
+        f[int(0.05 * height):int(0.2 * height), int(0.1 * width):int(0.25 * width)] = 255  # saturated patch
+    p = grid_tracks(n - 40, width, height, seed=seed + 2, frac=0.97)
+    r = np.random.default_rng(seed)
+    edge = np.stack([r.uniform(-8, width + 8, 40), np.concatenate([r.uniform(-8, 12, 20), r.uniform(height - 12, height + 8, 20)])], 1).astype(np.float32)
+    return f0, f1, np.concatenate([p, edge]).astype(np.float32)
