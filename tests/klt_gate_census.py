@@ -105,6 +105,9 @@ def synthetic():
         p0 = m.apply(7, synth.grid_tracks(2000, 1920, 1080, seed=1).astype(float)).astype(np.float32)
         res[f"synthetic_c2_{name}_baseline_params"] = census(f1, f0, p0, lk_coarse=dict(max_level=2))
         res[f"synthetic_c2_{name}_ref_params"] = census(f1, f0, p0)
+    f0, f1, p0 = synth.gate_scene()  # the scene built to fire every gate (tests/test_gpu_klt.py::test_klt_main_on_the_scene_that_fires_every_status_gate)
+    res["synthetic_gate_scene_ref_params"] = census(f1, f0, p0)
+    res["synthetic_gate_scene_baseline_params"] = census(f1, f0, p0, lk_coarse=dict(max_level=2))
     return res
 
 
