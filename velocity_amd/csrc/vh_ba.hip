@@ -8,6 +8,7 @@
 //     H = [[U  W],[W^T V]] + I,   S = V + I - W^T (U+I)^-1 W,   S dc = gc - W^T (U+I)^-1 gp,   dp = (U+I)^-1 (gp - W dc)
 // Everything stays on the device for all iterations (the convergence test only sets a device flag).
 #include "vh_ba.hpp"
+#include <type_traits>
 #include "vh_ws.hpp"
 #include <algorithm>
 #include <cstdlib>
@@ -454,18 +455,30 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 //     VALU / LDS   : Z_{g+1} = L^T W of the NEXT group from its raw record (-> the other Z buffer), the reduced right-hand side and the
 //                    thread-owned entries of the diagonal blocks V_c of the next group
 // so the vector work of a group hides behind the matrix-core time of the previous one, and there is exactly one workgroup barrier per group.
-#define BA_RAW_WORDS 7  // ceil((20 * 21 + 9) / 64): lane-words of a raw record for nc <= 21
-
-struct BaRawOff {                 // loop-invariant per lane: where its words of a raw record live in global memory
-    const double* base[BA_RAW_WORDS];
-    int stride[BA_RAW_WORDS];     // doubles per point (0: lane has no such word)
+// Two sizes of the same kernel (template NP = padded width of the reduced system): NP = 128 (up to 21 cameras: an 8 x 8 tile grid, 36 upper-triangle tiles,
+// ONE launch) and, round 4, NP = 256 (22..42 cameras: 16 x 16 tiles, 136 upper-triangle tiles in TWO launches of 68 -- a consumer wavefront then holds 17
+// tiles = 136 accumulator registers; both launches rebuild Z, which is the cheap part).  Tile rows are paired (W, NT-1-W): NT+1 tiles per wavefront job.
+template <int NP>
+struct BaSchurCfg {
+    static constexpr int NT = NP / 16;               // tile rows / columns
+    static constexpr int NH = NP / 64;               // reduced columns per producer lane
+    static constexpr int NRW = NP == 128 ? 7 : 14;   // lane-words of a raw record: ceil((20 nc + 9) / 64) for nc <= 21 / 42
+    static constexpr int ND = NP == 128 ? 3 : 6;     // diagonal-block entries per producer thread: ceil(36 nc / 256)
+    static constexpr int NACC = NT + 1;              // tiles of one consumer job
 };
 
-__device__ __forceinline__ void ba_raw_offsets(BaRawOff& O, const BaJob& J, int lane)
+template <int NRW>
+struct BaRawOff {                 // loop-invariant per lane: where its words of a raw record live in global memory
+    const double* base[NRW];
+    int stride[NRW];              // doubles per point (0: lane has no such word)
+};
+
+template <int NRW>
+__device__ __forceinline__ void ba_raw_offsets(BaRawOff<NRW>& O, const BaJob& J, int lane)
 {
-    const int nt = J.nt, nc = J.nc, nw = 20 * nc + 9;
+    const int nc = J.nc, nw = 20 * nc + 9;
 #pragma unroll
-    for (int j = 0; j < BA_RAW_WORDS; j++) {
+    for (int j = 0; j < NRW; j++) {
         const int w = min(lane + 64 * j, nw - 1);  // clamped: surplus lanes re-load the last word (never stored)
         const double* b;
         int st;
@@ -481,73 +494,94 @@ __device__ __forceinline__ void ba_raw_offsets(BaRawOff& O, const BaJob& J, int 
 }
 
 // the lane's words of the raw record of point min(i, i_last) (branch-free: unconditional loads, all in flight together)
-__device__ __forceinline__ void ba_raw_fetch(double (&R)[BA_RAW_WORDS], const BaRawOff& O, int i, int i_last)
+template <int NRW>
+__device__ __forceinline__ void ba_raw_fetch(double (&R)[NRW], const BaRawOff<NRW>& O, int i, int i_last)
 {
     i = min(i, i_last);
 #pragma unroll
-    for (int j = 0; j < BA_RAW_WORDS; j++) R[j] = O.base[j][(size_t)O.stride[j] * i];
+    for (int j = 0; j < NRW; j++) R[j] = O.base[j][(size_t)O.stride[j] * i];
 }
 
-__device__ __forceinline__ void ba_raw_park(const double (&R)[BA_RAW_WORDS], double* __restrict__ rec, int lane, int nwords, bool live)
+template <int NRW>
+__device__ __forceinline__ void ba_raw_park(const double (&R)[NRW], double* __restrict__ rec, int lane, int nwords, bool live)
 {
 #pragma unroll
-    for (int j = 0; j < BA_RAW_WORDS; j++) {
+    for (int j = 0; j < NRW; j++) {
         const int w = lane + 64 * j;
         if (w < nwords) rec[w] = live ? R[j] : 0.0;  // a dead point (past the chunk) is all zeros: it adds nothing anywhere
     }
 }
 
 // per-lane LDS offsets (doubles, inside a raw record) of what the Z rows of column q = lane + 64 h need
+template <int NH, int ND>
 struct BaColOff {
-    int jp[2], ju[2], rr[2];
-    int da[3], db[3];  // diagonal-block entry e = tid + 256 k of this thread: offsets 12 c + ka, 12 c + kb inside a record (clamped)
+    int jp[NH], ju[NH], rr[NH];
+    int da[ND], db[ND];  // diagonal-block entry e = tid + 256 k of this thread: offsets 12 c + ka, 12 c + kb inside a record (clamped)
 };
 
-// consumer wavefront W (matrix cores): the 3 K-slabs of its 9 upper-triangle tiles (tile row W: columns W..7, tile row 7-W: columns 7-W..7)
-template <int W>
-__device__ __forceinline__ void ba_consume(double4v (&acc)[9], const double* __restrict__ sZc, int lane)
+// consumer job W (matrix cores): the 3 K-slabs of its NT + 1 upper-triangle tiles (tile row W: columns W..NT-1, tile row NT-1-W: columns NT-1-W..NT-1)
+template <int NP, int W>
+__device__ __forceinline__ void ba_consume(double4v (&acc)[NP / 16 + 1], const double* __restrict__ sZc, int lane)
 {
-    constexpr int R1 = W, R2 = 7 - W, T0 = R1 < R2 ? R1 : R2;
+    constexpr int NT = NP / 16, R1 = W, R2 = NT - 1 - W, T0 = R1 < R2 ? R1 : R2;
     const int cc = lane & 15;
 #pragma unroll
     for (int k0 = 0; k0 < 12; k0 += 4) {
         const int kr = k0 + (lane >> 4);
-        double zf[8];
+        if constexpr (NT <= 8) {
+            double zf[NT];
 #pragma unroll
-        for (int t = T0; t < 8; t++) zf[t] = sZc[kr * BA_NPAD + 16 * t + cc];
+            for (int t = T0; t < NT; t++) zf[t] = sZc[kr * NP + 16 * t + cc];
 #pragma unroll
-        for (int t = R1; t < 8; t++) acc[t - R1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R1], zf[t], acc[t - R1], 0, 0, 0);
+            for (int t = R1; t < NT; t++) acc[t - R1] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R1], zf[t], acc[t - R1], 0, 0, 0);
 #pragma unroll
-        for (int t = R2; t < 8; t++) acc[8 - R1 + t - R2] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R2], zf[t], acc[8 - R1 + t - R2], 0, 0, 0);
+            for (int t = R2; t < NT; t++) acc[NT - R1 + t - R2] = __builtin_amdgcn_mfma_f64_16x16x4f64(zf[R2], zf[t], acc[NT - R1 + t - R2], 0, 0, 0);
+        } else {
+            // 16 tile columns: the operand of a tile is read right before its instruction (all 16 at once would be 32 more live registers next to the
+            // 136 accumulator registers); the tiles of row R2 read their columns a second time
+            const double a1 = sZc[kr * NP + 16 * R1 + cc], a2 = sZc[kr * NP + 16 * R2 + cc];
+#pragma unroll
+            for (int t = R1; t < NT; t++) {
+                const double b = t == R1 ? a1 : (t == R2 ? a2 : sZc[kr * NP + 16 * t + cc]);
+                acc[t - R1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[t - R1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = R2; t < NT; t++) {
+                const double b = t == R2 ? a2 : sZc[kr * NP + 16 * t + cc];
+                acc[NT - R1 + t - R2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, acc[NT - R1 + t - R2], 0, 0, 0);
+            }
+        }
     }
 }
 
 // producer wavefront pw: Z rows 3 pw .. 3 pw + 2 of its point from the point's raw record (already parked in LDS by this very wavefront),
 // plus the point's share of the reduced right-hand side
-__device__ __forceinline__ void ba_produce_z(double (&accR)[2], double* __restrict__ sZn, const double* __restrict__ rec, const BaColOff& C, int nc, int nq,
-                                             int lane, int pw)
+template <int NP>
+__device__ __forceinline__ void ba_produce_z(double (&accR)[NP / 64], double* __restrict__ sZn, const double* __restrict__ rec,
+                                             const BaColOff<NP / 64, BaSchurCfg<NP>::ND>& C, int nc, int nq, int lane, int pw)
 {
     const double* lt = rec + 20 * nc;  // L, tp: wave-uniform
     const double L0 = lt[0], L1 = lt[1], L2 = lt[2], L3 = lt[3], L4 = lt[4], L5 = lt[5], t0 = lt[6], t1 = lt[7], t2 = lt[8];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < NP / 64; h++) {
         const double* jp = rec + C.jp[h];
         const double ju = rec[C.ju[h]], jv = rec[C.ju[h] + 6], ru = rec[C.rr[h]], rv = rec[C.rr[h] + 1];
         const double w0 = jp[0] * ju + jp[3] * jv, w1 = jp[1] * ju + jp[4] * jv, w2 = jp[2] * ju + jp[5] * jv;
         // L^T is upper triangular: rows (l00 l10 l20), (0 l11 l21), (0 0 l22); L is stored l00 l10 l11 l20 l21 l22
         const double z0 = L0 * w0 + L1 * w1 + L3 * w2, z1 = L2 * w1 + L4 * w2, z2 = L5 * w2;
         accR[h] += ju * ru + jv * rv - (w0 * t0 + w1 * t1 + w2 * t2);  // a dead point's record is zeros; lanes with q >= nq hold a duplicate that is never stored
-        const int q = lane + 64 * h;  // < 128 = the row pitch: columns >= nq are written as zeros
+        const int q = lane + 64 * h;  // < NP = the row pitch: columns >= nq are written as zeros
         const bool on = q < nq;
-        sZn[(3 * pw) * BA_NPAD + q] = on ? z0 : 0.0; sZn[(3 * pw + 1) * BA_NPAD + q] = on ? z1 : 0.0; sZn[(3 * pw + 2) * BA_NPAD + q] = on ? z2 : 0.0;
+        sZn[(3 * pw) * NP + q] = on ? z0 : 0.0; sZn[(3 * pw + 1) * NP + q] = on ? z1 : 0.0; sZn[(3 * pw + 2) * NP + q] = on ? z2 : 0.0;
     }
 }
 
 // producer threads: their entries of the diagonal blocks V_c, summed over the 4 points of a group (records of all four producers)
-__device__ __forceinline__ void ba_produce_diag(double (&accD)[3], const double* __restrict__ raw4, int RAWW, const BaColOff& C)
+template <int NH, int ND>
+__device__ __forceinline__ void ba_produce_diag(double (&accD)[ND], const double* __restrict__ raw4, int RAWW, const BaColOff<NH, ND>& C)
 {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < ND; k++) {
         double v = 0.0;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -559,37 +593,43 @@ __device__ __forceinline__ void ba_produce_diag(double (&accD)[3], const double*
     }
 }
 
-template <int W>
-__device__ __forceinline__ void ba_syrk_store(const double4v (&acc)[9], double* __restrict__ Sp, int lane, int nq)
+template <int NP, int W>
+__device__ __forceinline__ void ba_syrk_store(const double4v (&acc)[NP / 16 + 1], double* __restrict__ Sp, int lane, int nq)
 {
-    constexpr int R1 = W, R2 = 7 - W;
+    constexpr int NT = NP / 16, R1 = W, R2 = NT - 1 - W;
     // f64 C/D layout of the 16x16x4 instruction: lane holds rows (lane >> 4) + 4 rg, column lane & 15
 #pragma unroll
-    for (int t = R1; t < 8; t++)
+    for (int t = R1; t < NT; t++)
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
             const int row = 16 * R1 + (lane >> 4) + 4 * rg, col = 16 * t + (lane & 15);
             if (row < nq && col < nq) Sp[(size_t)row * nq + col] = -acc[t - R1][rg];
         }
 #pragma unroll
-    for (int t = R2; t < 8; t++)
+    for (int t = R2; t < NT; t++)
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
             const int row = 16 * R2 + (lane >> 4) + 4 * rg, col = 16 * t + (lane & 15);
-            if (row < nq && col < nq) Sp[(size_t)row * nq + col] = -acc[8 - R1 + t - R2][rg];
+            if (row < nq && col < nq) Sp[(size_t)row * nq + col] = -acc[NT - R1 + t - R2][rg];
         }
 }
 
 // workgroup barrier that orders LDS traffic only: outstanding GLOBAL loads (the prefetch) stay in flight across it
 __device__ __forceinline__ void ba_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// 8 wavefronts, specialised: wavefronts 0-3 CONSUME (matrix cores: 9 tiles each of Z_g^T Z_g), wavefronts 4-7 PRODUCE (fetch the raw records two
+// 8 wavefronts, specialised: wavefronts 0-3 CONSUME (matrix cores: NT + 1 tiles each of Z_g^T Z_g), wavefronts 4-7 PRODUCE (fetch the raw records two
 // groups ahead, park them in LDS, turn them into Z_{g+1}, the reduced right-hand side and the diagonal blocks).  Every SIMD hosts one wavefront
 // of each kind, so its matrix pipe and its vector pipe are fed by different instruction streams and really run at the same time -- a single
 // wavefront issues in order and serialised the two (measured: MFMA, VALU and memory time simply added up).  One workgroup barrier per group.
+// `pass` (NP = 256 only): consumer jobs 4 pass .. 4 pass + 3 of the NT / 2 = 8.  The diagonal blocks V_c and the right-hand side are accumulated and added by
+// the LAST pass: by then every tile they touch is final (the earlier pass is a finished launch, this block's own tiles are stored before barrier (C)).
 #define BA_SCHUR_THREADS 512
+template <int NP, int PASS>
 __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur_mfma(BaJob J)
 {
+    constexpr int pass = PASS;
+    using Cfg = BaSchurCfg<NP>;
+    constexpr int NH = Cfg::NH, NRW = Cfg::NRW, ND = Cfg::ND;
     ba_select_window(J, blockIdx.y);
     if (*J.done) return;
     const int nt = J.nt, nc = J.nc, nq = 6 * nc, tid = threadIdx.x, lane = tid & 63;
@@ -599,104 +639,111 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur_mfma(BaJob J)
     const int ptid = tid & 255;        // thread index within its half
     const int RAWW = 20 * nc + 10, nwords = 20 * nc + 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sZ = reinterpret_cast<double*>(smem);   // [2][12][128]
-    double* sRaw = sZ + 2 * 12 * BA_NPAD;           // [2][4][RAWW] raw records
-    double* sR = sRaw + 2 * 4 * RAWW;               // [4][128] rhs partials of the four producer waves
+    double* sZ = reinterpret_cast<double*>(smem);   // [2][12][NP]
+    double* sRaw = sZ + 2 * 12 * NP;                // [2][4][RAWW] raw records
+    double* sR = sRaw + 2 * 4 * RAWW;               // [4][NP] rhs partials of the four producer waves
     const int chunk = (nt + gridDim.x - 1) / gridDim.x;
     const int i0 = blockIdx.x * chunk, i1 = min(nt, i0 + chunk);
     const long long nent = (long long)nq * nq;
+    const bool last_pass = pass == Cfg::NT / 8 - 1;
     if (i0 >= i1) {  // the last workgroups of a launch can own no point (nt not a multiple of the chunk): their partials are zeros
-        double* Sp0 = J.Spart + (size_t)blockIdx.x * ((size_t)nq * nq);
-        for (long long e = tid; e < (long long)nq * nq; e += BA_SCHUR_THREADS) Sp0[e] = 0.0;
-        if (tid < nq) J.Rpart[(size_t)blockIdx.x * nq + tid] = 0.0;
+        if (pass == 0) {
+            double* Sp0 = J.Spart + (size_t)blockIdx.x * ((size_t)nq * nq);
+            for (long long e = tid; e < (long long)nq * nq; e += BA_SCHUR_THREADS) Sp0[e] = 0.0;
+            if (tid < nq) J.Rpart[(size_t)blockIdx.x * nq + tid] = 0.0;
+        }
         return;
     }
-    for (int q = tid; q < 2 * 12 * BA_NPAD; q += BA_SCHUR_THREADS) sZ[q] = 0.0;  // zero padding of both buffers (columns >= nq stay zero)
+    for (int q = tid; q < 2 * 12 * NP; q += BA_SCHUR_THREADS) sZ[q] = 0.0;  // zero padding of both buffers (columns >= nq stay zero)
     const int i_last = i1 - 1;
     double* Sp = J.Spart + (size_t)blockIdx.x * nent;
 
     if (producer) {
-        double accD[3] = {0.0, 0.0, 0.0};  // diagonal-block entries e = ptid + 256 k < nc * 36
-        double accR[2] = {0.0, 0.0};       // rhs entries q = lane, lane + 64 of the points this wave handled
-        BaRawOff off;
-        ba_raw_offsets(off, J, lane);
-        BaColOff col;
+        double accD[ND];   // diagonal-block entries e = ptid + 256 k < nc * 36
+        double accR[NH];   // rhs entries q = lane + 64 h of the points this wave handled
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int k = 0; k < ND; k++) accD[k] = 0.0;
+#pragma unroll
+        for (int h = 0; h < NH; h++) accR[h] = 0.0;
+        BaRawOff<NRW> off;
+        ba_raw_offsets<NRW>(off, J, lane);
+        BaColOff<NH, ND> col;
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
             const int q = min(lane + 64 * h, nq - 1), c = q / 6, k = q - 6 * c;  // clamped: columns >= nq compute garbage that is stored as zeros
             col.jp[h] = 12 * nc + 6 * c; col.ju[h] = 12 * c + k; col.rr[h] = 18 * nc + 2 * c;
         }
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < ND; k++) {
             const int e = min(ptid + 256 * k, nc * 36 - 1);  // clamped: the final store is guarded
             const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
             col.da[k] = 12 * c + ka; col.db[k] = 12 * c + kb;
         }
         // prologue: record and Z of group 0 (buffers 0)
-        double Ra[BA_RAW_WORDS], Rb[BA_RAW_WORDS];
-        ba_raw_fetch(Ra, off, i0 + pw, i_last);
-        ba_raw_fetch(Rb, off, i0 + 4 + pw, i_last);
+        double Ra[NRW], Rb[NRW];
+        ba_raw_fetch<NRW>(Ra, off, i0 + pw, i_last);
+        ba_raw_fetch<NRW>(Rb, off, i0 + 4 + pw, i_last);
         __syncthreads();  // (A) sZ zero-fill complete
-        ba_raw_park(Ra, sRaw + pw * RAWW, lane, nwords, i0 + pw < i1);
-        ba_raw_fetch(Ra, off, i0 + 8 + pw, i_last);
+        ba_raw_park<NRW>(Ra, sRaw + pw * RAWW, lane, nwords, i0 + pw < i1);
+        ba_raw_fetch<NRW>(Ra, off, i0 + 8 + pw, i_last);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own record is readable by this wave (LDS ops of a wave complete in order)
-        ba_produce_z(accR, sZ, sRaw + pw * RAWW, col, nc, nq, lane, pw);
+        ba_produce_z<NP>(accR, sZ, sRaw + pw * RAWW, col, nc, nq, lane, pw);
         ba_lds_barrier();  // (B) Z(0) and the records of group 0 complete
         // steady state, iteration g (consumers run MFMA(g) meanwhile): Rb = raw(g+1), Ra = raw(g+2); raw(g) lives in sRaw[buf]
         int buf = 0;
         for (int ig = i0; ig < i1; ig += 4, buf ^= 1) {
             double* recn = sRaw + ((buf ^ 1) * 4 + pw) * RAWW;
-            if (!(J.dbg & 16)) ba_raw_park(Rb, recn, lane, nwords, ig + 4 + pw < i1);
+            if (!(J.dbg & 16)) ba_raw_park<NRW>(Rb, recn, lane, nwords, ig + 4 + pw < i1);
 #pragma unroll
-            for (int j = 0; j < BA_RAW_WORDS; j++) Rb[j] = Ra[j];
-            if (!(J.dbg & 4)) ba_raw_fetch(Ra, off, ig + 12 + pw, i_last);  // raw(g+3): two groups ahead (three measured no different)
+            for (int j = 0; j < NRW; j++) Rb[j] = Ra[j];
+            if (!(J.dbg & 4)) ba_raw_fetch<NRW>(Ra, off, ig + 12 + pw, i_last);  // raw(g+3): two groups ahead (three measured no different)
             asm volatile("" ::: "memory");
-            if (!(J.dbg & 2)) ba_produce_diag(accD, sRaw + buf * 4 * RAWW, RAWW, col);  // group g: all four records are complete since the last barrier
+            if (!(J.dbg & 2) && last_pass) ba_produce_diag<NH, ND>(accD, sRaw + buf * 4 * RAWW, RAWW, col);  // group g: all four records are complete since the last barrier
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (!(J.dbg & 32)) ba_produce_z(accR, sZ + (buf ^ 1) * 12 * BA_NPAD, recn, col, nc, nq, lane, pw);  // Z(g+1)
+            if (!(J.dbg & 32)) ba_produce_z<NP>(accR, sZ + (buf ^ 1) * 12 * NP, recn, col, nc, nq, lane, pw);  // Z(g+1)
             if (!(J.dbg & 8)) ba_lds_barrier();  // Z(g+1) and records g+1 complete; consumers are done with Z(g)
         }
         // epilogue: after the consumers stored their tiles, add the diagonal blocks and write the rhs partial
-        sR[pw * BA_NPAD + lane] = accR[0];
-        sR[pw * BA_NPAD + lane + 64] = accR[1];
+#pragma unroll
+        for (int h = 0; h < NH; h++) sR[pw * NP + lane + 64 * h] = accR[h];
         __threadfence_block();
         __syncthreads();  // (C)
+        if (last_pass) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int e = ptid + 256 * k;
-            if (e < nc * 36) {
-                const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
-                // a 6x6 camera block can straddle two 16x16 tiles: entries with tile(row) > tile(col) are never read (k_ba_reduce mirrors the
-                // upper triangle), so only the others are stored
-                const int row = 6 * c + ka, col_ = 6 * c + kb;
-                if ((row >> 4) <= (col_ >> 4)) Sp[(size_t)row * nq + col_] += accD[k];
+            for (int k = 0; k < ND; k++) {
+                const int e = ptid + 256 * k;
+                if (e < nc * 36) {
+                    const int c = e / 36, rr = e - 36 * c, ka = rr / 6, kb = rr - 6 * ka;
+                    // a 6x6 camera block can straddle two 16x16 tiles: entries with tile(row) > tile(col) are never read (k_ba_reduce mirrors the
+                    // upper triangle), so only the others are stored
+                    const int row = 6 * c + ka, col_ = 6 * c + kb;
+                    if ((row >> 4) <= (col_ >> 4)) Sp[(size_t)row * nq + col_] += accD[k];
+                }
             }
+            for (int q = ptid; q < nq; q += 256) J.Rpart[(size_t)blockIdx.x * nq + q] = sR[q] + sR[NP + q] + sR[2 * NP + q] + sR[3 * NP + q];
         }
-        if (ptid < nq) J.Rpart[(size_t)blockIdx.x * nq + ptid] = sR[ptid] + sR[BA_NPAD + ptid] + sR[2 * BA_NPAD + ptid] + sR[3 * BA_NPAD + ptid];
     } else {
-        double4v acc[9];
-#pragma unroll
-        for (int t = 0; t < 9; t++) acc[t] = double4v{0.0, 0.0, 0.0, 0.0};
         __syncthreads();   // (A)
         ba_lds_barrier();  // (B)
-        int buf = 0;
-        for (int ig = i0; ig < i1; ig += 4, buf ^= 1) {
-            const double* Zc = sZ + buf * 12 * BA_NPAD;
-            if (!(J.dbg & 1))
-            switch (pw) {
-            case 0: ba_consume<0>(acc, Zc, lane); break;
-            case 1: ba_consume<1>(acc, Zc, lane); break;
-            case 2: ba_consume<2>(acc, Zc, lane); break;
-            default: ba_consume<3>(acc, Zc, lane); break;
+        // one loop per consumer job (not one loop with a switch inside): the accumulators of the four jobs then never meet in a phi node -- with the switch
+        // inside the loop hipcc shuffled all NT + 1 tiles through v_mov_b64 every group and, at NP = 256, spilled six of them
+        auto run_job = [&](auto wtag) {
+            constexpr int W = decltype(wtag)::value;
+            double4v acc[Cfg::NACC];
+#pragma unroll
+            for (int t = 0; t < Cfg::NACC; t++) acc[t] = double4v{0.0, 0.0, 0.0, 0.0};
+            int buf = 0;
+            for (int ig = i0; ig < i1; ig += 4, buf ^= 1) {
+                if (!(J.dbg & 1)) ba_consume<NP, W>(acc, sZ + buf * 12 * NP, lane);
+                if (!(J.dbg & 8)) ba_lds_barrier();
             }
-            if (!(J.dbg & 8)) ba_lds_barrier();
-        }
-        // the upper-triangle tiles of -Z^T Z
-        switch (pw) {
-        case 0: ba_syrk_store<0>(acc, Sp, lane, nq); break;
-        case 1: ba_syrk_store<1>(acc, Sp, lane, nq); break;
-        case 2: ba_syrk_store<2>(acc, Sp, lane, nq); break;
-        default: ba_syrk_store<3>(acc, Sp, lane, nq); break;
+            ba_syrk_store<NP, W>(acc, Sp, lane, nq);  // the upper-triangle tiles of -Z^T Z
+        };
+        switch (pw) {  // job 4 PASS + pw
+        case 0: run_job(std::integral_constant<int, 4 * PASS + 0>{}); break;
+        case 1: run_job(std::integral_constant<int, 4 * PASS + 1>{}); break;
+        case 2: run_job(std::integral_constant<int, 4 * PASS + 2>{}); break;
+        default: run_job(std::integral_constant<int, 4 * PASS + 3>{}); break;
         }
         __threadfence_block();
         __syncthreads();  // (C)
@@ -1066,6 +1113,196 @@ __global__ __launch_bounds__(1024) void k_ba_solve_big(BaJob J)
     for (int q = tid; q < nq; q += 1024) J.dc[q] = A[(size_t)q * ld + nq] / A[(size_t)q * ld + q];
 }
 
+// Schur stage 2b for more than 124 unknowns (21+ cameras): BLOCKED CHOLESKY across launches.  The augmented system of 125..768 unknowns does not fit the
+// register file of one CU (252 x 253 doubles = 510 KB of its 512 KB), which is what made the register-resident Gauss-Jordan of round 2 spill (620 VGPRs,
+// 1.3 ms per solve at 36-42 cameras) and the in-L2 elimination crawl (5 ms at 50).  S is SPD (Schur complement of J^T J + I), so S = L L^T, right-looking,
+// panels of 32 columns, in place in the lower triangle of Sfull (it stays in L2); the right-hand side rides along as one more row (stored where it already
+// is: column nq), so when the last panel is done it holds y = L^-1 rhs.  Per panel two launches:
+//   k_ba_chol_panel : ONE workgroup -- the 32 x 32 diagonal block factored in LDS, then every row below it (one thread per row, the rhs row included)
+//                     forward-substituted against it (32 registers per row)
+//   k_ba_chol_update: the trailing lower triangle (and the rhs row) minus the panel's outer product, one workgroup per 32 x 32 tile
+// and at the end k_ba_chol_back: L^T dc = y, panel by panel from the last (a matrix-vector product over the rows below, then a 32-step triangular solve).
+// ~14 + 9 us per panel, 8 panels at 252 unknowns.  Same result as the elimination kernels to rounding (no pivoting needed or done in either).
+#define BA_CH_NB 32
+__global__ __launch_bounds__(256) void k_ba_chol_panel(BaJob J, int k0)
+{
+    ba_select_window(J, blockIdx.y);
+    if (*J.done) return;
+    const int nq = J.nq, ld = nq + 1, tid = threadIdx.x;
+    const int nb = min(BA_CH_NB, nq - k0);
+    double* A = J.Sfull;
+    __shared__ double sD[BA_CH_NB][BA_CH_NB + 1];
+    __shared__ double sV[256][BA_CH_NB + 1];
+    for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += 256) {
+        const int i = e / BA_CH_NB, j = e - i * BA_CH_NB;
+        sD[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * ld + k0 + j] : (i == j ? 1.0 : 0.0);  // (a short last panel is padded with the identity)
+    }
+    __syncthreads();
+    // unblocked right-looking Cholesky of the diagonal block, in LDS: per step every thread reads what it needs of column k, then the column is scaled and
+    // the trailing block updated (two barriers per step)
+    for (int k = 0; k < BA_CH_NB; k++) {
+        const double dkk = sD[k][k];
+        const double inv = 1.0 / sqrt(dkk);
+        // elements (i, j), k < j <= i, of the trailing block (the thread's 4 slots of the 32 x 32 square; the upper part and the finished columns idle)
+        double up[4], li[4];
+        int ei[4], ej[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = tid + 256 * u;  // over the 32 x 32 square; only the lower part behind column k works
+            const int i = e / BA_CH_NB, j = e - i * BA_CH_NB;
+            ei[u] = i; ej[u] = j;
+            const bool on = e < BA_CH_NB * BA_CH_NB && j > k && i >= j;
+            li[u] = on ? sD[i][k] : 0.0;
+            up[u] = on ? sD[j][k] : 0.0;
+        }
+        const double ck = (tid > k && tid < BA_CH_NB) ? sD[tid][k] : 0.0;  // column k below the diagonal: thread i scales its entry
+        __syncthreads();
+        if (tid == k) sD[k][k] = dkk * inv;  // sqrt(dkk)
+        if (tid > k && tid < BA_CH_NB) sD[tid][k] = ck * inv;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (up[u] != 0.0 || li[u] != 0.0) sD[ei[u]][ej[u]] = __builtin_fma(-(li[u] * inv), up[u] * inv, sD[ei[u]][ej[u]]);
+        __syncthreads();
+    }
+    // the factor of the diagonal block goes back (lower triangle)
+    for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += 256) {
+        const int i = e / BA_CH_NB, j = e - i * BA_CH_NB;
+        if (i < nb && j <= i) A[(size_t)(k0 + i) * ld + k0 + j] = sD[i][j];
+    }
+    // rows below the block + the rhs row: v <- v L_D^-T (forward substitution, one thread per row).  The rows travel through LDS in slabs of 256 so that
+    // the global accesses are coalesced (consecutive threads = consecutive columns of a row; a thread walking its own row touched 64 cache lines per load)
+    const int mrows = nq - k0 - nb;  // rows below; index mrows = the rhs row
+    for (int t0 = 0; t0 <= mrows; t0 += 256) {
+        const int cnt = min(256, mrows + 1 - t0);
+        __syncthreads();  // (the previous slab's stores have been issued from sV)
+        for (int e = tid; e < cnt * BA_CH_NB; e += 256) {
+            const int rr = e / BA_CH_NB, j = e - rr * BA_CH_NB, t = t0 + rr;
+            double v = 0.0;
+            if (j < nb) v = t == mrows ? A[(size_t)(k0 + j) * ld + nq] : A[(size_t)(k0 + nb + t) * ld + k0 + j];
+            sV[rr][j] = v;
+        }
+        __syncthreads();
+        if (tid < cnt) {
+            double v[BA_CH_NB];
+#pragma unroll
+            for (int j = 0; j < BA_CH_NB; j++) v[j] = sV[tid][j];
+#pragma unroll
+            for (int j = 0; j < BA_CH_NB; j++) {
+                double acc = v[j];
+#pragma unroll
+                for (int k = 0; k < j; k++) acc = __builtin_fma(-v[k], sD[j][k], acc);
+                v[j] = acc / sD[j][j];
+            }
+#pragma unroll
+            for (int j = 0; j < BA_CH_NB; j++) sV[tid][j] = v[j];
+        }
+        __syncthreads();
+        for (int e = tid; e < cnt * BA_CH_NB; e += 256) {
+            const int rr = e / BA_CH_NB, j = e - rr * BA_CH_NB, t = t0 + rr;
+            if (j < nb) {
+                if (t == mrows) A[(size_t)(k0 + j) * ld + nq] = sV[rr][j];
+                else A[(size_t)(k0 + nb + t) * ld + k0 + j] = sV[rr][j];
+            }
+        }
+    }
+}
+
+// trailing update after panel k0: A[i][j] -= sum_k L[i][k0+k] L[j][k0+k] for the lower-triangle tile (blockIdx.x >= blockIdx.y) of 32 x 32 behind the panel;
+// tile row index == number of row tiles means the rhs row (y[j] -= sum_k yp[k] L[j][k0+k])
+__global__ __launch_bounds__(256) void k_ba_chol_update(BaJob J, int k0)
+{
+    ba_select_window(J, blockIdx.z);
+    if (*J.done) return;
+    const int nq = J.nq, ld = nq + 1, tid = threadIdx.x;
+    const int nb = min(BA_CH_NB, nq - k0), r0 = k0 + nb;
+    const int ntile = (nq - r0 + BA_CH_NB - 1) / BA_CH_NB;
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (tj >= ntile || ti > ntile || ti < tj) return;
+    double* A = J.Sfull;
+    const bool rhs = ti == ntile;
+    __shared__ double sLi[BA_CH_NB][BA_CH_NB + 1], sLj[BA_CH_NB][BA_CH_NB + 1];
+    for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += 256) {
+        const int i = e / BA_CH_NB, k = e - i * BA_CH_NB;
+        const int gi = r0 + ti * BA_CH_NB + i, gj = r0 + tj * BA_CH_NB + i;
+        double li = 0.0;
+        if (k < nb) {
+            if (rhs) li = i == 0 ? A[(size_t)(k0 + k) * ld + nq] : 0.0;  // the rhs row's panel entries (already solved): one row
+            else if (gi < nq) li = A[(size_t)gi * ld + k0 + k];
+        }
+        sLi[i][k] = li;
+        sLj[i][k] = (k < nb && gj < nq) ? A[(size_t)gj * ld + k0 + k] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int e = tid + 256 * u, i = e / BA_CH_NB, j = e - i * BA_CH_NB;
+        const int gi = r0 + ti * BA_CH_NB + i, gj = r0 + tj * BA_CH_NB + j;
+        if (gj >= nq) continue;
+        if (rhs) {
+            if (i != 0) continue;
+        } else if (gi >= nq || gj > gi) continue;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < BA_CH_NB; k++) acc = __builtin_fma(sLi[i][k], sLj[j][k], acc);
+        double* dst = rhs ? A + (size_t)gj * ld + nq : A + (size_t)gi * ld + gj;
+        *dst -= acc;
+    }
+}
+
+// L^T dc = y, from the last panel to the first (one workgroup)
+__global__ __launch_bounds__(256) void k_ba_chol_back(BaJob J)
+{
+    ba_select_window(J, blockIdx.y);
+    if (*J.done) return;
+    const int nq = J.nq, ld = nq + 1, tid = threadIdx.x;
+    const double* A = J.Sfull;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* sx = reinterpret_cast<double*>(smem);  // [nq] solution so far
+    __shared__ double sT[8][BA_CH_NB];
+    __shared__ double sD[BA_CH_NB][BA_CH_NB + 1];
+    __shared__ double st[BA_CH_NB];
+    const int npan = (nq + BA_CH_NB - 1) / BA_CH_NB;
+    for (int p = npan - 1; p >= 0; p--) {
+        const int k0 = p * BA_CH_NB, nb = min(BA_CH_NB, nq - k0), r0 = k0 + nb;
+        // t[j] = y[k0 + j] - sum_{i >= r0} L[i][k0 + j] x[i]: 8 row slices x 32 columns
+        const int j = tid & (BA_CH_NB - 1), part = tid >> 5;
+        double acc = 0.0;
+        if (j < nb)
+            for (int i = r0 + part; i < nq; i += 8) acc = __builtin_fma(A[(size_t)i * ld + k0 + j], sx[i], acc);
+        sT[part][j] = acc;
+        for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += 256) {
+            const int i = e / BA_CH_NB, jj = e - i * BA_CH_NB;
+            sD[i][jj] = (i < nb && jj <= i) ? A[(size_t)(k0 + i) * ld + k0 + jj] : (i == jj ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (tid < BA_CH_NB) {
+            double t = tid < nb ? A[(size_t)(k0 + tid) * ld + nq] : 0.0;
+            for (int q = 0; q < 8; q++) t -= sT[q][tid];
+            st[tid] = t;
+        }
+        __syncthreads();
+        // L_D^T x = t: x[j] from the last to the first; after x[j], every earlier entry drops its term (one wavefront, wave-synchronous through LDS)
+        if (tid < 64) {
+            for (int jj = BA_CH_NB - 1; jj >= 0; jj--) {
+                double xj = 0.0;
+                if (tid == 0) { xj = st[jj] / sD[jj][jj]; st[jj] = xj; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                xj = st[jj];
+                if (tid < jj) st[tid] = __builtin_fma(-sD[jj][tid], xj, st[tid]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+        }
+        __syncthreads();
+        if (tid < nb) sx[k0 + tid] = st[tid];
+        __syncthreads();
+    }
+    for (int q = tid; q < nq; q += 256) J.dc[q] = sx[q];
+}
+
 // back-substitution dp = tp - Y dc, update x += 0.9 delta, rms(delta) and the stop flag (NLS.py:235-240)
 __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
 {
@@ -1318,8 +1555,18 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     const long long nent = (long long)nq * nq;
     const int npass = (int)((nent + (long long)BA_THREADS * BA_EPT - 1) / ((long long)BA_THREADS * BA_EPT));
     const size_t lds = sizeof(double) * (size_t)(6 * nq + 12 * (nc + 1) + 16);
-    const size_t lds_mfma = sizeof(double) * (size_t)(24 * BA_NPAD + 2 * 4 * (20 * nc + 10) + 4 * BA_NPAD);
-    const bool use_mfma = nq <= BA_NPAD && !P.force_valu && P.model == 0;  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
+    const int npad = nq <= BA_NPAD ? BA_NPAD : 2 * BA_NPAD;  // matrix-core Schur kernel: 128-wide (<= 21 cameras) or 256-wide in two passes (<= 42)
+    const size_t lds_mfma = sizeof(double) * (size_t)(24 * npad + 2 * 4 * (20 * nc + 10) + 4 * npad);
+    const bool use_mfma = nq <= 252 && !P.force_valu && P.model == 0;  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
+    if (use_mfma && lds_mfma > 64 * 1024) {
+        static bool attr_set = false;  // (per process; the attribute is per function)
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_schur_mfma<256, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_schur_mfma<256, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+    }
     J.zmode = use_mfma ? 1 : 0;
     { const char* e = getenv("VH_BA_DBG"); J.dbg = e ? atoi(e) : 0; }
     // one wavefront per point, grid-strided: every block ends with an atomic on one address, so keep the block count low
@@ -1340,7 +1587,11 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
             hipLaunchKernelGGL(k_ba_jac<true>, dim3((nt + ppb - 1) / ppb, nw), dim3(BA_THREADS), 0, s, J);
             vh_prof_stop(pc, rec, VH_PROF_BA_JAC, s);
             rec = vh_prof_start(pc, s);
-            hipLaunchKernelGGL(k_ba_schur_mfma, dim3(nparts, nw), dim3(BA_SCHUR_THREADS), lds_mfma, s, J);
+            if (npad == BA_NPAD) hipLaunchKernelGGL((k_ba_schur_mfma<128, 0>), dim3(nparts, nw), dim3(BA_SCHUR_THREADS), lds_mfma, s, J);
+            else {
+                hipLaunchKernelGGL((k_ba_schur_mfma<256, 0>), dim3(nparts, nw), dim3(BA_SCHUR_THREADS), lds_mfma, s, J);
+                hipLaunchKernelGGL((k_ba_schur_mfma<256, 1>), dim3(nparts, nw), dim3(BA_SCHUR_THREADS), lds_mfma, s, J);
+            }
             vh_prof_stop(pc, rec, VH_PROF_BA_SCHUR, s);
         } else {
             int rec = vh_prof_start(pc, s);
@@ -1360,9 +1611,18 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         // up to 124 unknowns: block Gauss-Jordan on the matrix cores; above: register-resident VALU Gauss-Jordan (256 threads x 64 doubles, then 1024 threads)
         if (nq <= BA_GJ_MAXQ && !(J.dbg & 64)) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1, nw), dim3(64 * BA_GJ_WAVES), 0, s, J);
         else if (nq + 1 <= 128) hipLaunchKernelGGL((k_ba_solve<8, 8, 16>), dim3(1, nw), dim3(256), 0, s, J, nparts);
-        else if (nq <= 192) hipLaunchKernelGGL((k_ba_solve<6, 7, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
-        else if (nq <= 256) hipLaunchKernelGGL((k_ba_solve<8, 9, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
-        else hipLaunchKernelGGL(k_ba_solve_big, dim3(1, nw), dim3(1024), sizeof(double) * (size_t)(2 * nq + 1), s, J);
+        else if (J.dbg & 128) {  // the elimination kernels of rounds 2-3, kept as a second implementation for the tests (VH_BA_DBG=128)
+            if (nq <= 192) hipLaunchKernelGGL((k_ba_solve<6, 7, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
+            else if (nq <= 256) hipLaunchKernelGGL((k_ba_solve<8, 9, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
+            else hipLaunchKernelGGL(k_ba_solve_big, dim3(1, nw), dim3(1024), sizeof(double) * (size_t)(2 * nq + 1), s, J);
+        } else {  // 125+ unknowns: blocked Cholesky, two launches per 32-column panel + the back-substitution
+            for (int k0 = 0; k0 < nq; k0 += BA_CH_NB) {
+                hipLaunchKernelGGL(k_ba_chol_panel, dim3(1, nw), dim3(256), 0, s, J, k0);
+                const int r0 = std::min(nq, k0 + BA_CH_NB), ntile = (nq - r0 + BA_CH_NB - 1) / BA_CH_NB;
+                if (ntile > 0) hipLaunchKernelGGL(k_ba_chol_update, dim3(ntile + 1, ntile, nw), dim3(256), 0, s, J, k0);
+            }
+            hipLaunchKernelGGL(k_ba_chol_back, dim3(1, nw), dim3(256), sizeof(double) * (size_t)nq, s, J);
+        }
         vh_prof_stop(pc, rec, VH_PROF_BA_SOLVE, s);
         rec = vh_prof_start(pc, s);
         hipLaunchKernelGGL(k_ba_update, dim3(upd_blocks, nw), dim3(BA_THREADS), 0, s, J, it);
