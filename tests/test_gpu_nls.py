@@ -209,10 +209,11 @@ def test_nls_batch_sharded_phases_match_single_call(golden):
     close(tr2[:, 0], golden[f"{tag}_trace"][:, 0], 2e-5)
 
 
-@pytest.mark.parametrize("nt,nf", [(40, 12), (30, 22), (30, 26), (24, 36), (24, 61), (300, 45)])
+@pytest.mark.parametrize("nt,nf", [(40, 12), (30, 22), (30, 26), (24, 36), (24, 61), (300, 45), (260, 25), (300, 37), (200, 43)])
 def test_nls_batch_many_cameras_vs_oracle(golden, nt, nf):
-    """6(nf-1) = 66 / 126 / 150 / 210 / 360 / 264 reduced unknowns: the matrix-core block Gauss-Jordan (<= 124), the three register tilings of the VALU
-    Gauss-Jordan (<= 127, <= 192, <= 256) and the in-place global-memory solve for more than 42 cameras (the reference has no camera limit)."""
+    """6(nf-1) = 66 / 126 / 150 / 210 / 360 / 264 / 144 / 216 / 252 reduced unknowns: the matrix-core block Gauss-Jordan (<= 124 unknowns), the blocked
+    Cholesky across launches (125+; round 4 -- the register Gauss-Jordan tilings it replaces spilled from 193 unknowns), the 128-wide (<= 21 cameras) and the
+    256-wide two-pass matrix-core Schur kernel (22..42 cameras: nf = 25, 26, 36, 37, 43) and the VALU Schur kernel above (the reference has no camera limit)."""
     from oracle import nls_oracle as O
     from velocity_amd.NLS import fcnNLS_batch
 
@@ -235,6 +236,34 @@ def test_nls_batch_many_cameras_vs_oracle(golden, nt, nf):
     close(tr[:, 0], etr[:, 0], 1e-6)       # rms residual per iteration
     close(cw, ecw, 1e-4, 1e-6)
     close(pw, epw, 1e-4, 1e-6)
+
+
+@pytest.mark.parametrize("nt,nf", [(300, 25), (200, 43), (120, 51)])
+def test_nls_batch_cholesky_and_wide_schur_equal_the_round3_kernels(golden, nt, nf, monkeypatch):
+    """Second implementation check for 22+ cameras: blocked Cholesky + 256-wide matrix-core Schur (default) against the elimination kernels of rounds 2-3
+    (VH_BA_DBG=128) and against the VALU Schur kernel (vh_debug_ba_force_valu) -- same trace and state to rounding."""
+    from velocity_amd import _lib as L
+    from velocity_amd import synth
+    from velocity_amd.NLS import fcnNLS_batch
+
+    P, pw0, cw0 = synth.ba_scene(nt, nf, seed=60 + nf)
+    outs = []
+    for dbg, valu in ((None, 0), ("128", 0), (None, 1)):
+        if dbg is None:
+            monkeypatch.delenv("VH_BA_DBG", raising=False)
+        else:
+            monkeypatch.setenv("VH_BA_DBG", dbg)
+        L.load().vh_debug_ba_force_valu(valu)
+        try:
+            outs.append(fcnNLS_batch(golden["K32"], P.copy(), pw0, cw0, return_info=True))
+        finally:
+            L.load().vh_debug_ba_force_valu(0)
+    monkeypatch.delenv("VH_BA_DBG", raising=False)
+    for cw, pw, x, tr in outs[1:]:
+        assert len(tr) == len(outs[0][3])
+        close(tr[:, 0], outs[0][3][:, 0], 1e-8)
+        close(cw, outs[0][0], 1e-6, 1e-8)
+        close(pw, outs[0][1], 1e-6, 1e-8)
 
 
 @pytest.mark.parametrize("nt,nf", [(260, 2), (517, 3), (200, 3)])

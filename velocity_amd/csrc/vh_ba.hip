@@ -1122,8 +1122,38 @@ __global__ __launch_bounds__(1024) void k_ba_solve_big(BaJob J)
 //                     forward-substituted against it (32 registers per row)
 //   k_ba_chol_update: the trailing lower triangle (and the rhs row) minus the panel's outer product, one workgroup per 32 x 32 tile
 // and at the end k_ba_chol_back: L^T dc = y, panel by panel from the last (a matrix-vector product over the rows below, then a 32-step triangular solve).
-// ~14 + 9 us per panel, 8 panels at 252 unknowns.  Same result as the elimination kernels to rounding (no pivoting needed or done in either).
+// Measured at 252 unknowns (8 panels): panel kernel 17-32 us (4.6 us the register Cholesky of the diagonal block, up to 9 us the rows below, the rest
+// launch + three dependent L2 round trips), update 6.7 us, back-substitution 28 us: 265 us per solve against 1331 us (the spilling elimination kernel).  Same result as the elimination kernels to rounding (no pivoting needed or done in either).
 #define BA_CH_NB 32
+// wave-uniform copy of lane `l`'s double (l is a constant after unrolling: two v_readlane_b32 with an immediate lane)
+__device__ __forceinline__ double ba_readlane_f64(double v, int l)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// 1 / sqrt(x): v_rsq_f64 + two Newton steps (relative error ~1e-16)
+__device__ __forceinline__ double ba_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    return y;
+}
+// Cholesky of a 32 x 32 SPD block held one ROW per lane (lanes 0..31 of one wavefront, a[j] = entry (lane, j), upper part zero): right-looking, the
+// pivot and the column below it travel by v_readlane (constant lane numbers after unrolling: the whole factorisation is straight-line code, no LDS, no
+// barrier).  The LDS version with two workgroup barriers per column took 1 us per column (35 us per panel kernel).
+__device__ __forceinline__ void ba_chol32_rows(double (&a)[BA_CH_NB])
+{
+#pragma unroll
+    for (int k = 0; k < BA_CH_NB; k++) {
+        const double inv = ba_rsqrt(ba_readlane_f64(a[k], k));
+        a[k] = a[k] * inv;  // L(i, k) for the lanes below the pivot; the pivot lane gets sqrt(d); lanes above hold zeros
+#pragma unroll
+        for (int j = k + 1; j < BA_CH_NB; j++) a[j] = __builtin_fma(-a[k], ba_readlane_f64(a[k], j), a[j]);
+    }
+}
 __global__ __launch_bounds__(256) void k_ba_chol_panel(BaJob J, int k0)
 {
     ba_select_window(J, blockIdx.y);
@@ -1132,66 +1162,67 @@ __global__ __launch_bounds__(256) void k_ba_chol_panel(BaJob J, int k0)
     const int nb = min(BA_CH_NB, nq - k0);
     double* A = J.Sfull;
     __shared__ double sD[BA_CH_NB][BA_CH_NB + 1];
+    __shared__ double sDt[BA_CH_NB][BA_CH_NB];  // transposed factor: sDt[k][j] = L_D[j][k] -- the column a forward-substitution step needs is one contiguous row
     __shared__ double sV[256][BA_CH_NB + 1];
-    for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += 256) {
-        const int i = e / BA_CH_NB, j = e - i * BA_CH_NB;
-        sD[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * ld + k0 + j] : (i == j ? 1.0 : 0.0);  // (a short last panel is padded with the identity)
-    }
-    __syncthreads();
-    // unblocked right-looking Cholesky of the diagonal block, in LDS: per step every thread reads what it needs of column k, then the column is scaled and
-    // the trailing block updated (two barriers per step)
-    for (int k = 0; k < BA_CH_NB; k++) {
-        const double dkk = sD[k][k];
-        const double inv = 1.0 / sqrt(dkk);
-        // elements (i, j), k < j <= i, of the trailing block (the thread's 4 slots of the 32 x 32 square; the upper part and the finished columns idle)
-        double up[4], li[4];
-        int ei[4], ej[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int e = tid + 256 * u;  // over the 32 x 32 square; only the lower part behind column k works
-            const int i = e / BA_CH_NB, j = e - i * BA_CH_NB;
-            ei[u] = i; ej[u] = j;
-            const bool on = e < BA_CH_NB * BA_CH_NB && j > k && i >= j;
-            li[u] = on ? sD[i][k] : 0.0;
-            up[u] = on ? sD[j][k] : 0.0;
-        }
-        const double ck = (tid > k && tid < BA_CH_NB) ? sD[tid][k] : 0.0;  // column k below the diagonal: thread i scales its entry
-        __syncthreads();
-        if (tid == k) sD[k][k] = dkk * inv;  // sqrt(dkk)
-        if (tid > k && tid < BA_CH_NB) sD[tid][k] = ck * inv;
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (up[u] != 0.0 || li[u] != 0.0) sD[ei[u]][ej[u]] = __builtin_fma(-(li[u] * inv), up[u] * inv, sD[ei[u]][ej[u]]);
-        __syncthreads();
-    }
-    // the factor of the diagonal block goes back (lower triangle)
-    for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += 256) {
-        const int i = e / BA_CH_NB, j = e - i * BA_CH_NB;
-        if (i < nb && j <= i) A[(size_t)(k0 + i) * ld + k0 + j] = sD[i][j];
-    }
-    // rows below the block + the rhs row: v <- v L_D^-T (forward substitution, one thread per row).  The rows travel through LDS in slabs of 256 so that
-    // the global accesses are coalesced (consecutive threads = consecutive columns of a row; a thread walking its own row touched 64 cache lines per load)
-    const int mrows = nq - k0 - nb;  // rows below; index mrows = the rhs row
-    for (int t0 = 0; t0 <= mrows; t0 += 256) {
-        const int cnt = min(256, mrows + 1 - t0);
-        __syncthreads();  // (the previous slab's stores have been issued from sV)
+    __shared__ double sDi[BA_CH_NB];
+    const int mrows = nq - k0 - nb;  // rows below the block; index mrows = the rhs row
+    // slab of up to 256 rows below the block (+ the rhs row) into LDS, coalesced (consecutive threads = consecutive columns of a row; a thread walking its own
+    // row touched 64 cache lines per load)
+    auto load_slab = [&](int t0, int cnt) {
         for (int e = tid; e < cnt * BA_CH_NB; e += 256) {
             const int rr = e / BA_CH_NB, j = e - rr * BA_CH_NB, t = t0 + rr;
             double v = 0.0;
             if (j < nb) v = t == mrows ? A[(size_t)(k0 + j) * ld + nq] : A[(size_t)(k0 + nb + t) * ld + k0 + j];
             sV[rr][j] = v;
         }
-        __syncthreads();
+    };
+    for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += 256) {
+        const int i = e / BA_CH_NB, j = e - i * BA_CH_NB;
+        sD[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * ld + k0 + j] : (i == j ? 1.0 : 0.0);  // (a short last panel is padded with the identity)
+    }
+    load_slab(0, min(256, mrows + 1));  // does not depend on the factorisation: its round trip overlaps the diagonal block's
+    __syncthreads();
+    // the diagonal block is factored by ONE wavefront in registers (a row per lane), the reciprocals of its diagonal are kept for the rows below
+    if (tid < 64) {
+        const int i = tid & (BA_CH_NB - 1);  // (lanes 32..63 duplicate lanes 0..31; only the lower 32 are read through v_readlane)
+        double a[BA_CH_NB];
+#pragma unroll
+        for (int j = 0; j < BA_CH_NB; j++) a[j] = sD[i][j];
+        ba_chol32_rows(a);
+        if (tid < BA_CH_NB) {
+#pragma unroll
+            for (int j = 0; j < BA_CH_NB; j++) { sD[i][j] = a[j]; sDt[j][i] = a[j]; }
+            double d = 0.0;
+#pragma unroll
+            for (int j = 0; j < BA_CH_NB; j++) d = j == i ? a[j] : d;
+            sDi[i] = 1.0 / d;
+        }
+    }
+    __syncthreads();
+    // the factor of the diagonal block goes back (lower triangle)
+    for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += 256) {
+        const int i = e / BA_CH_NB, j = e - i * BA_CH_NB;
+        if (i < nb && j <= i) A[(size_t)(k0 + i) * ld + k0 + j] = sD[i][j];
+    }
+    // rows below the block + the rhs row: v <- v L_D^-T, one thread per row, RIGHT-looking (v[k] is final, then every later entry drops its term: the 31 - k
+    // updates of a step are independent and their operands -- row k of the transposed factor -- are read in one go; the left-looking form waited for LDS
+    // after nearly every multiply-add: 270 waits, 7 us)
+    for (int t0 = 0; t0 <= mrows; t0 += 256) {
+        const int cnt = min(256, mrows + 1 - t0);
+        if (t0 > 0) {
+            __syncthreads();  // (the previous slab's stores have been issued from sV)
+            load_slab(t0, cnt);
+            __syncthreads();
+        }
         if (tid < cnt) {
             double v[BA_CH_NB];
 #pragma unroll
             for (int j = 0; j < BA_CH_NB; j++) v[j] = sV[tid][j];
 #pragma unroll
-            for (int j = 0; j < BA_CH_NB; j++) {
-                double acc = v[j];
+            for (int k = 0; k < BA_CH_NB; k++) {
+                v[k] = v[k] * sDi[k];
 #pragma unroll
-                for (int k = 0; k < j; k++) acc = __builtin_fma(-v[k], sD[j][k], acc);
-                v[j] = acc / sD[j][j];
+                for (int j = k + 1; j < BA_CH_NB; j++) v[j] = __builtin_fma(-v[k], sDt[k][j], v[j]);
             }
 #pragma unroll
             for (int j = 0; j < BA_CH_NB; j++) sV[tid][j] = v[j];
@@ -1281,20 +1312,21 @@ __global__ __launch_bounds__(256) void k_ba_chol_back(BaJob J)
             st[tid] = t;
         }
         __syncthreads();
-        // L_D^T x = t: x[j] from the last to the first; after x[j], every earlier entry drops its term (one wavefront, wave-synchronous through LDS)
+        // L_D^T x = t: x[j] from the last to the first; after x[j], every earlier entry drops its term.  One wavefront, lane i holds column i of L_D and t_i;
+        // x_j travels by v_readlane (straight-line code; the LDS version with two wave barriers per step cost 4 us per panel)
         if (tid < 64) {
+            const int i = tid & (BA_CH_NB - 1);
+            double c[BA_CH_NB];
+#pragma unroll
+            for (int jj = 0; jj < BA_CH_NB; jj++) c[jj] = sD[jj][i];  // L_D[jj][i]: zero above the diagonal (jj < i)
+            double t = st[i];
+            const double rinv = 1.0 / sD[i][i];
+#pragma unroll
             for (int jj = BA_CH_NB - 1; jj >= 0; jj--) {
-                double xj = 0.0;
-                if (tid == 0) { xj = st[jj] / sD[jj][jj]; st[jj] = xj; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                xj = st[jj];
-                if (tid < jj) st[tid] = __builtin_fma(-sD[jj][tid], xj, st[tid]);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const double xj = ba_readlane_f64(t, jj) * ba_readlane_f64(rinv, jj);
+                t = i == jj ? xj : __builtin_fma(-c[jj], xj, t);
             }
+            if (tid < BA_CH_NB) st[i] = t;
         }
         __syncthreads();
         if (tid < nb) sx[k0 + tid] = st[tid];
