@@ -403,6 +403,14 @@ def test_nls_batch_windows_equal_single_calls(golden, capsys):
         scw, spw, sx, strace = fcnNLS_batch(K32, P.copy(), pw0, cw0, return_info=True)
         close(multi[w][3][:, 0], strace[:, 0], 1e-8)   # observed 1.2e-9: other partition of the partial sums + the gauge mode
         close(multi[w][2], sx, 1e-6, 1e-8)
+    # 30 cameras: the 256-wide two-pass matrix-core Schur kernel and the blocked Cholesky, window index in grid.y / grid.z
+    scenes = [synth.ba_scene(120, 31, seed=300 + w) for w in range(4)]
+    multi = fcnNLS_batch_windows(K32, [s[0] for s in scenes], [s[1] for s in scenes], [s[2] for s in scenes], return_info=True)
+    for w in (0, 3):
+        P, pw0, cw0 = scenes[w]
+        scw, spw, sx, strace = fcnNLS_batch(K32, P.copy(), pw0, cw0, return_info=True)
+        close(multi[w][3][:, 0], strace[:, 0], 1e-8)
+        close(multi[w][2], sx, 1e-6, 1e-8)
     capsys.readouterr()
     with pytest.raises(ValueError):
         fcnNLS_batch_windows(K32, [scenes[0][0], synth.ba_scene(40, 8)[0]], [scenes[0][1], synth.ba_scene(40, 8)[1]], [scenes[0][2], synth.ba_scene(40, 8)[2]])
