@@ -114,6 +114,15 @@ def load():
                     "(hipcc --offload-arch=gfx950). velocity_amd has no CPU fallback."
                 )
             have = _build.file_build_id(path)
+            # ONE HIP runtime per process: torch's wheel bundles its own libamdhip64.so / libhsa-runtime64.so and loads them RTLD_GLOBAL; libvelocity_hip.so
+            # links /opt/rocm's libamdhip64.so.7.  Loaded AFTER torch, our hip* symbols bind to the runtime torch already brought (global scope comes first):
+            # one runtime, shared allocations and streams.  Loaded BEFORE torch they bind to /opt/rocm's copy, torch later initialises its own, and the second
+            # HSA initialisation in the process finds "no ROCm-capable device" (seen as vh_ctx_create failing after __graft_entry__.build() had loaded this
+            # library first).  So torch -- the plumbing for device memory and streams anyway -- is imported first, whatever the caller's import order was.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass  # a torch-free consumer of the C ABI: /opt/rocm's runtime is the only one
             if override:
                 import sys
 
