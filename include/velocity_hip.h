@@ -202,7 +202,8 @@ typedef struct {
     const float* p;         /* n_cur x 2 compacted current points                              */
     const int* ids;         /* n_cur   global ids of the rows of p                             */
     const double* p3;       /* N0 x 3  world points                                            */
-    const float* P;         /* [5,N0,nhist] history (vidExample.py:128-129,151-153)            */
+    const float* P;         /* history (vidExample.py:128-129,151-153), FRAME-MAJOR [nhist][5][N0]: entry (row, track, frame) at
+                             * P[(frame * 5 + row) * N0 + track]; the reference's array is its transpose to [5,N0,nhist]  */
     const float* B;         /* [nhist,14]  (vidExample.py:44,142-146)                          */
     const float* S;         /* [nhist,9]   (vidExample.py:45,164)                              */
     const int* n_cur;

@@ -916,7 +916,8 @@ extern "C" VH_API int vh_msv1_t(vh_ctx* c, const double* K, const float* P, cons
     MsvJob J;
     memset(&J, 0, sizeof(J));
     for (int k = 0; k < 9; k++) J.K[k] = (double)K[k];
-    J.P = P; J.B = B; J.ids = ids; J.ng = ng; J.N0 = N0; J.nhist = nhist; J.nf = ii + 1; J.max_iter = 1000; J.f32_rays = f32_rays;
+    J.P = P; J.P_rs = (size_t)N0 * nhist; J.P_ts = (size_t)nhist; J.P_fs = 1;  // the reference's [5, N0, nhist]
+    J.B = B; J.ids = ids; J.ng = ng; J.N0 = N0; J.nhist = nhist; J.nf = ii + 1; J.max_iter = 1000; J.f32_rays = f32_rays;
     J.U = U_scratch; J.b0 = b0; J.x_out = x_out; J.info_out = info;
     vh_launch_msv1(J, (hipStream_t)stream);
     VH_LAUNCH_CHECK();

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(MSV_THREADS) void k_msv1(MsvJob J)
     for (int q = tid; q < ng * nf; q += NLS_THREADS) {
         const int g = q % ng, j = q / ng;
         const int id = J.ids ? J.ids[g] : g;
-        const float pu = J.P[((size_t)0 * J.N0 + id) * J.nhist + j], pv = J.P[((size_t)1 * J.N0 + id) * J.nhist + j];
+        const float pu = J.P[(size_t)id * J.P_ts + (size_t)j * J.P_fs], pv = J.P[J.P_rs + (size_t)id * J.P_ts + (size_t)j * J.P_fs];
         double r[3];
         if (J.f32_rays) uvec_f32(pu, pv, (float)K[6], (float)K[7], (float)K[0], r);  // K and P float32 -> numpy works in float32
         else uvec_f64((double)pu, (double)pv, K[6], K[7], K[0], r);
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(MSV_THREADS) void k_msv1(MsvJob J)
             J.b0[3 * g] = b0; J.b0[3 * g + 1] = b1; J.b0[3 * g + 2] = b2;
             double u, v, ju[3], jv[3];
             fd_rows_t(K, b0, b1, b2, u, v, ju, jv);
-            const double zu = (double)J.P[((size_t)0 * J.N0 + id) * J.nhist + (nf - 1)];
-            const double zv = (double)J.P[((size_t)1 * J.N0 + id) * J.nhist + (nf - 1)];
+            const double zu = (double)J.P[(size_t)id * J.P_ts + (size_t)(nf - 1) * J.P_fs];
+            const double zv = (double)J.P[J.P_rs + (size_t)id * J.P_ts + (size_t)(nf - 1) * J.P_fs];
             accumulate<3>(acc, ju, jv, zu - u, zv - v);
         }
         block_sum_f64<9, NLS_WAVES>(acc, sh);

@@ -24,7 +24,8 @@ struct PoseJob {
 // fcnMSV1_t (MSV.py:8-49)
 struct MsvJob {
     double K[9];
-    const float* P;       // [5, N0, nhist] float32 history (vidExample.py:128)
+    const float* P;       // float32 history (vidExample.py:128): entry (row, track, frame) at P[row * P_rs + track * P_ts + frame * P_fs]
+    size_t P_rs, P_ts, P_fs;  // the reference's [5, N0, nhist]: (N0 nhist, nhist, 1); the session's frame-major [nhist, 5, N0]: (N0, 1, 5 N0)
     const float* B;       // [nhist, 14] float32
     const int* ids;       // ng global track ids (nonzero(vg)), may be null (identity)
     const int* ng_ptr;

@@ -10,6 +10,12 @@
 #include "vh_ws.hpp"
 #include "vh_pose_dev.hpp"
 
+// History P (vidExample.py:128-129: [5, N0, n] in the reference) is kept FRAME-MAJOR on the device, [nhist][5][N0]: a frame writes its five rows as five
+// contiguous runs.  In the reference's layout the entries of one frame are nhist floats apart: 10 000 single-float stores per stream and frame, each into
+// its own cache line -- at 256 streams 2.6 M partial-line writes per step, which is what made k_sess_frame take 140 us there and 70 us for one stream.
+// velocity_amd/driver.py::TrackerSession.state() hands the reference's [5, N0, nhist] view to the caller.
+__device__ __host__ __forceinline__ size_t sess_P(int row, int track, int frame, int N0) { return ((size_t)frame * 5 + row) * (size_t)N0 + track; }
+
 struct vh_session {
     vh_ctx* ctx;
     int batch, N0, nhist, w, h, msv_frame, k_is_f32;
@@ -110,14 +116,14 @@ __device__ __forceinline__ void sess_book_b(SessStream& S, const uint8_t* const*
     if (i < nh) {
         for (int k = tid; k < S.n_cur; k += 256) {
             const int g = S.ids[k];
-            S.P[((size_t)0 * N0 + g) * nh + i] = S.p_cur[2 * k];
-            S.P[((size_t)1 * N0 + g) * nh + i] = S.p_cur[2 * k + 1];
-            S.P[((size_t)4 * N0 + g) * nh + i] = (float)i;
+            S.P[sess_P(0, g, i, N0)] = S.p_cur[2 * k];
+            S.P[sess_P(1, g, i, N0)] = S.p_cur[2 * k + 1];
+            S.P[sess_P(4, g, i, N0)] = (float)i;
         }
         for (int j = tid; j < S.n_pose; j += 256) {
             const int g = S.sel_pw[j];
-            S.P[((size_t)2 * N0 + g) * nh + i] = (float)S.p_proj[2 * j];
-            S.P[((size_t)3 * N0 + g) * nh + i] = (float)S.p_proj[2 * j + 1];
+            S.P[sess_P(2, g, i, N0)] = (float)S.p_proj[2 * j];
+            S.P[sess_P(3, g, i, N0)] = (float)S.p_proj[2 * j + 1];
         }
     }
     if (tid == 0) {
@@ -202,10 +208,10 @@ __global__ __launch_bounds__(256) void k_sess_init(SessStream* ss, const float* 
         S.ids[g] = g;
         S.p_cur[2 * g] = p[2 * g]; S.p_cur[2 * g + 1] = p[2 * g + 1];
         for (int c = 0; c < 3; c++) S.p3[3 * g + c] = p3[3 * g + c];
-        S.P[((size_t)0 * N0 + g) * nh] = p[2 * g];
-        S.P[((size_t)1 * N0 + g) * nh] = p[2 * g + 1];
-        if (vp[g]) { S.P[((size_t)2 * N0 + g) * nh] = p[2 * g]; S.P[((size_t)3 * N0 + g) * nh] = p[2 * g + 1]; }  // p_ = p[vp]
-        S.P[((size_t)4 * N0 + g) * nh] = 0.f;
+        S.P[sess_P(0, g, 0, N0)] = p[2 * g];
+        S.P[sess_P(1, g, 0, N0)] = p[2 * g + 1];
+        if (vp[g]) { S.P[sess_P(2, g, 0, N0)] = p[2 * g]; S.P[sess_P(3, g, 0, N0)] = p[2 * g + 1]; }  // p_ = p[vp]
+        S.P[sess_P(4, g, 0, N0)] = 0.f;
     }
     if (tid == 0) {
         S.n_cur = N0; S.n_pose = 0; S.frame_i = 0; S.pp = 0; S.klt_flags = 0; S.small_ready = 0;
@@ -335,7 +341,8 @@ static int session_step(vh_session* s, const uint8_t* const* frames_dev, float t
         MsvJob J;
         memset(&J, 0, sizeof(J));
         for (int k = 0; k < 9; k++) J.K[k] = H.K[k];
-        J.P = H.P; J.B = H.B; J.ids = H.ids; J.ng_ptr = &s->d_ss[b].n_cur; J.ng = 0; J.N0 = s->N0; J.nhist = s->nhist;
+        J.P = H.P; J.P_rs = (size_t)s->N0; J.P_ts = 1; J.P_fs = (size_t)5 * s->N0;  // the session's frame-major history
+        J.B = H.B; J.ids = H.ids; J.ng_ptr = &s->d_ss[b].n_cur; J.ng = 0; J.N0 = s->N0; J.nhist = s->nhist;
         J.nf = s->msv_frame + 1; J.max_iter = 1000; J.f32_rays = s->k_is_f32;  // P is float32 always; K as the caller holds it
         J.U = H.msv_U; J.b0 = H.msv_b0; J.x_out = s->d_ss[b].msv_x; J.info_out = s->d_ss[b].msv_info;
         vh_launch_msv1(J, st);

@@ -114,7 +114,8 @@ class TrackerSession:
         return out
 
     def state(self, slot=0):
-        """Host copy of the stream state: dict(vg, vp, p, P, B, S, p3, t, res, n_cur, n_pose, frame_i, klt_flags)."""
+        """Host copy of the stream state: dict(vg, vp, p, P, B, S, p3, t, res, n_cur, n_pose, frame_i, klt_flags).
+        P comes back in the reference's [5, N0, nhist] layout (the device keeps it frame-major, [nhist, 5, N0]: include/velocity_hip.h)."""
         v = self.view(slot)
         n0, nh = self.n0, self.nhist
         n_cur = int(self._rd(v.n_cur, 1, np.int32)[0])
@@ -122,7 +123,7 @@ class TrackerSession:
         return dict(
             vg=self._rd(v.vg, n0, np.uint8).astype(bool), vp=self._rd(v.vp, n0, np.uint8).astype(bool),
             p=self._rd(v.p, 2 * n_cur, np.float32).reshape(n_cur, 2), ids=self._rd(v.ids, n_cur, np.int32),
-            P=self._rd(v.P, 5 * n0 * nh, np.float32).reshape(5, n0, nh), B=self._rd(v.B, nh * 14, np.float32).reshape(nh, 14),
+            P=np.ascontiguousarray(self._rd(v.P, 5 * n0 * nh, np.float32).reshape(nh, 5, n0).transpose(1, 2, 0)), B=self._rd(v.B, nh * 14, np.float32).reshape(nh, 14),
             S=self._rd(v.S, nh * 9, np.float32).reshape(nh, 9), p3=self._rd(v.p3, 3 * n0, np.float64).reshape(n0, 3),
             t=self._rd(v.t, 3, np.float32), res=float(self._rd(v.res, 1, np.float64)[0]), n_cur=n_cur, n_pose=n_pose,
             frame_i=int(self._rd(v.frame_i, 1, np.int32)[0]), klt_flags=int(self._rd(v.klt_flags, 1, np.int32)[0]),
