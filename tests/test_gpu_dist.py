@@ -67,6 +67,27 @@ def test_sharded_ba_world_n_equals_single_call(tmp_path, tag, world):
     _run_ranks(tmp_path, body, world=world)
 
 
+def test_sharded_ba_with_30_cameras_world2(tmp_path):
+    """The point-sharded solve on the 22..42-camera route (round 4: 256-wide two-pass matrix-core Schur kernel per rank, one all-reduce of the 180 x 181
+    reduced system, blocked Cholesky on every rank) == the single-call BA."""
+    body = (
+        "from velocity_amd import synth\n"
+        "from velocity_amd.NLS import fcnNLS_batch\n"
+        "from velocity_amd.dist import fcnNLS_batch_sharded\n"
+        "g = np.load(os.path.join(os.environ['VH_REPO'], 'tests', 'golden', 'nls_golden.npz'))\n"
+        "P, pw0, cw0 = synth.ba_scene(150, 31, seed=91)\n"
+        "cw2, pw2, tr2 = fcnNLS_batch_sharded(g['K32'], P.copy(), pw0, cw0)\n"
+        "import io, contextlib\n"
+        "with contextlib.redirect_stdout(io.StringIO()):\n"
+        "    cw, pw, x, tr = fcnNLS_batch(g['K32'], P.copy(), pw0, cw0, return_info=True)\n"
+        "assert len(tr2) == len(tr)\n"
+        "np.testing.assert_allclose(tr2[:, 0], tr[:, 0], rtol=1e-8)\n"
+        "np.testing.assert_allclose(cw2, cw, rtol=1e-6, atol=1e-7)\n"
+        "np.testing.assert_allclose(pw2, pw, rtol=1e-6, atol=1e-7)\n"
+    )
+    _run_ranks(tmp_path, body, world=2)
+
+
 def test_track_state_exchange_world2_real_sessions(tmp_path):
     """Two ranks, each tracking its own stream (different motion) with a real TrackerSession on the shared device; the packed states
     are all-gathered and every rank must see BOTH streams' state exactly as the owners hold it."""
