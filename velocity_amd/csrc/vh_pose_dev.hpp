@@ -48,6 +48,65 @@ __device__ __forceinline__ void block_sum_f64_all(double* v, double* sh)
     }
 }
 
+// The 9 sums of the 3-DoF normal equations (6 entries of J^T J, 3 of J^T r) of one wavefront, TRANSPOSING while folding: v_permlane32_swap puts the upper
+// half-wave of one value beside the lower half-wave of another, so one add folds TWO values 64 -> 32 lanes, v_permlane16_swap does the same for the
+// 16-lane rows, and the last four steps are row rotations (DPP).  5 + 3 swap-folds and 3 x 4 rotate-adds (60 instructions) instead of 9 x 6 butterflies
+// through ds_bpermute (two per step and value: 160 instructions and six LDS-crossbar round trips); the totals end up in lanes 0 / 16 / 32 / 48, which store
+// them.  One barrier, then every thread adds the per-wave sums in the same order (block_sum_f64_all's contract).
+__device__ __forceinline__ double pose_u2d(unsigned lo, unsigned hi) { return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); }
+__device__ __forceinline__ double fold32_pair_f64(double a, double b)  // lanes 0..31: a[l] + a[l+32], lanes 32..63: b[l-32] + b[l]
+{
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    return pose_u2d(lo[0], hi[0]) + pose_u2d(lo[1], hi[1]);
+}
+__device__ __forceinline__ double fold16_pair_f64(double a, double b)  // rows 0/2: a[row] + a[row+1], rows 1/3: b[row-1] + b[row]
+{
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    return pose_u2d(lo[0], hi[0]) + pose_u2d(lo[1], hi[1]);
+}
+template <int N>
+__device__ __forceinline__ double row_ror_add_f64(double v)  // v[l] + v[(l + N) mod 16 within the 16-lane row]
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x120 + N, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x120 + N, 0xf, 0xf, false);
+    return v + pose_u2d(lo, hi);
+}
+__device__ __forceinline__ double row_sum_f64(double v)
+{
+    v = row_ror_add_f64<8>(v);
+    v = row_ror_add_f64<4>(v);
+    v = row_ror_add_f64<2>(v);
+    return row_ror_add_f64<1>(v);
+}
+template <int NLS_WAVES>
+__device__ __forceinline__ void block_sum9_f64_all(double* v, double* sh)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double r0 = fold32_pair_f64(v[0], v[1]), r1 = fold32_pair_f64(v[2], v[3]), r2 = fold32_pair_f64(v[4], v[5]), r3 = fold32_pair_f64(v[6], v[7]);
+    const double r4 = fold32_pair_f64(v[8], v[8]);
+    // rows of q0: v0 v2 v1 v3; of q1: v4 v6 v5 v7; of q2: v8 (four times)
+    const double q0 = row_sum_f64(fold16_pair_f64(r0, r1)), q1 = row_sum_f64(fold16_pair_f64(r2, r3)), q2 = row_sum_f64(fold16_pair_f64(r4, r4));
+    if ((lane & 15) == 0) {
+        const int row = lane >> 4, i0 = ((row & 1) << 1) | (row >> 1);
+        sh[i0 * NLS_WAVES + wave] = q0;
+        sh[(4 + i0) * NLS_WAVES + wave] = q1;
+        if (row == 0) sh[8 * NLS_WAVES + wave] = q2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < NLS_WAVES; q++) s += sh[k * NLS_WAVES + q];
+        v[k] = s;
+    }
+}
+
 // uv of camera-frame point b:  pscale(b @ K)   (fzK, NLS.py:71-78)
 __device__ __forceinline__ void project_cam(const double* K, double b0, double b1, double b2, double& u, double& v)
 {
@@ -160,6 +219,24 @@ __device__ double lm_update(const double* acc, double gain, double* x)
     return sqrt(ss / NP);
 }
 
+// The 3-DoF update.  A = J^T J + I is symmetric positive definite, so delta = A^-1 g needs no pivoting: adjugate / determinant, ONE division on the
+// dependency chain where the pivoted elimination above has six (every thread runs this between two reductions of the LM loop: its latency is paid per
+// iteration).  Returns sum(d^2); the caller's stop rule  rms(d) = sqrt(sum / 3) < 1e-8  (NLS.py:125) is evaluated as  sum < POSE_STOP3, the smallest double
+// whose rms is not below 1e-8 (sqrt and the division by 3 are monotone and correctly rounded: the two tests agree for EVERY double, checked by bisection).
+#define POSE_STOP3 0x1.59e05f1e2674dp-52
+__device__ __forceinline__ double lm_update3(const double* acc, double gain, double* x)
+{
+    const double a = acc[0] + 1.0, b = acc[1], c = acc[2], d = acc[3] + 1.0, e = acc[4], f = acc[5] + 1.0;  // constant +I damping (NLS.py:115)
+    const double A = d * f - e * e, B = c * e - b * f, C = b * e - c * d;
+    const double D = a * f - c * c, E = b * c - a * e, F = a * d - b * b;
+    const double id = gain / (a * A + b * B + c * C);
+    const double d0 = (A * acc[6] + B * acc[7] + C * acc[8]) * id;
+    const double d1 = (B * acc[6] + D * acc[7] + E * acc[8]) * id;
+    const double d2 = (C * acc[6] + E * acc[7] + F * acc[8]) * id;
+    x[0] += d0; x[1] += d1; x[2] += d2;
+    return d0 * d0 + d1 * d1 + d2 * d2;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // estimateWorldCameraPose (NLS.py:9-33).  mode 0: fcnNLS_t (3 DoF), mode 1: fcnNLS_Rt (6 DoF).
 // ---------------------------------------------------------------------------------------------------------------
@@ -226,14 +303,14 @@ __device__ __forceinline__ void pose_solve(const PoseJob& J)
                     fd_rows_t(K, b0, b1, b2, u, v, ju, jv);
                     accumulate<3>(acc, ju, jv, (double)J.p[2 * ip] - u, (double)J.p[2 * ip + 1] - v);
                 }
-                block_sum_f64_all<9, NLS_WAVES>(acc, sh2[par]);
+                block_sum9_f64_all<NLS_WAVES>(acc, sh2[par]);
                 par ^= 1;
                 {
                     double x[3] = {x0, x1, x2};
-                    const double r = lm_update<3>(acc, gain, x);
+                    const double ssd = lm_update3(acc, gain, x);
                     s_x[0] = x[0]; s_x[1] = x[1]; s_x[2] = x[2];
                     s_iters = it + 1;
-                    if (r < 1e-8) s_stop = 1;
+                    if (ssd < POSE_STOP3) s_stop = 1;
                 }
             } else {
                 double x[6], R0[9], Rk[3][9];

@@ -39,18 +39,19 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // order-preserving compactions -- the surviving tracks and, among them, the pose tracks -- come from one block-wide exclusive scan of the two
 // per-thread counts.  `vp &= vg` only ever changes the entries of CURRENT tracks (a dropped track's vg and vp are already 0), so the two mask
 // updates are per-track stores instead of passes over all N0 entries.
+template <int NT>
 __device__ __forceinline__ void sess_book_a(SessStream& S)
 {
-    constexpr int EPT = 16;
+    constexpr int EPT = 4096 / NT, NW = NT / 64;
     const int tid = threadIdx.x, n = S.n_cur, wave = tid >> 6, lane = tid & 63;
-    __shared__ int s_tot[2][4], s_base[2];
+    __shared__ int s_tot[2][NW], s_base[2];
     uint8_t* const vg = S.vg;
     uint8_t* const vp = S.vp;
     int* const ids = S.ids;
     if (tid == 0) { s_base[0] = 0; s_base[1] = 0; }
     __syncthreads();
-    for (int c0 = 0; c0 < n || c0 == 0; c0 += 256 * EPT) {  // one pass for up to 4096 tracks
-        const int per = min(EPT, (min(n - c0, 256 * EPT) + 255) / 256);
+    for (int c0 = 0; c0 < n || c0 == 0; c0 += NT * EPT) {  // one pass for up to 4096 tracks
+        const int per = min(EPT, (min(n - c0, NT * EPT) + NT - 1) / NT);
         const int b = c0 + tid * per, e = min(n, b + per);
         int id[EPT];
         float px[EPT], py[EPT];
@@ -95,8 +96,7 @@ __device__ __forceinline__ void sess_book_a(SessStream& S)
             }
         __syncthreads();
         if (tid == 0) {
-            s_base[0] += s_tot[0][0] + s_tot[0][1] + s_tot[0][2] + s_tot[0][3];
-            s_base[1] += s_tot[1][0] + s_tot[1][1] + s_tot[1][2] + s_tot[1][3];
+            for (int w = 0; w < NW; w++) { s_base[0] += s_tot[0][w]; s_base[1] += s_tot[1][w]; }
         }
         __syncthreads();
     }
@@ -107,6 +107,7 @@ __device__ __forceinline__ void sess_book_a(SessStream& S)
 }
 
 // results records B, S and history P (vidExample.py:142-146, 151-153, 164); then advance the frame state
+template <int NT>
 __device__ __forceinline__ void sess_book_b(SessStream& S, const uint8_t* const* frames, float time_s, float frame_no, const float* times,
                                             const float* frame_nos)
 {
@@ -114,13 +115,13 @@ __device__ __forceinline__ void sess_book_b(SessStream& S, const uint8_t* const*
     if (frame_nos) frame_no = frame_nos[blockIdx.x];
     const int tid = threadIdx.x, i = S.frame_i + 1, nh = S.nhist, N0 = S.N0;
     if (i < nh) {
-        for (int k = tid; k < S.n_cur; k += 256) {
+        for (int k = tid; k < S.n_cur; k += NT) {
             const int g = S.ids[k];
             S.P[sess_P(0, g, i, N0)] = S.p_cur[2 * k];
             S.P[sess_P(1, g, i, N0)] = S.p_cur[2 * k + 1];
             S.P[sess_P(4, g, i, N0)] = (float)i;
         }
-        for (int j = tid; j < S.n_pose; j += 256) {
+        for (int j = tid; j < S.n_pose; j += NT) {
             const int g = S.sel_pw[j];
             S.P[sess_P(2, g, i, N0)] = (float)S.p_proj[2 * j];
             S.P[sess_P(3, g, i, N0)] = (float)S.p_proj[2 * j + 1];
@@ -155,28 +156,31 @@ __device__ __forceinline__ void sess_book_b(SessStream& S, const uint8_t* const*
     }
 }
 
-__global__ __launch_bounds__(256) void k_sess_book_a(SessStream* ss_all) { sess_book_a(ss_all[blockIdx.x]); }
+__global__ __launch_bounds__(256) void k_sess_book_a(SessStream* ss_all) { sess_book_a<256>(ss_all[blockIdx.x]); }
 __global__ __launch_bounds__(256) void k_sess_book_b(SessStream* ss_all, const uint8_t* const* frames, float time_s, float frame_no,
                                                      const float* times, const float* frame_nos)
 {
-    sess_book_b(ss_all[blockIdx.x], frames, time_s, frame_no, times, frame_nos);
+    sess_book_b<256>(ss_all[blockIdx.x], frames, time_s, frame_no, times, frame_nos);
 }
 
 // The whole post-tracking part of a frame in ONE launch (N0 <= 4096): vg[vg] = v, vp &= vg, compaction and pose-track selection
 // (vidExample.py:135-139), estimateWorldCameraPose(findR=False) with every LM iteration (NLS.py:9-33,102-129), then the B / S / P records
 // (vidExample.py:142-153,164).  Three dependent launches of one workgroup each before; same code, same results.
-__global__ __launch_bounds__(256) void k_sess_frame(SessStream* ss_all, const uint8_t* const* frames, float time_s, float frame_no,
-                                                    const float* times, const float* frame_nos)
+// 512 threads: the two bookkeeping halves are chains of dependent memory round trips and the LM loop a chain of dependent float64 operations, so two
+// wavefronts per SIMD hide what one cannot: 67 -> 56 us at 256 streams (the stand-alone pose kernel gains nothing from it: 2.75 vs 3.05 us per iteration)
+#define SESS_NT 512
+__global__ __launch_bounds__(SESS_NT) void k_sess_frame(SessStream* ss_all, const uint8_t* const* frames, float time_s, float frame_no,
+                                                        const float* times, const float* frame_nos)
 {
     SessStream& S = ss_all[blockIdx.x];
-    sess_book_a(S);
+    sess_book_a<SESS_NT>(S);
     __threadfence_block();
     __syncthreads();
     const PoseJob J = S.pose;
-    pose_solve<0, 256>(J);
+    pose_solve<0, SESS_NT>(J);
     __threadfence_block();
     __syncthreads();
-    sess_book_b(S, frames, time_s, frame_no, times, frame_nos);
+    sess_book_b<SESS_NT>(S, frames, time_s, frame_no, times, frame_nos);
 }
 
 // p3[vg] = p3hat - t ; vp = vg   (vidExample.py:159-160)
@@ -323,7 +327,7 @@ static int session_step(vh_session* s, const uint8_t* const* frames_dev, float t
     if (r) return r;
     if (s->N0 <= 4096) {
         const int rec = vh_prof_start(s->ctx, st);
-        hipLaunchKernelGGL(k_sess_frame, dim3(nb), dim3(256), 0, st, s->d_ss, frames_dev, time_s, frame_no, times_dev, frame_nos_dev);
+        hipLaunchKernelGGL(k_sess_frame, dim3(nb), dim3(SESS_NT), 0, st, s->d_ss, frames_dev, time_s, frame_no, times_dev, frame_nos_dev);
         vh_prof_stop(s->ctx, rec, VH_PROF_SESSION, st);
     } else {  // more pose tracks than 256 threads keep in registers: the 1024-thread pose kernel between the two bookkeeping halves
         hipLaunchKernelGGL(k_sess_book_a, dim3(nb), dim3(256), 0, st, s->d_ss);
