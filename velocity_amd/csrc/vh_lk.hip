@@ -787,12 +787,40 @@ __device__ void lk_track_strip(const PyrDesc& PI, const PyrDesc& PJ, int win, in
                               n_iter, n_setup, want_err);
 }
 
+
+// XCD-aware block order of the batched LK launches.  The dispatcher deals consecutive workgroups (linear id L = y gridDim.x + x) round-robin to the 8 XCDs,
+// so with y = stream every stream's tracks are spread over all eight L2s and each L2 sees the pyramids of every stream in flight.  Re-indexed so that
+// the workgroups of stream y all have L mod 8 == y mod 8: streams are taken in sets of 8 (8 gridDim.x consecutive ids), id q of a set -> stream q mod 8 of
+// the set, track block q / 8.  A stream then lives in ONE L2, and the eight streams of a set advance together.  (A last set of m < 8 streams is dealt
+// q mod m: valid, just not XCD-pure.)  Pure re-indexing: every (x, y) is produced exactly once.
+// Measured at 256 streams (A/B on one box, three rounds): the 51x51 fine stage 3820 -> 3790 us; the 15x15 coarse stages 633 / 1077 -> 1168 / 1369 us --
+// one stream's small pyramid levels are a few hundred cache lines, and all of a stream's wavefronts hammering ONE L2's channels for them is exactly the
+// hot-spotting the round robin avoids.  So: REMAP for the fine-stage kernel only.
+#ifndef LK_XCD_REMAP
+#define LK_XCD_REMAP 1
+#endif
+template <bool REMAP>
+__device__ __forceinline__ void lk_block_xy(unsigned& bx, unsigned& by)
+{
+    bx = blockIdx.x; by = blockIdx.y;
+    if (REMAP && LK_XCD_REMAP && gridDim.y > 1) {
+        const unsigned nx = gridDim.x, L = blockIdx.y * nx + blockIdx.x;
+        const unsigned set = L / (8u * nx), q = L - set * 8u * nx;
+        const unsigned m = min(8u, gridDim.y - set * 8u);
+        const unsigned xq = q / m;
+        by = set * 8u + (q - xq * m);
+        bx = xq;
+    }
+}
+
 template <int WIN_T>
 __global__ __launch_bounds__(64) void k_lk_strip(const void* job_tab, size_t tab_stride)
 {
-    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
+    unsigned blk_x, blk_y;
+    lk_block_xy<false>(blk_x, blk_y);
+    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
-    const int pt = blockIdx.x;
+    const int pt = (int)blk_x;
     if (pt >= n) return;
     const int lane = threadIdx.x;
     const int win = WIN_T ? WIN_T : job.win;
@@ -1297,9 +1325,11 @@ __device__ __forceinline__ void lk3_track(const PyrDesc& PI, const PyrDesc& PJ, 
 template <int WIN, int NW, int M>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? 3 : 4))) void k_lk3(const void* job_tab, size_t tab_stride)
 {
-    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
+    unsigned blk_x, blk_y;
+    lk_block_xy<true>(blk_x, blk_y);
+    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
-    const int pt = blockIdx.x;
+    const int pt = (int)blk_x;
     if (pt >= n) return;
     const int tid = threadIdx.x;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1666,9 +1696,11 @@ template <int WIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_lk_q(const void* job_tab, size_t tab_stride)
 {
     static_assert(WIN <= 15, "lane WIN of every 16-lane row carries the extra bottom row");
-    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
+    unsigned blk_x, blk_y;
+    lk_block_xy<false>(blk_x, blk_y);
+    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
-    const int pt = blockIdx.x * 4 + (threadIdx.x >> 4);
+    const int pt = (int)blk_x * 4 + (threadIdx.x >> 4);
     if (pt >= n) return;  // whole 16-lane rows leave together
     const int r = threadIdx.x & 15;
 
@@ -2027,9 +2059,11 @@ template <int WIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_lk_o(const void* job_tab, size_t tab_stride)
 {
     static_assert(WIN == 15, "8 lanes x 2 rows: row 15 is the dummy that feeds nothing");
-    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
+    unsigned blk_x, blk_y;
+    lk_block_xy<false>(blk_x, blk_y);
+    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
-    const int pt = blockIdx.x * 8 + (threadIdx.x >> 3);
+    const int pt = (int)blk_x * 8 + (threadIdx.x >> 3);
     if (pt >= n) return;  // whole 8-lane groups leave together
     const int r = threadIdx.x & 7;
 
