@@ -788,27 +788,29 @@ __device__ void lk_track_strip(const PyrDesc& PI, const PyrDesc& PJ, int win, in
 }
 
 
-// XCD-aware block order of the batched LK launches.  The dispatcher deals consecutive workgroups (linear id L = y gridDim.x + x) round-robin to the 8 XCDs,
-// so with y = stream every stream's tracks are spread over all eight L2s and each L2 sees the pyramids of every stream in flight.  Re-indexed so that
-// the workgroups of stream y all have L mod 8 == y mod 8: streams are taken in sets of 8 (8 gridDim.x consecutive ids), id q of a set -> stream q mod 8 of
-// the set, track block q / 8.  A stream then lives in ONE L2, and the eight streams of a set advance together.  (A last set of m < 8 streams is dealt
-// q mod m: valid, just not XCD-pure.)  Pure re-indexing: every (x, y) is produced exactly once.
-// Measured at 256 streams (A/B on one box, three rounds): the 51x51 fine stage 3820 -> 3790 us; the 15x15 coarse stages 633 / 1077 -> 1168 / 1369 us --
-// one stream's small pyramid levels are a few hundred cache lines, and all of a stream's wavefronts hammering ONE L2's channels for them is exactly the
-// hot-spotting the round robin avoids.  So: REMAP for the fine-stage kernel only.
+// XCD-aware, stream-interleaved block order of the batched LK launches (round 4).  The dispatcher deals consecutive workgroups (linear id
+// L = y gridDim.x + x) round-robin to the 8 XCDs, in order.  With y = stream and x = track block, a stream's tracks are spread over all eight L2s, each L2
+// sees the pyramids of every stream in flight, and the streams run one after the other.  Re-indexed: streams are taken in sets of G (G gridDim.x
+// consecutive ids), id q of a set -> stream q mod G of the set, track block q / G.  With G a multiple of 8 every workgroup of stream y has L mod 8 == y mod 8:
+// a stream lives in ONE L2 (its pyramid levels are read again and again by neighbouring tracks, both directions, every level and iteration), and G / 8
+// streams share an XCD at any time, which evens out their run times for the in-order dispatcher.  (A last set of m < G streams is dealt q mod m: valid,
+// XCD-pure only if m is a multiple of 8.)  Pure re-indexing: every (x, y) is produced exactly once, results are unchanged.
+// Measured (tools/exp/lko_group_sweep*.sh, C2, one box): coarse k_lk_o at 256 streams 632 / 1076 us (natural order) -> 524 / 935 us for G = 64 .. 256
+// (G = 31 / 63: 565 / 960; G = 8, ONE stream per XCD: 1169 / 1369 -- the XCDs drift apart and the in-order dispatcher waits for the slowest); fine k_lk3
+// 3830 -> 3661 us at G = 8, 3675 at 16, 3725 at 32.  Small batches gain most: 8 streams 13.2 k -> 18.2 k frames/s, 32 streams 26.4 k -> 34.4 k.
 #ifndef LK_XCD_REMAP
 #define LK_XCD_REMAP 1
 #endif
 template <bool REMAP>
-__device__ __forceinline__ void lk_block_xy(unsigned& bx, unsigned& by)
+__device__ __forceinline__ void lk_block_xy(unsigned& bx, unsigned& by, unsigned G = 8u)
 {
     bx = blockIdx.x; by = blockIdx.y;
-    if (REMAP && LK_XCD_REMAP && gridDim.y > 1) {
+    if (REMAP && LK_XCD_REMAP && gridDim.y > 1 && G > 1u) {
         const unsigned nx = gridDim.x, L = blockIdx.y * nx + blockIdx.x;
-        const unsigned set = L / (8u * nx), q = L - set * 8u * nx;
-        const unsigned m = min(8u, gridDim.y - set * 8u);
+        const unsigned set = L / (G * nx), q = L - set * G * nx;
+        const unsigned m = min(G, gridDim.y - set * G);
         const unsigned xq = q / m;
-        by = set * 8u + (q - xq * m);
+        by = set * G + (q - xq * m);
         bx = xq;
     }
 }
@@ -1323,10 +1325,10 @@ __device__ __forceinline__ void lk3_track(const PyrDesc& PI, const PyrDesc& PJ, 
 // (forcing 5 or 6 workgroups per CU through the second launch bound spills and measured 3-8 % slower; a 128-VGPR cap
 // + a 3-pixel search margin to fit 7 workgroups of the 2-wave variant per CU: 11 spilled registers, 5 % slower: not used)
 template <int WIN, int NW, int M>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? 3 : 4))) void k_lk3(const void* job_tab, size_t tab_stride)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? 3 : 4))) void k_lk3(const void* job_tab, size_t tab_stride, unsigned grp)
 {
     unsigned blk_x, blk_y;
-    lk_block_xy<true>(blk_x, blk_y);
+    lk_block_xy<true>(blk_x, blk_y, grp);
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
     const int pt = (int)blk_x;
@@ -1693,11 +1695,11 @@ __device__ __forceinline__ void lkq_track(const PyrDesc& PI, const PyrDesc& PJ, 
 }
 
 template <int WIN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_lk_q(const void* job_tab, size_t tab_stride)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_lk_q(const void* job_tab, size_t tab_stride, unsigned grp)
 {
     static_assert(WIN <= 15, "lane WIN of every 16-lane row carries the extra bottom row");
     unsigned blk_x, blk_y;
-    lk_block_xy<false>(blk_x, blk_y);
+    lk_block_xy<true>(blk_x, blk_y, grp);
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
     const int pt = (int)blk_x * 4 + (threadIdx.x >> 4);
@@ -2056,11 +2058,11 @@ __device__ __forceinline__ void lko_track(const PyrDesc& PI, const PyrDesc& PJ, 
 }
 
 template <int WIN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_lk_o(const void* job_tab, size_t tab_stride)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_lk_o(const void* job_tab, size_t tab_stride, unsigned grp)
 {
     static_assert(WIN == 15, "8 lanes x 2 rows: row 15 is the dummy that feeds nothing");
     unsigned blk_x, blk_y;
-    lk_block_xy<false>(blk_x, blk_y);
+    lk_block_xy<true>(blk_x, blk_y, grp);
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
     const int pt = (int)blk_x * 8 + (threadIdx.x >> 3);
@@ -2114,14 +2116,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
 template <int WIN>
 static int launch_lko(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lk_o<WIN>, dim3((max_n + 7) / 8, batch), dim3(64), 0, s, job_tab, tab_stride);
+    static const unsigned grp = getenv("VH_LKO_G") ? (unsigned)atoi(getenv("VH_LKO_G")) : 64u;  // (environment: experiments only)
+    hipLaunchKernelGGL(k_lk_o<WIN>, dim3((max_n + 7) / 8, batch), dim3(64), 0, s, job_tab, tab_stride, grp);
     return 0;
 }
 
 template <int WIN>
 static int launch_lkq(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lk_q<WIN>, dim3((max_n + 3) / 4, batch), dim3(64), 0, s, job_tab, tab_stride);
+    static const unsigned grp = getenv("VH_LKQ_G") ? (unsigned)atoi(getenv("VH_LKQ_G")) : 64u;  // (environment: experiments only)
+    hipLaunchKernelGGL(k_lk_q<WIN>, dim3((max_n + 3) / 4, batch), dim3(64), 0, s, job_tab, tab_stride, grp);
     return 0;
 }
 
@@ -2131,7 +2135,8 @@ static int launch_lk3(const void* job_tab, size_t tab_stride, int batch, int max
     // VH_LK_LDS_PAD (experiments only): extra dynamic LDS per workgroup = fewer resident wavefronts per SIMD (the occupancy sensitivity behind DESIGN.md section 9)
     static const int pad = [] { const char* e = getenv("VH_LK_LDS_PAD"); return e ? atoi(e) : 0; }();
     const int lds = LK3<WIN, NW, M>::LDS_BYTES + pad;
-    hipLaunchKernelGGL((k_lk3<WIN, NW, M>), dim3(max_n, batch), dim3(64 * NW), lds, s, job_tab, tab_stride);
+    static const unsigned grp = getenv("VH_LK3_G") ? (unsigned)atoi(getenv("VH_LK3_G")) : 16u;  // (environment: experiments only)
+    hipLaunchKernelGGL((k_lk3<WIN, NW, M>), dim3(max_n, batch), dim3(64 * NW), lds, s, job_tab, tab_stride, grp);
     return 0;
 }
 
