@@ -651,10 +651,13 @@ def valu_mix(kernel, setups, iters, per_setup=None, per_iter=None):
         r = rates.get(_RATE_ALIAS.get(op, op))
         if r is None:
             cls["unmeasured"] += f
-            r_eff = 14.5  # priced like the half-rate class
+            r_eff = 16.0  # priced like the half-rate class
         else:
             cls["full_rate" if r >= 20.0 else ("half_rate" if r >= 12.0 else "slow")] += f
-            r_eff = r
+            # the measurement CLASSIFIES the opcode; the ceiling uses the class's architectural issue rate (a wave64 instruction occupies its SIMD for 2 or
+            # 4 cycles = 32 / 16 lanes per clock: the single-opcode loops of the micro-benchmark sustain 23-27 / 13.9-14.5 of it, and a kernel that mixes
+            # opcodes and wavefronts can -- and round 4's does -- issue faster than they did), slow opcodes (f64, lane moves) their measured rate
+            r_eff = 32.0 if r >= 20.0 else (16.0 if r >= 12.0 else r)
         cyc += f / r_eff
         per_op.append((f / r_eff, op, f, r))
     per_op.sort(reverse=True)
@@ -786,7 +789,7 @@ def roofline_of(wl, m, world):
                note="track solve is VALU-issue bound (SURVEY §8d): frac = issued lane-instructions / launch time / (1024 SIMDs x 16 lanes x 2.4 GHz), the issue rate of "
                     "the half-rate opcode class the kernel is made of (mix.half_rate_frac); frac_abs prices the same lane-instructions against 32 lanes / clk / SIMD "
                     "(MI355X_MICROARCH.md: SIMD-32, 2-cycle wave64 issue), which only the full-rate class approaches (measured 23-27); frac_of_mix_ceiling against the "
-                    "rate a perfect scheduler would reach with THIS opcode mix at the measured per-opcode rates",
+                    "rate a perfect scheduler would reach with THIS opcode mix (opcodes classified by the micro-benchmark, priced at their class's architectural issue rate: 32 / 16 lanes per clock)",
                # the contract's HBM view of the same kernel (secondary: achieved GB/s of its algorithmic bytes, PMC traffic)
                hbm=hbm, traffic=traffic,
                op_model=dict(gops_per_launch=round(ops_fine / 1e9, 4), tops=round(model_tops, 3),

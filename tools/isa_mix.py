@@ -31,7 +31,7 @@ KERNELS = {
 
 
 def blocks_of(lines, sym):
-    start = next(i for i, l in enumerate(lines) if l.startswith(sym + ":"))
+    start = next(i for i, l in enumerate(lines) if re.match(re.escape(sym) + r"\w*:", l))  # (prefix: the parameter list may grow)
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     out, cur = [], dict(name="entry", depth=0, ops=collections.Counter(), byte_loads=0)
     for i in range(start + 1, end):
