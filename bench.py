@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--scene", default="plane", choices=["plane", "roll"],
                     help="plane: translation + zoom (the reference's plate-plane model); roll: + camera roll <= 0.05 deg/frame (SURVEY §8d's "
                          "rotation: the affine remap takes its gather path)")
+    ap.add_argument("--track-order", default="raster", choices=["raster", "shuffled"],
+                    help="order of the tracks of a stream: raster (the synthetic grid, default) or shuffled (what goodFeaturesToTrack's sort by corner "
+                         "response gives on real footage: neighbouring workgroups read unrelated windows)")
     ap.add_argument("--ring", type=int, default=60, help="distinct synthetic frames kept in HBM (one motion period)")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="keep timing further blocks of --steps steps until the timed region is at least this long (an external sampler can "
@@ -419,6 +422,8 @@ class Workload:
         # one texture set per `ring` streams, so no two resident streams ever work on the same pixels
         nsets = 1 if host_frames else (S + a.ring - 1) // a.ring
         self.K, self.motion, self.frames, self.p0 = make_ring(cfg, a.ring, dev, seed=0xC0FFEE + 7919 * rank, nsets=nsets, scene=scene)
+        if getattr(a, "track_order", "raster") == "shuffled":  # the order goodFeaturesToTrack gives (by corner response, i.e. spatially at random)
+            self.p0 = self.p0[np.random.default_rng(1234).permutation(N)]
         self.p3 = self.motion.world_points(self.p0)
         self.vp = np.ones(N, bool)  # every valid track takes part in the pose fit (the state after vidExample.py:160)
         G = max(1, min(groups, S))

@@ -256,6 +256,10 @@ VH_API void vh_debug_ransac_path(int mode);
 VH_API void vh_debug_ba_force_valu(int on);
 /* test hook: pyrDown with 2 / 4 / 8 output rows per thread whatever the launch size (0: chosen by size) */
 VH_API void vh_debug_pyr_rows(int rows);
+/* test hook: the LK launches of vh_klt_main / vh_session_step walk a stream's tracks in spatial order (a counting sort of the previous positions by
+ * 64 x 32-px cell, k_klt_setup) -- 1: always, 0: never, -1: default (from 24000 tracks in flight).  Launch order only: outputs keep the caller's
+ * indices and every result is bit-identical. */
+VH_API void vh_debug_klt_order(int mode);
 
 /* ---- measurement aids (bench.py): HIP-event timing of the LK launches + Newton-iteration statistics ------------- */
 VH_API int vh_profile_begin(vh_ctx* ctx, int max_launches);

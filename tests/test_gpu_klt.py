@@ -381,6 +381,43 @@ def test_klt_main_bit_exact_all_stages(seq, coarse_levels):
     assert np.array_equal(p_b, p) and np.array_equal(v_b, v)
 
 
+@pytest.fixture
+def spatial_launch_order():
+    """LK launches of KLTmain walk the tracks in spatial order (k_klt_setup's counting sort) whatever the load: the default only does above 24000
+    tracks in flight, which the full-size tests reach and the small ones do not."""
+    from velocity_amd import _lib as L
+
+    L.load().vh_debug_klt_order(1)
+    try:
+        yield
+    finally:
+        L.load().vh_debug_klt_order(-1)
+
+
+def test_klt_main_in_spatial_launch_order_is_bit_exact(seq, spatial_launch_order):
+    """Launch order only: outputs keep the caller's indices, every stage stays bit-exact -- on the grid tracks, on the same tracks shuffled (what
+    goodFeaturesToTrack's sort by corner response gives), with tracks outside the frame / NaN, one track and none."""
+    from velocity_amd import KLT
+
+    W, H, m, f0, f1, p0 = seq
+    rng = np.random.default_rng(3)
+    cases = [p0, p0[rng.permutation(len(p0))]]
+    odd = p0[rng.permutation(len(p0))].copy()
+    odd[::7] += np.float32(3000.0)   # far outside the frame: clamped cell keys
+    odd[3::11] = -odd[3::11]
+    odd[5] = np.nan
+    cases += [odd, p0[:1], p0[:0]]
+    for q in cases:
+        p, v, small, p_all, flags = KLT.KLTmain(f1, f0, None, q, return_all=True)
+        ep, ev, esmall, S = KO.klt_main(f1, f0, None, q, stages=True)
+        assert np.array_equal(v, ev) and np.array_equal(p_all, S["p_all"], equal_nan=True) and np.array_equal(p, ep, equal_nan=True)
+        assert flags == S["flags"]
+        if len(q):
+            G = KLT.klt_stages(len(q))
+            assert np.array_equal(G["p_small"], S["p_small"], equal_nan=True) and np.array_equal(G["v_small"], S["v_small"])
+            assert np.array_equal(G["p_coarse"], S["p_coarse"], equal_nan=True) and np.array_equal(G["v_coarse"], S["v_coarse"])
+
+
 @pytest.mark.parametrize("coarse_levels", [4, 2])
 def test_klt_main_on_the_scene_that_fires_every_status_gate(coarse_levels):
     """synth.gate_scene: independent foreground motion, a textureless band, a saturated patch, tracks across the frame border.  Unlike the plain scenes

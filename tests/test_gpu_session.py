@@ -184,11 +184,16 @@ def test_streams_started_at_different_times_keep_their_own_clock_and_msv_frame()
     assert oA.i == nfr + 1 and oB.i == nfr - 2 and oB.i >= 5  # both clips passed THEIR frame 5: both re-triangulated
 
 
-def test_session_with_more_than_4096_tracks_takes_the_unfused_path():
-    """N0 > 4096: the pose fit no longer fits the 256-thread fused frame kernel (bookkeeping, 1024-thread pose, records as three launches)."""
+@pytest.mark.parametrize("order", [-1, 1])
+def test_session_with_more_than_4096_tracks_takes_the_unfused_path(order):
+    """N0 > 4096: the pose fit no longer fits the 256-thread fused frame kernel (bookkeeping, 1024-thread pose, records as three launches).
+    order = 1: the LK launches walk the tracks in spatial order (vh_debug_klt_order; the counting sort then takes several passes per thread)."""
     import torch
 
+    from velocity_amd import _lib as L
     from velocity_amd.driver import TrackerSession
+
+    L.load().vh_debug_klt_order(order)
 
     W, H, n0, nframes = 960, 540, 4500, 4
     frames, p, p3, vp, K = _scene(W, H, n0, nframes, 31337)
@@ -204,6 +209,7 @@ def test_session_with_more_than_4096_tracks_takes_the_unfused_path():
         assert np.array_equal(st["vg"], orc.vg) and np.array_equal(st["vp"], orc.vp) and np.array_equal(st["p"], orc.p), i
         np.testing.assert_allclose(st["t"], orc.t, rtol=1e-5)
         np.testing.assert_allclose(st["res"], orc.residuals, rtol=1e-6)
+    L.load().vh_debug_klt_order(-1)
 
 
 def test_session_on_a_rolling_zooming_scene():

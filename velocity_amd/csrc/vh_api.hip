@@ -97,6 +97,7 @@ extern "C" VH_API int vh_ctx_create(vh_ctx** out, int batch, int max_w, int max_
             B.idx = (int*)(base + carve(sizeof(int) * max_pts));
             B.pairs = (float4*)(base + carve(sizeof(float4) * max_pts));
             B.counts = (int*)(base + carve(sizeof(int) * VH_RANSAC_ITERS));
+            B.order = (int*)(base + carve(sizeof(int) * max_pts));
         }
     }
     c->d_ws = (StreamWS*)(c->arena + ws_off);
@@ -153,17 +154,82 @@ __device__ void clamp_criteria(const vh_lk_params& lk, int& max_count, double& e
 
 __device__ void fill_lk_common(LKJob& J, const vh_lk_params& lk, const float* p_in, const int* n_ptr, int n)
 {
-    J.p_in = p_in; J.n_ptr = n_ptr; J.n = n; J.stats = nullptr;
+    J.p_in = p_in; J.n_ptr = n_ptr; J.n = n; J.stats = nullptr; J.order = nullptr;
     J.win = lk.win; J.max_level = lk.max_level;
     clamp_criteria(lk, J.max_count, J.eps2);
     J.err_out = nullptr; J.fbe_out = nullptr; J.praw_out = nullptr;
 }
 
 // ---- stage 0: descriptors of the quarter-scale stage (KLT.py:110-114) -------------------------------------------
-__global__ void k_klt_setup(StreamWS* ws_all, const SessStream* ss_all, const uint8_t* const* frames, vh_lk_params coarse, vh_lk_params fine)
+__device__ void klt_setup_descriptors(StreamWS& ws, const SessStream* ss_all, const uint8_t* const* frames, const vh_lk_params& coarse,
+                                      const vh_lk_params& fine, int use_order);
+
+// Launch order of a stream's tracks (use_order): the LK kernels read every track's windows out of the pyramids, and neighbouring workgroups run at the same
+// time on the same XCD (lk_block_xy) -- tracks that are neighbours in the IMAGE should be neighbours in the LAUNCH.  The reference's tracks come from
+// goodFeaturesToTrack, sorted by corner response, i.e. spatially at random: at 256 streams the ROI-stage launch then takes 1465 us instead of 936
+// (bench.py --track-order shuffled).  A counting sort of the previous positions by cell (64-px bands, 32-px columns inside a band: raster order of cells)
+// gives the launch the locality of a raster-ordered track list whatever order the caller keeps; outputs stay at the caller's indices.  The order inside
+// a cell is whatever the LDS atomics make it: it affects scheduling only, never a result.
+#define KO_BAND_SHIFT 6
+#define KO_COL_SHIFT 5
+#define KO_BANDS 40
+#define KO_COLS 128
+#define KO_THREADS 256
+__device__ __forceinline__ int klt_order_key(float x, float y)
 {
-    if (threadIdx.x != 0) return;
+    const int b = min(max((int)y >> KO_BAND_SHIFT, 0), KO_BANDS - 1), c = min(max((int)x >> KO_COL_SHIFT, 0), KO_COLS - 1);
+    return b * KO_COLS + c;
+}
+__device__ void klt_order_tracks(const float* p0, int n, int* order)
+{
+    __shared__ int bins[KO_BANDS * KO_COLS];
+    __shared__ int wsum[KO_THREADS / 64];
+    const int tid = threadIdx.x;
+    constexpr int PER = KO_BANDS * KO_COLS / KO_THREADS;
+    for (int k = tid; k < KO_BANDS * KO_COLS; k += KO_THREADS) bins[k] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += KO_THREADS) {
+        const float x = p0[2 * i], y = p0[2 * i + 1];
+        atomicAdd(&bins[klt_order_key(x == x ? x : 0.f, y == y ? y : 0.f)], 1);
+    }
+    __syncthreads();
+    // exclusive scan: a thread owns PER consecutive bins
+    int loc[PER], tot = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { loc[k] = tot; tot += bins[tid * PER + k]; }
+    int inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= o) inc += t;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    int base = inc - tot;
+    for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+#pragma unroll
+    for (int k = 0; k < PER; k++) bins[tid * PER + k] = base + loc[k];
+    __syncthreads();
+    for (int i = tid; i < n; i += KO_THREADS) {
+        const float x = p0[2 * i], y = p0[2 * i + 1];
+        order[atomicAdd(&bins[klt_order_key(x == x ? x : 0.f, y == y ? y : 0.f)], 1)] = i;
+    }
+}
+
+__global__ __launch_bounds__(KO_THREADS) void k_klt_setup(StreamWS* ws_all, const SessStream* ss_all, const uint8_t* const* frames, vh_lk_params coarse,
+                                                            vh_lk_params fine, int use_order)
+{
     StreamWS& ws = ws_all[blockIdx.x];
+    if (threadIdx.x == 0) klt_setup_descriptors(ws, ss_all, frames, coarse, fine, use_order);
+    if (!use_order) return;
+    __threadfence_block();
+    __syncthreads();
+    klt_order_tracks(ws.io.p0, ws.n, ws.bufs.order);
+}
+
+__device__ void klt_setup_descriptors(StreamWS& ws, const SessStream* ss_all, const uint8_t* const* frames, const vh_lk_params& coarse,
+                                      const vh_lk_params& fine, int use_order)
+{
     if (ss_all) {  // session mode: this frame's KLTmain call (vidExample.py:134) straight from the stream state
         const SessStream& S = ss_all[blockIdx.x];
         KltIO& o = ws.io;
@@ -189,6 +255,7 @@ __global__ void k_klt_setup(StreamWS* ws_all, const SessStream* ss_all, const ui
     const int n = io.n_ptr ? *io.n_ptr : io.n;
     ws.n = n;
     ws.flags = 0;
+    ws.order = use_order ? B.order : nullptr;
     const int dw = __double2int_rn(io.w * 0.25), dh = __double2int_rn(io.h * 0.25);
     const int cur = ws.pp & 1, prev = 1 - cur;
     uint8_t* small_cur = io.im_small ? io.im_small : B.small0[cur];
@@ -207,6 +274,7 @@ __global__ void k_klt_setup(StreamWS* ws_all, const SessStream* ss_all, const ui
     ws.pb[0] = PyrBuild{&J.I, io.reuse_prev_small ? 0 : 1, 0};
     ws.pb[1] = PyrBuild{&J.J, 1, 0};
     fill_lk_common(J, io.coarse, io.p0, nullptr, n);
+    J.order = ws.order;
     J.p_out = B.p_small; J.v_out = B.v_small;
     J.fbt = -1.f;
     J.in_scale = 0.25f; J.in_off[0] = 0.f; J.in_off[1] = 0.f;
@@ -301,6 +369,7 @@ __global__ __launch_bounds__(256) void k_klt_glue1(StreamWS* ws_all)
     ws.pb[0] = PyrBuild{&J.I, 1, 0};
     ws.pb[1] = PyrBuild{&J.J, 1, 0};
     fill_lk_common(J, lk, io.p0, nullptr, n);
+    J.order = ws.order;
     J.p_out = B.p_coarse; J.v_out = B.v_coarse;
     J.fbt = io.fbt_coarse;
     J.in_scale = 1.f; J.in_off[0] = (float)x0; J.in_off[1] = (float)y0;
@@ -359,6 +428,7 @@ __global__ void k_klt_glue2(StreamWS* ws_all)
     ws.pb[0] = PyrBuild{&J.I, 1, 0};
     ws.pb[1] = PyrBuild{&J.J, 1, 0};
     fill_lk_common(J, lk, io.p0, nullptr, ws.n);
+    J.order = ws.order;
     J.p_out = io.p_all; J.v_out = io.v;
     J.fbt = io.fbt_fine;
     J.in_scale = 1.f; J.in_off[0] = (float)x0; J.in_off[1] = (float)y0;
@@ -382,6 +452,9 @@ static int launch_lk_profiled(vh_ctx* c, int stage, const void* tab, size_t st, 
         vh_prof_stop((c), rec_, (stage), (s));        \
     } while (0)
 
+static int g_klt_order = getenv("VH_KLT_ORDER") ? atoi(getenv("VH_KLT_ORDER")) : -1;  // test hook: 1 always, 0 never, -1 by load
+extern "C" VH_API void vh_debug_klt_order(int mode) { g_klt_order = mode; }
+
 int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine, const SessStream* sess,
                     const uint8_t* const* frames, int n_max)
 {
@@ -389,7 +462,9 @@ int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_p
     StreamWS* ws = c->d_ws + slot;
     const size_t st = sizeof(StreamWS);
     const int lvl_c = min(coarse.max_level, VH_MAX_LEVELS - 1), lvl_f = min(fine.max_level, VH_MAX_LEVELS - 1);
-    hipLaunchKernelGGL(k_klt_setup, dim3(count), dim3(64), 0, s, ws, sess ? sess + slot : nullptr, frames, coarse, fine);
+    // spatial launch order of the tracks: pays from the load at which a stream's pyramids no longer sit in every L2 anyway (8 streams: no difference measured)
+    const int use_order = g_klt_order >= 0 ? g_klt_order : ((long long)count * mn >= 24000 ? 1 : 0);
+    hipLaunchKernelGGL(k_klt_setup, dim3(count), dim3(use_order ? KO_THREADS : 64), 0, s, ws, sess ? sess + slot : nullptr, frames, coarse, fine, use_order);
     VH_PROFILED(c, VH_PROF_RESIZE, s, vh_launch_resize_quarter(&ws->rs_src[0], &ws->rs_dst[0], st, 2, count, c->sw, c->sh, s));
     VH_PROFILED(c, VH_PROF_PYR, s, for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->sw, c->sh, s));
     int r = launch_lk_profiled(c, 0, &ws->lk, st, count, coarse.win, s, mn);

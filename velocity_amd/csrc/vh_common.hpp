@@ -52,6 +52,7 @@ struct LKJob {
     float* fbe_out;      // n     forward-backward error (may be null)
     float* praw_out;     // n x 2 un-mapped forward result in LK image coordinates (may be null)
     const int* n_ptr;    // device count of points (null -> n)
+    const int* order;    // may be null: LAUNCH order of the points (a permutation of 0..n-1: workgroup slot k solves point order[k]); results stay where they were
     unsigned long long* stats;  // may be null: [0] += Newton iterations, [1] += template set-ups (profiling aid)
     int n;
     int win, max_level, max_count;

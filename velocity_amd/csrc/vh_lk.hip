@@ -231,8 +231,8 @@ __global__ __launch_bounds__(64) void k_lk(const void* job_tab, size_t tab_strid
 {
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
-    const int pt = blockIdx.x;
-    if (pt >= n) return;
+    if ((int)blockIdx.x >= n) return;
+    const int pt = job.order ? job.order[blockIdx.x] : (int)blockIdx.x;  // launch slot -> point (LKJob::order)
     const int lane = threadIdx.x;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int kmax = (job.win * job.win + 63) / 64;
@@ -822,8 +822,8 @@ __global__ __launch_bounds__(64) void k_lk_strip(const void* job_tab, size_t tab
     lk_block_xy<false>(blk_x, blk_y);
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
-    const int pt = (int)blk_x;
-    if (pt >= n) return;
+    if ((int)blk_x >= n) return;
+    const int pt = job.order ? job.order[blk_x] : (int)blk_x;  // launch slot -> point (LKJob::order)
     const int lane = threadIdx.x;
     const int win = WIN_T ? WIN_T : job.win;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1331,8 +1331,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
     lk_block_xy<true>(blk_x, blk_y, grp);
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
-    const int pt = (int)blk_x;
-    if (pt >= n) return;
+    if ((int)blk_x >= n) return;
+    const int pt = job.order ? job.order[blk_x] : (int)blk_x;  // launch slot -> point (LKJob::order)
     const int tid = threadIdx.x;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int max_count = job.max_count;
@@ -1702,8 +1702,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     lk_block_xy<true>(blk_x, blk_y, grp);
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
-    const int pt = (int)blk_x * 4 + (threadIdx.x >> 4);
-    if (pt >= n) return;  // whole 16-lane rows leave together
+    const int slot = (int)blk_x * 4 + (threadIdx.x >> 4);
+    if (slot >= n) return;
+    const int pt = job.order ? job.order[slot] : slot;  // launch slot -> point (LKJob::order)  // whole 16-lane rows leave together
     const int r = threadIdx.x & 15;
 
     const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];
@@ -2065,8 +2066,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     lk_block_xy<true>(blk_x, blk_y, grp);
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
-    const int pt = (int)blk_x * 8 + (threadIdx.x >> 3);
-    if (pt >= n) return;  // whole 8-lane groups leave together
+    const int slot = (int)blk_x * 8 + (threadIdx.x >> 3);
+    if (slot >= n) return;  // whole 8-lane groups leave together
+    const int pt = job.order ? job.order[slot] : slot;  // launch slot -> point (LKJob::order)
     const int r = threadIdx.x & 7;
 
     const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];

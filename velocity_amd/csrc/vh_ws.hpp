@@ -21,6 +21,7 @@ struct StreamBufs {  // fixed after vh_ctx_create
     int* idx;
     float4* pairs;
     int* counts;
+    int* order;                            // launch order of the tracks (k_klt_setup's spatial counting sort), max_pts entries
 };
 
 struct KltIO {  // one KLTmain call (KLT.py:99)
@@ -54,6 +55,7 @@ struct StreamWS {
     int dxy[2];
     unsigned long long lk_stats[3][2];  // per KLTmain stage: Newton iterations, template set-ups (profiling aid)
     int n, m, rstatus, flags, pp, rbound;
+    const int* order;  // bufs.order when this call launches its LK kernels in spatial order, else null
 };
 
 struct vh_ctx {
