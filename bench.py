@@ -818,14 +818,18 @@ def headline_hbm(cfg, fps):
                 note="image-stage algorithmic bytes only: the step is VALU / latency bound, nowhere near HBM bound (as SURVEY §8d predicted)")
 
 
-def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev):
+def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev, track_order=None):
     """One more single-GPU workload next to the headline one; returns its summary (None when it does not fit / fails)."""
     try:
+        if track_order:
+            import copy
+            a = copy.copy(a)
+            a.track_order = track_order
         wl = Workload(a, CONFIGS[cfg_key], params, scene, streams, steps, warmup, dev, rank=0)
         m = wl.measure(steps, warmup, 1.0, torch.cuda.synchronize, lambda t: t)
         fps = wl.S * m["timed_steps"] / m["elapsed"]
-        out = dict(workload=f"{cfg_key} / params {params} / scene {scene}", streams=streams, value=round(fps, 2), unit="frames/s",
-                   ms_per_step=round(1e3 * m["elapsed"] / m["timed_steps"], 4), timed_steps=m["timed_steps"], tracks_alive_frac=round(m["alive"], 4),
+        out = dict(workload=f"{cfg_key} / params {params} / scene {scene}" + (f" / tracks {track_order}" if track_order else ""), streams=streams, value=round(fps, 2),
+                   unit="frames/s", ms_per_step=round(1e3 * m["elapsed"] / m["timed_steps"], 4), timed_steps=m["timed_steps"], tracks_alive_frac=round(m["alive"], 4),
                    pose_t=[round(float(x), 5) for x in m["st"]["t"]], pose_t_truth=[round(float(x), 5) for x in m["truth"]],
                    rms_residual_px=round(m["st"]["res"], 5),
                    lk_us_per_launch=[round(1e3 * m["prof"]["ms_sum"][k] / max(m["prof"]["launches"][k], 1), 2) for k in range(3)])
@@ -937,6 +941,8 @@ def main():
             legs["ref_params"] = extra_leg(a, a.config, "ref" if a.params == "baseline" else "baseline", a.scene, S, 60, 10, dev)
             legs["other_config"] = extra_leg(a, "c3" if c2 else "c2", a.params, a.scene, 64 if c2 else 128, 24 if c2 else 60, 6, dev)  # 64 4K streams = 320 000 tracks in flight
             legs["roll_scene"] = extra_leg(a, a.config, a.params, "roll" if a.scene == "plane" else "plane", S, 60, 10, dev)
+            # the headline scene hands its tracks over in raster order; goodFeaturesToTrack sorts by corner response (spatially at random): same work, the other order
+            legs["shuffled_tracks"] = extra_leg(a, a.config, a.params, a.scene, S, 60, 10, dev, track_order="shuffled" if a.track_order == "raster" else "raster")
             out["extras"] = legs
         if not a.no_ba and world == 1:
             out["ba"] = bench_ba(cpu_seconds=a.cpu_seconds)
