@@ -798,22 +798,29 @@ __device__ void lk_track_strip(const PyrDesc& PI, const PyrDesc& PJ, int win, in
 // Measured (tools/exp/lko_group_sweep*.sh, C2, one box): coarse k_lk_o at 256 streams 632 / 1076 us (natural order) -> 524 / 935 us for G = 64 .. 256
 // (G = 31 / 63: 565 / 960; G = 8, ONE stream per XCD: 1169 / 1369 -- the XCDs drift apart and the in-order dispatcher waits for the slowest); fine k_lk3
 // 3830 -> 3661 us at G = 8, 3675 at 16, 3725 at 32.  Small batches gain most: 8 streams 13.2 k -> 18.2 k frames/s, 32 streams 26.4 k -> 34.4 k.
+// Most of it is the INTERLEAVING (resident workgroups come from many streams instead of one or two, all at the same pyramid level of the same images);
+// the same order rotated off the XCDs (LK_GRP_ROTATE) keeps 95-98 %: 8 streams 17.9 k against 18.3 k pinned, 256 streams 40.9 k against 41.6 k.
 #ifndef LK_XCD_REMAP
 #define LK_XCD_REMAP 1
 #endif
+#define LK_GRP_ROTATE 0x10000u  // flag in the group argument: stream (q + q / m) mod m instead of q mod m -- interleaved, but NOT pinned to an XCD
 template <bool REMAP>
-__device__ __forceinline__ void lk_block_xy(unsigned& bx, unsigned& by, unsigned G = 8u)
+__device__ __forceinline__ void lk_block_xy(unsigned& bx, unsigned& by, unsigned grp = 8u)
 {
     bx = blockIdx.x; by = blockIdx.y;
+    const unsigned G = grp & 0xffffu;
     if (REMAP && LK_XCD_REMAP && gridDim.y > 1 && G > 1u) {
         const unsigned nx = gridDim.x, L = blockIdx.y * nx + blockIdx.x;
         const unsigned set = L / (G * nx), q = L - set * G * nx;
         const unsigned m = min(G, gridDim.y - set * G);
         const unsigned xq = q / m;
-        by = set * G + (q - xq * m);
+        by = set * G + ((q - xq * m) + ((grp & LK_GRP_ROTATE) ? xq : 0u)) % m;
         bx = xq;
     }
 }
+// group argument of a launch: sets of `g` streams; pinned from 64 streams on (8+ streams share an XCD: their run times even out), rotated below (a stream's
+// workgroups visit every XCD, so a stream that carries more tracks than the others cannot hold one XCD -- and with it the in-order dispatcher -- back)
+static inline unsigned lk_group_arg(unsigned g, int batch) { return g | (batch < 64 ? LK_GRP_ROTATE : 0u); }
 
 template <int WIN_T>
 __global__ __launch_bounds__(64) void k_lk_strip(const void* job_tab, size_t tab_stride)
@@ -2119,7 +2126,7 @@ template <int WIN>
 static int launch_lko(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
     static const unsigned grp = getenv("VH_LKO_G") ? (unsigned)atoi(getenv("VH_LKO_G")) : 64u;  // (environment: experiments only)
-    hipLaunchKernelGGL(k_lk_o<WIN>, dim3((max_n + 7) / 8, batch), dim3(64), 0, s, job_tab, tab_stride, grp);
+    hipLaunchKernelGGL(k_lk_o<WIN>, dim3((max_n + 7) / 8, batch), dim3(64), 0, s, job_tab, tab_stride, lk_group_arg(grp, batch));
     return 0;
 }
 
@@ -2127,7 +2134,7 @@ template <int WIN>
 static int launch_lkq(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
     static const unsigned grp = getenv("VH_LKQ_G") ? (unsigned)atoi(getenv("VH_LKQ_G")) : 64u;  // (environment: experiments only)
-    hipLaunchKernelGGL(k_lk_q<WIN>, dim3((max_n + 3) / 4, batch), dim3(64), 0, s, job_tab, tab_stride, grp);
+    hipLaunchKernelGGL(k_lk_q<WIN>, dim3((max_n + 3) / 4, batch), dim3(64), 0, s, job_tab, tab_stride, lk_group_arg(grp, batch));
     return 0;
 }
 
@@ -2138,7 +2145,7 @@ static int launch_lk3(const void* job_tab, size_t tab_stride, int batch, int max
     static const int pad = [] { const char* e = getenv("VH_LK_LDS_PAD"); return e ? atoi(e) : 0; }();
     const int lds = LK3<WIN, NW, M>::LDS_BYTES + pad;
     static const unsigned grp = getenv("VH_LK3_G") ? (unsigned)atoi(getenv("VH_LK3_G")) : 16u;  // (environment: experiments only)
-    hipLaunchKernelGGL((k_lk3<WIN, NW, M>), dim3(max_n, batch), dim3(64 * NW), lds, s, job_tab, tab_stride, grp);
+    hipLaunchKernelGGL((k_lk3<WIN, NW, M>), dim3(max_n, batch), dim3(64 * NW), lds, s, job_tab, tab_stride, lk_group_arg(grp, batch));
     return 0;
 }
 
