@@ -600,7 +600,7 @@ def lk_valu_model():
 
 def coarse_kernel_name(tracks):
     """routing of vh_launch_lk for the 15x15 window (velocity_amd/csrc/vh_lk.hip)"""
-    return "k_lk_o<15>" if tracks >= 24000 else ("k_lk_q<15>" if tracks >= 3000 else "k_lk_strip<15>")
+    return "k_lk_o<15>" if tracks >= 30000 else ("k_lk_q<15>" if tracks >= 3000 else "k_lk_strip<15>")
 
 
 def valu_rates():

@@ -2166,7 +2166,7 @@ static int launch_strip(const void* job_tab, size_t tab_stride, int batch, int m
 // 1 / 2 / 4 wavefronts per track, 8 = 8-tracks-per-wave kernel (15x15), 0 = default routing
 static int g_lk_force_generic = getenv("VH_LK_FORCE") ? atoi(getenv("VH_LK_FORCE")) : 0;  // (environment: experiments only)
 void vh_lk_force_generic(int on) { g_lk_force_generic = on; }
-static long long g_lko_min_tracks = getenv("VH_LKO_MIN") ? atoll(getenv("VH_LKO_MIN")) : 24000;  // (environment: experiments only)
+static long long g_lko_min_tracks = getenv("VH_LKO_MIN") ? atoll(getenv("VH_LKO_MIN")) : 30000;  // (environment: experiments only)
 
 int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s)
 {
