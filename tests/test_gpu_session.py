@@ -85,6 +85,40 @@ def test_session_batch_streams_are_independent():
         np.testing.assert_allclose(st["t"], orcs[b].t, rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,n0", [(20, 170), (70, 64)])
+def test_session_batches_with_partial_stream_sets(B, n0):
+    """The LK launches re-index their workgroups by sets of streams (lk_block_xy: 16 for the fine kernel, 64 for the coarse ones; rotated below 64 streams,
+    XCD-pinned from 64 on).  20 streams = a full fine set + a tail of 4, one (rotated) coarse set; 70 streams = a pinned coarse set of 64 + a tail of 6.
+    Streams carry different scenes and different track counts (every third stream loses half of its tracks before the first step): each stream must
+    still equal its own oracle, bit for bit."""
+    import torch
+
+    from velocity_amd.driver import TrackerSession
+
+    W, H, nframes = 320, 240, 3
+    assert B * n0 >= 3000  # the 4-tracks-per-wavefront coarse kernel (the strip kernel below that is not re-indexed)
+    scenes = [_scene(W, H, n0, nframes, 4000 + 31 * b) for b in range(B)]
+    t0 = np.float32([1.5, 0.45, 3.6])
+    ses = TrackerSession(scenes[0][4], W, H, n0, nhist=nframes, batch=B, msv_frame=0)
+    orcs = []
+    for b, (frames, p, p3, vp, K) in enumerate(scenes):
+        if b % 3 == 1:
+            p = p.copy()
+            p[n0 // 2:] = np.float32([-60.0, -60.0])  # dies in the first step: this stream's launches are half empty from then on
+        ses.init_stream(b, frames[0], p, p3, vp, t0)
+        orcs.append(SessionOracle(K, frames[0], p, p3, vp, t0, nhist=nframes, msv_frame=0))
+    for i in range(1, nframes):
+        ts = np.float32(i / 30.0)
+        ses.step([torch.from_numpy(scenes[b][0][i]).cuda() for b in range(B)], time_s=ts, frame_no=i)
+        for b in range(B):
+            orcs[b].step(scenes[b][0][i], ts, i)
+    for b in range(B):
+        st = ses.state(b)
+        assert np.array_equal(st["vg"], orcs[b].vg) and np.array_equal(st["vp"], orcs[b].vp), b
+        assert np.array_equal(st["p"], orcs[b].p), b
+        np.testing.assert_allclose(st["t"], orcs[b].t, rtol=1e-5)
+
+
 @pytest.mark.parametrize("pinned", [False, True])
 def test_host_frame_feeder_gives_the_same_tracks(pinned):
     """Frames uploaded through the pinned double-buffered feeder (side stream) == frames already resident in HBM."""
