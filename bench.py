@@ -13,9 +13,14 @@ data-path collective) and all-gathers the packed track state every 30 frames (co
 
 The line carries, next to the contract's fields: `roofline` (dominant kernel, measured live with HIP events inside the
 library), `cpu_baseline` (the CPU port on all host cores AND on one core), `ba` (config 5: LM iterations/s of one window
-and of 8 / 64 batched windows, with its own structured-CPU baseline), and at N = 1 the `extras` legs: one stream alone
-(the literal C2 workload: latency), the reference's own LK parameters (utils/KLT.py:106-107), config C3 (4K / 5000
-tracks) and the camera-roll scene that drives the affine remap through its gather path.
+and of 8 / 64 batched windows, with its own structured-CPU baseline), and at N = 1 the `extras` legs: the HARD SCENE
+(noise, gain drift, moving foreground, textureless band: every KLTmain gate fires) and the reference's REAL STILLS, each
+at 256 and 8 streams; one stream alone (latency); the drop-in route (KLT.KLTmain + NLS.estimateWorldCameraPose per call);
+the reference's own LK parameters (utils/KLT.py:106-107); config C3 (4K / 5000 tracks); the camera-roll scene; shuffled
+track order.
+
+Support code lives in benchlib/ (workloads, roofline objects, BA legs); everything that touches oracle/ -- the CPU
+baselines and the post-run parity attestation `verified` -- is in THIS file (the only bench code allowed to import it).
 """
 import argparse
 import ctypes as C
@@ -31,29 +36,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-CONFIGS = {
-    # BASELINE.json configs[1] / configs[2]
-    "c2": dict(w=1920, h=1080, n=2000, levels=3, name="C2 synthetic 1080p@30fps, 2000 KLT tracks, 3 pyramid levels"),
-    "c3": dict(w=3840, h=2160, n=5000, levels=4, name="C3 synthetic 4K@30fps, 5000 KLT tracks, 4 pyramid levels"),
-}
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-CLOCK_GHZ = 2.4
-N_SIMD = 256 * 4
+from benchlib.ba import bench_ba, bench_ba_multi_gpu  # noqa: E402
+from benchlib.roofline import CONFIGS, HBM_PEAK_GBS, headline_hbm, roofline_of  # noqa: E402,F401  (re-exported: tests/test_bench_cpu.py)
+from benchlib.workload import EpisodeWorkload, Workload  # noqa: E402
 
-
-def valu_peak():
-    """VALU issue peak in T lane-instructions/s for the integer / packed-16 instruction mix of the LK kernels, from the committed
-    micro-benchmark (tools/ubench/valu_rate.hip -> profiles/r02_valu_rate.json: lanes per clock per SIMD of v_dot2_i32_i16, v_perm_b32,
-    v_add_u32, v_mad_i32_i24 at 1-8 waves per SIMD).  Falls back to the 16 lanes/clk the round-1 SQ counters showed."""
-    path = os.path.join(ROOT, "profiles", "r02_valu_rate.json")
-    lanes, src = 16.0, "assumed 16 lanes/clk/SIMD (profiles/r01_lk_sq_pmc.md); micro-benchmark file missing"
-    try:
-        j = json.load(open(path))
-        lanes = float(j["summary"]["int_valu_lanes_per_clk_per_simd"])
-        src = "profiles/r02_valu_rate.json (tools/ubench/valu_rate.hip)"
-    except Exception:
-        pass
-    return N_SIMD * lanes * CLOCK_GHZ * 1e9 / 1e12, lanes, src
 
 
 def host_cores():
@@ -103,6 +89,7 @@ def parse():
                          "`verified` (0 disables)")
     ap.add_argument("--no-ba", action="store_true", help="skip the BA (config 5) leg")
     ap.add_argument("--only-ba", action="store_true", help="run only the BA (config 5) leg and print its object (profiling aid)")
+    ap.add_argument("--only-leg", default="", help="run only one episode leg and print its object: hard_scene[:streams] | real_texture[:streams] (profiling aid)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (single stream, reference parameters, C3, roll scene)")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("VH_BENCH_GROUPS", 1)),
                     help="split the resident streams into this many sessions on separate HIP streams (their latency-bound stages overlap)")
@@ -136,21 +123,6 @@ def self_launch(a):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
-
-def make_ring(cfg, ring, device, seed, nsets=1, scene="plane"):
-    """nsets x `ring` frames of a periodic plane motion (one texture per set) + the tracks / world points of frame 0."""
-    from velocity_amd import synth
-
-    W, H = cfg["w"], cfg["h"]
-    K = synth.K_1080P.copy()
-    if W != 1920:
-        K[:2, :2] *= W / 1920.0
-        K[2, 0], K[2, 1] = W / 2 + 0.5, H / 2 + 0.5
-    roll = synth.oscillating_roll(period=float(ring)) if scene == "roll" else None
-    m = synth.PlaneMotion(K, z0=3.6, traj=synth.oscillating_traj(period=float(ring)), roll=roll)
-    frames = torch.stack([synth.render_frame(W, H, m, k, seed=seed + 104729 * t, device=device) for t in range(nsets) for k in range(ring)])
-    p0 = synth.grid_tracks(cfg["n"], W, H, seed=(seed & 0xFF) + 1)
-    return K, m, frames, p0
 
 
 def cpu_baseline(cfg, K, frames, p0, p3, vp, lkc, lkf, budget_s, threads):
@@ -186,636 +158,135 @@ def cpu_baseline(cfg, K, frames, p0, p3, vp, lkc, lkf, budget_s, threads):
                 sample=f"{done} frames of stream 0 ({cfg['w']}x{cfg['h']}, {cfg['n']} tracks), oracle C/OpenMP KLT + NumPy NLS, {dt:.1f} s")
 
 
-# ----------------------------------------------------------------------------------------------------------------------------------
-# config 5: bundle adjustment
-# ----------------------------------------------------------------------------------------------------------------------------------
-def bench_ba(nt=5000, nf=20, repeats=3, cpu_seconds=12.0, windows=(1, 8, 64), min_seconds=0.4):
-    """BASELINE config 5: sliding-window BA, 20 keyframes x 5000 full-length tracks, 10 LM iterations (fcnNLS_batch): one window, and
-    `windows` independent windows batched into the same launches (vh_nls_batch_multi) -- the mode that fills the chip."""
-    from velocity_amd import _lib as L
+
+def ba_cpu_baseline(out, first, cpu_seconds):
+    """The structured CPU restatement (oracle/nls_oracle.py::ba_schur_step: NumPy einsum / LAPACK on the host's cores) on the same C5 window: the dense
+    reference path itself is infeasible at C5 (J^T alone 24 GB, ~10 min / iteration)."""
+    from oracle import nls_oracle as NO
     from velocity_amd import synth
+    import contextlib
 
-    K = synth.K_1080P
-    ws = L.workspace()
-    L.check(ws.lib.vh_ba_graph_replay(ws.handle, 1), "vh_ba_graph_replay")  # opt-in: the solve buffers below are allocated once per window count and reused
-    K64 = L.host_K(K)
-    nc = nf - 1
-    nx, nz = 3 * nt + 6 * nc, 2 * nt * nf
-    out = dict(workload=f"C5 BA: {nf} keyframes x {nt} tracks (nx={nx}, nz={nz}), 10 LM iterations per window",
-               method="compact FD Jacobian; point-block Schur complement with the reduced camera system on v_mfma_f64_16x16x4_f64; "
-                      "block Gauss-Jordan (4x4 pivot blocks, SPD, pivot-free) in the MFMA accumulators",
-               timing="HIP events around each 10-iteration solve on the launch stream; median of the second half of the repetitions "
-                      "(iters_per_s), best (iters_per_s_best) and host wall incl. enqueue + synchronize (iters_per_s_host_wall)",
-               dense_equivalent_flop_per_iter=2.0 * nx ** 2 * nz, by_windows={})
-    first = None
-    for nw in windows:
-        if not hasattr(ws.lib, "vh_nls_batch_multi") and nw > 1:
-            continue
-        zs, xs = [], []
-        for w in range(nw):
-            P, pw0, cw0 = synth.ba_scene(nt, nf, seed=5 + w)
-            z, x0, _, _ = synth.ba_pack(P, pw0, cw0)
-            zs.append(z)
-            xs.append(x0)
-            if w == 0 and first is None:
-                first = (P, pw0, cw0)
-        zd = L.to_dev(np.stack(zs), torch.float64)
-        x0d = L.to_dev(np.stack(xs), torch.float64)
-        nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
-        scratch = torch.empty((nw, nbytes), dtype=torch.uint8, device="cuda")
-        trace = torch.zeros((nw, 10, 2), dtype=torch.float64, device="cuda")
-        info = torch.zeros((nw, 2), dtype=torch.int32, device="cuda")
-        # timed with HIP events on the launch stream (the device time of the whole 10-iteration solve, first kernel to last); repeated until
-        # `min_seconds` of solves have run (the first ones also bring the clocks up after the CPU legs): median AND best are reported, the
-        # headline figure is the median.  The host wall time of the same solves (enqueue + synchronize) is kept next to it.
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dev_ms, wall_ms, t_begin = [], [], time.perf_counter()
-        xd = torch.empty_like(x0d)  # pointer stable (vh_ba_graph_replay): the state is re-initialised in place before every solve
-        while len(dev_ms) < repeats + 1 or (time.perf_counter() - t_begin < min_seconds and len(dev_ms) < 400):
-            xd.copy_(x0d)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ev0.record()
-            if nw == 1:
-                L.check(ws.lib.vh_nls_batch(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, 10, L.dptr(trace), L.dptr(info),
-                                            L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch")
-            else:
-                L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, nw, 10, L.dptr(trace),
-                                                  L.dptr(info), L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
-            ev1.record()
-            torch.cuda.synchronize()
-            wall_ms.append(1e3 * (time.perf_counter() - t0))
-            dev_ms.append(ev0.elapsed_time(ev1))
-        its = int(info.cpu()[:, 0].sum())
-        tr = trace.cpu().numpy()
-        half = len(dev_ms) // 2  # the first half is warm-up (clock ramp after the idle CPU legs)
-        med, best, wmed = float(np.median(dev_ms[half:])), float(min(dev_ms)), float(np.median(wall_ms[half:]))
-        out["by_windows"][str(nw)] = dict(iters_per_s=round(1e3 * its / med, 1), ms_per_window_iter=round(med / its, 5), solves_timed=len(dev_ms),
-                                          iters_per_s_best=round(1e3 * its / best, 1), iters_per_s_host_wall=round(1e3 * its / wmed, 1),
-                                          rms_residual_first=round(float(tr[0, 0, 0]), 4), rms_residual_last=round(float(tr[0, -1, 0]), 4))
-        del scratch, zd, x0d
-    # ---- roofline of the BA kernels: one PROFILED solve per window count (HIP events around every kernel inside the library; the solve is then
-    # launched plainly, not replayed from its graph) ----
-    def profiled(nw):
-        zs, xs = zip(*[synth.ba_pack(*synth.ba_scene(nt, nf, seed=5 + w))[:2] for w in range(nw)])
-        zd, xd = L.to_dev(np.stack(zs), torch.float64), L.to_dev(np.stack(xs), torch.float64)
-        nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
-        scratch = torch.empty((nw, nbytes), dtype=torch.uint8, device="cuda")
-        trace = torch.zeros((nw, 10, 2), dtype=torch.float64, device="cuda")
-        info = torch.zeros((nw, 2), dtype=torch.int32, device="cuda")
-        res = None
-        for rep in range(3):  # the last repetition counts (warm caches / clocks)
-            x = xd.clone()
-            L.check(ws.lib.vh_profile_begin(ws.handle, 80), "vh_profile_begin")
-            L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(x), nt, nc, nw, 10, L.dptr(trace), L.dptr(info),
-                                              L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
-            ms, n = (C.c_double * 16)(), (C.c_int * 16)()
-            L.check(ws.lib.vh_profile_end_stages(ws.handle, 16, ms, n), "vh_profile_end_stages")
-            res = {k: 1e3 * ms[i] / max(n[i], 1) for k, i in (("k_ba_jac", 8), ("k_ba_schur_mfma", 9), ("k_ba_reduce", 10), ("k_ba_solve_mfma", 11), ("k_ba_update", 12))}
-        return res
+    z, x0, nt, nc = synth.ba_pack(*first)
+    Kd = synth.K_1080P.astype(float)
+    cores = host_cores()
+    with contextlib.ExitStack() as stack:
+        try:
+            from threadpoolctl import threadpool_limits
 
-    try:
-        nwr = max(w for w in windows)
-        kus = profiled(nwr)
-        # launch shape of k_ba_schur_mfma (velocity_amd/csrc/vh_api.hip::vh_nls_batch_multi): nparts workgroups per window, each walks its chunk of tie
-        # points in groups of 4; a group = 27 v_mfma_f64_16x16x4_f64 (2048 flop each) on each of the 4 consumer wavefronts
-        parts = max(1, min(256, nt // 16))
-        cap = max(16, 512 // nwr)
-        nparts = cap if (nwr > 1 and parts > cap) else parts
-        chunk = -(-nt // nparts)
-        groups = sum(-(-max(0, min(nt, (b + 1) * chunk) - b * chunk) // 4) for b in range(nparts))
-        mfma = nwr * groups * 4 * 27
-        flop = mfma * 2048.0
-        t = kus["k_ba_schur_mfma"] * 1e-6
-        tf = flop / t / 1e12
-        m_meas = nt * nf
-        rows = [dict(kernel="k_ba_jac<true>", us=round(kus["k_ba_jac"], 2), alg_bytes=int(nwr * (m_meas * 20 * 8 + 2 * m_meas * 8 + 3 * nt * 8 + 9 * nt * 8)),
-                     note="writes the 20 Jacobian / residual planes (160 B per measurement), reads z and x"),
-                dict(kernel="k_ba_schur_mfma", us=round(kus["k_ba_schur_mfma"], 2), alg_bytes=int(nwr * (m_meas * 20 * 8 + 9 * nt * 8)),
-                     note="reads the planes + L, tp once"),
-                dict(kernel="k_ba_reduce", us=round(kus["k_ba_reduce"], 2), alg_bytes=int(nwr * nparts * (6 * nc) ** 2 * 8 * 0.56), note="upper-triangle tiles of the partial systems"),
-                dict(kernel="k_ba_solve_mfma", us=round(kus["k_ba_solve_mfma"], 2), alg_bytes=int(nwr * (6 * nc) * (6 * nc + 1) * 8),
-                     note="one workgroup per window: latency bound (29 dependent block-elimination rounds)"),
-                dict(kernel="k_ba_update", us=round(kus["k_ba_update"], 2), alg_bytes=int(nwr * (m_meas * 18 * 8 + 12 * nt * 8)), note="reads 18 of the 20 planes again, updates x")]
-        for r in rows:
-            r["hbm_gbs"] = round(r["alg_bytes"] / (r["us"] * 1e-6) / 1e9, 1) if r["us"] > 0 else None
-            r["hbm_frac"] = round(r["hbm_gbs"] / HBM_PEAK_GBS, 4) if r["hbm_gbs"] else None
-        busy, bsrc = None, None
-        import glob as _glob
-        for name in [os.path.basename(f) for f in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_ba_pmc.json")), reverse=True)]:
-            bp = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(bp):
-                try:
-                    bj = json.load(open(bp))
-                    busy = bj.get("kernels", bj).get("k_ba_schur_mfma", {}).get("mfma_busy_frac")
-                    bsrc = f"profiles/{name} (SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 2.4 GHz x 1024 SIMDs) of a rocprofv3 --pmc pass; not measured in this run)"
-                except Exception:
-                    pass
-                break
-        out["roofline"] = dict(bound="mfma", kernel=f"k_ba_schur_mfma ({nwr} windows per launch)", achieved=round(tf, 2), peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s",
-                               frac=round(tf / MFMA_F64_PEAK_TFLOPS, 4), us_per_launch=round(kus["k_ba_schur_mfma"], 2), mfma_instr_per_launch=int(mfma),
-                               flop_per_launch=flop, mfma_busy_frac_pmc=busy, mfma_busy_source=bsrc, windows=nwr, nparts_per_window=nparts,
-                               note="issued v_mfma_f64_16x16x4_f64 x 2048 flop / kernel time (HIP events inside the library) against the dense f64 matrix peak; f64 MFMA and "
-                                    "VALU instructions of co-resident wavefronts do not overlap on gfx950 (profiles/r02_mfma_overlap.json), so the producers' VALU time adds",
-                               kernels=rows, us_per_iteration_all_windows=round(sum(r["us"] for r in rows), 1))
-        k1 = profiled(1)
-        out["single_window_kernels_us"] = {k: round(v, 2) for k, v in k1.items()}
-    except Exception as e:  # the roofline leg must never take the BA numbers down with it
-        out["roofline"] = dict(error=f"{type(e).__name__}: {e}"[:300])
-    one = out["by_windows"]["1"]
-    out.update(iters_per_s=one["iters_per_s"], ms_per_iter=one["ms_per_window_iter"], rms_residual_first=one["rms_residual_first"],
-               rms_residual_last=one["rms_residual_last"])
-    if cpu_seconds > 0 and first is not None:
-        # the structured CPU restatement (oracle/nls_oracle.py::ba_schur_step: NumPy einsum / LAPACK on the host's cores): the dense
-        # reference path itself is infeasible at C5 (J^T alone 24 GB, ~10 min / iteration; BASELINE.md section 2)
-        from oracle import nls_oracle as NO
-
-        z, x0, _, _ = synth.ba_pack(*first)
-        Kd = K.astype(float)
-        cores = host_cores()
-        import contextlib
-
-        with contextlib.ExitStack() as stack:
-            try:
-                from threadpoolctl import threadpool_limits
-
-                stack.enter_context(threadpool_limits(limits=cores))
-            except ImportError:  # pragma: no cover
-                pass
-            NO.ba_schur_step(x0, z, Kd, nc, nt)  # warm-up (BLAS thread pool)
-            x, done, t0 = x0.copy(), 0, time.perf_counter()
-            while done < 10 and time.perf_counter() - t0 < cpu_seconds:
-                delta, f = NO.ba_schur_step(x, z, Kd, nc, nt)
-                x = x + delta
-                done += 1
-            dt = time.perf_counter() - t0
-        out["cpu_baseline"] = dict(value=round(done / dt, 3), unit="LM iterations/s", cores=cores, kind="port",
-                                   sample=f"{done} LM iterations of the same C5 window, structured (Schur) NumPy restatement, {dt:.1f} s; the dense "
-                                          "reference path (utils/NLS.py:228-235) is infeasible at this size")
-        out["gpu_over_cpu"] = round(one["iters_per_s"] / out["cpu_baseline"]["value"], 1)
-    return out
-
-
-def bench_ba_multi_gpu(rank, world, barrier, reduce_max, nt=5000, nf=20, windows_per_gpu=8):
-    """Config 5 on N GPUs, both ways: (a) replicas -- every rank solves its own `windows_per_gpu` independent
-    windows, no collective (the mode that scales: a sliding-window tracker has one window per stream); (b) ONE window with its tie
-    points sharded over the ranks and two all-reduces per LM iteration (Amdahl-limited by the replicated 114 x 114 solve)."""
-    from velocity_amd import _lib as L
-    from velocity_amd import dist as vdist
-    from velocity_amd import synth
-
-    K = synth.K_1080P
-    ws = L.workspace()
-    K64 = L.host_K(K)
-    nc, nw = nf - 1, windows_per_gpu
-    packs = [synth.ba_pack(*synth.ba_scene(nt, nf, seed=5 + rank * nw + w)) for w in range(nw)]
-    zd = L.to_dev(np.stack([p[0] for p in packs]), torch.float64)
-    x0d = L.to_dev(np.stack([p[1] for p in packs]), torch.float64)
-    nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
-    scratch = torch.empty((nw, nbytes), dtype=torch.uint8, device="cuda")
-    trace = torch.zeros((nw, 10, 2), dtype=torch.float64, device="cuda")
-    info = torch.zeros((nw, 2), dtype=torch.int32, device="cuda")
-    best = None
-    for _ in range(3):
-        xd = x0d.clone()
-        barrier()
-        t0 = time.perf_counter()
-        L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, nw, 10, L.dptr(trace), L.dptr(info),
-                                          L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
-        barrier()
-        dt = reduce_max(time.perf_counter() - t0)
-        best = dt if best is None else min(best, dt)
-    out = dict(workload=f"C5 BA: {nf} keyframes x {nt} tracks, 10 LM iterations per window",
-               replicas=dict(windows_per_gpu=nw, n_gpus=world, iters_per_s=round(world * nw * 10 / best, 1), collective="none"))
-    P, pw0, cw0 = synth.ba_scene(nt, nf, seed=5)
-    best = None
-    for _ in range(3):
-        barrier()
-        tm = {}
-        _cw, _pw, tr = vdist.fcnNLS_batch_sharded(K, P, pw0, cw0, timing=tm)
-        dt = reduce_max(tm["loop_ms"] * 1e-3)  # HIP events around the LM loop of every rank (phases + all-reduces), max over ranks
-        best = dt if best is None else min(best, dt)
-    out["point_sharded"] = dict(n_gpus=world, iters_per_s=round(len(tr) / best, 1), ms_per_iter=round(1e3 * best / len(tr), 4),
-                                collective="2 all-reduces per LM iteration (104 KB + 8 B)", rms_residual_last=round(float(tr[-1, 0]), 4),
-                                timing="HIP events around the LM iterations (host-side packing and the final point gather excluded)",
-                                note="Amdahl-limited by the replicated reduced-system solve")
-    return out
+            stack.enter_context(threadpool_limits(limits=cores))
+        except ImportError:  # pragma: no cover
+            pass
+        NO.ba_schur_step(x0, z, Kd, nc, nt)  # warm-up (BLAS thread pool)
+        x, done, t0 = x0.copy(), 0, time.perf_counter()
+        while done < 10 and time.perf_counter() - t0 < cpu_seconds:
+            delta, f = NO.ba_schur_step(x, z, Kd, nc, nt)
+            x = x + delta
+            done += 1
+        dt = time.perf_counter() - t0
+    out["cpu_baseline"] = dict(value=round(done / dt, 3), unit="LM iterations/s", cores=cores, kind="port",
+                               sample=f"{done} LM iterations of the same C5 window, structured (Schur) NumPy restatement, {dt:.1f} s; the dense "
+                                      "reference path (utils/NLS.py:228-235) is infeasible at this size")
+    out["gpu_over_cpu"] = round(out["iters_per_s"] / out["cpu_baseline"]["value"], 1)
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------
-# the tracker workload
+# parity attestation of a run that was just timed (OUTSIDE the timed region; oracle = the checker, never the product)
 # ----------------------------------------------------------------------------------------------------------------------------------
-class Workload:
-    """`streams` resident video streams of one config on this rank's GPU: sessions, frame rings, the step loop."""
+def _compare(st, o, ids0):
+    same = (np.array_equal(st["ids"], ids0[o.vg]) and np.array_equal(st["p"], o.p) and np.array_equal(st["vp"][ids0], o.vp)
+            and np.array_equal(st["vg"][ids0], o.vg))
+    dt = float(np.max(np.abs(st["t"] - o.t) / np.maximum(np.abs(o.t), 1e-3)))
+    dres = abs(st["res"] - o.residuals) / max(abs(o.residuals), 1e-12)
+    return bool(same), dt, dres
 
-    def __init__(self, a, cfg, params, scene, streams, steps, warmup, dev, rank, groups=1, host_frames=False):
-        from velocity_amd.driver import TrackerSession
 
-        self.a, self.cfg, self.S, self.N, self.W, self.H = a, cfg, streams, cfg["n"], cfg["w"], cfg["h"]
-        S, N, W, H = self.S, self.N, self.W, self.H
-        lvl = cfg["levels"] - 1 if params == "baseline" else 4
-        self.lkc, self.lkf = dict(max_level=lvl), (dict(max_count=a.fine_max_count) if getattr(a, "fine_max_count", 0) > 0 else dict())
-        if getattr(a, "coarse_max_count", 0) > 0:
-            self.lkc["max_count"] = a.coarse_max_count
-        self.params, self.scene, self.ring = params, scene, a.ring
-        nhist = min(warmup + steps + 3, 512)
-        # one texture set per `ring` streams, so no two resident streams ever work on the same pixels
-        nsets = 1 if host_frames else (S + a.ring - 1) // a.ring
-        self.K, self.motion, self.frames, self.p0 = make_ring(cfg, a.ring, dev, seed=0xC0FFEE + 7919 * rank, nsets=nsets, scene=scene)
-        if getattr(a, "track_order", "raster") == "shuffled":  # the order goodFeaturesToTrack gives (by corner response, i.e. spatially at random)
-            self.p0 = self.p0[np.random.default_rng(1234).permutation(N)]
-        self.p3 = self.motion.world_points(self.p0)
-        self.vp = np.ones(N, bool)  # every valid track takes part in the pose fit (the state after vidExample.py:160)
-        G = max(1, min(groups, S))
-        assert S % G == 0, "--streams must be a multiple of --groups"
-        self.G, self.SG = G, S // G
-        SG = self.SG
-        self.sessions = [TrackerSession(self.K, W, H, N, nhist=nhist, batch=SG, lk_coarse=self.lkc, lk_fine=self.lkf, msv_frame=0) for _ in range(G)]
-        self.hip_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(G - 1)]
-        # streams of one texture set share its ring but run at different phases, so every launch sees S different frame pairs
-        self.phase = [(7 * b) % a.ring for b in range(S)]
-        fset = [0 if host_frames else b // a.ring for b in range(S)]
-        self.fset = fset
-        if host_frames:
-            self.phase = [b % a.ring for b in range(S)]  # consecutive phases: one step's batch is a contiguous slice of the extended host ring
-        base_ptr, fbytes = self.frames.data_ptr(), W * H
-        for b in range(S):
-            self.sessions[b // SG].init_stream(b % SG, self.frames[fset[b] * a.ring + self.phase[b]],
-                                               self.motion.apply(self.phase[b], self.p0.astype(float)).astype(np.float32),
-                                               self.p3 + self.motion.t(self.phase[b]), self.vp, np.float32([0, 0, 0]))
-        tables = torch.empty((a.ring, S), dtype=torch.int64)
-        for k in range(a.ring):
-            for b in range(S):
-                tables[k, b] = base_ptr + (fset[b] * a.ring + (self.phase[b] + k) % a.ring) * fbytes
-        self.tables = tables.to(dev)
-        self.feeder = None
-        if host_frames:
-            from velocity_amd.driver import HostFrameFeeder
+def verify(wl, first, nframes=4, which=None):
+    """The state of a few resident streams is handed to the CPU oracle (oracle/session_oracle.py), the whole session advances `nframes` more frames
+    through the very launch sequence that was timed (all streams, same kernel routes), and the chosen streams are compared frame by frame: track
+    positions, validity masks and track ids bit for bit, pose and residual to 1e-5."""
+    from oracle.session_oracle import SessionOracle
 
-            assert G == 1, "--host-frames is measured with one session group"
-            self.feeder = HostFrameFeeder(S, H, W, depth=3)
-            reps = (S + a.ring - 1) // a.ring + 1
-            self.host_ring = torch.cat([self.frames[: a.ring].cpu()] * reps, 0)[: a.ring + S].contiguous().pin_memory()  # the decoder's pinned output
+    if wl.feeder is not None:
+        return dict(skipped="host-frames mode")
+    which = sorted(set(which if which is not None else [0, wl.S - 1]))
+    a, SG = wl.a, wl.SG
+
+    def frame_of(b, i):
+        return wl.frames[wl.fset[b] * a.ring + (wl.phase[b] + i) % a.ring]
+
+    torch.cuda.synchronize()
+    orcs, ids0 = {}, {}
+    for b in which:
+        st = wl.sessions[b // SG].state(b % SG)
+        vg = st["vg"]
+        ids0[b] = np.nonzero(vg)[0]
+        orcs[b] = SessionOracle(wl.K, frame_of(b, first - 1).cpu().numpy(), st["p"], st["p3"][vg], st["vp"][vg], st["B"][0, 0:3], nhist=nframes + 2,
+                                lk_coarse=wl.lkc, lk_fine=wl.lkf, msv_frame=0)
+    ok, worst_t, worst_res, tracks = True, 0.0, 0.0, {}
+    for k in range(nframes):
+        i = first + k
+        wl.run(i, 1)
         torch.cuda.synchronize()
-
-    def run(self, first, count, ex=None):
-        from velocity_amd import _lib as L
-
-        a, G, SG = self.a, self.G, self.SG
-        for i in range(first, first + count):
-            if self.feeder is not None:
-                k = i % a.ring
-                s_ = self.feeder.put(self.host_ring[k : k + self.S])  # stream b <- frame (b + i) % ring, straight from pinned memory
-                self.sessions[0].step(frames_table=self.feeder.get(s_), time_s=i / 30.0, frame_no=i)
-                self.feeder.after_step(s_)
-                continue
-            row = self.tables[i % a.ring]
-            for g in range(G):
-                with torch.cuda.stream(self.hip_streams[g]):
-                    self.sessions[g].step(frames_table=row[g * SG:(g + 1) * SG], time_s=i / 30.0, frame_no=i)
-            if ex is not None and ex.due(i):
-                ex.wait()  # stream ordered under RCCL: the previous gather has read `local` before the packs below overwrite it
-                for g in range(G):
-                    with torch.cuda.stream(self.hip_streams[g]):
-                        L.check(self.sessions[g].lib.vh_session_pack_state(self.sessions[g].handle, L.dptr(ex.local[g * SG:(g + 1) * SG]), L.stream_ptr()),
-                                "vh_session_pack_state")
-                for g in range(1, G):  # side streams: the collective is issued from the current stream, which must see their packs
-                    self.hip_streams[0].wait_stream(self.hip_streams[g])
-                ex.start()  # no host synchronisation: the collective waits for the current stream itself (dist.TrackStateExchange.start)
-
-    def measure(self, steps, warmup, min_seconds, barrier, reduce_max, ex=None):
-        """W warm-up steps, then EXACTLY `steps` timed steps between barrier + synchronize; if that took less than min_seconds, further
-        blocks of `steps` steps are timed the same way (all ranks agree on the count) and `value` is computed over all timed steps."""
-        from velocity_amd import _lib as L
-
-        ses = self.sessions[0]
-        self.run(1, warmup, ex)
-        barrier()
-        # every stage is timed when the launches are long (many tracks in flight); a latency run (few streams) times its three LK launches only -- an event
-        # record between two 5 us kernels is not free
-        L.check(ses.lib.vh_profile_detail(ses.ws.handle, 1 if self.N * self.SG >= 3000 else 0), "vh_profile_detail")
-        L.check(ses.lib.vh_profile_begin(ses.ws.handle, 32 * steps + 32), "vh_profile_begin")
-        barrier()
-        t0 = time.perf_counter()
-        self.run(1 + warmup, steps, ex)
-        if ex is not None:
-            ex.wait()
-        barrier()
-        elapsed = reduce_max(time.perf_counter() - t0)
-        prof = dict(ms_sum=(C.c_double * 3)(), launches=(C.c_int * 3)(), iters=(C.c_ulonglong * 3)(), setups=(C.c_ulonglong * 3)())
-        L.check(ses.lib.vh_profile_end(ses.ws.handle, prof["ms_sum"], prof["launches"], prof["iters"], prof["setups"]), "vh_profile_end")
-        stage_ms, stage_n = (C.c_double * 16)(), (C.c_int * 16)()
-        L.check(ses.lib.vh_profile_end_stages(ses.ws.handle, 16, stage_ms, stage_n), "vh_profile_end_stages")
-        rois = np.zeros((self.SG, 4), np.int32)
-        L.check(ses.lib.vh_klt_rois(ses.ws.handle, rois.ctypes.data_as(L.i32p)), "vh_klt_rois")
-        timed, blocks = steps, 1
-        if min_seconds > 0 and elapsed < min_seconds:
-            more = int(math.ceil((min_seconds - elapsed) / max(elapsed, 1e-6)))
-            barrier()
-            t0 = time.perf_counter()
-            self.run(1 + warmup + steps, more * steps, ex)
-            if ex is not None:
-                ex.wait()
-            barrier()
-            elapsed += reduce_max(time.perf_counter() - t0)
-            timed += more * steps
-            blocks += more
-        st = ses.state(0)
-        done = warmup + timed
-        self.done_steps = done
-        truth = self.motion.t((self.phase[0] + done) % self.ring) - self.motion.t(self.phase[0])
-        return dict(elapsed=elapsed, timed_steps=timed, blocks=blocks, prof=prof, st=st, alive=st["n_cur"] / self.N, truth=truth,
-                    stage_ms=list(stage_ms), stage_n=list(stage_n), rois=rois)
-
-    def verify(self, first, nframes=4, which=None):
-        """Parity attestation of the run that was just timed (OUTSIDE the timed region): the state of a few resident streams is handed to the
-        CPU oracle (oracle/session_oracle.py -- the checker, never the product), the whole session advances `nframes` more frames through the very
-        launch sequence that was timed (all streams, same kernel routes), and the chosen streams are compared frame by frame: track positions,
-        validity masks and track ids bit for bit, pose and residual to 1e-5."""
-        from oracle.session_oracle import SessionOracle
-
-        if self.feeder is not None:
-            return dict(skipped="host-frames mode")
-        which = sorted(set(which if which is not None else [0, self.S - 1]))
-        a, SG = self.a, self.SG
-
-        def frame_of(b, i):
-            return self.frames[self.fset[b] * a.ring + (self.phase[b] + i) % a.ring]
-
-        torch.cuda.synchronize()
-        orcs, ids0 = {}, {}
         for b in which:
-            st = self.sessions[b // SG].state(b % SG)
-            vg = st["vg"]
-            ids0[b] = np.nonzero(vg)[0]
-            orcs[b] = SessionOracle(self.K, frame_of(b, first - 1).cpu().numpy(), st["p"], st["p3"][vg], st["vp"][vg], st["B"][0, 0:3], nhist=nframes + 2,
-                                    lk_coarse=self.lkc, lk_fine=self.lkf, msv_frame=0)
-        ok, worst_t, worst_res, tracks = True, 0.0, 0.0, {}
-        for k in range(nframes):
-            i = first + k
-            self.run(i, 1)
-            torch.cuda.synchronize()
-            for b in which:
-                o = orcs[b]
-                o.step(frame_of(b, i).cpu().numpy(), np.float32(i / 30.0), i)
-                st = self.sessions[b // SG].state(b % SG)
-                same = (np.array_equal(st["ids"], ids0[b][o.vg]) and np.array_equal(st["p"], o.p) and np.array_equal(st["vp"][ids0[b]], o.vp)
-                        and np.array_equal(st["vg"][ids0[b]], o.vg))
-                ok = ok and bool(same)
-                worst_t = max(worst_t, float(np.max(np.abs(st["t"] - o.t) / np.maximum(np.abs(o.t), 1e-3))))
-                worst_res = max(worst_res, abs(st["res"] - o.residuals) / max(abs(o.residuals), 1e-12))
-                tracks[str(b)] = int(st["n_cur"])
-        return dict(streams=which, frames=nframes, bit_exact=ok, pose_within_1e5=bool(worst_t <= 1e-5 and worst_res <= 1e-5),
-                    max_rel_pose_t=float(f"{worst_t:.3g}"), max_rel_residual=float(f"{worst_res:.3g}"), tracks_compared=tracks,
-                    what="after the timed region: these resident streams vs oracle/session_oracle.py (C KLT + NumPy NLS) over further frames of the same "
-                         "launch sequence (all streams stepping); p / vg / vp / ids bit-exact, pose t and rms residual relative error")
-
-    def close(self):
-        torch.cuda.synchronize()
-        self.sessions, self.frames, self.tables, self.feeder = [], None, None, None
-        torch.cuda.empty_cache()
+            o = orcs[b]
+            o.step(frame_of(b, i).cpu().numpy(), np.float32(i / 30.0), i)
+            st = wl.sessions[b // SG].state(b % SG)
+            same, dt, dres = _compare(st, o, ids0[b])
+            ok, worst_t, worst_res = ok and same, max(worst_t, dt), max(worst_res, dres)
+            tracks[str(b)] = int(st["n_cur"])
+    return dict(streams=which, frames=nframes, bit_exact=ok, pose_within_1e5=bool(worst_t <= 1e-5 and worst_res <= 1e-5),
+                max_rel_pose_t=float(f"{worst_t:.3g}"), max_rel_residual=float(f"{worst_res:.3g}"), tracks_compared=tracks,
+                what="after the timed region: these resident streams vs oracle/session_oracle.py (C KLT + NumPy NLS) over further frames of the same "
+                     "launch sequence (all streams stepping); p / vg / vp / ids bit-exact, pose t and rms residual relative error")
 
 
-MFMA_F64_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: dense f64 matrix peak (v_mfma_f64_16x16x4_f64: 2048 flop / 64 cycles / SIMD)
+def verify_episode(wl, nframes=3, which=None):
+    """Episode workloads: one MORE episode of all streams (same launch sequence, same routes), a few streams against the oracle from the clip's frame 0:
+    p / vg / vp / ids bit for bit at every frame (tracks die on the gates inside the clip), pose and residual to 1e-5."""
+    from oracle.session_oracle import SessionOracle
 
+    which = sorted(set(which if which is not None else [0, wl.S - 1]))
+    e = getattr(wl, "episodes_done", 1)
+    nframes = min(nframes, wl.E)
+    orcs = {}
+    for b in which:
+        f = wl.start_index(b, e) if wl.kind == "hard_scene" else 0
+        orcs[b] = SessionOracle(wl.K, wl.frames[wl.frame_index(b, e, 0)].cpu().numpy(), wl.p_ring[f].cpu().numpy(), wl.p3_ring[f].cpu().numpy(),
+                                wl.vp.cpu().numpy().astype(bool), wl.t0, time0=np.float32(wl.time_of(0)), res0=getattr(wl, "res0", 0.0), nhist=wl.E + 2,
+                                lk_coarse=wl.lkc, lk_fine=wl.lkf, msv_frame=wl.msv_frame)
+    res = dict(ok=True, t=0.0, r=0.0, tracks={})
+    ids0 = np.arange(wl.N)
 
-def lk_valu_model():
-    """Wave instructions the fine-stage kernel issues as a function of its in-kernel counters (template set-ups, Newton iterations), fitted
-    against rocprofv3 SQ_INSTS_VALU passes at different iteration counts (tools/pmc_lk_calib.sh -> profiles/rNN_lk_valu_model.json, which also holds
-    the check run and the tolerance; tools/collect_profiles.sh re-fits it first, so a profile set and its model belong to the same kernel build).
-    The newest round's file is used.  Returns None when there is none."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_lk_valu_model.json")))
-    if not files:
-        return None
-    rel = os.path.relpath(files[-1], ROOT)
-    try:
-        j = json.load(open(files[-1]))
-        return dict(per_setup=float(j["wave_instr_per_setup"]), per_iter=float(j["wave_instr_per_newton_iter"]), tolerance=float(j["tolerance"]),
-                    kernel=j["kernel"], source=f"{rel} (tools/pmc_lk_calib.sh: SQ_INSTS_VALU fitted over runs with different iteration counts)",
-                    coarse=j.get("coarse"))
-    except Exception:
-        return None
-
-
-def coarse_kernel_name(tracks):
-    """routing of vh_launch_lk for the 15x15 window (velocity_amd/csrc/vh_lk.hip)"""
-    return "k_lk_o<15>" if tracks >= 30000 else ("k_lk_q<15>" if tracks >= 3000 else "k_lk_strip<15>")
-
-
-def valu_rates():
-    """opcode -> measured lanes / clk / SIMD (best over 1-4 waves per SIMD, 16 independent chains), from the newest profiles/rNN_valu_rate.json"""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_valu_rate.json")))
-    if not files:
-        return {}, None
-    best = {}
-    for r in json.load(open(files[-1]))["results"]:
-        if r["chains"] > 1:
-            k = r["inst"]
-            best[k] = max(best.get(k, 0.0), r["lanes_per_ns_per_simd"] / CLOCK_GHZ)
-    return best, os.path.relpath(files[-1], ROOT)
-
-
-_RATE_ALIAS = {  # ISA spelling (tools/isa_mix.py) -> name in the micro-benchmark
-    "v_dot2c_i32_i16": "v_dot2c_i32_i16 (VOP2)", "v_dot2c_i32_i16_dpp": "v_dot2c_i32_i16 row_shl:1 (DPP)", "v_add_u32_dpp": "v_add_u32 row_shr:1 (DPP)",
-    "v_sub_u32_dpp": "v_add_u32 row_shr:1 (DPP)", "v_mov_b32_dpp": "v_mov_b32 row_shr:1 (DPP)", "v_mul_i32_i24_sdwa": "v_mul_i32_i24 (SDWA)",
-    "v_subrev_u32": "v_sub_u32", "v_cndmask_b32": "v_cmp_lt_i32 + v_cndmask_b32 (pair)", "v_cmp_lt_i32": "v_cmp_lt_i32 + v_cndmask_b32 (pair)",
-    "v_cmp_gt_i32": "v_cmp_lt_i32 + v_cndmask_b32 (pair)", "v_cmp_le_i32": "v_cmp_lt_i32 + v_cndmask_b32 (pair)", "v_cmp_ge_i32": "v_cmp_lt_i32 + v_cndmask_b32 (pair)",
-    "v_readlane_b32": "v_readlane_b32 + v_writelane_b32 (pair)", "v_writelane_b32": "v_readlane_b32 + v_writelane_b32 (pair)", "v_pk_add_u16": "v_pk_add_u16",
-    "v_pk_mad_u16": "v_pk_mad_u16", "v_pk_sub_i16": "v_pk_sub_i16", "v_fmac_f64": "v_fma_f64", "v_pk_mul_f32": "v_pk_fma_f32", "v_pk_add_f32": "v_pk_fma_f32",
-    "v_fmac_f32": "v_fma_f32", "v_mul_lo_u32": "v_mul_lo_u32", "v_min_i32": "v_min_i32", "v_max_i32": "v_max_i32"}
-
-
-def valu_mix(kernel, setups, iters, per_setup=None, per_iter=None):
-    """Instruction mix of one launch of an LK kernel: the static opcode histograms of its set-up and Newton-iteration blocks (profiles/rNN_lk_isa_mix.json,
-    tools/isa_mix.py) weighted by the LIVE set-up / iteration counters (x the fitted wave instructions per set-up / iteration when a PMC fit exists,
-    else the static block sizes), every opcode priced with its measured issue rate (profiles/rNN_valu_rate.json).  Returns None without the files."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_lk_isa_mix.json")))
-    rates, rsrc = valu_rates()
-    if not files or not rates:
-        return None
-    k = json.load(open(files[-1]))["kernels"].get(kernel.replace(" ", ""))
-    if not k:
-        return None
-    hs, hi = k["setup"]["opcodes"], k["iteration"]["opcodes"]
-    ns, ni = float(sum(hs.values())), float(sum(hi.values()))
-    ws = (per_setup if per_setup else ns / (2 if kernel.startswith(("k_lk_o", "k_lk_q")) else 1)) * setups  # (the coarse kernels inline both directions: two static copies)
-    wi = (per_iter if per_iter else ni / (2 if kernel.startswith(("k_lk_o", "k_lk_q")) else 1)) * iters
-    tot = ws + wi
-    if tot <= 0:
-        return None
-    frac = {}
-    for h, n, w in ((hs, ns, ws), (hi, ni, wi)):
-        for op, c in h.items():
-            frac[op] = frac.get(op, 0.0) + (c / n) * (w / tot)
-    cls = dict(full_rate=0.0, half_rate=0.0, slow=0.0, unmeasured=0.0)
-    cyc, per_op = 0.0, []
-    for op, f in frac.items():
-        r = rates.get(_RATE_ALIAS.get(op, op))
-        if r is None:
-            cls["unmeasured"] += f
-            r_eff = 16.0  # priced like the half-rate class
-        else:
-            cls["full_rate" if r >= 20.0 else ("half_rate" if r >= 12.0 else "slow")] += f
-            # the measurement CLASSIFIES the opcode; the ceiling uses the class's architectural issue rate (a wave64 instruction occupies its SIMD for 2 or
-            # 4 cycles = 32 / 16 lanes per clock: the single-opcode loops of the micro-benchmark sustain 23-27 / 13.9-14.5 of it, and a kernel that mixes
-            # opcodes and wavefronts can -- and round 4's does -- issue faster than they did), slow opcodes (f64, lane moves) their measured rate
-            r_eff = 32.0 if r >= 20.0 else (16.0 if r >= 12.0 else r)
-        cyc += f / r_eff
-        per_op.append((f / r_eff, op, f, r))
-    per_op.sort(reverse=True)
-    return dict(full_rate_frac=round(cls["full_rate"], 4), half_rate_frac=round(cls["half_rate"], 4), slow_frac=round(cls["slow"], 4), unmeasured_frac=round(cls["unmeasured"], 4),
-                classes="full: measured >= 20 lanes/clk/SIMD (v_add_u32, v_sub_u32, v_and_b32, v_ashrrev_i32, f32 add / mul / fma ...); half: 12-20 (v_dot2*, v_perm, v_mad_i32_i24, "
-                        "v_lshl_add, v_pk_*, DPP ...); slow: < 12 (f64, v_cndmask pairs, lane moves); unmeasured opcodes are priced like the half-rate class",
-                mix_ceiling_lanes_per_clk_per_simd=round(1.0 / cyc, 2),
-                top5_by_issue_cycles=[dict(opcode=op, share_of_instructions=round(f, 4), share_of_issue_cycles=round(c / cyc, 4), lanes_per_clk=(round(r, 1) if r else None))
-                                      for c, op, f, r in per_op[:5]],
-                setup_share_of_instructions=round(ws / tot, 4),
-                source=f"{os.path.relpath(files[-1], ROOT)} (tools/isa_mix.py: static hot-path opcode histograms) x this run's set-up / iteration counters; rates from {rsrc}")
-
-
-def roofline_of(wl, m, world):
-    """roofline object: the dominant kernel (fine-stage LK launch) priced against the bound that really limits it -- VALU instruction issue -- with its
-    HBM figure next to it, and one row per other kernel family of the step (time from HIP events inside the library, algorithmic bytes, HBM fraction).
-    Everything in it is recomputable from the fields it carries."""
-    from velocity_amd import _lib as L
-
-    N, SG, cfg = wl.N, wl.SG, wl.cfg
-    prof = m["prof"]
-    ms_sum, launches, iters, setups = prof["ms_sum"], prof["launches"], prof["iters"], prof["setups"]
-    st_ms, st_n = m["stage_ms"], m["stage_n"]
-    wf, wc = 51, 15
-    us_fine = 1e3 * ms_sum[2] / max(launches[2], 1)
-    # algorithmic gather bytes per launch of session group 0 (SG streams): SURVEY §8d, KLT track solve row: 2 N L [(w+2)^2 + (w+1)^2], L = 1
-    bytes_fine = 2 * N * SG * 1 * ((wf + 2) ** 2 + (wf + 1) ** 2)
-    achieved = bytes_fine / (us_fine * 1e-6) / 1e9 if us_fine > 0 else 0.0
-    it_f = iters[2] / max(launches[2], 1)
-    su_f = setups[2] / max(launches[2], 1)
-    ops_fine = wf * wf * (47.0 * su_f + 12.0 * it_f)  # SURVEY §8d op model: 47 op/px set-up, 12 op/px per Newton iteration
-    # routing of vh_launch_lk (wavefronts per 51x51 track by the number of tracks in flight)
-    fine_kernel = "k_lk3<51, 1, 4>" if N * SG >= 3000 else ("k_lk3<51, 2, 4>" if N * SG >= 1024 else "k_lk3<51, 4, 4>")
-    # HBM bytes of that kernel are NOT measured by this run: they come from the PMC passes committed under profiles/ (collected at the stream count
-    # stored in the file, scaled linearly); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    traffic, sq_util, tsrc = None, None, None
-    import glob as _glob
-    for name in [os.path.basename(f) for f in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")), reverse=True)]:
-        tpath = os.path.join(ROOT, "profiles", name)
-        if cfg is CONFIGS["c2"] and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            k = tj.get(fine_kernel)
-            if k is not None:
-                traffic = int((2 * k["fetch_kib"] + k["write_kib"]) * 1024 * SG / tj["streams"])
-            sq_util = tj.get("sq_valu_issue_utilisation", {}).get(fine_kernel)
-            tsrc = f"profiles/{name} (rocprofv3 --pmc pass of an earlier run, scaled to {SG} streams; not measured in this run)"
-            break
-    peak_tops, lanes, peak_src = valu_peak()
-    model_tops = ops_fine / (us_fine * 1e-6) / 1e12 if us_fine > 0 else 0.0
-    # VALU instructions issued per launch: LIVE from this run's in-kernel counters through the calibrated per-set-up / per-iteration costs
-    issued, isrc, tol = None, None, None
-    vm = lk_valu_model()
-    if vm is not None and vm["kernel"] == fine_kernel:
-        issued = 64.0 * (vm["per_setup"] * su_f + vm["per_iter"] * it_f)
-        isrc, tol = f"64 lanes x ({vm['per_setup']:.1f} x set-ups + {vm['per_iter']:.1f} x Newton iterations) per launch, counters of THIS run; costs from {vm['source']}", vm["tolerance"]
-    else:
-        ppath = os.path.join(ROOT, "profiles", "r02_lk_sq_pmc.json")
-        if cfg is CONFIGS["c2"] and wl.params == "baseline" and os.path.exists(ppath):
-            pj = json.load(open(ppath))
-            k = pj.get("kernels", {}).get(fine_kernel)
-            if k and pj.get("streams"):
-                issued = 64.0 * k["SQ_INSTS_VALU"] * SG / pj["streams"]
-                sq_util = k.get("valu_issue_utilisation", sq_util)
-                isrc = f"profiles/r02_lk_sq_pmc.json (SQ_INSTS_VALU x 64 lanes of a rocprofv3 --pmc pass at {pj['streams']} streams, scaled to {SG}; not live)"
-    issued_tops = issued / (us_fine * 1e-6) / 1e12 if issued and us_fine > 0 else None
-    abs_peak = N_SIMD * 32 * CLOCK_GHZ * 1e9 / 1e12  # the guide's SIMD-32 figure: 32 lanes / clk / SIMD, the rate only the full-rate opcodes approach
-    mix = valu_mix(fine_kernel, su_f, it_f, vm["per_setup"] if vm and vm["kernel"] == fine_kernel else None, vm["per_iter"] if vm and vm["kernel"] == fine_kernel else None)
-
-    # ---- the other kernel families of a step: live HIP-event time + algorithmic bytes (ROI sizes read back from the device after the run) ----
-    def us(stage):
-        return 1e3 * st_ms[stage] / max(st_n[stage], 1) if st_n[stage] else None
-
-    steps_prof = max(launches[2], 1)
-    roi = m["rois"]  # [SG, 4] x0 x1 y0 y1 of the last frame
-    rw, rh = (roi[:, 1] - roi[:, 0]).astype(float), (roi[:, 3] - roi[:, 2]).astype(float)
-    roi_px = float((rw * rh).sum())
-    lc = cfg["levels"] - 1 if wl.params == "baseline" else 4
-    sw, sh = round(cfg["w"] * 0.25), round(cfg["h"] * 0.25)
-    rows = []
-
-    def row(kernel, stage, alg_bytes, per_step_launches, note):
-        t = us(stage)
-        if t is None:
+    def check(j):
+        if j > nframes:
             return
-        t_step = t * st_n[stage] / steps_prof  # stage time per step (a stage can launch more than once per step)
-        gbs = alg_bytes / (t_step * 1e-6) / 1e9 if t_step > 0 else 0.0
-        rows.append(dict(kernel=kernel, us_per_step=round(t_step, 2), launches_per_step=round(st_n[stage] / steps_prof, 2), alg_bytes_per_step=int(alg_bytes),
-                         hbm_gbs=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4), bytes=note))
+        for b in which:
+            o = orcs[b]
+            with np.errstate(all="ignore"):
+                o.step(wl.frames[wl.frame_index(b, e, j)].cpu().numpy(), np.float32(wl.time_of(j)), j)
+            st = wl.session.state(b)
+            same, dt, dres = _compare(st, o, ids0)
+            res["ok"] = res["ok"] and same
+            if o.vp.sum() >= 3:
+                res["t"], res["r"] = max(res["t"], dt), max(res["r"], dres)
+            res["tracks"][str(b)] = res["tracks"].get(str(b), []) + [int(st["n_cur"])]
 
-    gather_c = 2 * N * SG * (lc + 1) * ((wc + 2) ** 2 + (wc + 1) ** 2)
-    ck = coarse_kernel_name(N * SG)
-    cm = (vm or {}).get("coarse") if vm else None
-    for stg, nm in ((0, ck + " (stage 1: quarter-scale image)"), (1, ck + " (stage 2: ROI)")):
-        t = 1e3 * ms_sum[stg] / max(launches[stg], 1)
-        r_ = dict(kernel=nm, us_per_step=round(t, 2), launches_per_step=1.0, alg_bytes_per_step=int(gather_c),
-                  hbm_gbs=round(gather_c / (t * 1e-6) / 1e9, 1) if t > 0 else None, hbm_frac=round(gather_c / (t * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if t > 0 else None,
-                  bytes="2 N L [(w+2)^2 + (w+1)^2] gather bytes, w = 15, L = pyramid levels; VALU bound like the fine stage")
-        su_c, it_c = setups[stg] / max(launches[stg], 1), iters[stg] / max(launches[stg], 1)
-        r_["setups_per_launch"], r_["newton_iters_per_launch"] = int(su_c), int(it_c)
-        if cm and cm.get("kernel") == ck and t > 0:
-            # LIVE: this run's in-kernel counters through the fitted per-set-up / per-iteration wave-instruction costs (per TRACK counters: the idle lanes of
-            # a wavefront whose tracks need different iteration counts are inside the fitted per-iteration cost)
-            lane_instr = 64.0 * (cm["wave_instr_per_setup"] * su_c + cm["wave_instr_per_newton_iter"] * it_c)
-            r_["valu_frac"] = round(lane_instr / (t * 1e-6) / 1e12 / peak_tops, 4)
-            r_["valu_frac_abs"] = round(lane_instr / (t * 1e-6) / 1e12 / (N_SIMD * 32 * CLOCK_GHZ * 1e9 / 1e12), 4)
-            r_["issued_ginstr_per_launch"] = round(lane_instr / 1e9, 3)
-            r_["valu_source"] = f"64 lanes x ({cm['wave_instr_per_setup']:.1f} x set-ups + {cm['wave_instr_per_newton_iter']:.1f} x Newton iterations), counters of THIS run; costs fitted by tools/pmc_lk_calib.sh (tolerance {cm.get('tolerance')})"
-            r_["mix"] = valu_mix(ck, su_c, it_c, cm["wave_instr_per_setup"], cm["wave_instr_per_newton_iter"])
-        rows.append(r_)
-    row("k_roi_warp (stage 3: float32 affine map + 5-bit bilinear remap of the ROI)", 3, 2.0 * roi_px, 1, "ROI read + ROI written (sum over the streams' ROIs of the last frame)")
-    pyr_bytes = SG * sw * sh * sum(4.0 ** -l * 1.25 for l in range(lc)) + 2.0 * roi_px * sum(4.0 ** -l * 1.25 for l in range(lc))
-    row("k_pyr_down + k_pyr_pad (quarter-scale pyramid of the new frame; ROI pyramids of both frames)", 4, pyr_bytes, 2 * lc,
-        "level l reads 4^-l and writes 4^-(l+1) of its image: new quarter-scale frame + the two ROI crops")
-    row("k_ransac_fused (2 x estimateAffine2D)", 5, 2 * 2 * 16.0 * N * SG, 2, "pairs read once per call (16 B each): latency / VALU bound, the byte figure is nominal")
-    row("k_resize_quarter", 6, SG * (cfg["w"] * cfg["h"] / 16.0) * 2, 1, "1/16 of the pixels read, as many written")
-    row("k_sess_frame (bookkeeping + fused LM pose + records)", 7, SG * N * (8 + 24 + 2 + 4) * 1.0, 1, "track state read (p, p3, masks, ids): latency bound (all LM iterations in one workgroup)")
-    accounted = us_fine + sum(r["us_per_step"] for r in rows)
-    hbm = dict(achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), alg_bytes_per_launch=bytes_fine,
-               traffic=traffic, traffic_source=tsrc, note="algorithmic gather bytes 2 N [(51+2)^2 + (51+1)^2] per stream over the launch time: far below the HBM roof, the kernel is not memory bound")
-    out = dict(bound="valu", kernel=fine_kernel + " (fine stage: 51x51 window, level 0, fwd+bwd)",
-               achieved=round(issued_tops, 3) if issued_tops else None, peak=round(peak_tops, 1), unit="T lane-instr/s",
-               frac=round(issued_tops / peak_tops, 4) if issued_tops else None,
-               frac_abs=round(issued_tops / abs_peak, 4) if issued_tops else None, peak_abs=round(abs_peak, 1),
-               frac_of_mix_ceiling=(round(issued_tops / (N_SIMD * mix["mix_ceiling_lanes_per_clk_per_simd"] * CLOCK_GHZ * 1e9 / 1e12), 4) if issued_tops and mix else None),
-               mix=mix, us_per_launch=round(us_fine, 2),
-               issued_ginstr_per_launch=round(issued / 1e9, 3) if issued else None, issued_source=isrc, issued_model_tolerance=tol,
-               setups_per_launch=int(su_f), newton_iters_per_launch=int(it_f),
-               peak_lanes_per_clk_per_simd=lanes, peak_source=peak_src, simds=N_SIMD, clock_ghz=CLOCK_GHZ,
-               note="track solve is VALU-issue bound (SURVEY §8d): frac = issued lane-instructions / launch time / (1024 SIMDs x 16 lanes x 2.4 GHz), the issue rate of "
-                    "the half-rate opcode class the kernel is made of (mix.half_rate_frac); frac_abs prices the same lane-instructions against 32 lanes / clk / SIMD "
-                    "(MI355X_MICROARCH.md: SIMD-32, 2-cycle wave64 issue), which only the full-rate class approaches (measured 23-27); frac_of_mix_ceiling against the "
-                    "rate a perfect scheduler would reach with THIS opcode mix (opcodes classified by the micro-benchmark, priced at their class's architectural issue rate: 32 / 16 lanes per clock)",
-               # the contract's HBM view of the same kernel (secondary: achieved GB/s of its algorithmic bytes, PMC traffic)
-               hbm=hbm, traffic=traffic,
-               op_model=dict(gops_per_launch=round(ops_fine / 1e9, 4), tops=round(model_tops, 3),
-                             note="SURVEY §8d counts 47 op/px per set-up and 12 op/px per Newton iteration for a straightforward kernel; this kernel issues fewer "
-                                  "instructions for the same integers (packed int16 dot products), so the op model may exceed the issue peak -- frac prices issued instructions"),
-               newton_iters_per_track_dir=round(it_f / (2 * N * SG), 2), sq_valu_issue_utilisation=sq_util,
-               lk_us_per_launch=[round(1e3 * ms_sum[k] / max(launches[k], 1), 2) for k in range(3)],
-               lk_newton_iters_per_setup=[round(iters[k] / max(setups[k], 1), 2) for k in range(3)],
-               lk_setups_per_track=[round(setups[k] / max(launches[k], 1) / (N * SG), 2) for k in range(3)],
-               kernels=rows, step_us_accounted=round(accounted, 1), roi_mean_px=[round(float(rw.mean()), 1), round(float(rh.mean()), 1)])
-    return out
+    wl.run_episode(e, sync_each=check)
+    return dict(streams=which, frames=nframes, bit_exact=res["ok"], pose_within_1e5=bool(res["t"] <= 1e-5 and res["r"] <= 1e-5),
+                max_rel_pose_t=float(f"{res['t']:.3g}"), max_rel_residual=float(f"{res['r']:.3g}"), tracks_alive_by_frame=res["tracks"],
+                what="one more episode of all streams after the timed ones; these streams vs oracle/session_oracle.py from frame 0 of the clip: p / vg / vp / "
+                     "ids bit-exact at every frame, pose t and rms residual relative error")
 
 
-def headline_hbm(cfg, fps):
-    """SURVEY §8d 'Headline KLT number': (B_img + 21 N) bytes per tracked frame x frames/s against the HBM peak."""
-    L_ = cfg["levels"]
-    b_img = cfg["w"] * cfg["h"] * (1.0 + 2.0 * sum(4.0 ** -l for l in range(1, L_)))
-    per_frame = b_img + 21.0 * cfg["n"]
-    gbs = per_frame * fps / 1e9
-    return dict(bytes_per_frame=int(per_frame), achieved_gbs=round(gbs, 2), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 5),
-                note="image-stage algorithmic bytes only: the step is VALU / latency bound, nowhere near HBM bound (as SURVEY §8d predicted)")
+# ----------------------------------------------------------------------------------------------------------------------------------
+# extra legs
+# ----------------------------------------------------------------------------------------------------------------------------------
+def _kernel_table(r):
+    """Compact per-kernel microseconds of a step from a roofline object."""
+    t = {r["lk_kernels"][2] + " (fine)": r["us_per_launch"]}
+    for k in r["kernels"]:
+        t[k["kernel"].split(" (")[0] + (" (" + k["kernel"].split(" (")[1].split(":")[0] + ")" if k["kernel"].startswith("k_lk") else "")] = k["us_per_step"]
+    return t
 
 
 def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev, track_order=None):
@@ -831,14 +302,73 @@ def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev, track_orde
         out = dict(workload=f"{cfg_key} / params {params} / scene {scene}" + (f" / tracks {track_order}" if track_order else ""), streams=streams, value=round(fps, 2),
                    unit="frames/s", ms_per_step=round(1e3 * m["elapsed"] / m["timed_steps"], 4), timed_steps=m["timed_steps"], tracks_alive_frac=round(m["alive"], 4),
                    pose_t=[round(float(x), 5) for x in m["st"]["t"]], pose_t_truth=[round(float(x), 5) for x in m["truth"]],
-                   rms_residual_px=round(m["st"]["res"], 5),
+                   rms_residual_px=round(m["st"]["res"], 5), lk_kernels=m["lk_kernels"],
                    lk_us_per_launch=[round(1e3 * m["prof"]["ms_sum"][k] / max(m["prof"]["launches"][k], 1), 2) for k in range(3)])
         if a.verify_frames > 0:
-            out["verified"] = wl.verify(wl.done_steps + 1, nframes=min(a.verify_frames, 2))
+            out["verified"] = verify(wl, wl.done_steps + 1, nframes=min(a.verify_frames, 2))
         wl.close()
         return out
     except Exception as e:  # an extra leg must never take the headline number down with it
         return dict(workload=f"{cfg_key} / params {params} / scene {scene}", error=f"{type(e).__name__}: {e}"[:300])
+
+
+def episode_leg(a, kind, streams, dev, headline_fps=None):
+    """The hard scene / the reference's real stills as short clips (benchlib.workload.EpisodeWorkload): frames/s, Newton iterations per set-up and stage,
+    tracks alive per frame of the clip, per-kernel microseconds, the VALU fractions of the LK launches, and its own `verified`."""
+    try:
+        wl = EpisodeWorkload(kind, a, streams, dev)
+        m = wl.measure(min_seconds=1.0)
+        fps = wl.S * m["timed_steps"] / m["elapsed"]
+        r = roofline_of(wl, m, 1)
+        coarse = [k for k in r["kernels"] if k["kernel"].startswith("k_lk")]
+        out = dict(workload=wl.cfg["name"] + f"; clips of {wl.E} tracked frames, every stream re-initialised (untimed) between clips", streams=streams,
+                   value=round(fps, 2), unit="frames/s", ms_per_step=round(1e3 * m["elapsed"] / m["timed_steps"], 4), timed_steps=m["timed_steps"],
+                   episodes=m["episodes"], tracks=wl.N, tracks_alive_by_frame=m["alive_by_frame"],
+                   tracks_alive_frac_end=round(m["alive_by_frame"][-1] / wl.N, 4),
+                   lk_kernels=m["lk_kernels"], lk_newton_iters_per_setup=r["lk_newton_iters_per_setup"], lk_setups_per_track=r["lk_setups_per_track"],
+                   lk_us_per_launch=r["lk_us_per_launch"], kernels_us_per_step=_kernel_table(r), step_us_accounted=r["step_us_accounted"],
+                   valu_frac_fine=r["frac"], valu_frac_fine_of_class_peak=r["frac_of_class_peak"],
+                   valu_frac_coarse=[k.get("valu_frac") for k in coarse], valu_frac_coarse_of_class_peak=[k.get("valu_frac_of_class_peak") for k in coarse])
+        if headline_fps and kind == "hard_scene":
+            out["vs_headline"] = round(fps / headline_fps, 4)
+        if a.verify_frames > 0:
+            out["verified"] = verify_episode(wl, nframes=3 if kind == "hard_scene" else wl.E)
+        wl.close()
+        return out
+    except Exception as e:  # an extra leg must never take the headline number down with it
+        import traceback
+        return dict(workload=kind, streams=streams, error=f"{type(e).__name__}: {e}"[:300], where=traceback.format_exc()[-400:])
+
+
+def dropin_leg(a, cfg, dev, frames=24):
+    """What INTEGRATION.md's import switch gives a maintainer: the reference's loop body on the drop-in FUNCTIONS -- KLT.KLTmain (uploads both frames,
+    one host sync for the data-dependent shape of p[v], downloads) + NLS.estimateWorldCameraPose per frame, numpy in and out -- next to the
+    device-resident session on the same single stream."""
+    try:
+        from velocity_amd import KLT, NLS, synth
+        from benchlib.workload import make_ring
+
+        K, motion, ring, p0 = make_ring(cfg, a.ring, dev, seed=0xC0FFEE, nsets=1)
+        host = [ring[k].cpu().numpy() for k in range(min(a.ring, frames + 1))]
+        p3 = motion.world_points(p0)
+        lkc = dict(max_level=cfg["levels"] - 1)
+        vg, vp, p, small, R = np.ones(len(p0), bool), np.ones(len(p0), bool), p0.copy(), None, np.eye(3)
+        times = []
+        for i in range(1, len(host)):
+            t0 = time.perf_counter()
+            p, v, small = KLT.KLTmain(host[i], host[i - 1], small, p, lk_coarse=lkc)
+            vg[vg] = v
+            vp = vp & vg
+            t, R_, res, _ = NLS.estimateWorldCameraPose(K, p[vp[vg]], p3[vp], R=R, findR=False)
+            times.append(time.perf_counter() - t0)
+        ms = 1e3 * float(np.median(times[2:]))
+        return dict(workload=f"{cfg['name']}: ONE stream through the drop-in functions (numpy in / out per call)", ms_per_frame=round(ms, 3),
+                    frames_per_s=round(1e3 / ms, 1), frames=len(times), tracks_alive_frac=round(float(vg.mean()), 4), rms_residual_px=round(float(res), 5),
+                    pose_t=[round(float(x), 5) for x in t], pose_t_truth=[round(float(x), 5) for x in (motion.t(len(host) - 1) - motion.t(0))],
+                    note="compare extras.single_stream (the same stream device-resident): the difference is two frame uploads, the p[v] host sync and the "
+                         "downloads of every call")
+    except Exception as e:
+        return dict(error=f"{type(e).__name__}: {e}"[:300])
 
 
 def main():
@@ -874,7 +404,11 @@ def main():
     from velocity_amd import dist as vdist
 
     if a.only_ba:
-        print(json.dumps(bench_ba(cpu_seconds=0, windows=(1, 8, 64))))
+        print(json.dumps(bench_ba(windows=(1, 8, 64))[0]))
+        return
+    if a.only_leg:
+        kind, _, s_ = a.only_leg.partition(":")
+        print(json.dumps(episode_leg(a, kind, int(s_ or a.streams), dev)))
         return
     S, N = a.streams, cfg["n"]
     wl = Workload(a, cfg, a.params, a.scene, S, a.steps, a.warmup, dev, rank, groups=a.groups, host_frames=a.host_frames)
@@ -899,6 +433,7 @@ def main():
     if rank == 0:
         elapsed, timed = m["elapsed"], m["timed_steps"]
         value = S * world * timed / elapsed
+        # the head of the line is what a truncated record keeps: metric ... roofline, cpu_baseline first, the long objects after
         out = dict(metric="tracked frames/sec (KLT 2000 tracks + NLS pose, 1080p)" if a.config == "c2" else "tracked frames/sec (KLT 5000 tracks + NLS pose, 4K)",
                    value=round(value, 2), unit="frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=round(1e3 * elapsed / timed, 4), timed_steps=timed, timed_seconds=round(elapsed, 3),
@@ -909,13 +444,20 @@ def main():
                                stream_groups=wl.G,
                                parallelism=f"streams x{world} (1 rank per GPU" + (f", {'RCCL' if a.backend == 'nccl' else a.backend} all-gather of track state every {a.exchange_every} frames)" if use_dist else ")")),
                    per_stream_fps=round(value / (S * world), 2), tracks_alive_frac=round(m["alive"], 4),
-                   pose_t=[round(float(x), 5) for x in st["t"]], pose_t_truth=[round(float(x), 5) for x in m["truth"]], rms_residual_px=round(st["res"], 5),
-                   roofline=roofline_of(wl, m, world), headline_hbm=headline_hbm(cfg, value / world))
+                   pose_t=[round(float(x), 5) for x in st["t"]], pose_t_truth=[round(float(x), 5) for x in m["truth"]], rms_residual_px=round(st["res"], 5))
+        full_roofline = roofline_of(wl, m, world)
+        # compact roofline first (the contract's fields), the full object (mix, per-kernel rows) at the end of the line as `roofline_detail`
+        keys = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_of_class_peak", "peak_class", "us_per_launch", "issued_ginstr_per_launch",
+                "setups_per_launch", "newton_iters_per_launch", "newton_iters_per_track_dir", "lk_kernels", "lk_us_per_launch", "lk_newton_iters_per_setup",
+                "step_hbm", "peak_source", "peak_class_source")
+        out["roofline"] = {k: full_roofline.get(k) for k in keys}
+        out["roofline"]["detail"] = "roofline_detail (same line, further down): hbm view, opcode mix, one row per kernel family, notes"
+        out["headline_hbm"] = headline_hbm(cfg, value / world)
         out["build"] = L.build_info()  # which binary ran: vh_build_id() of the loaded library vs the hash of the tree's sources
         out["build_id"] = out["build"]["build_id"]
         cpu_args = (cfg, wl.K, wl.frames[: a.ring], wl.p0, wl.p3, wl.vp, wl.lkc, wl.lkf)
         if a.verify_frames > 0:
-            out["verified"] = wl.verify(wl.done_steps + 1, nframes=a.verify_frames)
+            out["verified"] = verify(wl, wl.done_steps + 1, nframes=a.verify_frames)
     if use_dist and ex is not None:
         desc = ex.describe()  # collective (all_gather_object): every rank calls it
         if rank == 0:
@@ -933,11 +475,22 @@ def main():
             out["cpu_baseline_1core"] = cpu_baseline(*cpu_args, a.cpu_seconds, 1)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     wl.close()
+    if not a.no_ba and world > 1:  # multi-GPU BA first: its point_sharded / replica figures belong in the head of the line
+        ba = bench_ba_multi_gpu(rank, world, barrier, reduce_max)
+        if rank == 0:
+            out["ba"] = ba
     if rank == 0:
         if not a.no_extras and world == 1 and not a.host_frames:
             c2 = a.config == "c2"
-            legs = dict(single_stream=extra_leg(a, a.config, a.params, a.scene, 1, 200, 20, dev))
+            legs = {}
+            # the load that looks like the reference's data: both at the headline's stream count and at 8 streams
+            legs["hard_scene"] = episode_leg(a, "hard_scene", S, dev, headline_fps=out["value"])
+            legs["hard_scene_8"] = episode_leg(a, "hard_scene", 8, dev)
+            legs["real_texture"] = episode_leg(a, "real_texture", S, dev)
+            legs["real_texture_8"] = episode_leg(a, "real_texture", 8, dev)
+            legs["single_stream"] = extra_leg(a, a.config, a.params, a.scene, 1, 200, 20, dev)
             legs["single_stream"]["latency_ms"] = legs["single_stream"].get("ms_per_step")
+            legs["drop_in_route"] = dropin_leg(a, cfg, dev)
             legs["ref_params"] = extra_leg(a, a.config, "ref" if a.params == "baseline" else "baseline", a.scene, S, 60, 10, dev)
             legs["other_config"] = extra_leg(a, "c3" if c2 else "c2", a.params, a.scene, 64 if c2 else 128, 24 if c2 else 60, 6, dev)  # 64 4K streams = 320 000 tracks in flight
             legs["roll_scene"] = extra_leg(a, a.config, a.params, "roll" if a.scene == "plane" else "plane", S, 60, 10, dev)
@@ -945,12 +498,11 @@ def main():
             legs["shuffled_tracks"] = extra_leg(a, a.config, a.params, a.scene, S, 60, 10, dev, track_order="shuffled" if a.track_order == "raster" else "raster")
             out["extras"] = legs
         if not a.no_ba and world == 1:
-            out["ba"] = bench_ba(cpu_seconds=a.cpu_seconds)
-    if not a.no_ba and world > 1:
-        ba = bench_ba_multi_gpu(rank, world, barrier, reduce_max)
-        if rank == 0:
+            ba, first = bench_ba()
+            if a.cpu_seconds > 0 and first is not None:
+                ba_cpu_baseline(ba, first, a.cpu_seconds)
             out["ba"] = ba
-    if rank == 0:
+        out["roofline_detail"] = full_roofline
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

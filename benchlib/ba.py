@@ -1,0 +1,202 @@
+"""BASELINE config 5 (bundle adjustment) legs of bench.py: device timing only; the CPU baseline of the same window lives in bench.py."""
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from .roofline import HBM_PEAK_GBS, MFMA_F64_PEAK_TFLOPS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# config 5: bundle adjustment
+# ----------------------------------------------------------------------------------------------------------------------------------
+def bench_ba(nt=5000, nf=20, repeats=3, windows=(1, 8, 64), min_seconds=0.4):
+    """BASELINE config 5: sliding-window BA, 20 keyframes x 5000 full-length tracks, 10 LM iterations (fcnNLS_batch): one window, and
+    `windows` independent windows batched into the same launches (vh_nls_batch_multi) -- the mode that fills the chip.
+    Returns (object, the first window's (P, pw0, cw0) for bench.py's CPU baseline of the same window)."""
+    from velocity_amd import _lib as L
+    from velocity_amd import synth
+
+    K = synth.K_1080P
+    ws = L.workspace()
+    L.check(ws.lib.vh_ba_graph_replay(ws.handle, 1), "vh_ba_graph_replay")  # opt-in: the solve buffers below are allocated once per window count and reused
+    K64 = L.host_K(K)
+    nc = nf - 1
+    nx, nz = 3 * nt + 6 * nc, 2 * nt * nf
+    out = dict(workload=f"C5 BA: {nf} keyframes x {nt} tracks (nx={nx}, nz={nz}), 10 LM iterations per window",
+               method="compact FD Jacobian; point-block Schur complement with the reduced camera system on v_mfma_f64_16x16x4_f64; "
+                      "block Gauss-Jordan (4x4 pivot blocks, SPD, pivot-free) in the MFMA accumulators",
+               timing="HIP events around each 10-iteration solve on the launch stream; median of the second half of the repetitions "
+                      "(iters_per_s), best (iters_per_s_best) and host wall incl. enqueue + synchronize (iters_per_s_host_wall)",
+               dense_equivalent_flop_per_iter=2.0 * nx ** 2 * nz, by_windows={})
+    first = None
+    for nw in windows:
+        if not hasattr(ws.lib, "vh_nls_batch_multi") and nw > 1:
+            continue
+        zs, xs = [], []
+        for w in range(nw):
+            P, pw0, cw0 = synth.ba_scene(nt, nf, seed=5 + w)
+            z, x0, _, _ = synth.ba_pack(P, pw0, cw0)
+            zs.append(z)
+            xs.append(x0)
+            if w == 0 and first is None:
+                first = (P, pw0, cw0)
+        zd = L.to_dev(np.stack(zs), torch.float64)
+        x0d = L.to_dev(np.stack(xs), torch.float64)
+        nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+        scratch = torch.empty((nw, nbytes), dtype=torch.uint8, device="cuda")
+        trace = torch.zeros((nw, 10, 2), dtype=torch.float64, device="cuda")
+        info = torch.zeros((nw, 2), dtype=torch.int32, device="cuda")
+        # timed with HIP events on the launch stream (the device time of the whole 10-iteration solve, first kernel to last); repeated until
+        # `min_seconds` of solves have run (the first ones also bring the clocks up after the CPU legs): median AND best are reported, the
+        # headline figure is the median.  The host wall time of the same solves (enqueue + synchronize) is kept next to it.
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dev_ms, wall_ms, t_begin = [], [], time.perf_counter()
+        xd = torch.empty_like(x0d)  # pointer stable (vh_ba_graph_replay): the state is re-initialised in place before every solve
+        while len(dev_ms) < repeats + 1 or (time.perf_counter() - t_begin < min_seconds and len(dev_ms) < 400):
+            xd.copy_(x0d)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev0.record()
+            if nw == 1:
+                L.check(ws.lib.vh_nls_batch(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, 10, L.dptr(trace), L.dptr(info),
+                                            L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch")
+            else:
+                L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, nw, 10, L.dptr(trace),
+                                                  L.dptr(info), L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
+            ev1.record()
+            torch.cuda.synchronize()
+            wall_ms.append(1e3 * (time.perf_counter() - t0))
+            dev_ms.append(ev0.elapsed_time(ev1))
+        its = int(info.cpu()[:, 0].sum())
+        tr = trace.cpu().numpy()
+        half = len(dev_ms) // 2  # the first half is warm-up (clock ramp after the idle CPU legs)
+        med, best, wmed = float(np.median(dev_ms[half:])), float(min(dev_ms)), float(np.median(wall_ms[half:]))
+        out["by_windows"][str(nw)] = dict(iters_per_s=round(1e3 * its / med, 1), ms_per_window_iter=round(med / its, 5), solves_timed=len(dev_ms),
+                                          iters_per_s_best=round(1e3 * its / best, 1), iters_per_s_host_wall=round(1e3 * its / wmed, 1),
+                                          rms_residual_first=round(float(tr[0, 0, 0]), 4), rms_residual_last=round(float(tr[0, -1, 0]), 4))
+        del scratch, zd, x0d
+    # ---- roofline of the BA kernels: one PROFILED solve per window count (HIP events around every kernel inside the library; the solve is then
+    # launched plainly, not replayed from its graph) ----
+    def profiled(nw):
+        zs, xs = zip(*[synth.ba_pack(*synth.ba_scene(nt, nf, seed=5 + w))[:2] for w in range(nw)])
+        zd, xd = L.to_dev(np.stack(zs), torch.float64), L.to_dev(np.stack(xs), torch.float64)
+        nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+        scratch = torch.empty((nw, nbytes), dtype=torch.uint8, device="cuda")
+        trace = torch.zeros((nw, 10, 2), dtype=torch.float64, device="cuda")
+        info = torch.zeros((nw, 2), dtype=torch.int32, device="cuda")
+        res = None
+        for rep in range(3):  # the last repetition counts (warm caches / clocks)
+            x = xd.clone()
+            L.check(ws.lib.vh_profile_begin(ws.handle, 80), "vh_profile_begin")
+            L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(x), nt, nc, nw, 10, L.dptr(trace), L.dptr(info),
+                                              L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
+            ms, n = (C.c_double * 16)(), (C.c_int * 16)()
+            L.check(ws.lib.vh_profile_end_stages(ws.handle, 16, ms, n), "vh_profile_end_stages")
+            res = {k: 1e3 * ms[i] / max(n[i], 1) for k, i in (("k_ba_jac", 8), ("k_ba_schur_mfma", 9), ("k_ba_reduce", 10), ("k_ba_solve_mfma", 11), ("k_ba_update", 12))}
+        return res
+
+    try:
+        nwr = max(w for w in windows)
+        kus = profiled(nwr)
+        # launch shape of k_ba_schur_mfma (velocity_amd/csrc/vh_api.hip::vh_nls_batch_multi): nparts workgroups per window, each walks its chunk of tie
+        # points in groups of 4; a group = 27 v_mfma_f64_16x16x4_f64 (2048 flop each) on each of the 4 consumer wavefronts
+        parts = max(1, min(256, nt // 16))
+        cap = max(16, 512 // nwr)
+        nparts = cap if (nwr > 1 and parts > cap) else parts
+        chunk = -(-nt // nparts)
+        groups = sum(-(-max(0, min(nt, (b + 1) * chunk) - b * chunk) // 4) for b in range(nparts))
+        mfma = nwr * groups * 4 * 27
+        flop = mfma * 2048.0
+        t = kus["k_ba_schur_mfma"] * 1e-6
+        tf = flop / t / 1e12
+        m_meas = nt * nf
+        rows = [dict(kernel="k_ba_jac<true>", us=round(kus["k_ba_jac"], 2), alg_bytes=int(nwr * (m_meas * 20 * 8 + 2 * m_meas * 8 + 3 * nt * 8 + 9 * nt * 8)),
+                     note="writes the 20 Jacobian / residual planes (160 B per measurement), reads z and x"),
+                dict(kernel="k_ba_schur_mfma", us=round(kus["k_ba_schur_mfma"], 2), alg_bytes=int(nwr * (m_meas * 20 * 8 + 9 * nt * 8)),
+                     note="reads the planes + L, tp once"),
+                dict(kernel="k_ba_reduce", us=round(kus["k_ba_reduce"], 2), alg_bytes=int(nwr * nparts * (6 * nc) ** 2 * 8 * 0.56), note="upper-triangle tiles of the partial systems"),
+                dict(kernel="k_ba_solve_mfma", us=round(kus["k_ba_solve_mfma"], 2), alg_bytes=int(nwr * (6 * nc) * (6 * nc + 1) * 8),
+                     note="one workgroup per window: latency bound (29 dependent block-elimination rounds)"),
+                dict(kernel="k_ba_update", us=round(kus["k_ba_update"], 2), alg_bytes=int(nwr * (m_meas * 18 * 8 + 12 * nt * 8)), note="reads 18 of the 20 planes again, updates x")]
+        for r in rows:
+            r["hbm_gbs"] = round(r["alg_bytes"] / (r["us"] * 1e-6) / 1e9, 1) if r["us"] > 0 else None
+            r["hbm_frac"] = round(r["hbm_gbs"] / HBM_PEAK_GBS, 4) if r["hbm_gbs"] else None
+        busy, bsrc = None, None
+        import glob as _glob
+        for name in [os.path.basename(f) for f in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_ba_pmc.json")), reverse=True)]:
+            bp = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(bp):
+                try:
+                    bj = json.load(open(bp))
+                    busy = bj.get("kernels", bj).get("k_ba_schur_mfma", {}).get("mfma_busy_frac")
+                    bsrc = f"profiles/{name} (SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 2.4 GHz x 1024 SIMDs) of a rocprofv3 --pmc pass; not measured in this run)"
+                except Exception:
+                    pass
+                break
+        out["roofline"] = dict(bound="mfma", kernel=f"k_ba_schur_mfma ({nwr} windows per launch)", achieved=round(tf, 2), peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s",
+                               frac=round(tf / MFMA_F64_PEAK_TFLOPS, 4), us_per_launch=round(kus["k_ba_schur_mfma"], 2), mfma_instr_per_launch=int(mfma),
+                               flop_per_launch=flop, mfma_busy_frac_pmc=busy, mfma_busy_source=bsrc, windows=nwr, nparts_per_window=nparts,
+                               note="issued v_mfma_f64_16x16x4_f64 x 2048 flop / kernel time (HIP events inside the library) against the dense f64 matrix peak; f64 MFMA and "
+                                    "VALU instructions of co-resident wavefronts do not overlap on gfx950 (profiles/r02_mfma_overlap.json), so the producers' VALU time adds",
+                               kernels=rows, us_per_iteration_all_windows=round(sum(r["us"] for r in rows), 1))
+        k1 = profiled(1)
+        out["single_window_kernels_us"] = {k: round(v, 2) for k, v in k1.items()}
+    except Exception as e:  # the roofline leg must never take the BA numbers down with it
+        out["roofline"] = dict(error=f"{type(e).__name__}: {e}"[:300])
+    one = out["by_windows"]["1"]
+    out.update(iters_per_s=one["iters_per_s"], ms_per_iter=one["ms_per_window_iter"], rms_residual_first=one["rms_residual_first"],
+               rms_residual_last=one["rms_residual_last"])
+    return out, first
+
+
+def bench_ba_multi_gpu(rank, world, barrier, reduce_max, nt=5000, nf=20, windows_per_gpu=8):
+    """Config 5 on N GPUs, both ways: (a) replicas -- every rank solves its own `windows_per_gpu` independent
+    windows, no collective (the mode that scales: a sliding-window tracker has one window per stream); (b) ONE window with its tie
+    points sharded over the ranks and two all-reduces per LM iteration (Amdahl-limited by the replicated 114 x 114 solve)."""
+    from velocity_amd import _lib as L
+    from velocity_amd import dist as vdist
+    from velocity_amd import synth
+
+    K = synth.K_1080P
+    ws = L.workspace()
+    K64 = L.host_K(K)
+    nc, nw = nf - 1, windows_per_gpu
+    packs = [synth.ba_pack(*synth.ba_scene(nt, nf, seed=5 + rank * nw + w)) for w in range(nw)]
+    zd = L.to_dev(np.stack([p[0] for p in packs]), torch.float64)
+    x0d = L.to_dev(np.stack([p[1] for p in packs]), torch.float64)
+    nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+    scratch = torch.empty((nw, nbytes), dtype=torch.uint8, device="cuda")
+    trace = torch.zeros((nw, 10, 2), dtype=torch.float64, device="cuda")
+    info = torch.zeros((nw, 2), dtype=torch.int32, device="cuda")
+    best = None
+    for _ in range(3):
+        xd = x0d.clone()
+        barrier()
+        t0 = time.perf_counter()
+        L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, nw, 10, L.dptr(trace), L.dptr(info),
+                                          L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
+        barrier()
+        dt = reduce_max(time.perf_counter() - t0)
+        best = dt if best is None else min(best, dt)
+    out = dict(workload=f"C5 BA: {nf} keyframes x {nt} tracks, 10 LM iterations per window",
+               replicas=dict(windows_per_gpu=nw, n_gpus=world, iters_per_s=round(world * nw * 10 / best, 1), collective="none"))
+    P, pw0, cw0 = synth.ba_scene(nt, nf, seed=5)
+    best = None
+    for _ in range(3):
+        barrier()
+        tm = {}
+        _cw, _pw, tr = vdist.fcnNLS_batch_sharded(K, P, pw0, cw0, timing=tm)
+        dt = reduce_max(tm["loop_ms"] * 1e-3)  # HIP events around the LM loop of every rank (phases + all-reduces), max over ranks
+        best = dt if best is None else min(best, dt)
+    out["point_sharded"] = dict(n_gpus=world, iters_per_s=round(len(tr) / best, 1), ms_per_iter=round(1e3 * best / len(tr), 4),
+                                collective="2 all-reduces per LM iteration (104 KB + 8 B)", rms_residual_last=round(float(tr[-1, 0]), 4),
+                                timing="HIP events around the LM iterations (host-side packing and the final point gather excluded)",
+                                note="Amdahl-limited by the replicated reduced-system solve")
+    return out
+

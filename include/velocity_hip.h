@@ -194,6 +194,25 @@ VH_API int vh_good_features(vh_ctx* ctx, const uint8_t* im, int w, int h, int st
 VH_API int vh_corner_subpix(vh_ctx* ctx, const uint8_t* im, int w, int h, int stride, float* pts, int n, int win, int max_iter,
                             double eps, void* stream);
 
+/* cv2.cornerSubPix / goodFeaturesToTrack scratch of this context (Harris planes, sort keys, Gaussian masks): created by the first frame-0 call, or
+ * explicitly here -- e.g. before a stream capture, inside which it cannot be allocated.  Sized for max(w x h, the context's max_w x max_h). */
+VH_API int vh_init_reserve(vh_ctx* ctx, int w, int h, void* stream);
+/* Frame-0 initialisation of one video, vidExample.py:105-127, as ONE device-resident launch sequence (no host round trip between its steps):
+ *   boxa / boxb = boundingRect(q, imshape, border=(0,0) / (border_x, border_y))                (:107-108, images.py:9-19; q_host: the 4 clicked corners, host)
+ *   p = goodFeaturesToTrack(im[boxb], max_corners, quality, 0, blockSize=block, useHarrisDetector=True, k) + boxb origin      (:109-112)
+ *   p = cornerSubPix(im, p, (win, win), (-1,-1), (EPS + MAX_ITER, subpix_iter, subpix_eps))                                   (:113-115)
+ *   p = concatenate((q, p))                                                                                                    (:116)
+ *   t, R, res = estimateWorldCameraPose(K, q, plate, findR=True)          (:118; plate_host: worldPointsLicensePlate, 4 x 3 float64, host)
+ *   p3 = addcol0(image2world(K, R, t, p)) @ R + t                                                                              (:119)
+ *   vp = insidebbox(p, boxa)                                                                                                   (:126, images.py:22-27)
+ * Outputs (device, sized for 4 + max_corners tracks): p_out [.. x 2] float32, p3_out [.. x 3] float64, vp_out uint8, t_out float[3], R_out double[9]
+ * (float32-rounded like NLS.py:180), res_out double[1], n_out int[1] = 4 + corners found (rows beyond it: vp 0, p3 0).  roi_host (may be NULL): host
+ * int[8] = boxa, boxb.  The outputs feed vh_session_init directly. */
+VH_API int vh_frame0_init(vh_ctx* ctx, const uint8_t* im, int w, int h, int stride, const float* q_host, const double* K_host,
+                          const double* plate_host, int border_x, int border_y, int max_corners, double quality, int block, double k,
+                          int subpix_win, int subpix_iter, double subpix_eps, float* p_out, double* p3_out, uint8_t* vp_out, float* t_out,
+                          double* R_out, double* res_out, int* n_out, int* roi_host, void* stream);
+
 /* ---- tracker session: the frame loop body of vidExample.py:133-160 on the device, for ctx->batch streams ------- */
 /* device pointers into the state of one stream (read with vh_copy_to_host / torch) */
 typedef struct {
@@ -215,6 +234,11 @@ typedef struct {
     const int* pose_info;   /* 2       iterations, converged                                   */
     const int* sel_pw;      /* n_pose  global ids of the pose tracks                           */
     const double* p_proj;   /* n_pose x 2                                                      */
+    /* (vh_version >= 104) layout of P in floats: entry (row, track, frame) at P[row * P_row_stride + track * P_track_stride + frame * P_frame_stride].
+     * Today (N0, 1, 5 N0) = frame-major [nhist][5][N0]; the reference's [5,N0,nhist] would read (N0 nhist, nhist, 1).  A C consumer indexes
+     * through these, never through a remembered layout (version 103 changed it from the reference's, silently for such a consumer). */
+    size_t P_row_stride, P_track_stride, P_frame_stride;
+    int n0, nhist;
 } vh_session_view;
 
 /* K_host: 9 doubles; k_is_float32 != 0: the caller's K array is float32 (vidExample.py:29-33), so fcnMSV1_t builds its rays in
@@ -226,6 +250,11 @@ VH_API void vh_session_destroy(vh_session* s);
 /* frame-0 state of stream `slot` (vidExample.py:116-131): p n0 x 2, p3 n0 x 3, vp n0 (device); t0_host = plate pose t */
 VH_API int vh_session_init(vh_session* s, int slot, const uint8_t* frame0, int stride, const float* p, const double* p3,
                            const uint8_t* vp, const float* t0_host, float time0, float frame_no, float res0, void* stream);
+/* the same straight from the outputs of vh_frame0_init, all still on the device (no read-back between frame 0 and the loop): t0_dev float[3], res0_dev
+ * double[1], n_dev int[1] = number of frame-0 tracks (may be NULL: n0).  With *n_dev < n0 the session runs the first *n_dev rows; the rest are tracks
+ * that never existed (vg = 0, history NaN, S[0,2] = *n_dev). */
+VH_API int vh_session_init_dev(vh_session* s, int slot, const uint8_t* frame0, int stride, const float* p, const double* p3, const uint8_t* vp,
+                               const float* t0_dev, const double* res0_dev, const int* n_dev, float time0, float frame_no, void* stream);
 /* one frame for every stream: frames_dev = device array of ctx->batch frame pointers (dense, w x h) */
 VH_API int vh_session_step(vh_session* s, const uint8_t* const* frames_dev, float time_s, float frame_no, void* stream);
 /* the same with one timestamp / frame number PER STREAM (device float[batch] each): independent videos with their own
@@ -243,7 +272,10 @@ VH_API int vh_session_ptrs(vh_session* s, int slot, vh_session_view* out_host);
 VH_API int vh_session_ingest_bgr(vh_session* s, const uint8_t* const* bgr_frames_dev, int bgr_stride, uint8_t* const* gray_frames_dev, void* stream);
 VH_API int vh_session_pack_state(vh_session* s, float* out, void* stream);
 
-/* test hook: route every LK window through one implementation -- 1: per-sample kernel, 2: strip kernel, 3: LDS-staged
+/* The vh_debug_* switches below are PROCESS-WIDE (atomics): they re-route every context of the process, and exist for the parity tests and A/B
+ * experiments only -- every route they select is bit-identical to the default one.  Not a per-stream control; do not flip them in a multi-tenant process
+ * for anything but a test.
+ * test hook: route every LK window through one implementation -- 1: per-sample kernel, 2: strip kernel, 3: LDS-staged
  * kernel, 4: 4-tracks-per-wavefront kernel (15x15 windows; others as in 2), 5 / 6 / 7: LDS-staged 51x51 kernel with 1 / 2 / 4
  * wavefronts per track (other windows: default routing), 0: default routing per window and load.  All are bit-identical. */
 VH_API void vh_debug_force_generic_lk(int on);
@@ -269,6 +301,9 @@ VH_API int vh_profile_end(vh_ctx* ctx, double* ms_sum, int* launches, unsigned l
  * 7 session frame kernel, 8-12 bundle adjustment (Jacobian, Schur complement, reduction, solve, update).  ms_sum / launches: nstages entries. */
 VH_API int vh_profile_detail(vh_ctx* ctx, int all_stages);  /* before vh_profile_begin: 1 = every stage (default), 0 = the LK launches only */
 VH_API int vh_profile_end_stages(vh_ctx* ctx, int nstages, double* ms_sum, int* launches);
+/* the kernel each of the three LK launches of the last vh_klt_main / vh_session_step took (the launcher's own routing decision, so nobody mirrors its
+ * thresholds): routes_host int[3] (ids of vh_debug_force_generic_lk), names_host char[3][32] (may be NULL) */
+VH_API int vh_profile_lk_routes(vh_ctx* ctx, int* routes_host, char* names_host);
 /* host copy of every stream's ROI (x0, x1, y0, y1) of the last KLTmain call (images.py:9-19 as KLT.py:121-123 applies it): 4 ints per stream */
 VH_API int vh_klt_rois(vh_ctx* ctx, int* roi_host);
 

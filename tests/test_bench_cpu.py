@@ -35,11 +35,15 @@ def test_roofline_object_is_recomputable_from_its_own_fields():
     wl = types.SimpleNamespace(N=N, SG=S, cfg=b.CONFIGS["c2"], params="baseline")
     r = b.roofline_of(wl, _fake_measurement(S, N, steps), 1)
     assert r["bound"] == "valu" and r["unit"] == "T lane-instr/s" and r["kernel"].startswith("k_lk3<51, 1, 4>")
-    # frac = issued lane-instructions / launch time / (SIMDs x lanes/clk x clock), every factor in the object
-    peak = r["simds"] * r["peak_lanes_per_clk_per_simd"] * r["clock_ghz"] * 1e9 / 1e12
-    assert abs(peak - r["peak"]) < 0.06
+    # frac = issued lane-instructions / launch time / (1024 SIMDs x 32 lanes x 2.4 GHz): what a reader derives from MI355X_MICROARCH.md alone
+    peak = r["simds"] * 32 * r["clock_ghz"] * 1e9 / 1e12
+    assert abs(peak - r["peak"]) < 0.06 and abs(r["peak"] - 78.6) < 0.1
     achieved = r["issued_ginstr_per_launch"] * 1e9 / (r["us_per_launch"] * 1e-6) / 1e12
     assert abs(achieved - r["achieved"]) < 2e-3 * r["achieved"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # the class-relative figure (the kernel is made of 4-cycle opcodes) is a separate, named field with its own peak and source
+    cls = r["simds"] * r["peak_class_lanes_per_clk_per_simd"] * r["clock_ghz"] * 1e9 / 1e12
+    assert abs(cls - r["peak_class"]) < 0.06 and abs(r["frac_of_class_peak"] - r["achieved"] / r["peak_class"]) < 1e-3
+    assert abs(r["frac_of_class_peak"] - 2 * r["frac"]) < 2e-3 and "valu_rate.json" in r["peak_class_source"]
     # the live instruction count = the calibrated model applied to the run's own counters
     import glob
 
@@ -57,11 +61,11 @@ def test_roofline_object_is_recomputable_from_its_own_fields():
     for k in r["kernels"]:
         assert abs(k["hbm_gbs"] - k["alg_bytes_per_step"] / (k["us_per_step"] * 1e-6) / 1e9) <= 0.06 + 1e-3 * k["hbm_gbs"]
         assert abs(k["hbm_frac"] - k["hbm_gbs"] / 8000.0) < 1e-4
+    for k in r["kernels"][:2]:  # the coarse LK rows carry both VALU fractions, the absolute one under the plain name
+        assert abs(k["valu_frac_of_class_peak"] - 2 * k["valu_frac"]) < 2e-3
     warp = [k for k in r["kernels"] if k["kernel"].startswith("k_roi_warp")][0]
     assert warp["alg_bytes_per_step"] == 2 * S * (1722 - 190) * (992 - 90)
     assert abs(r["step_us_accounted"] - (r["us_per_launch"] + sum(k["us_per_step"] for k in r["kernels"]))) < 0.2
-    # both fractions of the VALU view are recomputable from the line alone: the class-relative one (16 lanes / clk) and the absolute one (32 lanes / clk)
-    assert abs(r["peak_abs"] - r["simds"] * 32 * r["clock_ghz"] * 1e9 / 1e12) < 0.06 and abs(r["frac_abs"] - r["achieved"] / r["peak_abs"]) < 1e-3
     mx = r["mix"]
     if mx is not None:  # (needs profiles/rNN_lk_isa_mix.json + rNN_valu_rate.json)
         assert abs(mx["full_rate_frac"] + mx["half_rate_frac"] + mx["slow_frac"] + mx["unmeasured_frac"] - 1.0) < 2e-3
@@ -75,7 +79,9 @@ def test_latency_legs_carry_the_lk_rows_only():
     m = _fake_measurement(1, 2000, 200)
     m["stage_ms"], m["stage_n"] = [0.0] * 16, [0] * 16  # vh_profile_detail(0): only the three LK launches are timed
     wl = types.SimpleNamespace(N=2000, SG=1, cfg=b.CONFIGS["c2"], params="baseline")
+    m["lk_kernels"] = ["k_lk_strip<15>", "k_lk_strip<15>", "k_lk3<51, 2, 4>"]  # what vh_profile_lk_routes reports for 2000 tracks in flight
     r = b.roofline_of(wl, m, 1)
+    assert "vh_profile_lk_routes" in r["kernel_source"]
     assert r["kernel"].startswith("k_lk3<51, 2, 4>") and len(r["kernels"]) == 2  # 2000 tracks in flight: two wavefronts per track; the model is for <51,1,4>
     assert r["kernels"][0]["kernel"].startswith("k_lk_strip<15>")
 
@@ -86,3 +92,22 @@ def test_headline_hbm_and_host_cores():
     per_frame = 1920 * 1080 * (1 + 2 * (1 / 4 + 1 / 16)) + 21 * 2000
     assert h["bytes_per_frame"] == int(per_frame) and abs(h["achieved_gbs"] - per_frame * 33000 / 1e9) < 0.01
     assert 1 <= b.host_cores() <= (os.cpu_count() or 1)
+
+
+def test_step_hbm_is_the_committed_pmc_bytes_over_this_runs_step_time():
+    """roofline.step_hbm: sum of the PMC bytes of every kernel of a step (newest profiles/rNN_hbm_traffic.json, `step_total_kib`) over the step time."""
+    import glob
+
+    b = _bench()
+    S, N, steps = 256, 2000, 20
+    wl = types.SimpleNamespace(N=N, SG=S, cfg=b.CONFIGS["c2"], params="baseline")
+    m = _fake_measurement(S, N, steps)
+    m["step_us"] = 6000.0
+    r = b.roofline_of(wl, m, 1)
+    tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))[-1]))
+    if "step_total_kib" not in tj:
+        assert r["step_hbm"] is None
+        return
+    h = r["step_hbm"]
+    assert abs(h["bytes_per_step"] - tj["step_total_kib"] * 1024 * S / tj["streams"]) <= 1
+    assert abs(h["gbs"] - h["bytes_per_step"] / 6000e-6 / 1e9) < 0.06 and abs(h["frac_of_hbm_peak"] - h["gbs"] / 8000.0) < 1e-4

@@ -79,6 +79,39 @@ def test_c1_driver_flow_matches_oracle_and_ground_truth(golden):
     assert np.all(sp > 0) and sp.std() / sp.mean() < 0.05
 
 
+def test_c1_run_sequence_prints_the_reference_table(golden):
+    """The packaged driver (velocity_amd.driver.run_sequence = vidExample.py:52-178 minus decode and plots) on the C1 stand-in clip with the reference's own
+    parameters (ROI border (700, 500), 1000 corners, MSV at frame 5): header, one 9-column row per frame and the Speed / Res summary equal the oracle
+    driver's text line for line; state and records as the session test above."""
+    from oracle import driver_oracle as DO
+    from velocity_amd.driver import TABLE_HEADER, run_sequence
+    from velocity_amd.images import intrinsic_matrix_iphone6s_video
+
+    K = intrinsic_matrix_iphone6s_video()
+    q = golden["plate_IMG_4134_q"]
+    W, H, n = 1920, 1080, 9
+    motion = synth.PlaneMotion(K, z0=8.0, traj=lambda k: np.array([0.02 * k, 0.0, 0.37 * k * 0.25]))
+    frames = [synth.render_frame(W, H, motion, k).numpy() for k in range(n)]
+    times = [np.float32(k / 29.97) for k in range(n)]
+    fnos = [19 + k for k in range(n)]  # startframe 19 (vidExample.py:20)
+    ref = DO.run_sequence(frames, q, K, times, frame_numbers=fnos)
+    printed = []
+    got = run_sequence(frames, q, K, times=times, frame_numbers=fnos, clock=lambda: 0.0, out=printed.append, name="stand-in for IMG_4134.MOV")
+    assert printed == got["lines"] and printed[1] == TABLE_HEADER and printed[1] == ref["lines"][1]
+    assert got["n_tracks0"] == len(ref["frame0"]["p"]) > 100
+    from _helpers import same_table as _same_table
+
+    _same_table(got["lines"][2:-1], ref["lines"][2:])
+    assert np.array_equal(got["vg"], ref["vg"]) and np.array_equal(got["vp"], ref["vp"]) and np.array_equal(got["p"], ref["p"])
+    for r in (0, 1, 4):
+        assert np.array_equal(got["P"][r], ref["P"][r], equal_nan=True)
+    np.testing.assert_allclose(got["B"], ref["B"], rtol=1e-5, atol=1e-6)
+    assert got["B"][3, 13] == 22.0 and got["lines"][-1].startswith("Processed 9 images")
+    # live=False (no read-back inside the loop) prints the same rows
+    again = run_sequence(frames, q, K, times=times, frame_numbers=fnos, clock=lambda: 0.0, out=None, live=False)
+    assert again["lines"][:-1] == got["lines"][:-1]
+
+
 def test_bench_distributed_path_one_rank():
     """bench.py with the RCCL process group initialised (one rank): init, async all-gather of the packed track state, barrier and
     the MAX all-reduce of the timing -- the code path of `torch.distributed.run --nproc-per-node N bench.py --gpus N`."""

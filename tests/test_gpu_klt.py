@@ -443,6 +443,47 @@ def test_klt_main_on_the_scene_that_fires_every_status_gate(coarse_levels):
     assert int(ev.sum()) == c["survive"]
 
 
+@pytest.mark.parametrize("lk, fbt", [(dict(win=15, max_level=4, max_count=10, eps=0.1), 1.0), (dict(win=51, max_level=0, max_count=30, eps=0.001), 0.3)])
+def test_backward_pass_is_skipped_for_tracks_whose_forward_status_is_zero(lk, fbt):
+    """`v = v & v2 & (fbe < fbt)` (KLT.py:50) is 0 whatever the backward pass finds once the forward status is 0, and the point
+    returned is the forward one -- so every LK kernel skips that pass unless the caller asks for fbe itself.  On the gate scene (saturated patch,
+    textureless band, tracks beyond the border: forward status 0 for a real share of the tracks) every route must return the same bits with the skip
+    (fbe not requested: the KLTmain / session launches) and without it (fbe requested: the pass runs), equal the oracle, and run FEWER template
+    set-ups with the skip -- exactly the backward set-ups of the forward-dead tracks."""
+    L, C, torch = _lib()
+    f0, f1, p0 = synth.gate_scene()
+    H, W = f0.shape
+    n = len(p0)
+    ep2, ev, eerr = KO.lk_fb(f0, f1, p0, fbt=fbt, **lk)
+    efwd = KO.pyr_lk(f0, f1, p0, **lk)[1]
+    assert (~efwd).sum() >= 5, "the scene must kill tracks on the forward status"
+    ws = L.workspace(W, H, n)
+    a, b, p = torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), torch.from_numpy(p0).cuda()
+    prm = L.lk_params(lk)
+    routes = (1, 2, 3, 4, 8) if lk["win"] == 15 else (1, 2, 5, 6, 7)
+    for mode in routes:
+        ws.lib.vh_debug_force_generic_lk(mode)
+        got = {}
+        try:
+            for want_fbe in (False, True):
+                p2 = torch.zeros((n, 2), dtype=torch.float32, device="cuda")
+                v = torch.zeros(n, dtype=torch.uint8, device="cuda")
+                err = torch.zeros(n, dtype=torch.float32, device="cuda")
+                fbe = torch.zeros(n, dtype=torch.float32, device="cuda") if want_fbe else None
+                L.check(ws.lib.vh_profile_begin(ws.handle, 8), "vh_profile_begin")
+                L.check(ws.lib.vh_pyr_lk(ws.handle, L.dptr(a), L.dptr(b), W, H, W, W, L.dptr(p), n, C.byref(prm), C.c_float(fbt), L.dptr(p2), L.dptr(v), L.dptr(err),
+                                         L.dptr(fbe), L.stream_ptr()), "vh_pyr_lk")
+                ms, nl, it, su = (C.c_double * 3)(), (C.c_int * 3)(), (C.c_ulonglong * 3)(), (C.c_ulonglong * 3)()
+                L.check(ws.lib.vh_profile_end(ws.handle, ms, nl, it, su), "vh_profile_end")
+                got[want_fbe] = (p2.cpu().numpy(), v.cpu().numpy().astype(bool), err.cpu().numpy(), int(su[0]), int(it[0]))
+        finally:
+            ws.lib.vh_debug_force_generic_lk(0)
+        (pa, va, ea, sua, ita), (pb, vb, eb, sub, itb) = got[False], got[True]
+        assert np.array_equal(pa, pb) and np.array_equal(va, vb) and np.array_equal(ea, eb), f"route {mode}: the skip changed a result"
+        assert np.array_equal(pa, ep2) and np.array_equal(va, ev) and np.array_equal(ea, eerr), f"route {mode} differs from the oracle"
+        assert sua < sub and ita <= itb, f"route {mode}: the backward pass of the forward-dead tracks still ran ({sua} vs {sub} set-ups)"
+
+
 def test_klt_main_failure_path_matches(seq):
     """Unrelated frames: few survivors -> 'coarse-affine failure' branch (KLT.py:126-130) must agree with the oracle."""
     from velocity_amd import KLT
@@ -557,6 +598,71 @@ def test_frame0_features_bit_exact(seq):
     er = KO.corner_subpix(f0, pts, 5, 100, 0.001)
     assert np.array_equal(r, er)
     assert np.abs(r - pts).max() <= 5.0 and np.abs(r - pts).mean() > 0.01  # refined, never further than the window
+
+
+def _frame0_calls(L, C, torch, ws, img_t, W, H, nmax, iters):
+    """goodFeaturesToTrack + cornerSubPix of one context on the CURRENT stream, nothing read back: -> (corners tensor, count tensor)."""
+    out = torch.zeros((nmax, 2), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    L.check(ws.lib.vh_good_features(ws.handle, L.dptr(img_t), W, H, W, nmax, 0.01, 5, 0.04, L.dptr(out), L.dptr(cnt), L.stream_ptr()), "vh_good_features")
+    L.check(ws.lib.vh_corner_subpix(ws.handle, L.dptr(img_t), W, H, W, L.dptr(out), nmax, 5, iters, 0.001, L.stream_ptr()), "vh_corner_subpix")
+    return out, cnt
+
+
+def test_frame0_scratch_belongs_to_the_context_two_streams_run_concurrently():
+    """the detector's scratch (Harris planes, sort keys, counters, the cornerSubPix masks) is a member of the vh_ctx.  Two contexts on
+    two HIP streams run goodFeaturesToTrack + cornerSubPix at the same time on images of different sizes, 50 rounds, nothing synchronised in between:
+    every round of both must equal the oracle (round 4 shared ONE process-global scratch: the two raced on its keys and counters)."""
+    L, C, torch = _lib()
+    ims, exp, wss, streams = [], [], [], []
+    for k, (W, H, nmax) in enumerate(((640, 360, 400), (452, 500, 250))):
+        m = synth.AffineMotion(W, H, tx=2.0, ty=1.0)
+        f = synth.render_frame(W, H, m, 0, seed=500 + k).numpy()
+        e = KO.good_features(f, nmax, 0.01, 5, 0.04)
+        assert len(e) == nmax
+        exp.append(KO.corner_subpix(f, e, 5, 100, 0.001))
+        ims.append((torch.from_numpy(f).cuda(), W, H, nmax))
+        wss.append(L.Workspace(1, W, H, 1024))
+        streams.append(torch.cuda.Stream())
+    torch.cuda.synchronize()
+    results = [[], []]
+    for rnd in range(50):
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                t, W, H, nmax = ims[k]
+                results[k].append(_frame0_calls(L, C, torch, wss[k], t, W, H, nmax, 100))
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        for rnd, (out, cnt) in enumerate(results[k]):
+            assert int(cnt.item()) == ims[k][3], (k, rnd)
+            assert np.array_equal(out.cpu().numpy(), exp[k]), f"context {k}, round {rnd}: frame-0 features differ from the oracle"
+
+
+def test_frame0_features_inside_a_stream_capture():
+    """The frame-0 entry points queue kernels only (no hipStreamSynchronize, no allocation once vh_init_reserve has sized the scratch): legal under
+    hipStreamBeginCapture, and the replayed graph returns the oracle's corners."""
+    L, C, torch = _lib()
+    W, H, nmax = 640, 360, 300
+    f = synth.render_frame(W, H, synth.AffineMotion(W, H), 0, seed=77).numpy()
+    e = KO.corner_subpix(f, KO.good_features(f, nmax, 0.01, 5, 0.04), 5, 100, 0.001)
+    ws = L.Workspace(1, W, H, 1024)
+    img = torch.from_numpy(f).cuda()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        L.check(ws.lib.vh_init_reserve(ws.handle, W, H, L.stream_ptr()), "vh_init_reserve")
+        out = torch.zeros((nmax, 2), dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            L.check(ws.lib.vh_good_features(ws.handle, L.dptr(img), W, H, W, nmax, 0.01, 5, 0.04, L.dptr(out), L.dptr(cnt), L.stream_ptr()), "vh_good_features")
+            L.check(ws.lib.vh_corner_subpix(ws.handle, L.dptr(img), W, H, W, L.dptr(out), nmax, 5, 100, 0.001, L.stream_ptr()), "vh_corner_subpix")
+        assert int(cnt.item()) == 0, "capture must not execute anything"
+        for _ in range(2):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert int(cnt.item()) == nmax and np.array_equal(out.cpu().numpy(), e)
 
 
 def test_pyr_lk_fuzz_all_kernels_vs_oracle():

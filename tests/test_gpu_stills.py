@@ -19,6 +19,7 @@ from oracle import nls_oracle as NO  # noqa: E402 (checker only)
 from oracle.session_oracle import SessionOracle  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from _helpers import same_table as _same_table  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -26,99 +27,84 @@ def stills():
     return np.load(os.path.join(ROOT, "tests", "golden", "stills_gray.npz"))
 
 
-def _frame0(frames, q, K, border):
-    """vidExample.py:104-127 through the product's drop-in functions, each checked against the oracle."""
-    from velocity_amd import NLS
-    from velocity_amd.common import addcol0, image2world, worldPointsLicensePlate
-    from velocity_amd.images import boundingRect, cornerSubPix, goodFeaturesToTrack, insidebbox
+def _run_both(frames, times, q, K, border, msv_frame=5):
+    """velocity_amd.driver.run_sequence (vidExample.py:52-178 on the device: vh_frame0_init -> TrackerSession) against the oracle's driver."""
+    from oracle import driver_oracle as DO
+    from velocity_amd.driver import run_sequence
 
-    H, W = frames[0].shape
-    boxa = boundingRect(q, (H, W), border=(0, 0))
-    boxb = boundingRect(q, (H, W), border=border)
-    assert tuple(boxb) == KO.bounding_rect(q, (H, W), border)
-    roi = frames[0][boxb[2]:boxb[3], boxb[0]:boxb[1]]
-    off = np.float32([boxb[0], boxb[2]])
-    feats = goodFeaturesToTrack(roi, 1000, 0.01, 0, blockSize=5, useHarrisDetector=True).squeeze() + off
-    efeats = KO.good_features(roi, 1000, 0.01, 5, 0.04) + off
-    assert np.array_equal(feats, efeats), "Harris corners differ on the real still"
-    feats = cornerSubPix(frames[0], feats, (5, 5), (-1, -1), (3, 100, 0.001))
-    assert np.array_equal(feats, KO.corner_subpix(frames[0], efeats, 5, 100, 0.001)), "cornerSubPix differs on the real still"
-    p = np.concatenate((q, feats)).astype(np.float32)
-    t, R, res, _ = NLS.estimateWorldCameraPose(K, q, worldPointsLicensePlate("Chile"), findR=True)
-    et, eR, eres, _ = NO.estimate_world_camera_pose(K, q, NO.plate_world_points("Chile"), findR=True)
-    np.testing.assert_allclose(t, et, rtol=1e-5)
-    np.testing.assert_allclose(R, eR, rtol=1e-5, atol=1e-7)
-    np.testing.assert_allclose(res, eres, rtol=1e-4)  # 4-point Rt solve with dx = 1e-6 forward differences: the residual at the minimum carries ~1e-5 of rounding (as test_gpu_nls.py)
-    p3 = addcol0(image2world(K, R, t, p).astype(float)) @ R.astype(float) + t
-    ep3 = NO.hom0(NO.image_to_world(K, eR.astype(float), et, p).astype(float)) @ eR.astype(float) + et
-    np.testing.assert_allclose(p3, ep3, rtol=1e-6, atol=1e-7)
-    vp = insidebbox(p, boxa)
-    return p, ep3, vp, et, eres  # both sides start from the oracle's frame-0 state (the product's equals it to the tolerances above)
-
-
-def _run(frames, times, p, p3, vp, t, res, K, msv_frame=5):
-    import torch
-
-    from velocity_amd.driver import TrackerSession
-
-    n = len(frames)
-    H, W = frames[0].shape
-    orc = SessionOracle(K, frames[0], p, p3, vp, t, time0=np.float32(times[0]), res0=res, nhist=n, msv_frame=msv_frame)
-    ses = TrackerSession(K, W, H, len(p), nhist=n, batch=1, msv_frame=msv_frame)
-    ses.init_stream(0, frames[0], p, p3, vp, t, time0=float(np.float32(times[0])), res0=res)
-    log = []
-    for i in range(1, n):
-        with np.errstate(all="ignore"):
-            orc.step(frames[i], np.float32(times[i]), i)
-        ses.step([torch.from_numpy(frames[i]).cuda()], time_s=float(np.float32(times[i])), frame_no=i)
-        st = ses.state(0)
-        assert np.array_equal(st["vg"], orc.vg), f"vg differs at frame {i}"
-        assert np.array_equal(st["vp"], orc.vp), f"vp differs at frame {i}"
-        assert np.array_equal(st["ids"], np.nonzero(orc.vg)[0])
-        assert np.array_equal(st["p"], orc.p), f"tracked points differ at frame {i}"
-        log.append((i, int(orc.vg.sum()), int(orc.vp.sum()), st["klt_flags"]))
-        if orc.vp.sum() >= 3:
-            np.testing.assert_allclose(st["t"], orc.t, rtol=1e-5, err_msg=f"pose at frame {i}")
-            np.testing.assert_allclose(st["res"], orc.residuals, rtol=1e-5, atol=1e-9)
-    return ses.state(0), orc, log
+    with np.errstate(all="ignore"):
+        ref = DO.run_sequence(frames, q, K, times, roi_border=border, msv_frame=msv_frame)
+    got = run_sequence(frames, q, K, times=times, roi_border=border, msv_frame=msv_frame, clock=lambda: 0.0, out=None)
+    f0 = ref["frame0"]
+    # frame 0: Harris corners + cornerSubPix bit-exact, plate pose / world points to the contract
+    assert got["n_tracks0"] == len(f0["p"]) and got["boxa"] == f0["boxa"] and got["boxb"] == f0["boxb"]
+    assert np.array_equal(got["P"][0:2, :, 0].T, f0["p"]), "frame-0 points (Harris + cornerSubPix on the real still) differ"
+    np.testing.assert_allclose(got["t0"], f0["t"], rtol=1e-5)
+    np.testing.assert_allclose(got["R0"], f0["R"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(got["res0"], f0["res"], rtol=1e-4)  # 4-point Rt solve with dx = 1e-6 forward differences: ~1e-5 of rounding at the minimum
+    return got, ref
 
 
 def test_real_stills_full_loop_matches_oracle_and_the_labelled_speed(stills):
-    """Sequence B (IMG_4127..4133, full resolution): 7 frames, MSV at frame 5; 278 -> 87 tracks die on real gates."""
+    """Sequence B (IMG_4127..4133, full resolution): 7 frames, MSV at frame 5; 278 -> 87 tracks die on real gates.  The whole driver -- frame 0 included --
+    through run_sequence; the history P pins p / vg / vp of EVERY frame (P[0:2, vg, i] = p, P[2:4, vp, i] = p_proj, vidExample.py:151-153)."""
     frames, times, q, K = stills["b_frames"], stills["b_times"], stills["b_q"], stills["b_K"]
-    p, p3, vp, t, res = _frame0(frames, q, K, border=(180, 140))
-    assert len(p) > 200 and vp.sum() >= 20
-    st, orc, log = _run(frames, times, p, p3, vp, t, res, K)
-    print("frame, alive, pose tracks, klt flags:", log)
+    got, ref = _run_both(frames, times, q, K, (180, 140))
     n = len(frames)
-    assert st["frame_i"] == n - 1
-    alive = [a for _, a, _, _ in log]
-    assert alive[0] < 0.6 * len(p) and alive[-1] >= 50, "real motion must kill a real share of the tracks, and leave enough to measure"
-    assert log[-1][2] == log[-1][1], "after the MSV frame every live track is a pose track (vidExample.py:160)"
+    alive = [int(np.isfinite(got["P"][4, :, i]).sum()) for i in range(n)]
+    print("alive per frame:", alive)
+    assert alive[0] > 200 and alive[1] < 0.6 * alive[0] and alive[-1] >= 50, "real motion must kill a real share of the tracks, and leave enough to measure"
+    assert np.array_equal(got["vg"], ref["vg"]) and np.array_equal(got["vp"], ref["vp"]) and np.array_equal(got["p"], ref["p"])
+    assert np.array_equal(got["ids"], np.nonzero(ref["vg"])[0])
+    assert np.array_equal(got["vp"], got["vg"]), "after the MSV frame every live track is a pose track (vidExample.py:160)"
     for r in (0, 1, 4):
-        assert np.array_equal(st["P"][r], orc.P[r], equal_nan=True)
-    assert np.array_equal(np.isnan(st["P"][2:4]), np.isnan(orc.P[2:4]))
-    np.testing.assert_allclose(np.nan_to_num(st["P"][2:4]), np.nan_to_num(orc.P[2:4]), rtol=1e-5)
-    np.testing.assert_allclose(st["B"], orc.B, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(st["S"][1:, [0, 2, 4, 5]], orc.S[1:, [0, 2, 4, 5]], rtol=0, atol=0)
-    np.testing.assert_allclose(st["S"][1:, [3, 6, 7, 8]], orc.S[1:, [3, 6, 7, 8]], rtol=1e-4)
-    np.testing.assert_allclose(st["p3"], orc.p3, rtol=1e-4, atol=1e-5)
-    speed = st["S"][1:, 8]
-    print("speed km/h per frame:", speed)
+        assert np.array_equal(got["P"][r], ref["P"][r], equal_nan=True)
+    assert np.array_equal(np.isnan(got["P"][2:4]), np.isnan(ref["P"][2:4]))
+    np.testing.assert_allclose(np.nan_to_num(got["P"][2:4]), np.nan_to_num(ref["P"][2:4]), rtol=1e-5)
+    np.testing.assert_allclose(got["B"], ref["B"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got["S"][1:, [0, 2, 4, 5]], ref["S"][1:, [0, 2, 4, 5]], rtol=0, atol=0)
+    np.testing.assert_allclose(got["S"][1:, [3, 6, 7, 8]], ref["S"][1:, [3, 6, 7, 8]], rtol=1e-4)
+    np.testing.assert_allclose(got["p3"], ref["p3"], rtol=1e-4, atol=1e-5)
+    _same_table(got["lines"][:-1], ref["lines"])  # header, 7 rows, the Speed / Res summary (the last line is wall time)
+    print("\n".join(got["lines"]))
+    speed = got["S"][1:, 8]
     assert np.all((speed > 35) & (speed < 46)), speed  # the reference labels these stills "40km/h" (vidExample.py:26)
+    assert "Speed = 40." in got["lines"][-2] and "km/h" in got["lines"][-2]
+
+
+def test_run_sequence_drop_in_route_prints_the_same_table(stills):
+    """The same clip through the reference's own loop body on the drop-in functions (what INTEGRATION.md's import switch gives a maintainer): same table,
+    and the per-frame time of both routes side by side."""
+    from oracle import driver_oracle as DO
+    from velocity_amd.driver import run_sequence
+
+    frames, times, q, K = stills["b_frames"], stills["b_times"], stills["b_q"], stills["b_K"]
+    with np.errstate(all="ignore"):
+        ref = DO.run_sequence(frames, q, K, times, roi_border=(180, 140))
+    dropin = run_sequence(frames, q, K, times=times, roi_border=(180, 140), route="dropin", clock=lambda: 0.0, out=None)
+    _same_table(dropin["lines"][:-1], ref["lines"])
+    assert np.array_equal(dropin["vg"], ref["vg"]) and np.array_equal(dropin["p"], ref["p"])
+    for r in (0, 1, 4):
+        assert np.array_equal(dropin["P"][r], ref["P"][r], equal_nan=True)
+    # timing (real clock), second pass of each route (the first pays allocations / first launches)
+    for _ in range(2):
+        a = run_sequence(frames, q, K, times=times, roi_border=(180, 140), route="session", live=False, out=None)
+        b = run_sequence(frames, q, K, times=times, roi_border=(180, 140), route="dropin", out=None)
+    print(f"per tracked frame on the real stills (1024 x 768, 278 tracks): session route {a['ms_per_frame']:.3f} ms, drop-in route {b['ms_per_frame']:.3f} ms")
+    assert a["ms_per_frame"] < b["ms_per_frame"]
 
 
 def test_real_stills_fast_close_motion_kills_every_track_like_the_oracle(stills):
     """Sequence A (IMG_4122..4125 at 1/3 scale, the reference's own hand-clicked corners): the car moves ~150 px and shrinks to 0.7x between
-    frames 0 and 1 -- LK status, forward-backward and the coarse-affine failure all fire, no track survives; the session must agree with the
+    frames 0 and 1 -- LK status, forward-backward and the coarse-affine failure all fire, no track survives; the driver must agree with the
     oracle track for track and keep running on an empty state."""
     frames, times, q, K = stills["a_frames"], stills["a_times"], stills["a_q"], stills["a_K"]
-    p, p3, vp, t, res = _frame0(frames, q, K, border=(233, 167))
-    assert len(p) > 100
-    st, orc, log = _run(frames, times, p, p3, vp, t, res, K)
-    print("frame, alive, pose tracks, klt flags:", log)
-    assert log[0][1] == 0 and (log[0][3] & 1), "expected total loss with the coarse-affine failure flag at frame 1"
-    assert st["n_cur"] == 0 and np.all(np.isfinite(st["t"])) and np.isfinite(st["res"])
+    got, ref = _run_both(frames, times, q, K, (233, 167))
+    assert got["n_tracks0"] > 100
+    assert np.array_equal(got["vg"], ref["vg"]) and not got["vg"].any(), "expected total loss at frame 1"
+    assert got["klt_flags"] & 1, "the coarse-affine failure flag"
+    assert len(got["p"]) == 0 and np.all(np.isfinite(got["B"][:, 0:6]))
+    assert np.array_equal(got["S"][:, 2], ref["S"][:, 2])
 
 
 def test_real_stills_through_the_drop_in_functions_and_the_torch_op(stills):

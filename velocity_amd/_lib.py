@@ -30,7 +30,8 @@ class KltStages(C.Structure):
 
 class SessionView(C.Structure):
     _fields_ = [(k, vp) for k in ("vg", "vp", "p", "ids", "p3", "P", "B", "S", "n_cur", "n_pose", "t", "res", "frame_i", "klt_flags",
-                                  "pose_info", "sel_pw", "p_proj")]
+                                  "pose_info", "sel_pw", "p_proj")] + [(k, C.c_size_t) for k in ("P_row_stride", "P_track_stride", "P_frame_stride")] + [
+                                      ("n0", C.c_int), ("nhist", C.c_int)]
 
 
 LK_COARSE = dict(win=15, max_level=4, max_count=10, eps=0.1)  # utils/KLT.py:106
@@ -78,6 +79,7 @@ _SIGS = {
     "vh_session_create": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, f64p, C.c_int, C.POINTER(LKParams), C.POINTER(LKParams), C.c_int]),
     "vh_session_destroy": (None, [vp]),
     "vh_session_init": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, f32p, C.c_float, C.c_float, C.c_float, vp]),
+    "vh_session_init_dev": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp]),
     "vh_session_step": (C.c_int, [vp, vp, C.c_float, C.c_float, vp]),
     "vh_session_step_v": (C.c_int, [vp, vp, vp, vp, vp]),
     "vh_session_ptrs": (C.c_int, [vp, C.c_int, C.POINTER(SessionView)]),
@@ -92,6 +94,10 @@ _SIGS = {
     "vh_profile_end_stages": (C.c_int, [vp, C.c_int, f64p, i32p]),
     "vh_profile_detail": (C.c_int, [vp, C.c_int]),
     "vh_klt_rois": (C.c_int, [vp, i32p]),
+    "vh_profile_lk_routes": (C.c_int, [vp, i32p, C.c_char_p]),
+    "vh_init_reserve": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "vh_frame0_init": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32p, f64p, f64p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
+                                 C.c_int, C.c_int, C.c_double, vp, vp, vp, vp, vp, vp, vp, i32p, vp]),
     "vh_msv1_t": (C.c_int, [vp, f64p, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
 }
 

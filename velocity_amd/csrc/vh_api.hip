@@ -3,6 +3,7 @@
 // leave the GPU: small "glue" kernels write the job descriptors of the next stage into the per-stream workspace, and
 // every image / track kernel is launched over the maximum extent and reads its extent from there.  A frame is thus a
 // fixed sequence of launches with no host round trip (hipGraph-capturable), for any number of streams per launch.
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -27,7 +28,7 @@ int vh_fail(int code, const char* msg)
 }
 #define VH_LAUNCH_CHECK() VH_CHECK(hipGetLastError())
 
-extern "C" VH_API int vh_version(void) { return 103; }
+extern "C" VH_API int vh_version(void) { return 104; }
 void vh_lk_force_generic(int on);
 extern "C" VH_API void vh_debug_force_generic_lk(int on) { vh_lk_force_generic(on); }
 void vh_ransac_force_path(int mode);
@@ -117,6 +118,7 @@ extern "C" VH_API void vh_ctx_destroy(vh_ctx* c)
 {
     if (!c) return;
     vh_ba_graph_cache_free(c->ba_graphs);
+    vh_init_scratch_free(c);
     (void)hipFree(c->arena);
     if (c->bound_ev) (void)hipEventDestroy(c->bound_ev);
     for (int k = 0; k < 2 * c->prof_cap; k++) (void)hipEventDestroy(c->prof_ev[k]);
@@ -441,7 +443,9 @@ __global__ void k_klt_glue2(StreamWS* ws_all)
 static int launch_lk_profiled(vh_ctx* c, int stage, const void* tab, size_t st, int count, int win, hipStream_t s, int mn)
 {
     const int rec = vh_prof_start(c, s, 1);
-    const int r = vh_launch_lk(tab, st, count, mn, win, s);
+    int route = 0;
+    const int r = vh_launch_lk(tab, st, count, mn, win, s, &route);
+    if (c && stage >= 0 && stage < 3) { c->lk_route[stage] = route; c->lk_win[stage] = win; }
     vh_prof_stop(c, rec, stage, s);
     return r;
 }
@@ -452,8 +456,8 @@ static int launch_lk_profiled(vh_ctx* c, int stage, const void* tab, size_t st, 
         vh_prof_stop((c), rec_, (stage), (s));        \
     } while (0)
 
-static int g_klt_order = getenv("VH_KLT_ORDER") ? atoi(getenv("VH_KLT_ORDER")) : -1;  // test hook: 1 always, 0 never, -1 by load
-extern "C" VH_API void vh_debug_klt_order(int mode) { g_klt_order = mode; }
+static std::atomic<int> g_klt_order{getenv("VH_KLT_ORDER") ? atoi(getenv("VH_KLT_ORDER")) : -1};  // PROCESS-WIDE test hook: 1 always, 0 never, -1 by load
+extern "C" VH_API void vh_debug_klt_order(int mode) { g_klt_order.store(mode, std::memory_order_relaxed); }
 
 int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine, const SessStream* sess,
                     const uint8_t* const* frames, int n_max)
@@ -463,7 +467,8 @@ int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_p
     const size_t st = sizeof(StreamWS);
     const int lvl_c = min(coarse.max_level, VH_MAX_LEVELS - 1), lvl_f = min(fine.max_level, VH_MAX_LEVELS - 1);
     // spatial launch order of the tracks: pays from the load at which a stream's pyramids no longer sit in every L2 anyway (8 streams: no difference measured)
-    const int use_order = g_klt_order >= 0 ? g_klt_order : ((long long)count * mn >= 24000 ? 1 : 0);
+    const int order_mode = g_klt_order.load(std::memory_order_relaxed);
+    const int use_order = order_mode >= 0 ? order_mode : ((long long)count * mn >= 24000 ? 1 : 0);
     hipLaunchKernelGGL(k_klt_setup, dim3(count), dim3(use_order ? KO_THREADS : 64), 0, s, ws, sess ? sess + slot : nullptr, frames, coarse, fine, use_order);
     VH_PROFILED(c, VH_PROF_RESIZE, s, vh_launch_resize_quarter(&ws->rs_src[0], &ws->rs_dst[0], st, 2, count, c->sw, c->sh, s));
     VH_PROFILED(c, VH_PROF_PYR, s, for (int l = 0; l < lvl_c; l++) vh_launch_pyr_down_ws(&ws->pb[0], st, count, l, c->sw, c->sh, s));
@@ -567,6 +572,18 @@ extern "C" VH_API int vh_klt_rois(vh_ctx* c, int* roi_host)
     if (!c || !roi_host) return vh_fail(-1, "vh_klt_rois: bad arguments");
     VH_CHECK(hipDeviceSynchronize());
     for (int b = 0; b < c->batch; b++) VH_CHECK(hipMemcpy(roi_host + 4 * b, c->d_ws[b].roi, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// which kernel each of the three LK launches of the last KLTmain / session step took (the launcher's own decision, vh_lk_route): ids as
+// vh_debug_force_generic_lk, names as in DESIGN.md / rocprofv3 traces; names_host: 3 x 32 chars (may be null)
+extern "C" VH_API int vh_profile_lk_routes(vh_ctx* c, int* routes_host, char* names_host)
+{
+    if (!c || !routes_host) return vh_fail(-1, "vh_profile_lk_routes: bad arguments");
+    for (int k = 0; k < 3; k++) {
+        routes_host[k] = c->lk_route[k];
+        if (names_host) snprintf(names_host + 32 * k, 32, "%s", vh_lk_route_name(c->lk_route[k], c->lk_win[k]));
+    }
     return 0;
 }
 
@@ -771,6 +788,7 @@ extern "C" VH_API int vh_pyr_lk(vh_ctx* c, const uint8_t* im1, const uint8_t* im
     J.fbt = fbt;
     J.in_scale = 1.f; J.out_mode = VH_OUT_SCALE; J.out_scale = 1.f;
     StreamWS* ws = c->d_ws;
+    J.stats = ws->lk_stats[0];  // Newton iterations / template set-ups of this call (vh_profile_begin zeroes them, vh_profile_end reads them)
     VH_CHECK(vh_store(&ws->lk, J, s));
     VH_CHECK(vh_store(&ws->pb[0], PyrBuild{&ws->lk.I, 1, 0}, s));
     VH_CHECK(vh_store(&ws->pb[1], PyrBuild{&ws->lk.J, 1, 0}, s));
@@ -1014,8 +1032,8 @@ static int ba_parts(int nt, int nc)
     if (cap < p) p = cap < 1 ? 1 : (int)cap;
     return p;
 }
-static int g_ba_force_valu = 0;
-extern "C" VH_API void vh_debug_ba_force_valu(int on) { g_ba_force_valu = on; }
+static std::atomic<int> g_ba_force_valu{0};  // PROCESS-WIDE test hook (include/velocity_hip.h)
+extern "C" VH_API void vh_debug_ba_force_valu(int on) { g_ba_force_valu.store(on, std::memory_order_relaxed); }
 extern "C" VH_API void vh_debug_pyr_rows(int rows) { vh_pyr_force_rows(rows == 2 || rows == 4 || rows == 8 ? rows : 0); }
 
 extern "C" VH_API size_t vh_nls_batch_workspace(int nt, int nc) { return vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc)); }
@@ -1030,7 +1048,7 @@ extern "C" VH_API int vh_nls_batch(vh_ctx* c, const double* K_host, const double
     P.graph_cache = c->ba_graph_on ? &c->ba_graphs : nullptr;
     P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
-    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt, nc); P.force_valu = g_ba_force_valu;
+    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.nparts = ba_parts(nt, nc); P.force_valu = g_ba_force_valu.load(std::memory_order_relaxed);
     P.phase = -1; P.it = 0; P.add_identity = 1; P.count_cams = 1; P.defer_finalize = 0; P.model = 0;
     P.nwin = 1; P.ws_stride = P.z_stride = P.x_stride = P.trace_stride = P.info_stride = 0;
     P.nx_total = 3.0 * nt + 6.0 * nc; P.nz_total = 2.0 * nt * (nc + 1);
@@ -1052,7 +1070,7 @@ extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const double* K_host, const 
     P.graph_cache = c->ba_graph_on ? &c->ba_graphs : nullptr;
     P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
-    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.force_valu = g_ba_force_valu;
+    P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = max_iter; P.force_valu = g_ba_force_valu.load(std::memory_order_relaxed);
     // fewer partial systems per window when many windows fill the chip anyway (the partials are reduced through HBM)
     int parts = ba_parts(nt, nc), cap = 512 / nwin < 16 ? 16 : 512 / nwin;
     P.nparts = nwin > 1 && parts > cap ? cap : parts;
@@ -1102,7 +1120,7 @@ extern "C" VH_API int vh_nls_batch_phase(vh_ctx* c, const double* K_host, const 
     P.ctx = c;
     for (int k = 0; k < 9; k++) P.K[k] = (double)K_host[k];
     P.z = z; P.x = x; P.trace = trace; P.info = info; P.workspace = workspace; P.nt = nt; P.nc = nc; P.max_iter = 1; P.nparts = ba_parts(nt, nc);
-    P.force_valu = g_ba_force_valu;
+    P.force_valu = g_ba_force_valu.load(std::memory_order_relaxed);
     P.phase = phase; P.it = it; P.add_identity = rank0 ? 1 : 0; P.count_cams = rank0 ? 1 : 0; P.defer_finalize = 1; P.model = 0;
     P.nwin = 1; P.ws_stride = P.z_stride = P.x_stride = P.trace_stride = P.info_stride = 0;
     P.nx_total = 3.0 * nt_total + 6.0 * nc; P.nz_total = 2.0 * nt_total * (nc + 1);

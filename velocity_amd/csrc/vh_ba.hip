@@ -7,6 +7,7 @@
 // are solved through the point-block Schur complement -- algebraically the same delta as the dense inverse:
 //     H = [[U  W],[W^T V]] + I,   S = V + I - W^T (U+I)^-1 W,   S dc = gc - W^T (U+I)^-1 gp,   dp = (U+I)^-1 (gp - W dc)
 // Everything stays on the device for all iterations (the convergence test only sets a device flag).
+#include <atomic>
 #include "vh_ba.hpp"
 #include <type_traits>
 #include "vh_ws.hpp"
@@ -1591,12 +1592,17 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     const size_t lds_mfma = sizeof(double) * (size_t)(24 * npad + 2 * 4 * (20 * nc + 10) + 4 * npad);
     const bool use_mfma = nq <= 252 && !P.force_valu && P.model == 0;  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
     if (use_mfma && lds_mfma > 64 * 1024) {
-        static bool attr_set = false;  // (per process; the attribute is per function)
-        if (!attr_set) {
+        // the attribute is per function AND per device: one bit per device ordinal, set with an atomic OR (two host threads, or a process that drives
+        // a second GPU, each set it for their device; setting it twice is harmless)
+        static std::atomic<unsigned long long> attr_devs{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_schur_mfma<256, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_schur_mfma<256, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
             if (e != hipSuccess) return (int)e;
-            attr_set = true;
+            attr_devs.fetch_or(bit, std::memory_order_release);
         }
     }
     J.zmode = use_mfma ? 1 : 0;

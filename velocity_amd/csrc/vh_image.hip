@@ -1,6 +1,7 @@
 // Image-stage kernels of the KLT path: quarter-scale nearest decimation (K1), pyrDown (K2), shifted crop (K8) and
 // affine remap (K9).  All are HBM-bound byte kernels; descriptors are read from device memory because ROI sizes are
 // data dependent (bounding box of the tracks) and the whole frame pipeline runs without a host round trip.
+#include <atomic>
 #include <cstdlib>
 #include <algorithm>
 #include "vh_kernels.hpp"
@@ -593,8 +594,8 @@ __global__ __launch_bounds__(256) void k_pyr_pad(const void* pb_tab, size_t ws_s
     *reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(d.p) + (ptrdiff_t)y * d.stride + x) = v;
 }
 
-static int g_pyr_rows = 0;  // test hook: 2 / 4 / 8 output rows per thread whatever the launch size (0: by size)
-void vh_pyr_force_rows(int rb) { g_pyr_rows = rb; }
+static std::atomic<int> g_pyr_rows{0};  // PROCESS-WIDE test hook (include/velocity_hip.h): 2 / 4 / 8 output rows per thread whatever the launch size (0: by size)
+void vh_pyr_force_rows(int rb) { g_pyr_rows.store(rb, std::memory_order_relaxed); }
 
 void vh_launch_pyr_down_ws(const void* pb_tab, size_t ws_stride, int batch, int lvl, int max_w0, int max_h0, hipStream_t s)
 {
@@ -605,7 +606,8 @@ void vh_launch_pyr_down_ws(const void* pb_tab, size_t ws_stride, int batch, int 
     // 8 output rows per thread (19 source rows in flight, 136 VGPRs) once a launch is far beyond the chip (19 rows read per 16 produced instead of
     // 11 per 8: 271 -> 250 us for the 766 x 451 level of 256 streams; no gain below), 4 rows from ~1 Mpx, 2 for single-stream latency
     const long long px = (long long)w * h * batch;
-    const int rb = g_pyr_rows ? g_pyr_rows : (px >= (1ll << 25) ? 8 : px >= (1ll << 20) ? 4 : 2);
+    const int forced_rows = g_pyr_rows.load(std::memory_order_relaxed);
+    const int rb = forced_rows ? forced_rows : (px >= (1ll << 25) ? 8 : px >= (1ll << 20) ? 4 : 2);
     if (rb == 8) {
         dim3 grd((w + 255) / 256, (h + 31) / 32, batch * 2);
         hipLaunchKernelGGL(k_pyr_down<8>, grd, blk, 0, s, pb_tab, ws_stride, lvl);

@@ -9,6 +9,8 @@
 //   k_lk_strip<W>   strips of 4 samples per lane on packed 16-bit dot products, one wavefront per track, loads from L1/L2
 //   k_lk3<W,NW,M>   LDS-staged patch + search region, NW wavefronts per track, vertical strip runs (the 51x51 fine stage)
 //   k_lk_q<W>       4 tracks per wavefront, one 16-lane DPP row per track, template in registers (the 15x15 coarse stages)
+#include <atomic>
+
 #include "vh_kernels.hpp"
 #include "vh_valu.hpp"
 
@@ -248,9 +250,12 @@ __global__ __launch_bounds__(64) void k_lk(const void* job_tab, size_t tab_strid
     lk_track(job.I, job.J, job.win, job.max_count, job.eps2, px, py, fx, fy, st, err, ldsI, ldsD, lane, n_iter, n_setup, job.err_out != nullptr);
     float fbe = 0.f;
     if (job.fbt >= 0.f) {
-        float bx, by, e2;
-        int st2;
-        lk_track(job.J, job.I, job.win, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, ldsI, ldsD, lane, n_iter, n_setup, false);
+        float bx = 0.f, by = 0.f, e2;
+        int st2 = 0;
+        // forward status 0: `v = v & v2 & (fbe < fbt)` (KLT.py:50) is 0 whatever the backward pass finds, and the point returned is the forward one, so
+        // the backward pass is skipped unless the caller asked for fbe itself (vh_pyr_lk); in the 4- / 8-tracks-per-wavefront kernels the dead tracks'
+        // lanes sit out the pass (exec mask), and a wavefront whose tracks are all dead skips it
+        if (st || job.fbe_out) lk_track(job.J, job.I, job.win, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, ldsI, ldsD, lane, n_iter, n_setup, false);
         const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
         fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
         st = st && st2 && (fbe < job.fbt);
@@ -848,9 +853,9 @@ __global__ __launch_bounds__(64) void k_lk_strip(const void* job_tab, size_t tab
     lk_track_strip<WIN_T>(job.I, job.J, win, job.max_count, job.eps2, px, py, fx, fy, st, err, tI, tX, tY, lane, n_iter, n_setup, job.err_out != nullptr);
     float fbe = 0.f;
     if (job.fbt >= 0.f) {
-        float bx, by, e2;
-        int st2;
-        lk_track_strip<WIN_T>(job.J, job.I, win, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, tI, tX, tY, lane, n_iter, n_setup, false);
+        float bx = 0.f, by = 0.f, e2;
+        int st2 = 0;
+        if (st || job.fbe_out) lk_track_strip<WIN_T>(job.J, job.I, win, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, tI, tX, tY, lane, n_iter, n_setup, false);
         const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
         fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
         st = st && st2 && (fbe < job.fbt);
@@ -1358,6 +1363,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
     const bool want_err = job.err_out != nullptr;
 #pragma unroll 1
     for (int dir = 0; dir < ndir; dir++) {
+        if (dir == 1 && !st && !job.fbe_out) break;  // forward status 0 (block uniform): the backward pass cannot change v or p (see k_lk)
         const PyrDesc& PA = dir ? job.J : job.I;
         const PyrDesc& PB = dir ? job.I : job.J;
         float ox, oy, e;
@@ -1723,9 +1729,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     lkq_track<WIN>(job.I, job.J, job.max_count, job.eps2, px, py, fx, fy, st, err, r, n_iter, n_setup, job.err_out != nullptr);
     float fbe = 0.f;
     if (job.fbt >= 0.f) {
-        float bx, by, e2;
-        int st2;
-        lkq_track<WIN>(job.J, job.I, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, r, n_iter, n_setup, false);
+        float bx = 0.f, by = 0.f, e2;
+        int st2 = 0;
+        if (st || job.fbe_out) lkq_track<WIN>(job.J, job.I, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, r, n_iter, n_setup, false);
         const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
         fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
         st = st && st2 && (fbe < job.fbt);
@@ -2087,9 +2093,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     lko_track<WIN>(job.I, job.J, job.max_count, job.eps2, px, py, fx, fy, st, err, r, n_iter, n_setup, job.err_out != nullptr);
     float fbe = 0.f;
     if (job.fbt >= 0.f) {
-        float bx, by, e2;
-        int st2;
-        lko_track<WIN>(job.J, job.I, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, r, n_iter, n_setup, false);
+        float bx = 0.f, by = 0.f, e2;
+        int st2 = 0;
+        if (st || job.fbe_out) lko_track<WIN>(job.J, job.I, job.max_count, job.eps2, fx, fy, bx, by, st2, e2, r, n_iter, n_setup, false);
         const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
         fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
         st = st && st2 && (fbe < job.fbt);
@@ -2163,45 +2169,74 @@ static int launch_strip(const void* job_tab, size_t tab_stride, int batch, int m
 }
 
 // test hook: 1 = per-sample kernel, 2 = strip kernel, 3 = LDS-staged kernel, 4 = 4-tracks-per-wave kernel (15x15), 5 / 6 / 7 = LDS-staged 51x51 kernel with
-// 1 / 2 / 4 wavefronts per track, 8 = 8-tracks-per-wave kernel (15x15), 0 = default routing
-static int g_lk_force_generic = getenv("VH_LK_FORCE") ? atoi(getenv("VH_LK_FORCE")) : 0;  // (environment: experiments only)
-void vh_lk_force_generic(int on) { g_lk_force_generic = on; }
-static long long g_lko_min_tracks = getenv("VH_LKO_MIN") ? atoll(getenv("VH_LKO_MIN")) : 30000;  // (environment: experiments only)
+// 1 / 2 / 4 wavefronts per track, 8 = 8-tracks-per-wave kernel (15x15), 0 = default routing.
+// PROCESS-WIDE (every context of the process is re-routed; an atomic, so a flip while another thread launches is a clean switch between two
+// bit-identical implementations, never a torn value) -- a test / experiment switch, not a per-stream control.
+static std::atomic<int> g_lk_force_generic{getenv("VH_LK_FORCE") ? atoi(getenv("VH_LK_FORCE")) : 0};  // (environment: experiments only)
+void vh_lk_force_generic(int on) { g_lk_force_generic.store(on, std::memory_order_relaxed); }
+static const long long g_lko_min_tracks = getenv("VH_LKO_MIN") ? atoll(getenv("VH_LKO_MIN")) : 30000;  // (environment: experiments only)
 
-int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s)
+// Which kernel a launch of `batch` streams x `max_n` track slots with window `win` takes (the ids of the test hook above; 2 = the strip kernel of any
+// window <= 63, 1 = the per-sample kernel).  vh_launch_lk follows exactly this decision, and the profiling records report it (vh_profile_lk_routes), so
+// nobody has to mirror the thresholds.
+//
+// Default routing (measured on MI355X, profiles/): 51x51 fine stage -- the LDS-staged kernel; ONE wavefront per track (no barrier, no LDS exchange of
+// the window sums, the wave-uniform work done once per track) wins from ~3000 tracks in flight (2.32 ms vs 2.99 ms (2 per track) vs 4.5 ms (4 per
+// track) at 256 000 tracks); 2 and 4 per track shorten the critical path of a single track and are used below that (67 us vs 72 us for 2000 tracks).
+// 15x15 coarse stages -- 8 tracks per wavefront once the launch fills the chip at 8 per wavefront (>= 30 000 tracks), 4 per wavefront from ~3000
+// (53 / 89 us vs 55 / 99 us at 4000 tracks, 0.43 / 0.81 ms vs 0.9 / 1.7 ms at 256 000), below that the one-wave-per-track strip kernel has the
+// shorter critical path (43 / 73 us vs 51 / 82 us at 2000 tracks; the LDS-staged variant is 2.5x slower there).
+int vh_lk_route(int batch, int max_n, int win)
 {
-    if (max_n <= 0) return 0;
-    // Default routing (measured on MI355X, profiles/): the LDS-staged 4-wave kernel for the 51x51 fine stage (equal
-    // throughput, 25% lower latency than the strip kernel), the strip kernel for the 15x15 coarse stages (the staged
-    // variant is 2.5x slower there).  Mode 3 forces the staged kernel for both windows (tests).
-    const bool force_nw = g_lk_force_generic >= 5 && g_lk_force_generic <= 7;
-    if (g_lk_force_generic == 0 || g_lk_force_generic == 3 || (force_nw && win == 51)) {
-        if (win == 15 && g_lk_force_generic == 3) return launch_lk3<15, 1, 6>(job_tab, tab_stride, batch, max_n, s);
-        // Wavefronts per 51x51 track, measured on MI355X (C2, frame step with 1 .. 128 streams): ONE wavefront per track (13 strips per lane, no
-        // barrier, no LDS exchange of the window sums, the replicated wave-uniform work done once per track) wins from ~4000 tracks in flight
-        // up: 2.32 ms vs 2.99 ms (2 per track) vs 4.5 ms (4 per track) at 256 000 tracks; 2 and 4 per track shorten the critical path of a
-        // single track and are used below that (67 us vs 72 us for 2000 tracks).
+    const int force = g_lk_force_generic.load(std::memory_order_relaxed);
+    const long long tracks = (long long)max_n * batch;
+    const bool force_nw = force >= 5 && force <= 7;
+    if (force == 0 || force == 3 || (force_nw && win == 51)) {
+        if (win == 15 && force == 3) return 3;
         if (win == 51) {
-            const long long tracks = (long long)max_n * batch;
-            const int nw = force_nw ? (1 << (g_lk_force_generic - 5)) : (g_lk_force_generic == 3 ? 4 : tracks >= 3000 ? 1 : tracks >= 1024 ? 2 : 4);
-            if (nw == 1) return launch_lk3<51, 1, 4>(job_tab, tab_stride, batch, max_n, s);
-            if (nw == 2) return launch_lk3<51, 2, 4>(job_tab, tab_stride, batch, max_n, s);
-            return launch_lk3<51, 4, 4>(job_tab, tab_stride, batch, max_n, s);
+            const int nw = force_nw ? (1 << (force - 5)) : (force == 3 ? 4 : tracks >= 3000 ? 1 : tracks >= 1024 ? 2 : 4);
+            return nw == 1 ? 5 : nw == 2 ? 6 : 7;
         }
     }
-    // 15x15: 4 tracks per wavefront from ~3000 tracks in flight (measured: 53 / 89 us vs 55 / 99 us for the two coarse stages at 4000 tracks,
-    // 0.43 / 0.81 ms vs 0.9 / 1.7 ms at 256 000); below that the one-wave-per-track strip kernel has the shorter critical path (43 / 73 us vs
-    // 51 / 82 us at 2000 tracks).  Mode 4 forces it (tests).
-    // 8 tracks per wavefront (mode 8 forces it) once the launch fills the chip at 8 per wavefront.
-    if (win == 15 && (g_lk_force_generic == 8 || ((g_lk_force_generic == 0 || force_nw) && (long long)max_n * batch >= g_lko_min_tracks)))
-        return launch_lko<15>(job_tab, tab_stride, batch, max_n, s);
-    if (win == 15 && (g_lk_force_generic == 4 || ((g_lk_force_generic == 0 || force_nw) && (long long)max_n * batch >= 3000)))
-        return launch_lkq<15>(job_tab, tab_stride, batch, max_n, s);
-    if (g_lk_force_generic != 1 && win <= 63) {  // (modes 5..7 with another window than 51: default routing)
-        // int32 per-lane partial sums are exact up to 16 strips per lane (win <= 63)
+    if (win == 15 && (force == 8 || ((force == 0 || force_nw) && tracks >= g_lko_min_tracks))) return 8;
+    if (win == 15 && (force == 4 || ((force == 0 || force_nw) && tracks >= 3000))) return 4;
+    if (force != 1 && win <= 63) return 2;  // (modes 5..7 with another window than 51: default routing); int32 per-lane partial sums are exact up to 16 strips per lane
+    return 1;
+}
+
+const char* vh_lk_route_name(int route, int win)
+{
+    switch (route) {
+    case 1: return "k_lk";
+    case 2: return win == 15 ? "k_lk_strip<15>" : win == 51 ? "k_lk_strip<51>" : "k_lk_strip<0>";
+    case 3: return "k_lk3<15, 1, 6>";
+    case 4: return "k_lk_q<15>";
+    case 5: return "k_lk3<51, 1, 4>";
+    case 6: return "k_lk3<51, 2, 4>";
+    case 7: return "k_lk3<51, 4, 4>";
+    case 8: return "k_lk_o<15>";
+    default: return "none";
+    }
+}
+
+int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s, int* route_out)
+{
+    if (route_out) *route_out = 0;
+    if (max_n <= 0) return 0;
+    const int route = vh_lk_route(batch, max_n, win);
+    if (route_out) *route_out = route;
+    switch (route) {
+    case 3: return launch_lk3<15, 1, 6>(job_tab, tab_stride, batch, max_n, s);
+    case 5: return launch_lk3<51, 1, 4>(job_tab, tab_stride, batch, max_n, s);
+    case 6: return launch_lk3<51, 2, 4>(job_tab, tab_stride, batch, max_n, s);
+    case 7: return launch_lk3<51, 4, 4>(job_tab, tab_stride, batch, max_n, s);
+    case 8: return launch_lko<15>(job_tab, tab_stride, batch, max_n, s);
+    case 4: return launch_lkq<15>(job_tab, tab_stride, batch, max_n, s);
+    case 2:
         if (win == 15) return launch_strip<15>(job_tab, tab_stride, batch, max_n, win, s);
         if (win == 51) return launch_strip<51>(job_tab, tab_stride, batch, max_n, win, s);
         return launch_strip<0>(job_tab, tab_stride, batch, max_n, win, s);
+    default: break;
     }
     const int kmax = (win * win + 63) / 64;
     const size_t lds = (size_t)kmax * 64 * 6;

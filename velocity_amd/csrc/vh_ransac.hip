@@ -530,14 +530,15 @@ __global__ __launch_bounds__(512) void k_ransac_fused(const void* tab, size_t st
     }
 }
 
-static int g_ransac_force = 0;  // test hook: 1 = always the three-kernel path, 2 = the fused kernel whenever the problem fits it
-void vh_ransac_force_path(int mode) { g_ransac_force = mode; }
+static std::atomic<int> g_ransac_force{0};  // PROCESS-WIDE test hook (include/velocity_hip.h): 1 = always the three-kernel path, 2 = the fused kernel whenever the problem fits it
+void vh_ransac_force_path(int mode) { g_ransac_force.store(mode, std::memory_order_relaxed); }
 
 void vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
 {
     // up to RANSAC_FUSED_MAX pairs: one fused workgroup per stream, pairs / indices / counts resident in LDS (measured faster than the three
     // launches at every stream count, 1 .. 256: 4.53 -> 4.48 ms per step at 128 streams); more pairs: hypotheses spread over the chip
-    if (max_n <= RANSAC_FUSED_MAX && (g_ransac_force == 2 || g_ransac_force == 0)) {
+    const int force = g_ransac_force.load(std::memory_order_relaxed);
+    if (max_n <= RANSAC_FUSED_MAX && (force == 2 || force == 0)) {
         const size_t lds = (size_t)RANSAC_FUSED_MAX * (16 + 4) + (size_t)VH_RANSAC_ITERS * 4;
         // 69 KB of dynamic LDS (> the 64 KB default limit): the attribute is per device; 0 = not tried, 1 = granted, -1 = refused (three-kernel path)
         static std::atomic<signed char> attr_state[64];

@@ -196,17 +196,24 @@ __global__ __launch_bounds__(256) void k_sess_after_msv(SessStream* ss_all, int 
 }
 
 // frame-0 initialisation (vidExample.py:125-131, 151-153)
+// t0_dev / res0_dev / n_dev (all may be null): plate pose, its residual and the number of frame-0 tracks taken from DEVICE memory -- the outputs of
+// vh_frame0_init -- instead of the by-value arguments; with n_dev < N0 the tail rows are tracks that never existed (vg 0, history NaN)
 __global__ __launch_bounds__(256) void k_sess_init(SessStream* ss, const float* p, const double* p3, const uint8_t* vp, const uint8_t* frame0,
-                                                   float t0x, float t0y, float t0z, float time0, float frame_no, float res0)
+                                                   float t0x, float t0y, float t0z, float time0, float frame_no, float res0, const float* t0_dev,
+                                                   const double* res0_dev, const int* n_dev)
 {
     SessStream& S = *ss;
     const int tid = threadIdx.x, N0 = S.N0, nh = S.nhist;
+    const int n = n_dev ? min(max(*n_dev, 0), N0) : N0;
+    if (t0_dev) { t0x = t0_dev[0]; t0y = t0_dev[1]; t0z = t0_dev[2]; }
+    if (res0_dev) res0 = (float)*res0_dev;
     const float nanv = __int_as_float(0x7fc00000);
     for (size_t q = tid; q < (size_t)5 * N0 * nh; q += 256) S.P[q] = nanv;
     for (int q = tid; q < nh * 14; q += 256) S.B[q] = 0.f;
     for (int q = tid; q < nh * 9; q += 256) S.S[q] = 0.f;
     __syncthreads();
-    for (int g = tid; g < N0; g += 256) {
+    for (int g = n + tid; g < N0; g += 256) { S.vg[g] = 0; S.vp[g] = 0; }
+    for (int g = tid; g < n; g += 256) {
         S.vg[g] = 1;
         S.vp[g] = vp[g] ? 1 : 0;
         S.ids[g] = g;
@@ -218,11 +225,11 @@ __global__ __launch_bounds__(256) void k_sess_init(SessStream* ss, const float* 
         S.P[sess_P(4, g, 0, N0)] = 0.f;
     }
     if (tid == 0) {
-        S.n_cur = N0; S.n_pose = 0; S.frame_i = 0; S.pp = 0; S.klt_flags = 0; S.small_ready = 0;
+        S.n_cur = n; S.n_pose = 0; S.frame_i = 0; S.pp = 0; S.klt_flags = 0; S.small_ready = 0;
         S.B[0] = t0x; S.B[1] = t0y; S.B[2] = t0z; S.B[12] = time0; S.B[13] = frame_no;
         S.t[0] = t0x; S.t[1] = t0y; S.t[2] = t0z;
-        S.t0 = time0; S.r_total = 0.f; S.res = (double)res0;
-        S.S[0] = 0.f; S.S[2] = (float)N0; S.S[3] = res0; S.S[4] = nanv; S.S[8] = nanv;
+        S.t0 = time0; S.r_total = 0.f; S.res = res0_dev ? *res0_dev : (double)res0;
+        S.S[0] = 0.f; S.S[2] = (float)n; S.S[3] = res0; S.S[4] = nanv; S.S[8] = nanv;
         S.im0 = frame0;
     }
 }
@@ -298,21 +305,36 @@ extern "C" VH_API void vh_session_destroy(vh_session* s)
     delete s;
 }
 
-extern "C" VH_API int vh_session_init(vh_session* s, int slot, const uint8_t* frame0, int stride, const float* p, const double* p3,
-                                      const uint8_t* vp, const float* t0_host, float time0, float frame_no, float res0, void* stream)
+static int session_init(vh_session* s, int slot, const uint8_t* frame0, int stride, const float* p, const double* p3, const uint8_t* vp,
+                        const float* t0_host, float time0, float frame_no, float res0, const float* t0_dev, const double* res0_dev, const int* n_dev,
+                        void* stream)
 {
-    if (!s || slot < 0 || slot >= s->batch || !t0_host) return vh_fail(-1, "vh_session_init: bad arguments");
     if (stride != s->w) return vh_fail(-1, "vh_session_init: frames must be dense (stride == width)");
     vh_ctx_bind bound_(s->ctx, stream);
     hipStream_t st = bound_.s;
-    hipLaunchKernelGGL(k_sess_init, dim3(1), dim3(256), 0, st, s->d_ss + slot, p, p3, vp, frame0, t0_host[0], t0_host[1], t0_host[2], time0,
-                       frame_no, res0);
+    hipLaunchKernelGGL(k_sess_init, dim3(1), dim3(256), 0, st, s->d_ss + slot, p, p3, vp, frame0, t0_host ? t0_host[0] : 0.f, t0_host ? t0_host[1] : 0.f,
+                       t0_host ? t0_host[2] : 0.f, time0, frame_no, res0, t0_dev, res0_dev, n_dev);
     // quarter-scale copy of frame 0 = im0_small of the first step (pp starts at 0 -> previous index 1)
     int r = vh_resize_quarter(s->ctx, frame0, s->w, s->h, stride, s->h_ss[slot].small[1], stream);
     if (r) return r;
     s->h_frame[slot] = 0;  // a (re-)initialised slot starts a new clip: its MSV frame counts from here
     SESS_CHECK();
     return 0;
+}
+
+extern "C" VH_API int vh_session_init(vh_session* s, int slot, const uint8_t* frame0, int stride, const float* p, const double* p3,
+                                      const uint8_t* vp, const float* t0_host, float time0, float frame_no, float res0, void* stream)
+{
+    if (!s || slot < 0 || slot >= s->batch || !t0_host) return vh_fail(-1, "vh_session_init: bad arguments");
+    return session_init(s, slot, frame0, stride, p, p3, vp, t0_host, time0, frame_no, res0, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" VH_API int vh_session_init_dev(vh_session* s, int slot, const uint8_t* frame0, int stride, const float* p, const double* p3,
+                                          const uint8_t* vp, const float* t0_dev, const double* res0_dev, const int* n_dev, float time0,
+                                          float frame_no, void* stream)
+{
+    if (!s || slot < 0 || slot >= s->batch || !t0_dev || !res0_dev) return vh_fail(-1, "vh_session_init_dev: bad arguments");
+    return session_init(s, slot, frame0, stride, p, p3, vp, nullptr, time0, frame_no, 0.f, t0_dev, res0_dev, n_dev, stream);
 }
 
 static int session_step(vh_session* s, const uint8_t* const* frames_dev, float time_s, float frame_no, const float* times_dev,
@@ -428,5 +450,8 @@ extern "C" VH_API int vh_session_ptrs(vh_session* s, int slot, vh_session_view* 
     out->vg = H.vg; out->vp = H.vp; out->p = H.p_cur; out->ids = H.ids; out->p3 = H.p3; out->P = H.P; out->B = H.B; out->S = H.S;
     out->n_cur = &d->n_cur; out->n_pose = &d->n_pose; out->t = d->t; out->res = &d->res; out->frame_i = &d->frame_i;
     out->klt_flags = &d->klt_flags; out->pose_info = d->pose_info; out->sel_pw = H.sel_pw; out->p_proj = H.p_proj;
+    // history layout, in floats: entry (row, track, frame) of P at P[row * P_row_stride + track * P_track_stride + frame * P_frame_stride]
+    out->P_row_stride = (size_t)H.N0; out->P_track_stride = 1; out->P_frame_stride = (size_t)5 * H.N0;
+    out->n0 = H.N0; out->nhist = H.nhist;
     return 0;
 }

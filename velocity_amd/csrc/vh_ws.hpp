@@ -58,6 +58,17 @@ struct StreamWS {
     const int* order;  // bufs.order when this call launches its LK kernels in spatial order, else null
 };
 
+// scratch of the frame-0 detector (vh_init.hip: goodFeaturesToTrack / cornerSubPix), owned by the context that uses it
+struct InitScratch {
+    int* dxy;
+    float* resp;
+    unsigned long long *keys, *sorted;
+    unsigned* counters;  // [0] max (ordered bits), [1] candidate count, [2..3] pose info, [4] corner count of vh_frame0_init
+    float* mask;         // cornerSubPix Gaussian windows of every half-size 1..7, back to back
+    void* sort_tmp;
+    size_t sort_bytes, pixels;
+};
+
 struct vh_ctx {
     int batch, max_w, max_h, max_pts, sw, sh;
     char* arena;
@@ -76,6 +87,9 @@ struct vh_ctx {
     hipStream_t bound_stream;  // the stream whose work may still read this context's job descriptors (vh_ctx_bind)
     hipEvent_t bound_ev;       // recorded on bound_stream by vh_ctx_release at the end of every entry point: what a rebind waits for
     int bound;                 // 0: never used, 1: bound
+    int lk_route[3];           // kernel route (vh_lk_route ids) the last KLTmain took for its three LK launches (vh_profile_lk_routes)
+    int lk_win[3];
+    InitScratch init;          // created by the first frame-0 call (vh_init.hip)
 };
 
 // A vh_ctx parks the job descriptors of the calls in flight, so it serves ONE HIP stream at a time.  Enforced on the DEVICE: every entry point ends
@@ -87,14 +101,20 @@ static inline hipStream_t vh_ctx_bind_raw(vh_ctx* c, void* stream)
     hipStream_t s = (hipStream_t)stream;
     if (c) {
         if (c->bound && c->bound_stream != s && c->bound_ev) {
-            if (hipStreamWaitEvent(s, c->bound_ev, 0) != hipSuccess) (void)hipGetLastError();
+            // A capturing stream must not wait for an event recorded OUTSIDE its capture (an isolation violation that can invalidate the caller's
+            // capture): the wait is skipped there, and the rule is the caller's -- a context does not change stream inside a capture (the work it
+            // queued on its previous stream must have been ordered before the capture began; include/velocity_hip.h "Conventions").
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+            if (cs == hipStreamCaptureStatusNone && hipStreamWaitEvent(s, c->bound_ev, 0) != hipSuccess) (void)hipGetLastError();
         }
         c->bound_stream = s;
         c->bound = 1;
     }
     return s;
 }
-// end of an entry point: marks how far the bound stream has got with this context's descriptors (one event record, no synchronisation)
+// end of an entry point: marks how far the bound stream has got with this context's descriptors (one event record, no synchronisation).  It is recorded
+// by every call because a later rebind may find the previous stream already destroyed: only the event may be touched then.
 static inline void vh_ctx_release(vh_ctx* c)
 {
     if (!c || !c->bound) return;
@@ -156,6 +176,7 @@ struct SessStream {  // device resident, one per video stream
 int vh_run_klt_main(vh_ctx* c, int slot, int count, hipStream_t s, const vh_lk_params& coarse, const vh_lk_params& fine,
                     const SessStream* sess = nullptr, const uint8_t* const* frames = nullptr, int n_max = 0);
 int vh_fail(int code, const char* msg);
+void vh_init_scratch_free(vh_ctx* c);
 
 // optional HIP-event timing of individual launches (vh_profile_begin / vh_profile_end_stages): stage ids
 enum { VH_PROF_LK0 = 0, VH_PROF_LK1 = 1, VH_PROF_LK2 = 2, VH_PROF_WARP = 3, VH_PROF_PYR = 4, VH_PROF_RANSAC = 5, VH_PROF_RESIZE = 6, VH_PROF_SESSION = 7,

@@ -28,20 +28,23 @@ class TrackerSession:
         self._init_keep = []
 
     def init_stream(self, slot, frame0, p, p3, vp, t0, time0=0.0, frame_no=0.0, res0=0.0):
-        """Frame-0 state (vidExample.py:116-131): points p [n0,2], world points p3 [n0,3], pose mask vp, plate pose t0."""
+        """Frame-0 state (vidExample.py:116-131): points p [n0,2], world points p3 [n0,3], pose mask vp, plate pose t0.  numpy arrays or CUDA tensors
+        (tensors of the right dtype are used in place: a stream can be re-initialised without touching the host)."""
         torch = self.torch
         f0 = frame0 if isinstance(frame0, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frame0))
         f0 = f0.cuda().contiguous()
         assert f0.shape == (self.h, self.w) and f0.dtype == torch.uint8
-        pd = L.to_dev(np.asarray(p, np.float32), torch.float32)
-        p3d = L.to_dev(np.asarray(p3, np.float64), torch.float64)
-        vpd = L.to_dev(np.asarray(vp).astype(np.uint8), torch.uint8)
+
+        def dev(a, np_dtype, t_dtype):
+            return L.to_dev(a if isinstance(a, torch.Tensor) else np.asarray(a).astype(np_dtype), t_dtype)
+
+        pd, p3d, vpd = dev(p, np.float32, torch.float32), dev(p3, np.float64, torch.float64), dev(vp, np.uint8, torch.uint8)
         assert pd.shape == (self.n0, 2) and p3d.shape == (self.n0, 3) and vpd.shape == (self.n0,)
         t0 = np.ascontiguousarray(np.asarray(t0, np.float32).reshape(3))
         L.check(self.lib.vh_session_init(self.handle, slot, L.dptr(f0), self.w, L.dptr(pd), L.dptr(p3d), L.dptr(vpd), t0.ctypes.data_as(L.f32p),
                                          float(time0), float(frame_no), float(res0), L.stream_ptr()), "vh_session_init")
         self._keep[slot] = f0
-        self._init_keep.append((pd, p3d, vpd))
+        self._init_keep = [k for k in self._init_keep if k[0] != slot] + [(slot, pd, p3d, vpd)]
 
     def set_frames(self, frames):
         """frames: list of `batch` CUDA uint8 [H,W] tensors (kept alive until the next call replaces them)."""
@@ -211,3 +214,218 @@ class HostFrameFeeder:
         if self._last is not None:
             self.free[self._last].record(self.torch.cuda.current_stream())
         self._last = slot
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# the reference's driver (vidExample.py:52-178 minus decode and plots): frame-0 initialisation, the frame loop, the table and the summary
+# ----------------------------------------------------------------------------------------------------------------------------------
+TABLE_HEADER = ("\n" + "%13s" * 9) * 2 % ("image", "procTime", "pointTracks", "metric", "dt", "time", "dx", "distance", "speed",
+                                         "#", "(s)", "#", "(pixels)", "(s)", "(s)", "(m)", "(m)", "(km/h)")  # vidExample.py:51-74
+ROW_FORMAT = "{:13g}{:13.3f}{:13g}{:13.3f}{:13.3f}{:13.3f}{:13.2f}{:13.2f}{:13.1f}"  # vidExample.py:165
+
+
+def table_row(S_row):
+    """One line of the reference's results table (vidExample.py:164-165) from a 9-column float32 stats row."""
+    return ROW_FORMAT.format(*tuple(S_row))
+
+
+def summary_lines(S, n, frame_numbers, seconds):
+    """The closing lines of the reference's run (vidExample.py:177-178)."""
+    with np.errstate(all="ignore"):
+        a = f"\nSpeed = {S[1:, 8].mean():.2f} +/- {S[1:, 8].std():.2f} km/h\nRes = {S[1:, 3].mean():.3f} pixels"
+    b = f"Processed {n:g} images: {np.asarray(frame_numbers)[:]} in {seconds:.2f}s ({n / max(seconds, 1e-12):.2f}fps)\n"
+    return [a, b]
+
+
+def run_sequence(frames, q, K, fps=None, times=None, frame_numbers=None, plate="Chile", roi_border=(700, 500), max_corners=1000, quality=0.01,
+                 block=5, harris_k=0.04, subpix=(5, 100, 0.001), msv_frame=5, lk_coarse=None, lk_fine=None, route="session", live=True,
+                 out=print, clock=None, name="sequence"):
+    """The packaged counterpart of vidExample.py:52-178 (minus video decode and plots) on one clip.
+
+    frames  sequence of n uint8 [H, W] gray frames (numpy arrays or CUDA tensors): what `cv2.cvtColor(cap.read(), BGR2GRAY)` / `cv2.imread(.., 0)` hands
+            the reference's loop (vidExample.py:89-93)
+    q       float32 [4, 2]: the hand-clicked plate corners of frame 0 (the .mat file's `q`, vidExample.py:31-32)
+    K       the camera's 3 x 3 intrinsic matrix, reference layout (images.py:148-151)
+    fps / times / frame_numbers   B[i, 12] (seconds; `CAP_PROP_POS_MSEC / 1000` or the EXIF time) and B[i, 13] per frame: either `times` or `fps`
+    route   "session": frame 0 through vh_frame0_init (Harris -> cornerSubPix -> plate pose -> image2world -> insidebbox, ONE device sequence) straight
+            into a device-resident TrackerSession -- nothing but the frames goes up and nothing but the printed rows comes down;
+            "dropin": the reference's own loop body on the drop-in functions (KLT.KLTmain, NLS.estimateWorldCameraPose, MSV.fcnMSV1_t, images.*),
+            i.e. what INTEGRATION.md's import switch gives a maintainer: host arrays in and out of every call.
+    live    True prints every row as its frame finishes (one small read-back per frame, like the reference); False runs the whole clip first.
+    out     line sink (default print); clock: time source for the procTime column / fps line (default time.perf_counter).
+
+    Prints the reference's header, one 9-column row per frame (vidExample.py:165) and the `Speed = ... +/- ... km/h / Res = ...` summary (:177-178).
+    Returns dict(S, B, P, vg, vp, p, p3, lines, seconds, ms_per_frame, n_tracks0)."""
+    import time as _time
+
+    clock = clock or _time.perf_counter
+    n = len(frames)
+    assert n >= 2, "a clip needs at least two frames"
+    q = np.ascontiguousarray(np.asarray(q, np.float32).reshape(4, 2))
+    if times is None:
+        assert fps, "give `times` or `fps`"
+        times = [np.float32(k / fps) for k in range(n)]
+    times = [np.float32(t) for t in times]
+    frame_numbers = list(range(n)) if frame_numbers is None else list(frame_numbers)
+    lines = []
+
+    def emit(line):
+        lines.append(line)
+        if out is not None:
+            out(line)
+
+    emit(f"Starting image processing on {name} ...")  # vidExample.py:50
+    emit(TABLE_HEADER)
+    t_begin = clock()
+    if route == "dropin":
+        res = _run_dropin(frames, q, K, times, frame_numbers, plate, roi_border, max_corners, quality, block, harris_k, subpix, msv_frame, lk_coarse,
+                          lk_fine, emit, clock)
+    elif route == "session":
+        res = _run_session(frames, q, K, times, frame_numbers, plate, roi_border, max_corners, quality, block, harris_k, subpix, msv_frame, lk_coarse,
+                           lk_fine, emit, clock, live)
+    else:
+        raise ValueError("route must be 'session' or 'dropin'")
+    seconds = clock() - t_begin
+    for line in summary_lines(res["S"], n, frame_numbers, seconds):
+        emit(line)
+    res.update(lines=lines, seconds=seconds, ms_per_frame=1e3 * res.pop("loop_seconds") / (n - 1))
+    return res
+
+
+def _plate_points(country):
+    from .common import worldPointsLicensePlate
+
+    return worldPointsLicensePlate(country)
+
+
+def _run_session(frames, q, K, times, frame_numbers, plate, roi_border, max_corners, quality, block, harris_k, subpix, msv_frame, lk_coarse, lk_fine,
+                 emit, clock, live):
+    torch = L.torch_cuda()
+    tic = clock()
+    dev = [f if isinstance(f, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(f)) for f in frames]
+    dev = [f.cuda(non_blocking=True).contiguous() for f in dev]
+    H, W = dev[0].shape
+    n, cap = len(dev), 4 + int(max_corners)
+    ses = TrackerSession(K, W, H, cap, nhist=n, batch=1, lk_coarse=lk_coarse, lk_fine=lk_fine, msv_frame=msv_frame)
+    lib, ws = ses.lib, ses.ws
+    # frame 0 (vidExample.py:105-131): one device sequence; its outputs are the session's frame-0 state without touching the host
+    p = torch.empty((cap, 2), dtype=torch.float32, device="cuda")
+    p3 = torch.empty((cap, 3), dtype=torch.float64, device="cuda")
+    vp = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    t0 = torch.empty(3, dtype=torch.float32, device="cuda")
+    R0 = torch.empty(9, dtype=torch.float64, device="cuda")
+    res0 = torch.empty(1, dtype=torch.float64, device="cuda")
+    n0 = torch.empty(1, dtype=torch.int32, device="cuda")
+    rois = (C.c_int * 8)()
+    plate_w = np.ascontiguousarray(np.asarray(_plate_points(plate), np.float64).reshape(12))
+    win, it, eps = subpix
+    L.check(lib.vh_frame0_init(ws.handle, L.dptr(dev[0]), W, H, W, q.ctypes.data_as(L.f32p), ses.K64.ctypes.data_as(L.f64p), plate_w.ctypes.data_as(L.f64p),
+                               int(roi_border[0]), int(roi_border[1]), int(max_corners), float(quality), int(block), float(harris_k), int(win), int(it),
+                               float(eps), L.dptr(p), L.dptr(p3), L.dptr(vp), L.dptr(t0), L.dptr(R0), L.dptr(res0), L.dptr(n0), rois, L.stream_ptr()),
+            "vh_frame0_init")
+    L.check(lib.vh_session_init_dev(ses.handle, 0, L.dptr(dev[0]), W, L.dptr(p), L.dptr(p3), L.dptr(vp), L.dptr(t0), L.dptr(res0), L.dptr(n0),
+                                    float(times[0]), float(frame_numbers[0]), L.stream_ptr()), "vh_session_init_dev")
+    ses._keep[0] = dev[0]
+    ses._init_keep.append((0, p, p3, vp, t0, res0, n0))
+    view = ses.view(0)
+    rows = np.zeros((n, 9), np.float32)
+
+    def row(i):
+        r = ses._rd(C.c_void_p(view.S + 4 * 9 * i), 9, np.float32)  # one 36-byte read-back (synchronises, like the reference's print)
+        return r
+
+    proc = np.zeros(n)
+    if live:
+        rows[0] = row(0)
+        proc[0] = clock() - tic
+        rows[0, 1] = proc[0]
+        emit(table_row(rows[0]))
+    t_loop = clock()
+    for i in range(1, n):
+        tic = clock()
+        ses.step([dev[i]], time_s=float(times[i]), frame_no=float(frame_numbers[i]))
+        if live:
+            rows[i] = row(i)
+            proc[i] = clock() - tic
+            rows[i, 1] = proc[i]
+            emit(table_row(rows[i]))
+    torch.cuda.synchronize()
+    loop_seconds = clock() - t_loop
+    st = ses.state(0)
+    n_tr = int(n0.item())
+    if not live:  # the whole clip ran first: every row carries the mean time per frame
+        rows = st["S"].copy()
+        rows[0, 1] = 0.0
+        rows[1:, 1] = loop_seconds / (n - 1)
+        for i in range(n):
+            emit(table_row(rows[i]))
+    S = st["S"].copy()
+    S[:, 1] = rows[:, 1]
+    k = n_tr  # rows beyond the tracks found at frame 0 never existed (the session was sized for 4 + max_corners)
+    return dict(S=S, B=st["B"], P=st["P"][:, :k, :], vg=st["vg"][:k], vp=st["vp"][:k], p=st["p"], p3=st["p3"][:k], ids=st["ids"], n_tracks0=n_tr,
+                t0=t0.cpu().numpy(), R0=R0.cpu().numpy().reshape(3, 3), res0=float(res0.item()), boxa=tuple(rois[0:4]), boxb=tuple(rois[4:8]),
+                loop_seconds=loop_seconds, klt_flags=st["klt_flags"])
+
+
+def _run_dropin(frames, q, K, times, frame_numbers, plate, roi_border, max_corners, quality, block, harris_k, subpix, msv_frame, lk_coarse, lk_fine,
+                emit, clock):
+    """vidExample.py:75-165 statement by statement on the drop-in functions (numpy in / numpy out of every call)."""
+    from . import KLT, MSV, NLS
+    from .common import addcol0, image2world, norm
+    from .images import boundingRect, cornerSubPix, goodFeaturesToTrack, insidebbox
+
+    torch = L.torch_cuda()
+    frames = [f.cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f) for f in frames]
+    n = len(frames)
+    B = np.zeros([n, 14], np.float32)
+    S = np.zeros([n, 9], np.float32)
+    proc_dt = np.zeros(n)
+    t_loop = None
+    for i in range(n):
+        tic = clock()
+        if i == 1:
+            t_loop = tic
+        B[i, 12], B[i, 13] = times[i], frame_numbers[i]
+        im = frames[i]
+        if i == 0:
+            boxa = boundingRect(q, im.shape, border=(0, 0))
+            boxb = boundingRect(q, im.shape, border=tuple(roi_border))
+            roi = im[boxb[2]:boxb[3], boxb[0]:boxb[1]]
+            p = goodFeaturesToTrack(roi, max_corners, quality, 0, blockSize=block, useHarrisDetector=True, k=harris_k).reshape(-1, 2) + np.float32([boxb[0], boxb[2]])
+            p = cornerSubPix(im, p, (subpix[0], subpix[0]), (-1, -1), (3, subpix[1], subpix[2]))
+            p = np.concatenate((q, p))
+            t, R, residuals, _ = NLS.estimateWorldCameraPose(K, q, _plate_points(plate), findR=True)
+            p3 = addcol0(image2world(K, R, t, p).astype(float)) @ R + t
+            R = np.eye(3)
+            B[0, 0:3] = t
+            vg = np.ones(p.shape[0], dtype=bool)
+            vp = insidebbox(p, boxa)
+            p_ = p[vp]
+            P = np.full([5, p.shape[0], n], np.nan, np.float32)
+            im0_small, dt, dr, r, t0 = None, np.nan, 0, 0, B[0, 12]
+            n_tr, t_plate, R_plate, res_plate = len(p), t, None, residuals
+        else:
+            p, v, im0_small = KLT.KLTmain(im, im0, im0_small, p, lk_coarse=lk_coarse, lk_fine=lk_fine)
+            vg[vg] = v
+            vp = vp & vg
+            t, R, residuals, p_ = NLS.estimateWorldCameraPose(K, p[vp[vg]], p3[vp], R=R, findR=False)
+            dt = B[i, 12] - B[i - 1, 12]
+            dr = norm(t + B[0, 0:3] - B[i - 1, 0:3])
+            r += dr
+            B[i, 3:6] = t
+            B[i, 0:3] = B[0, 0:3] + t
+        im0 = im  # (the reference never assigns im0: SURVEY App. B intent)
+        P[0:2, vg, i] = p.T
+        P[2:4, vp, i] = p_.T
+        P[4, vg, i] = i
+        if i == msv_frame:
+            _tmsv, p3hatmsv = MSV.fcnMSV1_t(K, P, B, vg, i)
+            p3[vg] = p3hatmsv - t
+            vp = vg.copy()
+        proc_dt[i] = clock() - tic
+        with np.errstate(all="ignore"):
+            S[i, :] = (i, proc_dt[i], vg.sum(), residuals, dt, B[i, 12] - t0, dr, r, dr / dt * 3.6)
+        emit(table_row(S[i]))
+    loop_seconds = clock() - t_loop
+    return dict(S=S, B=B, P=P, vg=vg, vp=vp, p=p, p3=p3, ids=np.nonzero(vg)[0].astype(np.int32), n_tracks0=n_tr, t0=np.asarray(t_plate), R0=R_plate,
+                res0=float(res_plate), boxa=tuple(boxa), boxb=tuple(boxb), loop_seconds=loop_seconds, klt_flags=0)

@@ -210,3 +210,53 @@ def gate_scene(width=960, height=540, n=600, seed=21):
     r = np.random.default_rng(seed)
     edge = np.stack([r.uniform(-8, width + 8, 40), np.concatenate([r.uniform(-8, 12, 20), r.uniform(height - 12, height + 8, 20)])], 1).astype(np.float32)
     return f0, f1, np.concatenate([p, edge]).astype(np.float32)
+
+
+class HardScene:
+    """A load that looks like the reference's data instead of the easiest input the path can get: the periodic plate-plane
+    background of the bench + an independently moving foreground object with its own texture (~10 % of the track area: its tracks carry a residual
+    motion of up to `fg_speed` px/frame after the background affine has been compensated, the tracks on its outline see two motions), a fixed
+    textureless band and a saturated patch (the min-eigenvalue gate: forward status 0), per-frame gain drift (+/- `gain`) and additive sensor noise
+    (sigma `noise` gray levels, independent per frame and per texture set).  Every status gate of KLTmain (utils/KLT.py:47-50,116-117,126-130) fires on
+    it, and the fine stage needs several times the Newton iterations of the clean plane.  Rendering is torch (CPU or device); the frames are the
+    test vector -- the oracle reads the very pixels the device tracked, so nothing depends on the noise generator being reproducible across devices."""
+
+    def __init__(self, K, width, height, ring=60, z0=3.6, noise=2.0, gain=0.03, fg_speed=3.0, fg_rect=(0.46, 0.78, 0.34, 0.54), band=(0.80, 0.86),
+                 sat_rect=(0.12, 0.22, 0.12, 0.24)):
+        self.W, self.H, self.ring = width, height, ring
+        self.bg = PlaneMotion(K, z0=z0, traj=oscillating_traj(period=float(ring)))
+        self.noise, self.gain = float(noise), float(gain)
+        w = 2 * math.pi / ring
+        self.fg_amp = np.array([fg_speed / w, 0.4 * fg_speed / (2 * w)])  # d_k = (a sin(wk + 1), b sin(2wk)): at most fg_speed px/frame against the background
+        self.w = w
+        self.fg_rect = (fg_rect[0] * width, fg_rect[1] * width, fg_rect[2] * height, fg_rect[3] * height)  # x0 x1 y0 y1 in frame-0 coordinates
+        self.band = (int(band[0] * height), int(band[1] * height))
+        self.sat = (int(sat_rect[0] * width), int(sat_rect[1] * width), int(sat_rect[2] * height), int(sat_rect[3] * height))
+
+    def fg_offset(self, k):
+        return np.array([self.fg_amp[0] * math.sin(self.w * k + 1.0), self.fg_amp[1] * math.sin(2 * self.w * k)])
+
+    def frame(self, k, seed=0xC0FFEE, device="cpu"):
+        """uint8 [H,W] frame k (k is taken modulo the ring: the sequence is periodic, noise included)."""
+        k = k % self.ring
+        W, H = self.W, self.H
+        Ai = self.bg.inverse(k)
+        d = self.fg_offset(k)
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64, device=device), torch.arange(W, dtype=torch.float64, device=device), indexing="ij")
+        u = Ai[0, 0] * xs + Ai[0, 1] * ys + Ai[0, 2]
+        v = Ai[1, 0] * xs + Ai[1, 1] * ys + Ai[1, 2]
+        # the foreground object: the pixels whose pre-image under (background motion, then the object's own offset) lies in its frame-0 rectangle
+        uf = Ai[0, 0] * (xs - d[0]) + Ai[0, 1] * (ys - d[1]) + Ai[0, 2]
+        vf = Ai[1, 0] * (xs - d[0]) + Ai[1, 1] * (ys - d[1]) + Ai[1, 2]
+        x0, x1, y0, y1 = self.fg_rect
+        mask = (uf >= x0) & (uf < x1) & (vf >= y0) & (vf < y1)
+        t = torch.where(mask, texture(uf, vf, seed + 7001), texture(u, v, seed))
+        t = torch.clamp((t - 0.5) * 2.2 + 0.5, 0.0, 1.0)
+        val = 16.0 + 224.0 * t
+        val[self.band[0]:self.band[1], :] = 117.0
+        g = 1.0 + self.gain * math.sin(2 * self.w * k + 0.5)
+        gen = torch.Generator(device=device)
+        gen.manual_seed((int(seed) * 1000003 + k * 7919 + 17) & 0x7FFFFFFF)
+        val = g * val + self.noise * torch.randn((H, W), generator=gen, dtype=torch.float64, device=device)
+        val[self.sat[2]:self.sat[3], self.sat[0]:self.sat[1]] = 300.0
+        return torch.clamp(torch.round(val), 0, 255).to(torch.uint8)
