@@ -205,6 +205,55 @@ def test_c4_topology_eight_ranks_one_stream_each_exchange_with_live_state(tmp_pa
     assert "C4_DIST" in out
 
 
+def test_c4_full_size_two_ranks_exchange_at_frame_30(tmp_path):
+    """BASELINE config 4 at FULL SIZE on the two ranks one device can hold: every rank one 1920 x 1080 stream with 2000 tracks, 31
+    tracked frames, the all-gather of the packed track state fires at frame 30 on live state.  Each rank checks BOTH gathered records bit for bit
+    (ids, p; pose to 1e-5) against two SessionOracles.  What an 8-GPU node adds to this is RCCL itself: same streams, same records, same exchange."""
+    body = (
+        "from velocity_amd import synth, _lib as L, dist as vd\n"
+        "from velocity_amd.driver import TrackerSession\n"
+        "from oracle.session_oracle import SessionOracle\n"
+        "W, H, n, NF, EVERY = 1920, 1080, 2000, 32, 30\n"
+        "K = synth.K_1080P.copy()\n"
+        "lkc = dict(max_level=2)   # BASELINE config 2 / 4: 3 pyramid levels\n"
+        "def scene(r):\n"
+        "    m = synth.PlaneMotion(K, z0=3.6, traj=synth.oscillating_traj(period=40.0 + 7 * r))\n"
+        "    fr = [synth.render_frame(W, H, m, k, seed=0xC0FFEE + r, device='cuda').cpu().numpy() for k in range(NF)]\n"
+        "    p0 = m.apply(0, synth.grid_tracks(n, W, H, seed=1 + r).astype(float)).astype(np.float32)\n"
+        "    return fr, p0, m.world_points(p0), np.ones(n, bool)\n"
+        "fr, p0, p3, vp = scene(rank)\n"
+        "t0 = np.float32([0, 0, 0])\n"
+        "ses = TrackerSession(K, W, H, n, nhist=NF, batch=1, lk_coarse=lkc, msv_frame=0)\n"
+        "ses.init_stream(0, fr[0], p0, p3, vp, t0)\n"
+        "ex = vd.TrackStateExchange(1, n, every=EVERY, device='cuda')\n"
+        "fired = []\n"
+        "for i in range(1, NF):\n"
+        "    ses.step([torch.from_numpy(fr[i]).cuda()], time_s=float(np.float32(i / 30.0)), frame_no=i)\n"
+        "    if ex.due(i):\n"
+        "        ex.wait()\n"
+        "        L.check(ses.lib.vh_session_pack_state(ses.handle, L.dptr(ex.local), L.stream_ptr()), 'pack')\n"
+        "        ex.start()\n"
+        "        fired.append(i)\n"
+        "g = ex.wait().cpu()\n"
+        "assert fired == [30] and g.shape[0] == world == 2\n"
+        "assert g.shape[-1] == 8 + 3 * n   # 24 KB per stream (DESIGN section 7)\n"
+        "for r in range(world):\n"
+        "    f2, q0, q3, qv = (fr, p0, p3, vp) if r == rank else scene(r)\n"
+        "    orc = SessionOracle(K, f2[0], q0, q3, qv, t0, nhist=NF, lk_coarse=lkc, msv_frame=0)\n"
+        "    for i in range(1, 31):\n"
+        "        orc.step(f2[i], np.float32(i / 30.0), i)\n"
+        "    rec = vd.unpack_state(g[r, 0], n)\n"
+        "    assert rec['frame_i'] == 30 and rec['n_cur'] == int(orc.vg.sum()) > n // 2, (r, rec['frame_i'], rec['n_cur'])\n"
+        "    assert np.array_equal(rec['ids'], np.nonzero(orc.vg)[0]) and np.array_equal(rec['p'], orc.p), f'rank {rank}: stream {r} differs'\n"
+        "    np.testing.assert_allclose(rec['t'], orc.t, rtol=1e-5)\n"
+        "d = ex.describe()\n"
+        "assert d['world_size'] == 2 and d['exchanges'] == 1\n"
+        "if rank == 0: print('C4_FULL', json.dumps(d))\n"
+    )
+    out = _run_ranks(tmp_path, body, world=2, timeout=1500)
+    assert "C4_FULL" in out
+
+
 def test_bench_eight_ranks_oversubscribed_prints_n_gpus_8():
     """`python bench.py --gpus 8 --oversubscribe --backend gloo`: the driver's 8-GPU launch shape (8 ranks, weak scaling, exchange every 30
     frames) on one device; the line says n_gpus 8 and its dist record shows 8 ranks seen in the last gather."""

@@ -108,7 +108,7 @@ def test_c1_run_sequence_prints_the_reference_table(golden):
     np.testing.assert_allclose(got["B"], ref["B"], rtol=1e-5, atol=1e-6)
     assert got["B"][3, 13] == 22.0 and got["lines"][-1].startswith("Processed 9 images")
     # live=False (no read-back inside the loop) prints the same rows
-    again = run_sequence(frames, q, K, times=times, frame_numbers=fnos, clock=lambda: 0.0, out=None, live=False)
+    again = run_sequence(frames, q, K, times=times, frame_numbers=fnos, clock=lambda: 0.0, out=None, live=False, name="stand-in for IMG_4134.MOV")
     assert again["lines"][:-1] == got["lines"][:-1]
 
 

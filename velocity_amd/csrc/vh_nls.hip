@@ -132,7 +132,7 @@ __global__ void k_n_view(const double* A, const double* U, int nf, int nv, doubl
 // fcnMSV1_t (MSV.py:8-49): LM over the last camera translation; every iteration re-triangulates all points.
 // ---------------------------------------------------------------------------------------------------------------
 #define MSV_THREADS 1024
-__global__ __launch_bounds__(MSV_THREADS) void k_msv1(MsvJob J)
+__device__ __forceinline__ void msv1_body(const MsvJob& J)
 {
     constexpr int NLS_THREADS = MSV_THREADS, NLS_WAVES = MSV_THREADS / 64;
     const int tid = threadIdx.x;
@@ -206,6 +206,19 @@ __global__ __launch_bounds__(MSV_THREADS) void k_msv1(MsvJob J)
     }
 }
 
+__global__ __launch_bounds__(MSV_THREADS) void k_msv1(MsvJob J) { msv1_body(J); }
+
+// One workgroup per video stream of a session, ONE launch for all of them (round 4 launched a one-workgroup kernel per stream: 256 dependent launches
+// of ~0.2 ms each at the frame where every stream of a batch re-triangulates).  `tab` points at the MsvJob inside stream 0's device record, records are
+// `stride` bytes apart, and the stream's own frame counter sits `frame_off` bytes from its job: only the streams that are AT their MSV frame run
+// (vidExample.py:155 `if i == msvFrame`), the other workgroups leave at once.
+__global__ __launch_bounds__(MSV_THREADS) void k_msv1_tab(const void* tab, size_t stride, ptrdiff_t frame_off, int fire_frame)
+{
+    const char* base = reinterpret_cast<const char*>(tab) + (size_t)blockIdx.x * stride;
+    if (*reinterpret_cast<const int*>(base + frame_off) != fire_frame) return;
+    msv1_body(*reinterpret_cast<const MsvJob*>(base));
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------------------
@@ -244,4 +257,8 @@ void vh_launch_n_view(const double* A, const double* U, int nf, int nv, double* 
 void vh_launch_msv1(const MsvJob& job, hipStream_t s)
 {
     hipLaunchKernelGGL(k_msv1, dim3(1), dim3(MSV_THREADS), sizeof(double) * 3 * (size_t)job.nf, s, job);
+}
+void vh_launch_msv1_tab(const void* tab, size_t stride, ptrdiff_t frame_off, int fire_frame, int nf, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_msv1_tab, dim3(batch), dim3(MSV_THREADS), sizeof(double) * 3 * (size_t)nf, s, tab, stride, frame_off, fire_frame);
 }

@@ -46,3 +46,5 @@ void vh_launch_pixel2uvec_f32(float cx, float cy, float f, const float* p, int n
 void vh_launch_two_view(const double* A, const double* U, int nf, int nv, double* out, hipStream_t s);
 void vh_launch_n_view(const double* A, const double* U, int nf, int nv, double* out, hipStream_t s);
 void vh_launch_msv1(const MsvJob& job, hipStream_t s);
+// the same for `batch` jobs that live `stride` bytes apart in device memory; a job runs when the int `frame_off` bytes from it equals fire_frame
+void vh_launch_msv1_tab(const void* tab, size_t stride, ptrdiff_t frame_off, int fire_frame, int nf, int batch, hipStream_t s);

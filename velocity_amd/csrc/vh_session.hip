@@ -7,6 +7,8 @@
 
 #include <new>
 
+#include <stddef.h>
+
 #include "vh_ws.hpp"
 #include "vh_pose_dev.hpp"
 
@@ -289,6 +291,13 @@ extern "C" VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, i
         J.x0[0] = J.x0[1] = J.x0[2] = 0; J.x0[3] = 0; J.x0[4] = 0; J.x0[5] = 1;  // always restarted from t=[0,0,1] (NLS.py:9)
         J.p = S.p_cur; J.pw = S.p3; J.p_sel = S.sel_p; J.pw_sel = S.sel_pw; J.n_ptr = &d->n_pose; J.n = 0; J.mode = 0;
         J.t_out = d->t; J.R_out = nullptr; J.res_out = &d->res; J.p_proj = S.p_proj; J.info_out = d->pose_info;
+        MsvJob& M = S.msv;
+        memset(&M, 0, sizeof(M));
+        for (int k = 0; k < 9; k++) M.K[k] = S.K[k];
+        M.P = S.P; M.P_rs = (size_t)n0; M.P_ts = 1; M.P_fs = (size_t)5 * n0;  // the session's frame-major history
+        M.B = S.B; M.ids = S.ids; M.ng_ptr = &d->n_cur; M.ng = 0; M.N0 = n0; M.nhist = nhist;
+        M.nf = msv_frame + 1; M.max_iter = 1000; M.f32_rays = s->k_is_f32;  // P is float32 always; K as the caller holds it
+        M.U = S.msv_U; M.b0 = S.msv_b0; M.x_out = d->msv_x; M.info_out = d->msv_info;
     }
     hipError_t e = hipMemcpy(s->d_ss, s->h_ss, sizeof(SessStream) * s->batch, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(s->arena); delete[] s->h_ss; delete[] s->h_frame; delete s; vh_set_error("hipMemcpy(session)", e, __FILE__, __LINE__); return (int)e; }
@@ -361,18 +370,11 @@ static int session_step(vh_session* s, const uint8_t* const* frames_dev, float t
     bool any = false;
     for (int b = 0; b < nb; b++) {
         const int fi = ++s->h_frame[b];
-        if (!msv_ok || fi != s->msv_frame) continue;
-        any = true;
-        const SessStream& H = s->h_ss[b];
-        MsvJob J;
-        memset(&J, 0, sizeof(J));
-        for (int k = 0; k < 9; k++) J.K[k] = H.K[k];
-        J.P = H.P; J.P_rs = (size_t)s->N0; J.P_ts = 1; J.P_fs = (size_t)5 * s->N0;  // the session's frame-major history
-        J.B = H.B; J.ids = H.ids; J.ng_ptr = &s->d_ss[b].n_cur; J.ng = 0; J.N0 = s->N0; J.nhist = s->nhist;
-        J.nf = s->msv_frame + 1; J.max_iter = 1000; J.f32_rays = s->k_is_f32;  // P is float32 always; K as the caller holds it
-        J.U = H.msv_U; J.b0 = H.msv_b0; J.x_out = s->d_ss[b].msv_x; J.info_out = s->d_ss[b].msv_info;
-        vh_launch_msv1(J, st);
+        if (msv_ok && fi == s->msv_frame) any = true;
     }
+    // ONE launch for every stream: a workgroup runs only when its stream's own frame counter is at the MSV frame (k_msv1_tab)
+    if (any) vh_launch_msv1_tab(&s->d_ss[0].msv, sizeof(SessStream), (ptrdiff_t)offsetof(SessStream, frame_i) - (ptrdiff_t)offsetof(SessStream, msv),
+                                s->msv_frame, s->msv_frame + 1, nb, st);
     if (any) hipLaunchKernelGGL(k_sess_after_msv, dim3(nb), dim3(256), 0, st, s->d_ss, s->msv_frame);
     SESS_CHECK();
     return 0;

@@ -161,6 +161,7 @@ struct SessStream {  // device resident, one per video stream
     uint8_t* small[2];
     const uint8_t* im0;
     PoseJob pose;
+    MsvJob msv;      // this stream's fcnMSV1_t job (vidExample.py:155-158), fixed at session creation
     double K[9];
     double res;
     float t[3];
