@@ -503,6 +503,19 @@ def main():
                 ba_cpu_baseline(ba, first, a.cpu_seconds)
             out["ba"] = ba
         out["roofline_detail"] = full_roofline
+        if world > 1:  # what the 8-GPU run is for, where a truncated record still shows it: exchange cost and both BA modes
+            d, b = out.get("dist", {}), out.get("ba", {})
+            out["multi_gpu"] = dict(backend=d.get("backend"), world_size=d.get("world_size"), exchanges=d.get("exchanges"),
+                                    exchange_bytes_per_rank=d.get("bytes_per_rank_per_exchange"), exchange_host_ms_total=d.get("exchange_host_ms_total"),
+                                    exchange_device_us_idle=d.get("exchange_device_us_idle"), ranks_seen_in_last_gather=d.get("ranks_seen_in_last_gather"),
+                                    ba_point_sharded_iters_per_s=b.get("point_sharded", {}).get("iters_per_s"),
+                                    ba_point_sharded_ms_per_iter=b.get("point_sharded", {}).get("ms_per_iter"),
+                                    ba_replicas_iters_per_s=b.get("replicas", {}).get("iters_per_s"))
+        # the head of the line is what a truncated record keeps (BENCH_rNN.json's tail cut round 4's line): the contract's fields, the multi-GPU summary,
+        # roofline and cpu_baseline first; the long objects after
+        head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "multi_gpu",
+                "config", "roofline", "cpu_baseline", "verified", "build_id")
+        out = {**{k: out[k] for k in head if k in out}, **{k: v for k, v in out.items() if k not in head}}
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

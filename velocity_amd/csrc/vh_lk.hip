@@ -1196,6 +1196,7 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
         return;
     }
     D = __fdiv_rn(1.f, D);
+    const int ncI[2] = {-cI[0], -cI[1]};
 
     // packed byte pairs of window row y (strip column j) of the staged search region at window origin (inx, iny)
     // The strip starts at byte `off` of the staged row: its 5 bytes lie inside the two dwords at off >> 2, and the byte pair (c, c+1) is ONE
@@ -1226,13 +1227,20 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
         if (!region_holds(inx, iny)) restage(inx, iny);
         const StripWeights w = strip_weights(bilinear_weights(__fsub_rn(nx, (float)inx), __fsub_rn(ny, (float)iny)));
         n_iter++;
-        int b[2] = {-cI[0], -cI[1]};
+        int b[2] = {ncI[0], ncI[1]};  // (lanes without strips keep -c: the first strip of the others starts from it without a copy)
         if (lane_on) {
             // rows are read one strip ahead of their use, a scheduling barrier closes every strip (see the set-up loop)
             constexpr int PJP = C::PJ_PITCH >> 2;
             const unsigned sel0 = 0x0c010c00u + (unsigned)__builtin_amdgcn_readfirstlane((inx - rjx) & 3) * 0x00010001u;
-            const unsigned* rowA = pJ + (iny - rjy + rA) * PJP + (((inx - rjx) + 4 * jA) >> 2);
-            const unsigned* rowB = pJ + (iny - rjy + rB) * PJP + (((inx - rjx) + 4 * jB) >> 2);
+            unsigned oA = (unsigned)(C::OFF_PJ + 4 * ((iny - rjy + rA) * PJP + (((inx - rjx) + 4 * jA) >> 2)));
+            unsigned oB = (unsigned)(C::OFF_PJ + 4 * ((iny - rjy + rB) * PJP + (((inx - rjx) + 4 * jB) >> 2)));
+            // The byte offsets of the lane's two search columns are made OPAQUE to the compiler: it then keeps ONE base register per column and puts the
+            // row step (k + dr) * PJ_PITCH <= 816 bytes into the offset fields of ds_read2_b32 (8-bit dword offsets).  Left alone it folds OFF_PJ into
+            // every access's constant, which no longer fits the field, and spends one v_add_u32 per row read (10 per Newton iteration).  (The set-up's
+            // patch reads start at OFF_PI = 0 and fold already.)
+            asm volatile("" : "+v"(oA), "+v"(oB));
+            const unsigned* rowA = reinterpret_cast<const unsigned*>(smem + oA);
+            const unsigned* rowB = reinterpret_cast<const unsigned*>(smem + oB);
             const auto region_row = [&](int k, int dr) { return (k < C::KA ? rowA : rowB) + (k + dr) * PJP; };  // search row slot_row(k) + dr
             unsigned top[4];
             {
@@ -1256,8 +1264,13 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
                     strip_bilinear_pairs(top, bot, w, p01, p23);
                     const int slot = slot_base + k * slot_stride;
                     const uint2 vX = tX[slot], vY = tY[slot];
-                    b[0] = dot2(p23, vX.y, dot2(p01, vX.x, b[0]));
-                    b[1] = dot2(p23, vY.y, dot2(p01, vY.x, b[1]));
+                    if (k == 0) {  // the chains start at -c, which the next iteration needs again: three-address first link, no copy
+                        b[0] = dot2(p23, vX.y, dot2_keep(p01, vX.x, ncI[0]));
+                        b[1] = dot2(p23, vY.y, dot2_keep(p01, vY.x, ncI[1]));
+                    } else {
+                        b[0] = dot2(p23, vX.y, dot2(p01, vX.x, b[0]));
+                        b[1] = dot2(p23, vY.y, dot2(p01, vY.x, b[1]));
+                    }
 #pragma unroll
                     for (int c = 0; c < 4; c++) top[c] = bot[c];
                     __builtin_amdgcn_sched_barrier(0);

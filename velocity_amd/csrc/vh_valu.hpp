@@ -32,6 +32,14 @@ __device__ __forceinline__ int mad24_s(int a, int c)
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(K), "s"(c));
     return d;
 }
+// dot2 whose accumulator must SURVIVE (the start value of a chain that is needed again: the Newton accumulators restart at -c every iteration): the
+// three-address VOP3P form reads it as src2; hipcc's v_dot2c would copy it first (a v_mov per chain and iteration)
+__device__ __forceinline__ int dot2_keep(unsigned a, unsigned b, int c)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 // dot2 with a wave-uniform accumulator taken from an SGPR (a non-inline constant would otherwise cost a v_mov into the tied accumulator of v_dot2c)
 __device__ __forceinline__ int dot2_s(unsigned a, unsigned b, int c)
 {

@@ -97,8 +97,23 @@ class TrackStateExchange:
             me.update(device=d, name=pr.name, pci_bus_id=getattr(pr, "pci_bus_id", None), gcn_arch=getattr(pr, "gcnArchName", None))
         devs = [None] * self.world
         dist.all_gather_object(devs, me, group=self.group)
+        # one more exchange on an otherwise idle device, bracketed by events on the current stream: the collective's own device latency (every rank
+        # takes part; not counted in `exchanges`)
+        dev_us = None
+        if self.local.is_cuda:
+            n, hs = self.count, self.host_seconds
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            self.start()
+            self.wait()
+            e1.record()
+            torch.cuda.synchronize()
+            dev_us = round(1e3 * e0.elapsed_time(e1), 1)
+            self.count, self.host_seconds = n, hs
         return dict(backend=dist.get_backend(self.group), world_size=self.world, devices=devs, exchanges=self.count,
-                    exchange_host_ms_total=round(1e3 * self.host_seconds, 3), bytes_per_rank_per_exchange=int(self.local.numel() * 4))
+                    exchange_host_ms_total=round(1e3 * self.host_seconds, 3), bytes_per_rank_per_exchange=int(self.local.numel() * 4),
+                    exchange_device_us_idle=dev_us)
 
 
 # ----------------------------------------------------------------------------------------------------------------
