@@ -10,6 +10,6 @@ for r in 1 2 3; do
   for v in "$@"; do
     if [ "$v" = head ]; then unset VH_LIB; else export VH_LIB=$PWD/_exp/lib_$v.so; fi
     python bench.py --no-ba --no-extras --cpu-seconds 0 --verify-frames 0 2>/dev/null | tail -1 | python -c "
-import json,sys; j=json.loads(sys.stdin.read()); print('$v', j['build']['build_id'], j['value'], j['roofline']['lk_us_per_launch'], [round(k['us_per_step']) for k in j['roofline']['kernels']])"
+import json,sys; j=json.loads(sys.stdin.read()); print('$v', j['build']['build_id'], j['value'], j['roofline']['lk_us_per_launch'], [round(k['us_per_step']) for k in j['roofline_detail']['kernels']])"
   done
 done

@@ -1232,15 +1232,12 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
             // rows are read one strip ahead of their use, a scheduling barrier closes every strip (see the set-up loop)
             constexpr int PJP = C::PJ_PITCH >> 2;
             const unsigned sel0 = 0x0c010c00u + (unsigned)__builtin_amdgcn_readfirstlane((inx - rjx) & 3) * 0x00010001u;
-            unsigned oA = (unsigned)(C::OFF_PJ + 4 * ((iny - rjy + rA) * PJP + (((inx - rjx) + 4 * jA) >> 2)));
-            unsigned oB = (unsigned)(C::OFF_PJ + 4 * ((iny - rjy + rB) * PJP + (((inx - rjx) + 4 * jB) >> 2)));
-            // The byte offsets of the lane's two search columns are made OPAQUE to the compiler: it then keeps ONE base register per column and puts the
-            // row step (k + dr) * PJ_PITCH <= 816 bytes into the offset fields of ds_read2_b32 (8-bit dword offsets).  Left alone it folds OFF_PJ into
-            // every access's constant, which no longer fits the field, and spends one v_add_u32 per row read (10 per Newton iteration).  (The set-up's
-            // patch reads start at OFF_PI = 0 and fold already.)
-            asm volatile("" : "+v"(oA), "+v"(oB));
-            const unsigned* rowA = reinterpret_cast<const unsigned*>(smem + oA);
-            const unsigned* rowB = reinterpret_cast<const unsigned*>(smem + oB);
+            // (hipcc folds OFF_PJ into every row read's constant, which then no longer fits the 8-bit dword offsets of ds_read2_b32, and spends one
+            // v_add_u32 per row on the address.  Giving it ONE opaque base per column so that the row step goes into the offset fields removes those
+            // 10-20 instructions per Newton iteration -- and measured 4-5 % SLOWER in three forms, the last with the reads pinned to the top of
+            // their strips by hand: DESIGN.md section 9, round 5.  Left as the compiler writes it.)
+            const unsigned* rowA = pJ + (iny - rjy + rA) * PJP + (((inx - rjx) + 4 * jA) >> 2);
+            const unsigned* rowB = pJ + (iny - rjy + rB) * PJP + (((inx - rjx) + 4 * jB) >> 2);
             const auto region_row = [&](int k, int dr) { return (k < C::KA ? rowA : rowB) + (k + dr) * PJP; };  // search row slot_row(k) + dr
             unsigned top[4];
             {
