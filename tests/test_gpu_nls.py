@@ -266,29 +266,6 @@ def test_nls_batch_cholesky_and_wide_schur_equal_the_round3_kernels(golden, nt, 
         close(pw, outs[0][1], 1e-6, 1e-8)
 
 
-@pytest.mark.parametrize("nt,nf", [(200, 6), (517, 3), (260, 2), (5000, 20)])
-def test_nls_batch_fused_launch_sequence_equals_the_five_launch_one(golden, nt, nf, monkeypatch):
-    """Round 5: whole solves on the matrix-core path take 4 launches per LM iteration -- k_ba_solve_mfma also moves the cameras and rebuilds their
-    tables, k_ba_update_jac updates a block's points and writes their next Jacobian rows -- instead of 5 (VH_BA_FUSE=0).  Same arithmetic per point
-    and camera; only the order of the sum-of-squares atomics differs: trace and state equal to rounding, on windows whose blocks own 12, 85 and 128
-    points (poisoned workspace) and at the full C5 size."""
-    from velocity_amd import synth
-    from velocity_amd.NLS import fcnNLS_batch
-
-    P, pw0, cw0 = synth.ba_scene(nt, nf, seed=70 + nf)
-    outs = []
-    for fuse in ("1", "0"):
-        monkeypatch.setenv("VH_BA_FUSE", fuse)
-        outs.append(fcnNLS_batch(golden["K32"], P.copy(), pw0, cw0, return_info=True))
-    monkeypatch.delenv("VH_BA_FUSE", raising=False)
-    (cw, pw, x, tr), (cw0_, pw0_, x0_, tr0) = outs
-    assert len(tr) == len(tr0) >= 3
-    close(tr[:, 0], tr0[:, 0], 1e-11)
-    close(tr[:, 1], tr0[:, 1], 1e-7, 1e-13)
-    close(cw, cw0_, 1e-9, 1e-11)
-    close(pw, pw0_, 1e-9, 1e-11)
-
-
 @pytest.mark.parametrize("nt,nf", [(260, 2), (517, 3), (200, 3)])
 def test_nls_batch_two_and_three_frame_windows(golden, nt, nf, capsys):
     """2- and 3-frame windows: a k_ba_jac block owns 256 / nf = 128 / 85 whole points, more than the 64 point quads of its preparation tail

@@ -135,13 +135,15 @@ __device__ void inv3_sym(const double* U, double* Ui);
 // (the block's measurements are contiguous in all three arrays).  A block owns WHOLE points (256 / (nc+1) of them, the last threads idle), so
 // with PREP it also finishes what the point-block Schur complement needs per point -- U_i + I, its inverse, tp_i, the Cholesky factor of the
 // inverse -- straight from the LDS copy of the rows: the separate pass re-read 8 of the 20 planes from HBM (0.8 GB per iteration at 64 C5 windows).
-// (the body of k_ba_jac: also the second half of k_ba_update_jac, which hands over the block's freshly updated points in LDS as s_w)
 template <bool PREP>
-__device__ __forceinline__ void ba_jac_block(const BaJob& J, double (*s_out)[BA_THREADS + 1], double* s_ss, const double* s_w)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
 {
+    ba_select_window(J, blockIdx.y);
+    if (*J.done) return;
     const int nt = J.nt, nf = J.nc + 1;
     const int ppb = BA_THREADS / nf, i0 = blockIdx.x * ppb, npts = min(ppb, nt - i0);
     const int il = threadIdx.x / nf;
+    __shared__ double s_out[20][BA_THREADS + 1];  // component-major, padded: conflict-free on the way in, spread on the way out
     double ss = 0.0;
     double o[20];  // r (2) | Jp (6) | Jc (12)
 #pragma unroll
@@ -150,9 +152,7 @@ __device__ __forceinline__ void ba_jac_block(const BaJob& J, double (*s_out)[BA_
         const int i = i0 + il, c = threadIdx.x - il * nf;  // POINT-major measurement index m = i (nc+1) + c: a point's Jacobians are contiguous
         double K[9];
         for (int k = 0; k < 9; k++) K[k] = J.K[k];
-        double w[3];
-        if (s_w) { w[0] = s_w[3 * il]; w[1] = s_w[3 * il + 1]; w[2] = s_w[3 * il + 2]; }
-        else { w[0] = J.x[3 * i]; w[1] = J.x[3 * i + 1]; w[2] = J.x[3 * i + 2]; }
+        double w[3] = {J.x[3 * i], J.x[3 * i + 1], J.x[3 * i + 2]};
         if (J.model == 1) {
             // zhat = pscale((pw @ R + offset_c) @ K); columns of the compact Jacobian: point (3) | rpy (3), el, az, range_c
             const double* R0 = J.camR;
@@ -227,6 +227,7 @@ __device__ __forceinline__ void ba_jac_block(const BaJob& J, double (*s_out)[BA_
     for (int k = 0; k < 20; k++) s_out[k][threadIdx.x] = o[k];
     // sum of squared residuals of this iteration (trace only): one atomic per block, spread over 16 addresses -- thousands of
     // same-address atomics would serialise in L2 and dominate the kernel
+    __shared__ double s_ss[BA_THREADS / 64];
     ss = vh_wave_sum_f64(ss);
     if ((threadIdx.x & 63) == 0) s_ss[threadIdx.x >> 6] = ss;
     __syncthreads();
@@ -288,16 +289,6 @@ __device__ __forceinline__ void ba_jac_block(const BaJob& J, double (*s_out)[BA_
     double* Lo = J.Lc + 6 * (size_t)i;
     Lo[0] = l00; Lo[1] = l10; Lo[2] = l11; Lo[3] = l20; Lo[4] = l21; Lo[5] = l22;
     }
-}
-
-template <bool PREP>
-__global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
-{
-    ba_select_window(J, blockIdx.y);
-    if (*J.done) return;
-    __shared__ double s_out[20][BA_THREADS + 1];  // component-major, padded: conflict-free on the way in, spread on the way out
-    __shared__ double s_ss[BA_THREADS / 64];
-    ba_jac_block<PREP>(J, s_out, s_ss, nullptr);
 }
 
 __device__ void inv3_sym(const double* U, double* Ui)
@@ -1083,38 +1074,11 @@ __global__ __launch_bounds__(64 * BA_GJ_WAVES) void k_ba_solve_mfma(BaJob J)
         for (int rg = 0; rg < 4; rg++) s_rhs[16 * w + lr + 4 * rg] = acc[7][rg];
     }
     __syncthreads();
-    double dcv = 0.0;
     if (tid < nq) {
         const int r = tid >> 2, k = tid & 3;
         const double* Qr = s_pinv[r];
-        dcv = Qr[4 * k] * s_rhs[4 * r] + Qr[4 * k + 1] * s_rhs[4 * r + 1] + Qr[4 * k + 2] * s_rhs[4 * r + 2] + Qr[4 * k + 3] * s_rhs[4 * r + 3];
-        J.dc[tid] = dcv;
+        J.dc[tid] = Qr[4 * k] * s_rhs[4 * r] + Qr[4 * k + 1] * s_rhs[4 * r + 1] + Qr[4 * k + 2] * s_rhs[4 * r + 2] + Qr[4 * k + 3] * s_rhs[4 * r + 3];
     }
-    if (!J.fuse) return;
-    // fused sequence (BaJob::fuse): the cameras move HERE -- x_cam += 0.9 dc, their share of sum delta^2, and the rotation tables of the next
-    // iteration (what block 0 of k_ba_update does otherwise) -- so that k_ba_update_jac finds the new cameras final when it rebuilds the Jacobian rows
-    __shared__ double s_par[6 * (BA_GJ_MAXQ / 6 + 1)];
-    __shared__ double s_sq[BA_GJ_WAVES];
-    const int nt = J.nt, nc = J.nc;
-    double ssq = 0.0;
-    if (tid < nq) {
-        const int c = tid / 6, k = tid - 6 * c;
-        const double dl = dcv * 0.9;
-        const size_t idx = k < 3 ? (size_t)3 * nt + 3 * c + k : (size_t)3 * nt + 3 * nc + 3 * c + (k - 3);  // [points | camera positions | camera rpy] (NLS.py:203)
-        const double nv = J.x[idx] + dl;
-        J.x[idx] = nv;
-        s_par[idx - (size_t)3 * nt] = nv;
-        if (J.count_cams) ssq = dl * dl;
-    }
-    ssq = vh_wave_sum_f64(ssq);
-    if (lane == 0) s_sq[tid >> 6] = ssq;
-    __syncthreads();
-    if (tid == 0) {
-        double t = 0.0;
-        for (int k = 0; k < BA_GJ_WAVES; k++) t += s_sq[k];
-        atomicAdd(J.acc + 1, t);
-    }
-    for (int c = tid; c <= nc; c += 64 * BA_GJ_WAVES) ba_cam_tables(J, c, s_par);
 }
 
 // Schur stage 2b for MANY cameras (6 nc > 256: more unknowns than the register-resident kernels hold): Gauss-Jordan without pivoting (S is SPD) on the
@@ -1480,82 +1444,6 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
     }
 }
 
-// Fused sequence (BaJob::fuse, whole solves on the matrix-core path): point update of iteration `it` + Jacobian rows of iteration it + 1 in ONE
-// launch.  A block owns whole points in both halves (the ppb = 256 / (nc + 1) points of k_ba_jac), so it (i) applies dp_i = tp_i - L (L^T e_i),
-// e_i = sum_c Jp^T (Jc dc_c), to ITS points from the rows it wrote in the previous iteration (4 lanes per point, as k_ba_update), keeps the new
-// coordinates in LDS, and (ii) rebuilds the residual / Jacobian rows and the per-point preparation of the same points from them (ba_jac_block): the rows
-// are private to the block, so they are overwritten in place.  The cameras moved in k_ba_solve_mfma already (new positions in x, new tables in camR).
-// One launch boundary and one pass of block scheduling less per LM iteration; the last block finishes the iteration record like k_ba_update's.
-__global__ __launch_bounds__(BA_THREADS) void k_ba_update_jac(BaJob J, int it, int do_jac)
-{
-    ba_select_window(J, blockIdx.y);
-    if (*J.done) return;
-    const int nt = J.nt, nc = J.nc, nf = nc + 1, nq = J.nq, tid = threadIdx.x;
-    const int ppb = BA_THREADS / nf, i0 = blockIdx.x * ppb, npts = min(ppb, nt - i0);
-    __shared__ double s_out[20][BA_THREADS + 1];
-    __shared__ double s_ss[BA_THREADS / 64];
-    __shared__ double s_dc[6 * BA_MAX_NC];
-    __shared__ double s_w[3 * (BA_THREADS / 2)];  // new coordinates of the block's points (ppb <= 128)
-    __shared__ double sh[BA_THREADS / 64];
-    for (int q = tid; q < nq; q += BA_THREADS) s_dc[q] = J.dc[q];
-    __syncthreads();
-    double ss = 0.0;
-    const int sub = tid & 3;
-    for (int pl = tid >> 2; pl < ((npts + 15) / 16) * 16; pl += BA_THREADS / 4) {  // whole quads (and whole waves) stay together for the shuffles
-        const int i = i0 + min(pl, npts - 1);
-        double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-        for (int c = 1 + sub; c <= nc; c += 4) {
-            const size_t m = (size_t)i * nf + c;
-            const double* Jc = J.Jc + 12 * m;
-            const double* Jp = J.Jp + 6 * m;
-            const double* dq = s_dc + 6 * (c - 1);
-            double su = 0.0, sv = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) { su += Jc[k] * dq[k]; sv += Jc[6 + k] * dq[k]; }
-            e0 += Jp[0] * su + Jp[3] * sv; e1 += Jp[1] * su + Jp[4] * sv; e2 += Jp[2] * su + Jp[5] * sv;
-        }
-        e0 += __shfl_xor(e0, 1, 64); e1 += __shfl_xor(e1, 1, 64); e2 += __shfl_xor(e2, 1, 64);
-        e0 += __shfl_xor(e0, 2, 64); e1 += __shfl_xor(e1, 2, 64); e2 += __shfl_xor(e2, 2, 64);
-        if (sub == 0 && pl < npts) {
-            const double* Lp = J.Lc + 6 * (size_t)i;  // (U+I)^-1 = L L^T, L = l00 l10 l11 l20 l21 l22
-            const double z0 = Lp[0] * e0 + Lp[1] * e1 + Lp[3] * e2, z1 = Lp[2] * e1 + Lp[4] * e2, z2 = Lp[5] * e2;  // L^T e
-            const double d0 = Lp[0] * z0, d1 = Lp[1] * z0 + Lp[2] * z1, d2 = Lp[3] * z0 + Lp[4] * z1 + Lp[5] * z2;  // L (L^T e)
-            const double d[3] = {J.tp[3 * (size_t)i] - d0, J.tp[3 * (size_t)i + 1] - d1, J.tp[3 * (size_t)i + 2] - d2};
-            for (int k = 0; k < 3; k++) {
-                const double dl = d[k] * 0.9;
-                const double nv = J.x[3 * (size_t)i + k] + dl;
-                J.x[3 * (size_t)i + k] = nv;
-                s_w[3 * pl + k] = nv;
-                ss += dl * dl;
-            }
-        }
-    }
-    __syncthreads();
-    if (do_jac && npts > 0) ba_jac_block<true>(J, s_out, s_ss, s_w);
-    ss = vh_wave_sum_f64(ss);
-    if ((tid & 63) == 0) sh[tid >> 6] = ss;
-    __syncthreads();
-    if (tid == 0) {
-        double t = 0.0;
-        for (int k = 0; k < BA_THREADS / 64; k++) t += sh[k];
-        atomicAdd(J.acc + 1, t);
-        __threadfence();
-        const unsigned prev = atomicAdd(J.ticket, 1u);
-        if (prev == gridDim.x - 1) {  // last block: finish the iteration record (as k_ba_update)
-            const double nz = J.nz_total, nx = J.nx_total;
-            const double sumr = atomicAdd(J.acc, 0.0), sumd = atomicAdd(J.acc + 1, 0.0);
-            const double f = sqrt(sumr / nz), xr = sqrt(sumd / nx);
-            J.trace[2 * it] = f;
-            J.trace[2 * it + 1] = xr;
-            J.info[0] = it + 1;
-            if (xr < 1e-7) { J.info[1] = 1; *J.done = 1; }
-            J.acc[0] = 0.0; J.acc[1] = 0.0;
-            *J.ticket = 0u;
-            __threadfence();
-        }
-    }
-}
-
 // iteration record from the (all-reduced) sums of a sharded run
 __global__ void k_ba_finalize(BaJob J, int it)
 {
@@ -1719,11 +1607,6 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     }
     J.zmode = use_mfma ? 1 : 0;
     { const char* e = getenv("VH_BA_DBG"); J.dbg = e ? atoi(e) : 0; }
-    // whole solves on the matrix-core path with the accumulator-resident solve: 4 launches per LM iteration (k_ba_update_jac); the sharded phases
-    // (all-reduces between the launches) and the other solvers keep the 5-launch sequence.  VH_BA_FUSE=0: experiments / the tests' second implementation
-    const bool fuse_off = [] { const char* v = getenv("VH_BA_FUSE"); return v && v[0] == '0'; }();  // (read per call, like VH_BA_DBG: the tests flip it)
-    const bool fused = P.phase == -1 && use_mfma && nq <= BA_GJ_MAXQ && !(J.dbg & 64) && !fuse_off && !P.defer_finalize;
-    J.fuse = fused ? 1 : 0;
     // one wavefront per point, grid-strided: every block ends with an atomic on one address, so keep the block count low
     const int upd_cap = J.nwin > 1 ? std::max(16, 1024 / J.nwin) : 256;
     const int upd_blocks = std::min(use_mfma ? (4 * nt + BA_THREADS - 1) / BA_THREADS : (nt + BA_THREADS / 64 - 1) / (BA_THREADS / 64), upd_cap);
@@ -1783,32 +1666,6 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         hipLaunchKernelGGL(k_ba_update, dim3(upd_blocks, nw), dim3(BA_THREADS), 0, s, J, it);
         vh_prof_stop(pc, rec, VH_PROF_BA_UPDATE, s);
     };
-    // every LM iteration of a whole solve (after init)
-    auto run_all = [&]() {
-        if (!fused) {
-            for (int it = 0; it < P.max_iter; it++) { normal_equations(it); solve_update(it); }
-            return;
-        }
-        const int ppb = BA_THREADS / (nc + 1), jblocks = (nt + ppb - 1) / ppb;
-        hipLaunchKernelGGL(k_ba_cams, dim3((nc + 1 + 63) / 64, nw), dim3(64), 0, s, J);
-        int rec = vh_prof_start(pc, s);
-        hipLaunchKernelGGL(k_ba_jac<true>, dim3(jblocks, nw), dim3(BA_THREADS), 0, s, J);
-        vh_prof_stop(pc, rec, VH_PROF_BA_JAC, s);
-        for (int it = 0; it < P.max_iter; it++) {
-            rec = vh_prof_start(pc, s);
-            hipLaunchKernelGGL((k_ba_schur_mfma<128, 0>), dim3(nparts, nw), dim3(BA_SCHUR_THREADS), lds_mfma, s, J);
-            vh_prof_stop(pc, rec, VH_PROF_BA_SCHUR, s);
-            rec = vh_prof_start(pc, s);
-            hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((nent + nq + 63) / 64), nw), dim3(BA_THREADS), 0, s, J, nparts);
-            vh_prof_stop(pc, rec, VH_PROF_BA_REDUCE, s);
-            rec = vh_prof_start(pc, s);
-            hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1, nw), dim3(64 * BA_GJ_WAVES), 0, s, J);  // (J.fuse: also moves the cameras)
-            vh_prof_stop(pc, rec, VH_PROF_BA_SOLVE, s);
-            rec = vh_prof_start(pc, s);
-            hipLaunchKernelGGL(k_ba_update_jac, dim3(jblocks, nw), dim3(BA_THREADS), 0, s, J, it, it + 1 < P.max_iter ? 1 : 0);
-            vh_prof_stop(pc, rec, VH_PROF_BA_UPDATE, s);
-        }
-    };
     switch (P.phase) {
     case -1: {
         // whole solve: 2 + 5 max_iter dependent launches.  A sequence seen before (same job descriptor -- pointers, sizes, intrinsics -- and launch
@@ -1831,7 +1688,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
             bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 ok = init() == 0;
-                if (ok) run_all();
+                for (int it = 0; ok && it < P.max_iter; it++) { normal_equations(it); solve_update(it); }
                 ok = (hipStreamEndCapture(s, &g) == hipSuccess) && ok && g;
             }
             s = cs;
@@ -1845,7 +1702,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         if (e) e->seen++;
         int r = init();
         if (r) return r;
-        run_all();
+        for (int it = 0; it < P.max_iter; it++) { normal_equations(it); solve_update(it); }
         break;
     }
     case 0: { int r = init(); if (r) return r; break; }

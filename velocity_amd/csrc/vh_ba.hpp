@@ -31,8 +31,6 @@ struct BaJob {  // passed by value to every BA kernel
     int model;  // 0: fcnNLS_batch (free cameras, NLS.py:186-250); 1: fcnNLS_batch2 (joint rotation + straight-line trajectory, NLS.py:253-328)
     int add_identity, count_cams, defer_finalize;
     int dbg;    // experiment switches (VH_BA_DBG): 1 skip MFMA, 2 skip Z / diag VALU, 4 skip global fetch, 8 skip barrier, 64 VALU Gauss-Jordan solve
-    int fuse;   // 1 (whole solves on the matrix-core path): k_ba_solve_mfma also moves the cameras and rebuilds their tables, k_ba_update_jac updates a block's
-                // points and writes their NEXT Jacobian rows in one launch (4 launches per LM iteration instead of 5)
     int zmode;  // 1: Y holds Z = L^T W and Spart holds only the upper-triangle 16x16 tiles (k_ba_schur_mfma); 0: Y = (U+I)^-1 W, full Spart
     // batched independent windows (vh_nls_batch_multi): blockIdx.y selects the window; every pointer above is window 0's
     int nwin;
