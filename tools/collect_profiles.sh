@@ -36,10 +36,18 @@ for s in 1 2 4 8 16 32 64 128 256; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --streams $S --steps 40 --warmup 5 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/stats.log 2>&1
 find $OUT/stats -name "*kernel_trace.csv" -delete   # tens of MB; the per-kernel summary is what is kept
+# HBM traffic of EVERY library kernel of a step (roofline.step_hbm sums them): FETCH_SIZE and WRITE_SIZE in separate passes
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_o|k_lk_q|k_lk_strip|k_pyr_down|k_roi_warp' --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --streams $S --steps 6 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --kernel-include-regex '^(void )?k_' --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --streams $S --steps 6 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/pmc_$c.log 2>&1
   find $OUT/pmc_$c -name "*kernel_trace.csv" -delete
 done
+# the loads that look like the reference's data: both episode legs + the kernel stats of the hard scene
+python $R/bench.py --only-leg hard_scene:$S > $OUT/hard_scene.json 2> $OUT/hard_scene.err
+python $R/bench.py --only-leg hard_scene:8 > $OUT/hard_scene_8.json 2>> $OUT/hard_scene.err
+python $R/bench.py --only-leg real_texture:$S > $OUT/real_texture.json 2>> $OUT/hard_scene.err
+python $R/bench.py --only-leg real_texture:8 > $OUT/real_texture_8.json 2>> $OUT/hard_scene.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hard_stats -- python $R/bench.py --only-leg hard_scene:$S --verify-frames 0 > $OUT/hard_stats.log 2>&1
+find $OUT/hard_stats -name "*kernel_trace.csv" -delete
 # SQ counters of the LK kernels (two passes of <= 8 counters)
 P1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU"
 P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_LDS"

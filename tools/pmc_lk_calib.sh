@@ -22,7 +22,7 @@ pts, cpts = {}, {}
 for tag in ("default", "cap1", "cap3", "roll", "ccap1", "ccap2"):
     line = [l for l in open("$OUT/%s.log" % tag) if l.startswith("{")][-1]
     j = json.loads(line)
-    rf = j["roofline"]
+    rf = j.get("roofline_detail", j["roofline"])
     vals, cvals = {}, {}
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % tag, recursive=True):
         for r in csv.DictReader(open(f)):

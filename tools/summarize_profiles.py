@@ -35,7 +35,7 @@ json.dump(bench, open(os.path.join(DST, f"{tag}_bench_default.json"), "w"), inde
 sweep = {}
 for f in sorted(glob.glob(os.path.join(SRC, "sweep_*.json")), key=lambda p: int(p.split("_")[-1].split(".")[0])):
     d = last_json(f)
-    sweep[d["config"]["streams_per_gpu"]] = dict(frames_per_s=d["value"], ms_per_step=d["ms_per_step"], lk_us_per_launch=d["roofline"]["lk_us_per_launch"])
+    sweep[d["config"]["streams_per_gpu"]] = dict(frames_per_s=d["value"], ms_per_step=d["ms_per_step"], lk_us_per_launch=d["roofline"]["lk_us_per_launch"], lk_kernels=d["roofline"].get("lk_kernels"))
 json.dump(dict(_comment="python bench.py --streams S --steps 60 --warmup 10 --cpu-seconds 0 --no-ba (C2, one MI355X)", sweep=sweep),
           open(os.path.join(DST, f"{tag}_stream_sweep.json"), "w"), indent=1)
 
@@ -47,11 +47,14 @@ with open(os.path.join(DST, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w.writeheader()
     w.writerows(keep)
 
-traffic = {"_comment": "rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_o|k_lk_q|k_lk_strip|k_pyr_down|k_roi_warp' --pmc FETCH_SIZE (and, in a "
-           "separate pass, WRITE_SIZE) -- python bench.py --streams %d --steps 6 --warmup 2 --cpu-seconds 0 --no-ba. Averages per launch in the "
-           "counters' KiB units (launches of the first two steps dropped). Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports half "
-           "of the bytes of a wide coalesced read: bench.py doubles it. Infinity-Cache hits are included in FETCH_SIZE." % S,
+traffic = {"_comment": "rocprofv3 --kernel-trace --kernel-include-regex '^(void )?k_' --pmc FETCH_SIZE (and, in a separate pass, WRITE_SIZE) -- python bench.py "
+           "--streams %d --steps 6 --warmup 2 --cpu-seconds 0 --no-ba: EVERY library kernel of a frame step. Averages per launch in the counters' KiB units "
+           "(the first quarter of a kernel's launches dropped). Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports half of the bytes of a wide "
+           "coalesced read: bench.py doubles it. Infinity-Cache hits are included in FETCH_SIZE. step_total_kib = sum over all kernels and launches of "
+           "(2 x FETCH_SIZE + WRITE_SIZE) / number of frame steps in the pass (= launches of k_klt_setup; frame-0 kernels excluded): what roofline.step_hbm divides "
+           "by the step time." % S,
            "streams": S}
+_step_tot = {}
 for cname, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
     f = newest(os.path.join(SRC, f"pmc_{cname}", "**", "*counter_collection.csv"))
     per = {}
@@ -59,11 +62,17 @@ for cname, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
         if r["Counter_Name"] != cname:
             continue
         per.setdefault(r["Kernel_Name"].replace("void ", "").split("(")[0], []).append(float(r["Counter_Value"]))
+    nsteps = max(len(per.get("k_klt_setup", [])), 1)
+    _step_tot[key] = sum(sum(v) for k, v in per.items() if not k.startswith(("k_sess_init", "k_init_", "k_frame0"))) / nsteps
     for k, v in per.items():
         n = len(v)
         v = v[n // 4:]  # drop the warm-up quarter
         traffic.setdefault(k, {})[key] = round(sum(v) / len(v), 1)
         traffic[k]["launches"] = len(v)
+        traffic[k]["launches_per_step"] = round(n / nsteps, 2)
+if "fetch_kib" in _step_tot and "write_kib" in _step_tot:
+    traffic["step_total_kib"] = round(2 * _step_tot["fetch_kib"] + _step_tot["write_kib"], 1)
+    traffic["step_fetch_kib"], traffic["step_write_kib"] = round(_step_tot["fetch_kib"], 1), round(_step_tot["write_kib"], 1)
 
 
 def pmc_table(dirname):
@@ -178,10 +187,29 @@ if host:
                    "and are uploaded every step through velocity_amd.driver.HostFrameFeeder (PCIe-inclusive; never the headline value)",
                    frames_per_s=host), open(os.path.join(DST, f"{tag}_host_frames.json"), "w"), indent=1)
 
+# the loads that look like the reference's data: both episode legs (bench.py --only-leg) + the kernel stats of the hard scene
+hard = {}
+for name in ("hard_scene", "hard_scene_8", "real_texture", "real_texture_8"):
+    f = os.path.join(SRC, name + ".json")
+    if os.path.exists(f) and os.path.getsize(f) > 100:
+        hard[name] = last_json(f)
+if hard:
+    json.dump(dict(_comment="python bench.py --only-leg hard_scene:S / real_texture:S (benchlib.workload.EpisodeWorkload): short clips, every stream re-initialised "
+                            "(untimed) between clips; each object carries its own `verified` (streams vs the CPU oracle from frame 0 of a clip)", **hard),
+              open(os.path.join(DST, f"{tag}_hard_legs.json"), "w"), indent=1)
+hs = glob.glob(os.path.join(SRC, "hard_stats", "**", "*kernel_stats.csv"), recursive=True)
+if hs:
+    hrows = list(csv.DictReader(open(max(hs, key=os.path.getmtime))))
+    hkeep = [r for r in hrows if not r["Name"].startswith(("void at::", "void (anonymous", "__amd_rocclr"))]
+    with open(os.path.join(DST, f"{tag}_hard_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(hrows[0].keys()))
+        w.writeheader()
+        w.writerows(hkeep)
+
 # ---- human-readable summary
 lib = sum(float(r["TotalDurationNs"]) for r in keep if not r["Name"].startswith("k_sess_init"))
 steps = [int(r["Calls"]) for r in keep if "k_lk3" in r["Name"]][0]
-rf, cb = bench["roofline"], bench["cpu_baseline"]
+rf, cb = bench.get("roofline_detail", bench["roofline"]), bench["cpu_baseline"]
 cb1 = bench.get("cpu_baseline_1core", {})
 kname = rf["kernel"].split(" (")[0]
 gate = json.load(open(os.path.join(SRC, "gate.json")))
@@ -220,8 +248,8 @@ o.append(f"HBM traffic of that kernel (`profiles/{tag}_hbm_traffic.json`, separa
          f"bound (`roofline.bound = valu`): {ksq.get('valu_insts_per_wave', 0):.0f} VALU instructions per wavefront (= per track, both directions) in the PMC pass, "
          f"{64e-9 * ksq.get('SQ_INSTS_VALU', 0):.1f} G lane-instructions per launch; the bench line derives the same figure LIVE from the kernel's own counters "
          f"({rf['setups_per_launch']} set-ups, {rf['newton_iters_per_launch']} Newton iterations per launch) through the calibrated costs of "
-         f"`profiles/{tag}_lk_valu_model.json`: {rf['issued_ginstr_per_launch']} G = {rf['achieved']} T/s of the {rf['peak']} T lane-instruction/s issue peak "
-         f"of its (half-rate) instruction class -> frac {rf['frac']}; SQ issue utilisation {100 * ksq.get('valu_issue_utilisation', 0):.0f} % "
+         f"`profiles/{tag}_lk_valu_model.json`: {rf['issued_ginstr_per_launch']} G = {rf['achieved']} T/s of the {rf['peak']} T lane-instruction/s the guide's SIMD-32 "
+         f"issue rate gives -> `roofline.frac` {rf['frac']} ({rf.get('frac_of_class_peak')} of the {rf.get('peak_class')} T/s of the 4-cycle opcode class the kernel is made of); SQ issue utilisation {100 * ksq.get('valu_issue_utilisation', 0):.0f} % "
          f"(`profiles/{tag}_valu_rate.json` settles the issue rates; SQ counters in `profiles/{tag}_lk_sq_pmc.json`). "
          f"SURVEY's op model (47 op/px set-up, 12 op/px/iteration) prices the same launch at {rf['op_model']['gops_per_launch']} G operations.\n")
 o.append("Per-kernel rows of the bench line (`roofline.kernels`: HIP-event time inside the library, algorithmic bytes, HBM fraction):\n")
@@ -231,6 +259,19 @@ for r in rf["kernels"]:
 o.append("")
 o.append(f"Throughput vs resident streams (`profiles/{tag}_stream_sweep.json`, 60 steps each): "
          + ", ".join(f"{s_} -> {v['frames_per_s'] / 1e3:.2f} k" for s_, v in sweep.items()) + " frames/s.\n")
+if hard:
+    o.append(f"## Loads that look like the reference's data (`profiles/{tag}_hard_legs.json`, `{tag}_hard_kernel_stats.csv`)\n")
+    o.append("| leg | streams | frames/s | ms per step | Newton iterations per set-up (stage 1 / 2 / fine) | tracks alive, first -> last frame of a clip | LK launches us | bit-exact vs oracle |\n|---|---|---|---|---|---|---|---|")
+    for name, d in hard.items():
+        if "error" in d:
+            o.append(f"| {name} | - | error: {d['error'][:80]} | | | | | |")
+            continue
+        ab = d["tracks_alive_by_frame"]
+        o.append(f"| {name} | {d['streams']} | {d['value']:.0f} | {d['ms_per_step']} | {d['lk_newton_iters_per_setup']} | {ab[0]:.0f} -> {ab[-1]:.0f} | {d['lk_us_per_launch']} | "
+                 f"{d.get('verified', {}).get('bit_exact')} |")
+    if "hard_scene" in hard and "error" not in hard["hard_scene"]:
+        o.append(f"\nHard scene at {hard['hard_scene']['streams']} streams vs the headline: {hard['hard_scene']['value'] / bench['value']:.3f} x "
+                 f"({hard['hard_scene']['value']:.0f} / {bench['value']:.0f} frames/s); per kernel (us per step): {hard['hard_scene']['kernels_us_per_step']}.\n")
 if host:
     o.append(f"PCIe-inclusive (`bench.py --host-frames`, `profiles/{tag}_host_frames.json`: pinned host ring, 3-deep feeder on a side stream): "
              + ", ".join(f"{s_} streams {v / 1e3:.2f} k" for s_, v in host.items()) + " frames/s.\n")

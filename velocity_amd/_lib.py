@@ -112,7 +112,14 @@ def load():
         if _lib is None:
             from . import _build
 
-            want = _build.source_hash()
+            # a packaged copy without csrc/ (or without the header) cannot hash its sources: it then trusts the id embedded in the library and says so
+            try:
+                want = _build.source_hash()
+            except OSError as e:
+                import warnings
+
+                want = None
+                warnings.warn(f"velocity_amd: no source tree next to the library ({e}); loading it on the id it carries, unchecked")
             override = os.environ.get("VH_LIB")
             path = override or LIB_PATH
             if not os.path.exists(path):
@@ -134,7 +141,7 @@ def load():
                 import sys
 
                 print(f"velocity_amd: VH_LIB override: loading {path} (id {have}; the tree's sources hash to {want})", file=sys.stderr)
-            elif have is None or have.split("-")[0] != want:
+            elif want is not None and (have is None or have.split("-")[0] != want):
                 raise RuntimeError(
                     f"{path} was not built from this tree: it carries build id {have}, the sources hash to {want}-*. "
                     "Rebuild with `python -c 'import __graft_entry__ as g; g.build()'`."
@@ -146,7 +153,7 @@ def load():
             got = L.vh_build_id().decode()
             if got != have:
                 raise RuntimeError(f"{path}: vh_build_id() says {got}, the file's marker says {have}")
-            _info = {"build_id": got, "source_hash": want, "matches_source": got.split("-")[0] == want, "override": override or None}
+            _info = {"build_id": got, "source_hash": want, "matches_source": want is not None and got.split("-")[0] == want, "override": override or None}
             _lib = L
     return _lib
 
