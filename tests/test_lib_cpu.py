@@ -119,3 +119,24 @@ def test_loader_refuses_a_library_from_other_sources(tmp_path):
             "assert i['override'] and not i['matches_source'], i\nprint('OVERRIDE')\n") % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, VH_LIB=str(fake)))
     assert "OVERRIDE" in r.stdout and "VH_LIB override" in r.stderr, r.stdout + r.stderr
+
+
+def test_driver_table_text_is_the_references():
+    """run_sequence's printed text (header, 9-column row, summary) on the host side: the same strings the oracle driver builds from the reference's
+    format strings (vidExample.py:51-74,165,177-178), incl. the nan fields of row 0."""
+    from oracle import driver_oracle as DO
+    from velocity_amd import driver
+
+    assert driver.TABLE_HEADER == DO.HEADER and driver.ROW_FORMAT == DO.ROW
+    assert driver.TABLE_HEADER.count("\n") == 2 and "pointTracks" in driver.TABLE_HEADER and "(km/h)" in driver.TABLE_HEADER
+    rng = np.random.default_rng(3)
+    S = rng.uniform(0, 50, (6, 9)).astype(np.float32)
+    S[:, 0] = np.arange(6)
+    S[:, 2] = rng.integers(50, 1004, 6)
+    S[0, 4], S[0, 8] = np.nan, np.nan
+    for i in range(6):
+        assert driver.table_row(S[i]) == DO.ROW.format(*tuple(S[i]))
+    assert "nan" in driver.table_row(S[0]) and len(driver.table_row(S[1])) == 13 * 9
+    a, b = driver.summary_lines(S, 6, list(range(19, 25)), 0.5)
+    assert a == f"\nSpeed = {S[1:, 8].mean():.2f} +/- {S[1:, 8].std():.2f} km/h\nRes = {S[1:, 3].mean():.3f} pixels"
+    assert b.startswith("Processed 6 images: [19 20 21 22 23 24] in 0.50s (12.00fps)")

@@ -228,3 +228,29 @@ def test_gate_scene_fires_every_status_gate_in_the_oracle():
     s1, s2, s3 = c["stage1_quarter_scale_lk"], c["stage2_roi_translation_lk_fb1"], c["stage3_affine_warp_lk_fb03"]
     assert min(s1["fwd_status"], s2["fwd_status"], s2["bwd_status"], s3["fwd_status"], s3["bwd_status"]) > 0
     assert s1["ransac_outliers"] > 20 and s2["fb"] > 20 and s3["fb"] > 50 and 0.5 < c["survive"] / c["tracks"] < 0.85
+
+
+def test_hard_scene_fires_the_gates_and_is_periodic():
+    """synth.HardScene (bench.py's `hard_scene` leg): noise, gain drift, an independently moving foreground, a textureless band and a
+    saturated patch.  The sequence is periodic (noise included: the bench walks it as a ring), its parts are where the generator says, and -- unlike the
+    clean plane, where no gate ever fires -- the oracle's KLTmain loses tracks on the LK status AND the forward-backward gates while most survive."""
+    from klt_gate_census import census
+
+    from velocity_amd import synth
+
+    W, H, ring = 960, 540, 12
+    K = synth.K_1080P.copy()
+    K[:2, :2] *= 0.5
+    K[2, 0], K[2, 1] = W / 2 + 0.5, H / 2 + 0.5
+    hs = synth.HardScene(K, W, H, ring=ring)
+    f0, f1, f12 = hs.frame(0).numpy(), hs.frame(1).numpy(), hs.frame(ring).numpy()
+    assert np.array_equal(f0, f12) and not np.array_equal(f0, f1)
+    sx0, sx1, sy0, sy1 = hs.sat
+    assert (f0[sy0:sy1, sx0:sx1] == 255).all()
+    band = f0[hs.band[0]:hs.band[1], : W // 2].astype(float)  # (left half: the saturated patch and the foreground stay clear of it)
+    assert 1.0 < band.std() < 3.5 and abs(band.mean() - 117 * (1 + hs.gain * np.sin(0.5))) < 1.0  # flat gray + sensor noise sigma = 2
+    p0 = synth.grid_tracks(500, W, H, seed=5)
+    c = census(f1, f0, p0, lk_coarse=dict(max_level=2))
+    s2, s3 = c["stage2_roi_translation_lk_fb1"], c["stage3_affine_warp_lk_fb03"]
+    assert s3["fwd_status"] + s2["fwd_status"] > 0 and s3["fb"] > 5 and s2["fb"] > 5
+    assert 0.8 < c["survive"] / c["tracks"] < 0.995 and not c["coarse_affine_failure"]
