@@ -111,3 +111,24 @@ def test_step_hbm_is_the_committed_pmc_bytes_over_this_runs_step_time():
     h = r["step_hbm"]
     assert abs(h["bytes_per_step"] - tj["step_total_kib"] * 1024 * S / tj["streams"]) <= 1
     assert abs(h["gbs"] - h["bytes_per_step"] / 6000e-6 / 1e9) < 0.06 and abs(h["frac_of_hbm_peak"] - h["gbs"] / 8000.0) < 1e-4
+
+
+def test_the_line_cites_the_newest_profile_round():
+    """Every committed collection the roofline objects read -- VALU issue rates, the fitted instruction costs, the opcode mix, the HBM traffic passes, the
+    BA counters -- must come from the NEWEST round under profiles/ (round 4's line still cited round-2 / round-3 files)."""
+    import glob
+    import re
+
+    b = _bench()
+    S, N, steps = 256, 2000, 20
+    wl = types.SimpleNamespace(N=N, SG=S, cfg=b.CONFIGS["c2"], params="baseline")
+    m = _fake_measurement(S, N, steps)
+    m["step_us"] = 6000.0
+    r = b.roofline_of(wl, m, 1)
+    newest = max(int(re.match(r"r(\d\d)_", os.path.basename(f)).group(1)) for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*")))
+    cited = re.findall(r"profiles/r(\d\d)_\w+\.json", json.dumps(r))
+    assert cited, "the roofline object must name the collections it reads"
+    assert all(int(c) == newest for c in cited), f"stale profile cited: rounds {sorted(set(cited))}, newest is r{newest:02d}"
+    for kind in ("valu_rate.json", "lk_valu_model.json", "lk_isa_mix.json", "hbm_traffic.json", "ba_pmc.json"):
+        assert os.path.exists(os.path.join(ROOT, "profiles", f"r{newest:02d}_{kind}")), f"profiles/r{newest:02d}_{kind} is missing from the newest collection"
+    assert r["step_hbm"] is not None and r["step_hbm"]["gbs"] > 0
