@@ -133,3 +133,36 @@ def test_real_stills_through_the_drop_in_functions_and_the_torch_op(stills):
             e2, ev2, eerr = KO.lk_fb(fr[0], fr[1], p0, fbt=fbt, **kw)
             p2, v2, err = KLT.cv2calcOpticalFlowPyrLK(fr[0], fr[1], p0, None, fbt=fbt, **lk)
             assert np.array_equal(v2, ev2) and np.array_equal(p2, e2) and np.array_equal(err.ravel(), eerr), (tag, kw)
+
+
+def test_run_sequences_batches_clips_like_single_runs(stills):
+    """velocity_amd.driver.run_sequences: several clips as the streams of ONE session (one launch sequence per frame for all of them, every stream on its
+    own clock, frame 0 of each through vh_frame0_init on the device).  Three clips -- the real stills, the same stills with another set of time stamps, and
+    the stills mirrored left-right (other features, other deaths) -- must each equal their own run_sequence result: masks / points / history bit for bit,
+    records to 1e-6, the printed rows identical (procTime excluded)."""
+    from velocity_amd.driver import run_sequence, run_sequences
+
+    frames, times, q, K = stills["b_frames"], stills["b_times"], stills["b_q"], stills["b_K"]
+    W = frames.shape[2]
+    qm = q.copy()
+    qm[:, 0] = (W - 1) - qm[:, 0]
+    clips = [dict(frames=frames, q=q, times=times, name="b"),
+             dict(frames=frames, q=q, times=times * np.float32(1.5) + np.float32(2.0), frame_numbers=list(range(100, 100 + len(frames))), name="b slow"),
+             dict(frames=np.ascontiguousarray(frames[:, :, ::-1]), q=qm[[1, 0, 3, 2]], times=times, name="b mirrored")]
+    got = run_sequences(clips, K, roi_border=(180, 140))
+    for c, g in zip(clips, got):
+        one = run_sequence(c["frames"], c["q"], K, times=c["times"], frame_numbers=c.get("frame_numbers"), roi_border=(180, 140), out=None, live=False, name=c["name"])
+        assert g["n_tracks0"] == one["n_tracks0"] > 100 and g["boxb"] == one["boxb"]
+        assert np.array_equal(g["vg"], one["vg"]) and np.array_equal(g["vp"], one["vp"]) and np.array_equal(g["p"], one["p"]) and np.array_equal(g["ids"], one["ids"])
+        for r in (0, 1, 4):
+            assert np.array_equal(g["P"][r], one["P"][r], equal_nan=True)
+        np.testing.assert_allclose(g["B"], one["B"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(g["S"][:, [0, 2, 3, 4, 5, 6, 7, 8]], one["S"][:, [0, 2, 3, 4, 5, 6, 7, 8]], rtol=1e-6, equal_nan=True)
+        assert g["lines"][0] == one["lines"][0] and g["lines"][1] == one["lines"][1]
+        for a_, b_ in zip(g["lines"][2:-2], one["lines"][2:-2]):
+            assert a_[:13] == b_[:13] and a_[26:] == b_[26:], (a_, b_)  # every column but procTime
+        assert g["lines"][-2] == one["lines"][-2]  # Speed / Res summary
+    assert not np.array_equal(got[0]["p"], got[2]["p"]) and got[1]["S"][3, 4] != got[0]["S"][3, 4]
+    sp = got[1]["S"][1:, 8]
+    # the same motion on a 1.5 x slower clock (the EXIF time stamps are seconds of the day, ~5e4: float32 B[i, 12] resolves them to ~4 ms, hence 3 %)
+    np.testing.assert_allclose(sp, got[0]["S"][1:, 8] / 1.5, rtol=3e-2)

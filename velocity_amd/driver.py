@@ -429,3 +429,93 @@ def _run_dropin(frames, q, K, times, frame_numbers, plate, roi_border, max_corne
     loop_seconds = clock() - t_loop
     return dict(S=S, B=B, P=P, vg=vg, vp=vp, p=p, p3=p3, ids=np.nonzero(vg)[0].astype(np.int32), n_tracks0=n_tr, t0=np.asarray(t_plate), R0=R_plate,
                 res0=float(res_plate), boxa=tuple(boxa), boxb=tuple(boxb), loop_seconds=loop_seconds, klt_flags=0)
+
+
+def run_sequences(clips, K, plate="Chile", roi_border=(700, 500), max_corners=1000, quality=0.01, block=5, harris_k=0.04, subpix=(5, 100, 0.001),
+                  msv_frame=5, lk_coarse=None, lk_fine=None, out=None):
+    """Many clips at once: the throughput form of run_sequence.  `clips` = list of dict(frames, q, times[, frame_numbers, name]) of ONE frame size and
+    length; every clip is a stream of one device-resident TrackerSession, so a frame step is one launch sequence for all of them (vh_session_step_v: each
+    stream has its own clock).  Frame 0 of every clip runs through vh_frame0_init on the device, its outputs feed vh_session_init_dev directly; nothing is
+    read back before the last frame.  Returns one result dict per clip (the keys of run_sequence; `lines` = that clip's table and summary, printed through
+    `out` if given), each equal to what run_sequence returns for the clip alone."""
+    import time as _time
+
+    torch = L.torch_cuda()
+    nclip = len(clips)
+    assert nclip >= 1
+    n = len(clips[0]["frames"])
+    dev = [[(f if isinstance(f, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(f))).cuda().contiguous() for f in c["frames"]] for c in clips]
+    H, W = dev[0][0].shape
+    assert all(len(d) == n and d[0].shape == (H, W) for d in dev), "clips must share frame size and length"
+    cap = 4 + int(max_corners)
+    ses = TrackerSession(K, W, H, cap, nhist=n, batch=nclip, lk_coarse=lk_coarse, lk_fine=lk_fine, msv_frame=msv_frame)
+    lib, ws = ses.lib, ses.ws
+    plate_w = np.ascontiguousarray(np.asarray(_plate_points(plate), np.float64).reshape(12))
+    win, it, eps = subpix
+    times = np.stack([np.asarray(c["times"], np.float32) for c in clips])  # [clip, frame]
+    fnos = np.stack([np.asarray(c.get("frame_numbers", np.arange(n)), np.float32) for c in clips])
+    keep = []
+    t_begin = _time.perf_counter()
+    for b, c in enumerate(clips):
+        q = np.ascontiguousarray(np.asarray(c["q"], np.float32).reshape(4, 2))
+        bufs = (torch.empty((cap, 2), dtype=torch.float32, device="cuda"), torch.empty((cap, 3), dtype=torch.float64, device="cuda"),
+                torch.empty(cap, dtype=torch.uint8, device="cuda"), torch.empty(3, dtype=torch.float32, device="cuda"),
+                torch.empty(9, dtype=torch.float64, device="cuda"), torch.empty(1, dtype=torch.float64, device="cuda"),
+                torch.empty(1, dtype=torch.int32, device="cuda"))
+        p, p3, vp, t0, R0, res0, n0 = bufs
+        rois = (C.c_int * 8)()
+        L.check(lib.vh_frame0_init(ws.handle, L.dptr(dev[b][0]), W, H, W, q.ctypes.data_as(L.f32p), ses.K64.ctypes.data_as(L.f64p), plate_w.ctypes.data_as(L.f64p),
+                                   int(roi_border[0]), int(roi_border[1]), int(max_corners), float(quality), int(block), float(harris_k), int(win), int(it),
+                                   float(eps), L.dptr(p), L.dptr(p3), L.dptr(vp), L.dptr(t0), L.dptr(R0), L.dptr(res0), L.dptr(n0), rois, L.stream_ptr()),
+                "vh_frame0_init")
+        L.check(lib.vh_session_init_dev(ses.handle, b, L.dptr(dev[b][0]), W, L.dptr(p), L.dptr(p3), L.dptr(vp), L.dptr(t0), L.dptr(res0), L.dptr(n0),
+                                        float(times[b, 0]), float(fnos[b, 0]), L.stream_ptr()), "vh_session_init_dev")
+        ses._keep[b] = dev[b][0]
+        keep.append((bufs, tuple(rois)))
+    t_loop = _time.perf_counter()
+    for i in range(1, n):
+        ses.step([dev[b][i] for b in range(nclip)], time_s=times[:, i], frame_no=fnos[:, i])
+    torch.cuda.synchronize()
+    loop_seconds = _time.perf_counter() - t_loop
+    seconds = _time.perf_counter() - t_begin
+    results = []
+    for b, c in enumerate(clips):
+        st = ses.state(b)
+        (p, p3, vp, t0, R0, res0, n0), rois = keep[b]
+        k = int(n0.item())
+        S = st["S"].copy()
+        S[0, 1] = 0.0
+        S[1:, 1] = loop_seconds / (n - 1)  # every row carries the mean time of a frame step (of ALL clips)
+        lines = [f"Starting image processing on {c.get('name', f'clip {b}')} ...", TABLE_HEADER] + [table_row(S[i]) for i in range(n)]
+        lines += summary_lines(S, n, c.get("frame_numbers", list(range(n))), seconds)
+        if out is not None:
+            for ln in lines:
+                out(ln)
+        results.append(dict(S=S, B=st["B"], P=st["P"][:, :k, :], vg=st["vg"][:k], vp=st["vp"][:k], p=st["p"], p3=st["p3"][:k], ids=st["ids"], n_tracks0=k,
+                            t0=t0.cpu().numpy(), R0=R0.cpu().numpy().reshape(3, 3), res0=float(res0.item()), boxa=rois[0:4], boxb=rois[4:8],
+                            klt_flags=st["klt_flags"], lines=lines, seconds=seconds, ms_per_frame=1e3 * loop_seconds / (n - 1)))
+    return results
+
+
+def main(argv=None):
+    """`python -m velocity_amd.driver clip.npz [--seq b] [--route session|dropin]`: the reference's run (`python vidExample.py`) on a decoded clip.
+    clip.npz holds `<seq>_frames` uint8 [n, H, W], `<seq>_times` [n] seconds, `<seq>_q` [4, 2] plate corners and `<seq>_K` [3, 3] (the format of
+    tests/golden/stills_gray.npz); decoding videos is out of scope (no decoder in the image)."""
+    import argparse
+
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("clip")
+    ap.add_argument("--seq", default="b")
+    ap.add_argument("--route", default="session", choices=["session", "dropin"])
+    ap.add_argument("--border", type=int, nargs=2, default=None, help="ROI border around the plate (vidExample.py:108 uses 700 500; the 1024 x 768 stills fixture needs 180 140)")
+    ap.add_argument("--msv-frame", type=int, default=5)
+    a = ap.parse_args(argv)
+    d = np.load(a.clip)
+    fr = d[f"{a.seq}_frames"]
+    border = tuple(a.border) if a.border else ((700, 500) if fr.shape[2] >= 1900 else (180, 140))
+    run_sequence(fr, d[f"{a.seq}_q"], d[f"{a.seq}_K"], times=d[f"{a.seq}_times"], roi_border=border, msv_frame=a.msv_frame, route=a.route,
+                 name=f"{a.clip}:{a.seq}")
+
+
+if __name__ == "__main__":
+    main()
