@@ -200,6 +200,14 @@ def ba_cpu_baseline(out, first, cpu_seconds):
 # ----------------------------------------------------------------------------------------------------------------------------------
 # parity attestation of a run that was just timed (OUTSIDE the timed region; oracle = the checker, never the product)
 # ----------------------------------------------------------------------------------------------------------------------------------
+def _oracle_threads():
+    """The checker's OpenMP pool on the cores the box really grants (the GPU boxes show 256 logical CPUs under a 16-core quota: the default pool of 256
+    threads is throttled to a crawl -- the parity replays of a default run cost 20-30 s per leg before this)."""
+    from oracle import klt_oracle
+
+    klt_oracle.set_threads(klt_oracle.lib(), host_cores())
+
+
 def _compare(st, o, ids0):
     same = (np.array_equal(st["ids"], ids0[o.vg]) and np.array_equal(st["p"], o.p) and np.array_equal(st["vp"][ids0], o.vp)
             and np.array_equal(st["vg"][ids0], o.vg))
@@ -218,6 +226,7 @@ def verify(wl, first, nframes=4, which=None):
         return dict(skipped="host-frames mode")
     which = sorted(set(which if which is not None else [0, wl.S - 1]))
     a, SG = wl.a, wl.SG
+    _oracle_threads()
 
     def frame_of(b, i):
         return wl.frames[wl.fset[b] * a.ring + (wl.phase[b] + i) % a.ring]
@@ -254,6 +263,7 @@ def verify_episode(wl, nframes=3, which=None):
     from oracle.session_oracle import SessionOracle
 
     which = sorted(set(which if which is not None else [0, wl.S - 1]))
+    _oracle_threads()
     e = getattr(wl, "episodes_done", 1)
     nframes = min(nframes, wl.E)
     orcs = {}

@@ -10,6 +10,27 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _granted_cores():
+    """Cores the container's CPU quota grants (cgroup v2 cpu.max / v1 cfs quota), capped by the affinity mask."""
+    import math
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(math.ceil(int(q) / int(per)))))
+    except (OSError, ValueError):
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(math.ceil(q / per))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+# the C oracle's OpenMP pool: the GPU boxes show 256 logical CPUs under a 16-core quota, and 256 threads there are throttled to a crawl
+os.environ.setdefault("OMP_NUM_THREADS", str(_granted_cores()))
 os.environ.setdefault("VH_POISON_WORKSPACE", "1")  # BA workspaces start as NaN bit patterns: reads of never-written memory fail loudly
 
 
