@@ -269,7 +269,7 @@ def verify_episode(wl, nframes=3, which=None):
     orcs = {}
     for b in which:
         f = wl.start_index(b, e) if wl.kind == "hard_scene" else 0
-        if wl.kind == "real_texture" and orcs:  # every stream replays the same clip: one oracle run checks them all (its NumPy fcnMSV1_t alone takes ~40 s)
+        if wl.kind == "real_texture" and orcs:  # every stream replays the same clip: one oracle run checks them all 
             continue
         orcs[b] = SessionOracle(wl.K, wl.frames[wl.frame_index(b, e, 0)].cpu().numpy(), wl.p_ring[f].cpu().numpy(), wl.p3_ring[f].cpu().numpy(),
                                 wl.vp.cpu().numpy().astype(bool), wl.t0, time0=np.float32(wl.time_of(0)), res0=getattr(wl, "res0", 0.0), nhist=wl.E + 2,
@@ -353,8 +353,7 @@ def episode_leg(a, kind, streams, dev, headline_fps=None):
         if headline_fps and kind == "hard_scene":
             out["vs_headline"] = round(fps / headline_fps, 4)
         if a.verify_frames > 0:
-            # (the 8-stream stills leg stops before the MSV frame: the oracle's NumPy fcnMSV1_t takes ~40 s and the 256-stream leg covers it)
-            out["verified"] = verify_episode(wl, nframes=3 if kind == "hard_scene" else (wl.E if streams > 8 else 4))
+            out["verified"] = verify_episode(wl, nframes=3 if kind == "hard_scene" else wl.E)
         wl.close()
         return out
     except Exception as e:  # an extra leg must never take the headline number down with it

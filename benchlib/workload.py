@@ -306,7 +306,7 @@ class EpisodeWorkload:
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    def measure(self, min_seconds=1.0, warm_episodes=1, max_episodes=24):
+    def measure(self, min_seconds=1.0, warm_episodes=1, max_episodes=48):
         from velocity_amd import _lib as L
 
         ses = self.session
