@@ -1197,6 +1197,12 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
     }
     D = __fdiv_rn(1.f, D);
     const int ncI[2] = {-cI[0], -cI[1]};
+    constexpr int PJP = C::PJ_PITCH >> 2;
+    unsigned lcA = (unsigned)(C::OFF_PJ + 4 * (rA * PJP + jA)), lcB = (unsigned)(C::OFF_PJ + 4 * (rB * PJP + jB));  // (((inx - rjx) + 4 j) >> 2 = ((inx - rjx) >> 2) + j)
+    // opaque to the compiler, once per level.  NOT `asm volatile`: a volatile asm counts as a possible store to any memory, and every load of the
+    // pyramid descriptors behind it turns from a scalar load into a per-lane global load (round 5: +17 vector loads, -17 scalar loads and +48 VALU
+    // instructions per track, +25 % wait cycles, +4-5 % kernel time -- what made every earlier form of this change slower than the code it shortened)
+    asm("" : "+v"(lcA), "+v"(lcB));
 
     // packed byte pairs of window row y (strip column j) of the staged search region at window origin (inx, iny)
     // The strip starts at byte `off` of the staged row: its 5 bytes lie inside the two dwords at off >> 2, and the byte pair (c, c+1) is ONE
@@ -1230,14 +1236,13 @@ __device__ __forceinline__ void lk3_level(const ImgDesc I, const ImgDesc J, int 
         int b[2] = {ncI[0], ncI[1]};  // (lanes without strips keep -c: the first strip of the others starts from it without a copy)
         if (lane_on) {
             // rows are read one strip ahead of their use, a scheduling barrier closes every strip (see the set-up loop)
-            constexpr int PJP = C::PJ_PITCH >> 2;
             const unsigned sel0 = 0x0c010c00u + (unsigned)__builtin_amdgcn_readfirstlane((inx - rjx) & 3) * 0x00010001u;
-            // (hipcc folds OFF_PJ into every row read's constant, which then no longer fits the 8-bit dword offsets of ds_read2_b32, and spends one
-            // v_add_u32 per row on the address.  Giving it ONE opaque base per column so that the row step goes into the offset fields removes those
-            // 10-20 instructions per Newton iteration -- and measured 4-5 % SLOWER in three forms, the last with the reads pinned to the top of
-            // their strips by hand: DESIGN.md section 9, round 5.  Left as the compiler writes it.)
-            const unsigned* rowA = pJ + (iny - rjy + rA) * PJP + (((inx - rjx) + 4 * jA) >> 2);
-            const unsigned* rowB = pJ + (iny - rjy + rB) * PJP + (((inx - rjx) + 4 * jB) >> 2);
+            // address of the lane's first search row = (lane constant, fixed for the level) + (wave-uniform offset of this iteration's window origin); the
+            // lane constants were made opaque at level entry, so the compiler keeps ONE base register per column and puts the row step
+            // (k + dr) * PJ_PITCH <= 816 bytes into the offset fields of ds_read2_b32 instead of folding OFF_PJ into every access (one v_add per row)
+            const int uo = __builtin_amdgcn_readfirstlane(4 * ((iny - rjy) * PJP + ((inx - rjx) >> 2)));
+            const unsigned* rowA = reinterpret_cast<const unsigned*>(smem + (lcA + (unsigned)uo));
+            const unsigned* rowB = reinterpret_cast<const unsigned*>(smem + (lcB + (unsigned)uo));
             const auto region_row = [&](int k, int dr) { return (k < C::KA ? rowA : rowB) + (k + dr) * PJP; };  // search row slot_row(k) + dr
             unsigned top[4];
             {
