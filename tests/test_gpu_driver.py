@@ -112,6 +112,28 @@ def test_c1_run_sequence_prints_the_reference_table(golden):
     assert again["lines"][:-1] == got["lines"][:-1]
 
 
+def test_run_sequence_on_a_featureless_clip_keeps_only_the_plate_corners(golden):
+    """Edge of the frame-0 sequence: a flat gray clip has no Harris corner at all -- vh_frame0_init must hand over exactly the 4 clicked plate corners
+    (device-side count 4 + 0), the session must run on them (they die on the min-eigenvalue gate in frame 1) and keep stepping on an empty state, like
+    the oracle driver: same masks, same records, same table."""
+    from _helpers import same_table as _same_table
+    from oracle import driver_oracle as DO
+    from velocity_amd.driver import run_sequence
+    from velocity_amd.images import intrinsic_matrix_iphone6s_video
+
+    K = intrinsic_matrix_iphone6s_video()
+    q = golden["plate_IMG_4134_q"]
+    frames = [np.full((1080, 1920), 117, np.uint8) for _ in range(4)]
+    times = [np.float32(k / 29.97) for k in range(4)]
+    with np.errstate(all="ignore"):
+        ref = DO.run_sequence(frames, q, K, times, msv_frame=0)
+    got = run_sequence(frames, q, K, times=times, msv_frame=0, clock=lambda: 0.0, out=None)
+    assert got["n_tracks0"] == 4 == len(ref["frame0"]["p"]) and np.array_equal(got["P"][0:2, :, 0].T, ref["frame0"]["p"])
+    assert np.array_equal(got["vg"], ref["vg"]) and not got["vg"].any() and len(got["p"]) == 0
+    assert np.array_equal(got["S"][:, 2], ref["S"][:, 2]) and got["S"][0, 2] == 4 and got["S"][1, 2] == 0
+    _same_table(got["lines"][2:3], ref["lines"][2:3])  # row 0: four tracks, the plate-pose residual
+
+
 def test_bench_distributed_path_one_rank():
     """bench.py with the RCCL process group initialised (one rank): init, async all-gather of the packed track state, barrier and
     the MAX all-reduce of the timing -- the code path of `torch.distributed.run --nproc-per-node N bench.py --gpus N`."""
