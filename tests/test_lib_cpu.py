@@ -16,7 +16,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/velocity_hip.h but not exported"
         assert s in _lib._SIGS, f"{s} has no ctypes signature in velocity_amd/_lib.py"
-    assert L.vh_version() >= 100
+    assert L.vh_version() >= 104  # 104: vh_session_view carries the history strides, vh_frame0_init / vh_session_init_dev / vh_profile_lk_routes exist
 
 
 def test_shims_mirror_reference_signatures():
@@ -140,3 +140,19 @@ def test_driver_table_text_is_the_references():
     a, b = driver.summary_lines(S, 6, list(range(19, 25)), 0.5)
     assert a == f"\nSpeed = {S[1:, 8].mean():.2f} +/- {S[1:, 8].std():.2f} km/h\nRes = {S[1:, 3].mean():.3f} pixels"
     assert b.startswith("Processed 6 images: [19 20 21 22 23 24] in 0.50s (12.00fps)")
+
+
+def test_ctypes_structs_have_the_size_of_the_c_structs(tmp_path):
+    """The binding's ctypes mirrors of the header's structs (vh_lk_params, vh_klt_stages, vh_session_view -- which grew its stride fields at version 104)
+    against what a C compiler makes of include/velocity_hip.h."""
+    import ctypes as C
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "velocity_hip.h"\nint main(void) { printf("%zu %zu %zu\\n", sizeof(vh_lk_params), sizeof(vh_klt_stages), '
+                   'sizeof(vh_session_view)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    a, b, c = (int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    assert (a, b, c) == (C.sizeof(_lib.LKParams), C.sizeof(_lib.KltStages), C.sizeof(_lib.SessionView))
