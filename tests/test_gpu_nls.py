@@ -266,6 +266,46 @@ def test_nls_batch_cholesky_and_wide_schur_equal_the_round3_kernels(golden, nt, 
         close(pw, outs[0][1], 1e-6, 1e-8)
 
 
+@pytest.mark.parametrize("nt,nf", [(37, 44), (50, 129), (333, 97), (1001, 65), (9, 50)])
+def test_nls_batch_43_to_128_cameras_syrk_vs_valu_and_oracle(golden, nt, nf):
+    """43..128 free cameras (258..768 reduced unknowns): Z materialised by k_ba_zbuild + the K-split matrix-core SYRK k_ba_syrk_mfma (default) against the
+    VALU Schur kernel (vh_debug_ba_force_valu) and the oracle's structured solve.  Point counts that are no multiple of the split / of a 4-row slab,
+    a window with fewer points than an LDS stage, widths that end inside a 16-column tile (258 = 16 x 16 + 2) and the full 768."""
+    from velocity_amd import _lib as L
+    from velocity_amd import synth
+    from velocity_amd.NLS import fcnNLS_batch
+
+    P, pw0, cw0 = synth.ba_scene(nt, nf, seed=300 + nf)
+    outs = []
+    for force_valu in (0, 1):
+        L.load().vh_debug_ba_force_valu(force_valu)
+        try:
+            outs.append(fcnNLS_batch(golden["K32"], P.copy(), pw0, cw0, max_iter=4, return_info=True))
+        finally:
+            L.load().vh_debug_ba_force_valu(0)
+    (cw, pw, x, tr), (cw2, pw2, x2, tr2) = outs
+    assert np.all(np.isfinite(x)) and len(tr) == len(tr2) == 4
+    close(tr[:, 0], tr2[:, 0], 1e-8)
+    close(x, x2, 1e-6, 1e-8)
+    if nt * nf <= 8000:
+        ecw, epw, ex, etr = O.nls_batch_schur(golden["K32"], P.copy(), pw0, cw0, max_iter=4, return_info=True)
+        close(tr[:, 0], etr[:, 0], 1e-7)
+        close(x, ex, 1e-6, 1e-8)
+
+
+def test_nls_batch_windows_of_50_cameras(golden):
+    """Three independent 50-camera windows through one launch sequence (grid.z = window of the SYRK path) equal three single solves."""
+    from velocity_amd import synth
+    from velocity_amd.NLS import fcnNLS_batch, fcnNLS_batch_windows
+
+    scenes = [synth.ba_scene(120, 51, seed=400 + w) for w in range(3)]
+    multi = fcnNLS_batch_windows(golden["K32"], [s[0].copy() for s in scenes], [s[1] for s in scenes], [s[2] for s in scenes], max_iter=3, return_info=True)
+    for w, (P, pw0, cw0) in enumerate(scenes):
+        cw, pw, x, tr = fcnNLS_batch(golden["K32"], P.copy(), pw0, cw0, max_iter=3, return_info=True)
+        close(multi[w][2], x, 1e-12, 1e-14)
+        close(multi[w][3], tr, 1e-12)
+
+
 @pytest.mark.parametrize("nt,nf", [(260, 2), (517, 3), (200, 3)])
 def test_nls_batch_two_and_three_frame_windows(golden, nt, nf, capsys):
     """2- and 3-frame windows: a k_ba_jac block owns 256 / nf = 128 / 85 whole points, more than the 64 point quads of its preparation tail

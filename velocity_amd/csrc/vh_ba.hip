@@ -751,6 +751,177 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur_mfma(BaJob J)
     }
 }
 
+// ---- Schur stage 1 on the matrix cores, 43..128 cameras (253..768 reduced unknowns) ------------------------------------------------
+// Above 42 cameras a point's raw record (20 nc + 9 doubles) and a wavefront's share of the 16 x 16 tiles no longer fit LDS / the register file of
+// k_ba_schur_mfma, and the VALU kernel k_ba_points re-forms W and Y once per 16 384 entries of S (3.8 ms per iteration at 50 cameras, 170 ms at 128:
+// round 5).  Here the same contraction  S = V + I - sum_i Z_i^T Z_i  is split in two launches:
+//   k_ba_zbuild    : Z = L^T W of every point, materialised ONCE (J.Y, [3 nt][6 nc] row-major, 92 MB at 128 cameras x 5000 points), the reduced
+//                    right-hand side and the 6 x 6 diagonal blocks V_c of the chunk (written straight into the chunk's partial system)
+//   k_ba_syrk_mfma : a K-split symmetric rank-k update on v_mfma_f64_16x16x4_f64: workgroup (R <= C, split b) forms the 128 x 128 macro tile
+//                    (R, C) of -Z_b^T Z_b over the rows of chunk b, 32 rows of both operand panels per LDS stage, and adds the diagonal blocks
+//                    on the way out.  Z is read from L2 / the infinity cache 2 x (number of macro-tile columns) times.
+// The partial systems are summed by k_ba_reduce exactly as for the smaller kernels (upper-triangle 16 x 16 tiles, mirrored there).
+#define BA_ZB_PL 4  // points a k_ba_zbuild block works on at a time (threadIdx.y)
+__global__ __launch_bounds__(256 * BA_ZB_PL) void k_ba_zbuild(BaJob J)
+{
+    ba_select_window(J, blockIdx.z);
+    if (*J.done) return;
+    const int nt = J.nt, nc = J.nc, nq = 6 * nc, nf = nc + 1, tx = threadIdx.x, ty = threadIdx.y;
+    const int chunk = (nt + gridDim.x - 1) / gridDim.x;  // the chunk of k_ba_syrk_mfma's split blockIdx.x
+    const int i0 = blockIdx.x * chunk, i1 = min(nt, i0 + chunk);
+    // column q = 6 c + k of the reduced system (camera c + 1, parameter k)
+    const int q = blockIdx.y * 256 + tx;
+    const bool qon = q < nq;
+    const int qc = min(q, nq - 1), c = qc / 6, k = qc - 6 * c;
+    // entries of the diagonal blocks owned by this thread: e = e0 + tx + 256 j of this block's share of the 36 nc
+    constexpr int ND = 6;
+    const int nde = 36 * nc, per = (nde + (int)gridDim.y - 1) / (int)gridDim.y, e0 = blockIdx.y * per, e1 = min(nde, e0 + per);
+    int da[ND], db[ND];
+#pragma unroll
+    for (int j = 0; j < ND; j++) {
+        const int e = min(e0 + tx + 256 * j, nde - 1), ce = e / 36, rr = e - 36 * ce, ka = rr / 6, kb = rr - 6 * ka;
+        da[j] = 12 * (ce + 1) + ka; db[j] = 12 * (ce + 1) + kb;
+    }
+    double accR = 0.0, accD[ND];
+#pragma unroll
+    for (int j = 0; j < ND; j++) accD[j] = 0.0;
+    for (int i = i0 + ty; i < i1; i += BA_ZB_PL) {
+        const size_t mp = (size_t)i * nf, m = mp + (c + 1);
+        const double* jp = J.Jp + 6 * m;
+        const double* jc = J.Jc + 12 * m;
+        const double* Lp = J.Lc + 6 * (size_t)i;
+        const double* tp = J.tp + 3 * (size_t)i;
+        const double ju = jc[k], jv = jc[6 + k], ru = J.r[2 * m], rv = J.r[2 * m + 1];
+        const double w0 = jp[0] * ju + jp[3] * jv, w1 = jp[1] * ju + jp[4] * jv, w2 = jp[2] * ju + jp[5] * jv;
+        // L^T is upper triangular: rows (l00 l10 l20), (0 l11 l21), (0 0 l22); L is stored l00 l10 l11 l20 l21 l22
+        const double z0 = Lp[0] * w0 + Lp[1] * w1 + Lp[3] * w2, z1 = Lp[2] * w1 + Lp[4] * w2, z2 = Lp[5] * w2;
+        accR += ju * ru + jv * rv - (w0 * tp[0] + w1 * tp[1] + w2 * tp[2]);
+        if (qon) {
+            double* Z = J.Y + (size_t)(3 * i) * nq + q;
+            Z[0] = z0; Z[nq] = z1; Z[2 * (size_t)nq] = z2;
+        }
+        const double* jcp = J.Jc + 12 * mp;
+#pragma unroll
+        for (int j = 0; j < ND; j++) accD[j] += jcp[da[j]] * jcp[db[j]] + jcp[da[j] + 6] * jcp[db[j] + 6];
+    }
+    // the BA_ZB_PL point lanes are combined in a fixed order
+    __shared__ double sh[BA_ZB_PL][256];
+    double* Sp = J.Spart + (size_t)blockIdx.x * ((size_t)nq * nq);
+#pragma unroll
+    for (int jj = 0; jj <= ND; jj++) {
+        const int j = jj - 1;  // -1: the right-hand side
+        __syncthreads();
+        sh[ty][tx] = jj == 0 ? accR : accD[jj > 0 ? jj - 1 : 0];
+        __syncthreads();
+        if (ty == 0) {
+            double t = sh[0][tx];
+#pragma unroll
+            for (int u = 1; u < BA_ZB_PL; u++) t += sh[u][tx];
+            if (j < 0) {
+                if (qon) J.Rpart[(size_t)blockIdx.x * nq + q] = t;
+            } else {
+                const int e = e0 + tx + 256 * j;
+                if (e < e1) {
+                    const int ce = e / 36, rr = e - 36 * ce, ka = rr / 6, kb = rr - 6 * ka;
+                    Sp[(size_t)(6 * ce + ka) * nq + 6 * ce + kb] = t;  // k_ba_syrk_mfma adds -Z^T Z to it
+                }
+            }
+        }
+    }
+}
+
+#define BA_SY_KB 32  // rows of Z per LDS stage
+__global__ __launch_bounds__(256) void k_ba_syrk_mfma(BaJob J, int nm)
+{
+    ba_select_window(J, blockIdx.z);
+    if (*J.done) return;
+    const int nt = J.nt, nq = 6 * J.nc, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
+    // macro tile (R, C), R <= C, of the nm x nm grid of 128 x 128 tiles
+    int p = blockIdx.x, R = 0;
+    while (p >= nm - R) { p -= nm - R; R++; }
+    const int Cm = R + p;
+    const bool diag = R == Cm;
+    const int chunk = (nt + gridDim.y - 1) / gridDim.y;
+    const int i0 = blockIdx.y * chunk, i1 = min(nt, i0 + chunk);
+    const int r0 = 3 * i0, r1 = 3 * i1;
+    // LDS: [slab of 4 rows][16-column tile][lane = 16 (row & 3) + (column & 15)] -- an MFMA operand is one conflict-free 512-byte read
+    __shared__ __attribute__((aligned(16))) double sA[BA_SY_KB / 4 * 8 * 64];
+    __shared__ __attribute__((aligned(16))) double sB[BA_SY_KB / 4 * 8 * 64];
+    // staging: wave w fills tiles 2 w, 2 w + 1 of every slab; lane -> (tile of the pair, row of the slab, column pair)
+    const int st = 2 * wave + (lane >> 5), srow = (lane >> 3) & 3, scol = 16 * st + 2 * (lane & 7);
+    const bool a_on = 128 * R + scol < nq, b_on = !diag && 128 * Cm + scol < nq;  // nq is even: a column pair is inside or outside
+    const double* gA = J.Y + (size_t)(r0 + srow) * nq + 128 * R + scol;
+    const double* gB = J.Y + (size_t)(r0 + srow) * nq + 128 * Cm + scol;
+    const int lds_off = st * 64 + srow * 16 + 2 * (lane & 7);
+    typedef double double2v __attribute__((ext_vector_type(2)));
+    double2v pa[BA_SY_KB / 4], pb[BA_SY_KB / 4];
+    auto fetch = [&](int kb) {  // rows r0 + kb .. + BA_SY_KB - 1 of both panels -> registers (zeros past the chunk / past column nq)
+#pragma unroll
+        for (int j = 0; j < BA_SY_KB / 4; j++) {
+            const int row = r0 + kb + 4 * j + srow;
+            const bool on = row < r1;
+            const size_t off = (size_t)(kb + 4 * j) * nq;
+            pa[j] = (on && a_on) ? *reinterpret_cast<const double2v*>(gA + off) : double2v{0.0, 0.0};
+            if (!diag) pb[j] = (on && b_on) ? *reinterpret_cast<const double2v*>(gB + off) : double2v{0.0, 0.0};
+        }
+    };
+    double4v acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = double4v{0.0, 0.0, 0.0, 0.0};
+    const bool dead = diag && wr > wc;  // every tile of this wavefront lies below the diagonal
+    const double* sBp = diag ? sA : sB;
+    if (r0 < r1) fetch(0);
+    for (int kb = 0; r0 + kb < r1; kb += BA_SY_KB) {
+        __syncthreads();  // the previous stage has been read
+#pragma unroll
+        for (int j = 0; j < BA_SY_KB / 4; j++) {
+            *reinterpret_cast<double2v*>(sA + j * 512 + lds_off) = pa[j];
+            if (!diag) *reinterpret_cast<double2v*>(sB + j * 512 + lds_off) = pb[j];
+        }
+        __syncthreads();
+        if (r0 + kb + BA_SY_KB < r1) fetch(kb + BA_SY_KB);  // in flight while the matrix cores work on this stage
+        if (!dead) {
+#pragma unroll
+            for (int sl = 0; sl < BA_SY_KB / 4; sl++) {
+                double a[4], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    a[t] = sA[(sl * 8 + 4 * wr + t) * 64 + lane];
+                    b[t] = sBp[(sl * 8 + 4 * wc + t) * 64 + lane];
+                }
+#pragma unroll
+                for (int ta = 0; ta < 4; ta++)
+#pragma unroll
+                    for (int tb = 0; tb < 4; tb++) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+            }
+        }
+    }
+    if (dead) return;
+    // f64 C/D layout of the 16x16x4 instruction: lane holds rows (lane >> 4) + 4 rg, column lane & 15
+    double* Sp = J.Spart + (size_t)blockIdx.y * ((size_t)nq * nq);
+#pragma unroll
+    for (int ta = 0; ta < 4; ta++)
+#pragma unroll
+        for (int tb = 0; tb < 4; tb++) {
+            const int tr = 8 * R + 4 * wr + ta, tc = 8 * Cm + 4 * wc + tb;
+            if (tr > tc) continue;  // k_ba_reduce mirrors the upper-triangle tiles
+            const bool near = tc - tr <= 1;  // a 6 x 6 camera block lies in one tile or straddles two neighbours
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) {
+                const int row = 16 * tr + (lane >> 4) + 4 * rg, col = 16 * tc + (lane & 15);
+                if (row < nq && col < nq) {
+                    double v = -acc[ta][tb][rg];
+                    double* dst = Sp + (size_t)row * nq + col;
+                    if (near && row / 6 == col / 6) v += *dst;  // V_c, left there by k_ba_zbuild
+                    *dst = v;
+                }
+            }
+        }
+}
+
 // Schur stage 2a: sum the per-workgroup partials into the augmented system and add +I.  A block handles 64 consecutive
 // entries; each of its 4 wavefronts sums a fixed slice of the partials (512-byte coalesced reads, 8 in flight), then the
 // slices are combined in a fixed order (deterministic).
@@ -1591,6 +1762,11 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     const int npad = nq <= BA_NPAD ? BA_NPAD : 2 * BA_NPAD;  // matrix-core Schur kernel: 128-wide (<= 21 cameras) or 256-wide in two passes (<= 42)
     const size_t lds_mfma = sizeof(double) * (size_t)(24 * npad + 2 * 4 * (20 * nc + 10) + 4 * npad);
     const bool use_mfma = nq <= 252 && !P.force_valu && P.model == 0;  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
+    // 43..128 cameras: Z materialised + K-split SYRK on the matrix cores (k_ba_zbuild / k_ba_syrk_mfma).  nm macro tiles of 128 per dimension; the
+    // first `nsplit` partial systems are used: about one resident round of workgroups (2 per CU), every split at least one LDS stage of points
+    const bool use_syrk = nq > 252 && !P.force_valu && P.model == 0;
+    const int nm = (nq + 127) / 128, npairs = nm * (nm + 1) / 2;
+    const int nsplit = use_syrk ? std::max(1, std::min(std::min(nparts, (512 + npairs - 1) / npairs), (nt + 10) / 11)) : nparts;
     if (use_mfma && lds_mfma > 64 * 1024) {
         // the attribute is per function AND per device: one bit per device ordinal, set with an atomic OR (two host threads, or a process that drives
         // a second GPU, each set it for their device; setting it twice is harmless)
@@ -1605,11 +1781,11 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
             attr_devs.fetch_or(bit, std::memory_order_release);
         }
     }
-    J.zmode = use_mfma ? 1 : 0;
+    J.zmode = (use_mfma || use_syrk) ? 1 : 0;
     { const char* e = getenv("VH_BA_DBG"); J.dbg = e ? atoi(e) : 0; }
     // one wavefront per point, grid-strided: every block ends with an atomic on one address, so keep the block count low
     const int upd_cap = J.nwin > 1 ? std::max(16, 1024 / J.nwin) : 256;
-    const int upd_blocks = std::min(use_mfma ? (4 * nt + BA_THREADS - 1) / BA_THREADS : (nt + BA_THREADS / 64 - 1) / (BA_THREADS / 64), upd_cap);
+    const int upd_blocks = std::min((use_mfma || use_syrk) ? (4 * nt + BA_THREADS - 1) / BA_THREADS : (nt + BA_THREADS / 64 - 1) / (BA_THREADS / 64), upd_cap);
     const unsigned nw = (unsigned)J.nwin;
     auto init = [&]() -> int {
         hipLaunchKernelGGL(k_ba_init, dim3(1, nw), dim3(64), 0, s, J, flags);
@@ -1631,6 +1807,14 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
                 hipLaunchKernelGGL((k_ba_schur_mfma<256, 1>), dim3(nparts, nw), dim3(BA_SCHUR_THREADS), lds_mfma, s, J);
             }
             vh_prof_stop(pc, rec, VH_PROF_BA_SCHUR, s);
+        } else if (use_syrk) {
+            int rec = vh_prof_start(pc, s);
+            hipLaunchKernelGGL(k_ba_jac<true>, dim3((nt + ppb - 1) / ppb, nw), dim3(BA_THREADS), 0, s, J);
+            vh_prof_stop(pc, rec, VH_PROF_BA_JAC, s);
+            rec = vh_prof_start(pc, s);
+            hipLaunchKernelGGL(k_ba_zbuild, dim3(nsplit, (nq + 255) / 256, nw), dim3(256, BA_ZB_PL), 0, s, J);
+            hipLaunchKernelGGL(k_ba_syrk_mfma, dim3(npairs, nsplit, nw), dim3(256), 0, s, J, nm);
+            vh_prof_stop(pc, rec, VH_PROF_BA_SCHUR, s);
         } else {
             int rec = vh_prof_start(pc, s);
             hipLaunchKernelGGL(k_ba_jac<false>, dim3((nt + ppb - 1) / ppb, nw), dim3(BA_THREADS), 0, s, J);
@@ -1641,7 +1825,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
             vh_prof_stop(pc, rec, VH_PROF_BA_SCHUR, s);
         }
         const int rec = vh_prof_start(pc, s);
-        hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((nent + nq + 63) / 64), nw), dim3(BA_THREADS), 0, s, J, nparts);
+        hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((nent + nq + 63) / 64), nw), dim3(BA_THREADS), 0, s, J, nsplit);
         vh_prof_stop(pc, rec, VH_PROF_BA_REDUCE, s);
     };
     auto solve_update = [&](int it) {
@@ -1673,7 +1857,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         // throttled host otherwise shows up as idle gaps between the 10-60 us kernels of a single window).  The second sighting builds the graph.
         BaGraphKey key;
         memset(&key, 0, sizeof(key));
-        memcpy(&key.J, &J, sizeof(J)); key.flags0 = flags; key.max_iter = P.max_iter; key.nparts = nparts; key.use_mfma = use_mfma ? 1 : 0;
+        memcpy(&key.J, &J, sizeof(J)); key.flags0 = flags; key.max_iter = P.max_iter; key.nparts = nparts; key.use_mfma = use_mfma ? 1 : (use_syrk ? 2 : 0);
         BaGraphCache* gc = profiling ? nullptr : ba_graph_cache(P.graph_cache);
         BaGraphEntry* e = gc ? gc->find(key, s) : nullptr;
         if (e && e->exec && !gc->disabled) {
