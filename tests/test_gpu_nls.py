@@ -238,17 +238,18 @@ def test_nls_batch_many_cameras_vs_oracle(golden, nt, nf):
     close(pw, epw, 1e-4, 1e-6)
 
 
-@pytest.mark.parametrize("nt,nf", [(300, 25), (200, 43), (120, 51)])
+@pytest.mark.parametrize("nt,nf", [(300, 25), (200, 43), (120, 51), (60, 129)])
 def test_nls_batch_cholesky_and_wide_schur_equal_the_round3_kernels(golden, nt, nf, monkeypatch):
     """Second implementation check for 22+ cameras: blocked Cholesky + 256-wide matrix-core Schur (default) against the elimination kernels of rounds 2-3
-    (VH_BA_DBG=128) and against the VALU Schur kernel (vh_debug_ba_force_valu) -- same trace and state to rounding."""
+    (VH_BA_DBG=128), the right-looking two-launch Cholesky of round 4 (VH_BA_DBG=256; default since round 5: left-looking, one launch per panel) and against
+    the VALU Schur kernel (vh_debug_ba_force_valu) -- same trace and state to rounding."""
     from velocity_amd import _lib as L
     from velocity_amd import synth
     from velocity_amd.NLS import fcnNLS_batch
 
     P, pw0, cw0 = synth.ba_scene(nt, nf, seed=60 + nf)
     outs = []
-    for dbg, valu in ((None, 0), ("128", 0), (None, 1)):
+    for dbg, valu in ((None, 0), ("128", 0), (None, 1), ("256", 0)):
         if dbg is None:
             monkeypatch.delenv("VH_BA_DBG", raising=False)
         else:
@@ -302,8 +303,8 @@ def test_nls_batch_windows_of_50_cameras(golden):
     multi = fcnNLS_batch_windows(golden["K32"], [s[0].copy() for s in scenes], [s[1] for s in scenes], [s[2] for s in scenes], max_iter=3, return_info=True)
     for w, (P, pw0, cw0) in enumerate(scenes):
         cw, pw, x, tr = fcnNLS_batch(golden["K32"], P.copy(), pw0, cw0, max_iter=3, return_info=True)
-        close(multi[w][2], x, 1e-12, 1e-14)
-        close(multi[w][3], tr, 1e-12)
+        close(multi[w][2], x, 1e-9, 1e-11)  # (a window of a batch is K-split differently from a single one: another summation order)
+        close(multi[w][3], tr, 1e-9)
 
 
 @pytest.mark.parametrize("nt,nf", [(260, 2), (517, 3), (200, 3)])

@@ -51,8 +51,8 @@ def run(nt, nf, reps=3, iters=4):
 
 if __name__ == "__main__":
     nts = [int(a) for a in sys.argv[1:]] or [5000, 1000]
-    out = []
+    nfs = [int(a) for a in os.environ.get("BA_NF", "20,43,51,65,97,129").split(",")]
     for nt in nts:
-        for nf in (20, 43, 51, 65, 97, 129):
+        for nf in nfs:
             r = run(nt, nf)
             print(json.dumps(r), flush=True)

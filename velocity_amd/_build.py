@@ -18,8 +18,10 @@ HEADER = os.path.join(HERE, "..", "include", "velocity_hip.h")
 OUT = os.path.join(HERE, "libvelocity_hip.so")
 SOURCES = ["vh_image.hip", "vh_lk.hip", "vh_ransac.hip", "vh_nls.hip", "vh_ba.hip", "vh_session.hip", "vh_init.hip", "vh_api.hip"]
 # -ffp-contract=off: the parity contract with the CPU restatement is bit-exact track bookkeeping, so no fused multiply-adds
+# -amdgpu-mfma-vgpr-form: matrix-core accumulators stay in ordinary VGPRs.  With the default (AGPR form) hipcc keeps an accumulator that lives across a loop
+# in VGPRs and copies it into AGPRs and back around every loop body (k_ba_syrk_mfma: 256 v_accvgpr moves + a pipeline drain per 128 MFMAs)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 TORCH_OUT = os.path.join(HERE, "libvelocity_torch.so")
 TORCH_SRC = os.path.join(CSRC, "vh_torch_ops.cpp")
 _MARK = re.compile(rb"VH_BUILD_ID=([0-9a-f]{24}-[0-9a-f]{8})")

@@ -20,6 +20,7 @@
 #define BA_THREADS 256
 #define BA_EPT 64  // Schur entries owned by one thread per pass
 #define BA_MAX_NC 128                       // free cameras (the reference has no limit; the workspace grows with (6 nc)^2 per partial system)
+#define BA_ZB_MAX 256                        // workgroups of k_ba_zbuild (43+ cameras): one partial right-hand side / set of diagonal blocks each
 #define BA_RQ (6 * BA_MAX_NC / BA_THREADS)  // reduced right-hand-side entries owned by one thread of the VALU Schur kernel
 
 // batched windows: shift every pointer of the job to window w (the job travels by value, so this edits the kernel's own copy)
@@ -27,7 +28,7 @@ __device__ __forceinline__ void ba_select_window(BaJob& J, int w)
 {
     if (w == 0) return;
     const size_t d = (size_t)w * (J.ws_stride / sizeof(double));
-    J.camR += d; J.r += d; J.Jp += d; J.Jc += d; J.tp += d; J.Lc += d; J.Y += d; J.Spart += d; J.Rpart += d; J.Sfull += d; J.dc += d; J.acc += d; J.rslot += d;
+    J.camR += d; J.r += d; J.Jp += d; J.Jc += d; J.tp += d; J.Lc += d; J.Y += d; J.Spart += d; J.Rpart += d; J.Dpart += d; J.Sfull += d; J.dc += d; J.acc += d; J.rslot += d;
     J.done = reinterpret_cast<int*>(reinterpret_cast<char*>(J.done) + (size_t)w * J.ws_stride);
     J.ticket = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(J.ticket) + (size_t)w * J.ws_stride);
     J.z += (size_t)w * J.z_stride; J.x += (size_t)w * J.x_stride; J.trace += (size_t)w * J.trace_stride; J.info += (size_t)w * J.info_stride;
@@ -756,10 +757,11 @@ __global__ __launch_bounds__(BA_SCHUR_THREADS) void k_ba_schur_mfma(BaJob J)
 // k_ba_schur_mfma, and the VALU kernel k_ba_points re-forms W and Y once per 16 384 entries of S (3.8 ms per iteration at 50 cameras, 170 ms at 128:
 // round 5).  Here the same contraction  S = V + I - sum_i Z_i^T Z_i  is split in two launches:
 //   k_ba_zbuild    : Z = L^T W of every point, materialised ONCE (J.Y, [3 nt][6 nc] row-major, 92 MB at 128 cameras x 5000 points), the reduced
-//                    right-hand side and the 6 x 6 diagonal blocks V_c of the chunk (written straight into the chunk's partial system)
+//                    right-hand side and the 6 x 6 diagonal blocks V_c (one partial per workgroup: J.Rpart / J.Dpart, summed by k_ba_reduce)
 //   k_ba_syrk_mfma : a K-split symmetric rank-k update on v_mfma_f64_16x16x4_f64: workgroup (R <= C, split b) forms the 128 x 128 macro tile
-//                    (R, C) of -Z_b^T Z_b over the rows of chunk b, 32 rows of both operand panels per LDS stage, and adds the diagonal blocks
-//                    on the way out.  Z is read from L2 / the infinity cache 2 x (number of macro-tile columns) times.
+//                    (R, C) of -Z_b^T Z_b over the rows of chunk b, 32 rows of both operand panels per LDS stage.  One workgroup per CU (the
+//                    16 tiles of a wavefront are 128 accumulator registers), so the launch is sized to ONE resident round: npairs x nsplit <= 256.
+//                    Z is read from L2 / the infinity cache 2 x (number of macro-tile columns) times.
 // The partial systems are summed by k_ba_reduce exactly as for the smaller kernels (upper-triangle 16 x 16 tiles, mirrored there).
 #define BA_ZB_PL 4  // points a k_ba_zbuild block works on at a time (threadIdx.y)
 __global__ __launch_bounds__(256 * BA_ZB_PL) void k_ba_zbuild(BaJob J)
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(256 * BA_ZB_PL) void k_ba_zbuild(BaJob J)
     ba_select_window(J, blockIdx.z);
     if (*J.done) return;
     const int nt = J.nt, nc = J.nc, nq = 6 * nc, nf = nc + 1, tx = threadIdx.x, ty = threadIdx.y;
-    const int chunk = (nt + gridDim.x - 1) / gridDim.x;  // the chunk of k_ba_syrk_mfma's split blockIdx.x
+    const int chunk = (nt + gridDim.x - 1) / gridDim.x;  // (its own partition of the points: nothing to do with the K splits of k_ba_syrk_mfma)
     const int i0 = blockIdx.x * chunk, i1 = min(nt, i0 + chunk);
     // column q = 6 c + k of the reduced system (camera c + 1, parameter k)
     const int q = blockIdx.y * 256 + tx;
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(256 * BA_ZB_PL) void k_ba_zbuild(BaJob J)
     }
     // the BA_ZB_PL point lanes are combined in a fixed order
     __shared__ double sh[BA_ZB_PL][256];
-    double* Sp = J.Spart + (size_t)blockIdx.x * ((size_t)nq * nq);
+    double* Dp = J.Dpart + (size_t)blockIdx.x * nde;
 #pragma unroll
     for (int jj = 0; jj <= ND; jj++) {
         const int j = jj - 1;  // -1: the right-hand side
@@ -821,17 +823,14 @@ __global__ __launch_bounds__(256 * BA_ZB_PL) void k_ba_zbuild(BaJob J)
                 if (qon) J.Rpart[(size_t)blockIdx.x * nq + q] = t;
             } else {
                 const int e = e0 + tx + 256 * j;
-                if (e < e1) {
-                    const int ce = e / 36, rr = e - 36 * ce, ka = rr / 6, kb = rr - 6 * ka;
-                    Sp[(size_t)(6 * ce + ka) * nq + 6 * ce + kb] = t;  // k_ba_syrk_mfma adds -Z^T Z to it
-                }
+                if (e < e1) Dp[e] = t;  // entry (ka, kb) of V_c at 36 c + 6 ka + kb: k_ba_reduce adds the partials to the diagonal blocks
             }
         }
     }
 }
 
-#define BA_SY_KB 32  // rows of Z per LDS stage
-__global__ __launch_bounds__(256) void k_ba_syrk_mfma(BaJob J, int nm)
+#define BA_SY_KB 16  // rows of Z per LDS stage
+__global__ __launch_bounds__(256, 2) void k_ba_syrk_mfma(BaJob J, int nm)
 {
     ba_select_window(J, blockIdx.z);
     if (*J.done) return;
@@ -884,18 +883,28 @@ __global__ __launch_bounds__(256) void k_ba_syrk_mfma(BaJob J, int nm)
         __syncthreads();
         if (r0 + kb + BA_SY_KB < r1) fetch(kb + BA_SY_KB);  // in flight while the matrix cores work on this stage
         if (!dead) {
+            // software pipeline: the operands of slab s + 1 are read before the 16 matrix-core instructions of slab s are issued (a wavefront blocks at
+            // every MFMA issue, so reads placed after them expose their LDS round trip)
+            double a[4], b[4], an[4], bn[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { a[t] = sA[(4 * wr + t) * 64 + lane]; b[t] = sBp[(4 * wc + t) * 64 + lane]; }
 #pragma unroll
             for (int sl = 0; sl < BA_SY_KB / 4; sl++) {
-                double a[4], b[4];
+                if (sl + 1 < BA_SY_KB / 4) {
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    a[t] = sA[(sl * 8 + 4 * wr + t) * 64 + lane];
-                    b[t] = sBp[(sl * 8 + 4 * wc + t) * 64 + lane];
+                    for (int t = 0; t < 4; t++) {
+                        an[t] = sA[((sl + 1) * 8 + 4 * wr + t) * 64 + lane];
+                        bn[t] = sBp[((sl + 1) * 8 + 4 * wc + t) * 64 + lane];
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ta = 0; ta < 4; ta++)
 #pragma unroll
                     for (int tb = 0; tb < 4; tb++) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; t++) { a[t] = an[t]; b[t] = bn[t]; }
             }
         }
     }
@@ -908,16 +917,10 @@ __global__ __launch_bounds__(256) void k_ba_syrk_mfma(BaJob J, int nm)
         for (int tb = 0; tb < 4; tb++) {
             const int tr = 8 * R + 4 * wr + ta, tc = 8 * Cm + 4 * wc + tb;
             if (tr > tc) continue;  // k_ba_reduce mirrors the upper-triangle tiles
-            const bool near = tc - tr <= 1;  // a 6 x 6 camera block lies in one tile or straddles two neighbours
 #pragma unroll
             for (int rg = 0; rg < 4; rg++) {
                 const int row = 16 * tr + (lane >> 4) + 4 * rg, col = 16 * tc + (lane & 15);
-                if (row < nq && col < nq) {
-                    double v = -acc[ta][tb][rg];
-                    double* dst = Sp + (size_t)row * nq + col;
-                    if (near && row / 6 == col / 6) v += *dst;  // V_c, left there by k_ba_zbuild
-                    *dst = v;
-                }
+                if (row < nq && col < nq) Sp[(size_t)row * nq + col] = -acc[ta][tb][rg];
             }
         }
 }
@@ -925,7 +928,8 @@ __global__ __launch_bounds__(256) void k_ba_syrk_mfma(BaJob J, int nm)
 // Schur stage 2a: sum the per-workgroup partials into the augmented system and add +I.  A block handles 64 consecutive
 // entries; each of its 4 wavefronts sums a fixed slice of the partials (512-byte coalesced reads, 8 in flight), then the
 // slices are combined in a fixed order (deterministic).
-__global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts)
+// nparts_r / ndpart (43+ cameras): partial right-hand sides and partial diagonal blocks V_c of the k_ba_zbuild workgroups (otherwise nparts and 0)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts, int nparts_r, int ndpart)
 {
     ba_select_window(J, blockIdx.y);
     if (*J.done) return;
@@ -944,9 +948,18 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts)
     }
     if (e < ntot && !lower) {
         constexpr int NS = BA_THREADS / 64;
-        const int per = (nparts + NS - 1) / NS, p0 = slice * per, p1 = min(nparts, p0 + per);
+        const int np = e < nent ? nparts : nparts_r;
+        const int per = (np + NS - 1) / NS, p0 = slice * per, p1 = min(np, p0 + per);
         const double* src = e < nent ? J.Spart + e : J.Rpart + (e - nent);
         const size_t step = e < nent ? (size_t)nent : (size_t)nq;
+        if (ndpart && e < nent) {  // an entry of a diagonal block: + the partials of V_c
+            const int a = (int)(e / nq), b = (int)(e - (long long)a * nq), ca = a / 6;
+            if (ca == b / 6) {
+                const double* d = J.Dpart + 36 * ca + 6 * (a - 6 * ca) + (b - 6 * ca);
+                const int dper = (ndpart + NS - 1) / NS, d0 = slice * dper, d1 = min(ndpart, d0 + dper);
+                for (int q = d0; q < d1; q++) s += d[(size_t)q * (36 * (size_t)J.nc)];
+            }
+        }
         int p = p0;
         for (; p + 8 <= p1; p += 8) {
             double v[8];
@@ -1452,8 +1465,179 @@ __global__ __launch_bounds__(256) void k_ba_chol_update(BaJob J, int k0)
     }
 }
 
-// L^T dc = y, from the last panel to the first (one workgroup)
-__global__ __launch_bounds__(256) void k_ba_chol_back(BaJob J)
+// LEFT-looking panel step (round 5): ONE launch per panel instead of two, and the rows below the diagonal block are spread over workgroups instead of walked
+// by one.  Workgroup b owns BA_CL_RB rows below the block (the rhs row is the last one).  Nothing right of column k0 has been touched yet, so it first
+// brings the panel's columns of its rows up to date -- C = A[rows, k0:k0+32] - L[rows, 0:k0] L[k0:k0+32, 0:k0]^T, the same for the 32 diagonal rows (every
+// workgroup forms the diagonal block redundantly: 32 x 32 x k0 flops buy the absence of a grid-wide dependency) -- then factors the diagonal block (one
+// wavefront, registers, as above) and forward-substitutes its rows.  Only workgroup 0 writes the diagonal factor back.
+// At 768 unknowns (24 panels): 1115 + 175 us for k_ba_chol_panel + k_ba_chol_update per solve before.
+#define BA_CL_RB 32
+#define BA_CL_KC 128                          // columns of L per LDS stage
+#define BA_CL_XP (BA_CL_KC + 2)               // pitch = 4 banks mod 64: the 16 rows x 4 columns of an MFMA operand read hit 64 different banks
+#define BA_CL_LDS ((BA_CH_NB + BA_CL_RB) * BA_CL_XP * 8)
+__global__ __launch_bounds__(256) void k_ba_chol_left(BaJob J, int k0)
+{
+    ba_select_window(J, blockIdx.y);
+    if (*J.done) return;
+    const int nq = J.nq, ld = nq + 1, tid = threadIdx.x;
+    const int nb = min(BA_CH_NB, nq - k0), r0 = k0 + nb;
+    const int mrows = nq - r0;  // rows below the block; index mrows = the rhs row
+    const int t0 = blockIdx.x * BA_CL_RB, cnt = min(BA_CL_RB, mrows + 1 - t0);
+    double* A = J.Sfull;
+    constexpr int KC = BA_CL_KC, XP = BA_CL_XP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double (*sX)[XP] = reinterpret_cast<double (*)[XP]>(smem);  // [64][XP]: rows 0..31 the diagonal rows, 32.. this workgroup's rows
+    // (after the products the same memory holds the diagonal block, its transposed factor, this workgroup's rows and the reciprocal diagonal)
+    double (*sD)[BA_CH_NB + 1] = reinterpret_cast<double (*)[BA_CH_NB + 1]>(smem);
+    double (*sDt)[BA_CH_NB] = reinterpret_cast<double (*)[BA_CH_NB]>(smem + sizeof(double) * BA_CH_NB * (BA_CH_NB + 1));
+    double (*sV)[BA_CH_NB + 1] = reinterpret_cast<double (*)[BA_CH_NB + 1]>(smem + sizeof(double) * (BA_CH_NB * (BA_CH_NB + 1) + BA_CH_NB * BA_CH_NB));
+    double* sDi = reinterpret_cast<double*>(smem + sizeof(double) * (BA_CH_NB * (BA_CH_NB + 1) + BA_CH_NB * BA_CH_NB + BA_CL_RB * (BA_CH_NB + 1)));
+    // staging: thread -> 32 elements of a 64 x 128 chunk; wavefront w reads rows w, w + 4, ... -- one row (2 x 512 contiguous bytes) per pair of load
+    // instructions, so a row's address is wave uniform (scalar base + one shared lane offset: no vector arithmetic per load).  The next chunk is in
+    // flight while the matrix cores work on this one: the panel's columns come from the infinity cache / HBM (written by other XCDs in the previous
+    // launch), ~1.7 us per round trip, against ~2 us of matrix-core time per chunk.
+    // Row r of a chunk is diagonal row k0 + r (r < 32) or own row t0 + r - 32; rows without data (a short last panel, the tail of the last workgroup) read
+    // some valid row instead: a row of garbage only reaches outputs that are dropped.  The rhs row's y (stride ld) is an extra load of the wavefront it
+    // belongs to.  Every load is UNCONDITIONAL (a branch around a load costs a full wait per element); the f64 matrix-core instruction blocks the vector
+    // pipeline for its 64 cycles, so every VALU instruction saved here is time saved.
+    const int sc = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = sc;
+    const double* rowp[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int r = wave + 4 * u, t = t0 + r - BA_CH_NB;
+        rowp[u] = A + (size_t)(r < BA_CH_NB ? k0 + min(r, nb - 1) : (t < mrows ? r0 + t : 0)) * ld;
+    }
+    const int t_rhs = mrows - t0;  // own-row index of the rhs row, if this workgroup has it
+    const bool has_rhs = t_rhs >= 0 && t_rhs < BA_CL_RB && (t_rhs & 3) == wave;  // (wave uniform: rows of sX are dealt to wavefronts modulo 4)
+    double pre[32], yv[2] = {0.0, 0.0};
+    auto fetch = [&](int kc) {
+        const int c0 = min(sc, k0 - 1 - kc), c1 = min(sc + 64, k0 - 1 - kc);  // (a ragged last chunk re-reads its last column; zeroed on the way to LDS)
+#pragma unroll
+        for (int u = 0; u < 16; u++) { pre[2 * u] = rowp[u][kc + c0]; pre[2 * u + 1] = rowp[u][kc + c1]; }
+        yv[0] = A[(size_t)(kc + c0) * ld + nq]; yv[1] = A[(size_t)(kc + c1) * ld + nq];
+    };
+    // the products run on the matrix cores (v_mfma_f64_16x16x4_f64: C[r][c] += sum_k X[r][k] X[c][k], both operands straight from the staged rows; the
+    // VALU form needed 6 bytes of LDS traffic per multiply-add and was bound by it).  Wavefront w owns output rows 16 w .. 16 w + 15 (w < 2: the diagonal
+    // block, w >= 2: this workgroup's rows), tile columns 0 and 1.  Lane: row (lane >> 4) + 4 rg of the tile, column lane & 15.  Two accumulators per
+    // tile (even / odd slabs).
+    double4v acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = double4v{0.0, 0.0, 0.0, 0.0};
+    // the entries the products are subtracted from (independent of the loop: their round trip overlaps it); unconditional loads, masked
+    double org[2][4];
+#pragma unroll
+    for (int tc = 0; tc < 2; tc++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int r = 16 * wave + (lane >> 4) + 4 * rg, c = 16 * tc + (lane & 15), t = t0 + r - BA_CH_NB;
+            const int cl = min(c, nb - 1);
+            unsigned idx = 0u, m = c < nb ? ~0u : 0u;
+            if (r < BA_CH_NB) { idx = (unsigned)((k0 + min(r, nb - 1)) * ld + k0 + cl); m &= (r < nb && c <= r) ? ~0u : 0u; }
+            else if (t < mrows) idx = (unsigned)((r0 + t) * ld + k0 + cl);
+            else if (t == mrows) idx = (unsigned)((k0 + cl) * ld + nq);
+            else m = 0u;
+            const unsigned long long bits = __builtin_bit_cast(unsigned long long, A[idx]);
+            org[tc][rg] = __builtin_bit_cast(double, bits & (((unsigned long long)m << 32) | m));
+        }
+    if (k0 > 0) fetch(0);
+    for (int kc = 0; kc < k0; kc += KC) {
+        __syncthreads();  // the previous chunk has been read
+        if (kc + KC <= k0) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) { sX[wave + 4 * u][sc] = pre[2 * u]; sX[wave + 4 * u][sc + 64] = pre[2 * u + 1]; }
+            if (has_rhs) { sX[BA_CH_NB + t_rhs][sc] = yv[0]; sX[BA_CH_NB + t_rhs][sc + 64] = yv[1]; }
+        } else {  // ragged last chunk (k0 is a multiple of 32, a chunk has 128 columns)
+            const bool on0 = kc + sc < k0, on1 = kc + sc + 64 < k0;
+#pragma unroll
+            for (int u = 0; u < 16; u++) { sX[wave + 4 * u][sc] = on0 ? pre[2 * u] : 0.0; sX[wave + 4 * u][sc + 64] = on1 ? pre[2 * u + 1] : 0.0; }
+            if (has_rhs) { sX[BA_CH_NB + t_rhs][sc] = on0 ? yv[0] : 0.0; sX[BA_CH_NB + t_rhs][sc + 64] = on1 ? yv[1] : 0.0; }
+        }
+        __syncthreads();
+        if (kc + KC < k0) fetch(kc + KC);
+        // (wavefront 0's second tile lies above the diagonal and is never used; skipping it with a branch made hipcc shuffle the accumulators through
+        // v_accvgpr_mov behind s_nop 15 in every slab)
+        // software pipeline: the operands of step s + 1 are read BEFORE the four matrix-core instructions of step s are issued.  A wavefront blocks at
+        // every MFMA issue (64 cycles each), so with the reads after them the LDS round trip of every step was exposed: 52 ns per MFMA instead of 27
+        double o[6], n[6];
+        const auto read_ops = [&](double (&d)[6], int ks) {
+            d[0] = sX[16 * wave + (lane & 15)][ks + (lane >> 4)]; d[1] = sX[16 * wave + (lane & 15)][ks + 4 + (lane >> 4)];
+            d[2] = sX[lane & 15][ks + (lane >> 4)]; d[3] = sX[16 + (lane & 15)][ks + (lane >> 4)];
+            d[4] = sX[lane & 15][ks + 4 + (lane >> 4)]; d[5] = sX[16 + (lane & 15)][ks + 4 + (lane >> 4)];
+        };
+        read_ops(o, 0);
+#pragma unroll
+        for (int ks = 0; ks < KC; ks += 8) {
+            if (ks + 8 < KC) read_ops(n, ks + 8);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o[0], o[2], acc[0], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(o[1], o[4], acc[2], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o[0], o[3], acc[1], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(o[1], o[5], acc[3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 6; q++) o[q] = n[q];
+        }
+    }
+    __syncthreads();  // sX is dead: its memory becomes sD / sDt / sV / sDi
+#pragma unroll
+    for (int tc = 0; tc < 2; tc++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int r = 16 * wave + (lane >> 4) + 4 * rg, c = 16 * tc + (lane & 15);
+            const double v = org[tc][rg] - (acc[tc][rg] + acc[tc + 2][rg]);
+            if (r < BA_CH_NB) sD[r][c] = (r < nb && c <= r) ? v : (r == c ? 1.0 : 0.0);  // (a short last panel is padded with the identity)
+            else sV[r - BA_CH_NB][c] = c < nb ? v : 0.0;
+        }
+    __syncthreads();
+    if (tid < 64) {
+        const int i = tid & (BA_CH_NB - 1);  // (lanes 32..63 duplicate lanes 0..31; only the lower 32 are read through v_readlane)
+        double a[BA_CH_NB];
+#pragma unroll
+        for (int j = 0; j < BA_CH_NB; j++) a[j] = sD[i][j];
+        ba_chol32_rows(a);
+        if (tid < BA_CH_NB) {
+#pragma unroll
+            for (int j = 0; j < BA_CH_NB; j++) { sD[i][j] = a[j]; sDt[j][i] = a[j]; }
+            double d = 0.0;
+#pragma unroll
+            for (int j = 0; j < BA_CH_NB; j++) d = j == i ? a[j] : d;
+            sDi[i] = 1.0 / d;
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += 256) {
+            const int i = e / BA_CH_NB, j = e - i * BA_CH_NB;
+            if (i < nb && j <= i) A[(size_t)(k0 + i) * ld + k0 + j] = sD[i][j];
+        }
+    // own rows: v <- v L_D^-T, one thread per row, right-looking (see k_ba_chol_panel)
+    if (tid < cnt) {
+        double v[BA_CH_NB];
+#pragma unroll
+        for (int j = 0; j < BA_CH_NB; j++) v[j] = sV[tid][j];
+#pragma unroll
+        for (int k = 0; k < BA_CH_NB; k++) {
+            v[k] = v[k] * sDi[k];
+#pragma unroll
+            for (int j = k + 1; j < BA_CH_NB; j++) v[j] = __builtin_fma(-v[k], sDt[k][j], v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < BA_CH_NB; j++) sV[tid][j] = v[j];
+    }
+    __syncthreads();
+    for (int e = tid; e < cnt * BA_CH_NB; e += 256) {
+        const int rr = e / BA_CH_NB, j = e - rr * BA_CH_NB, t = t0 + rr;
+        if (j < nb) {
+            if (t == mrows) A[(size_t)(k0 + j) * ld + nq] = sV[rr][j];
+            else A[(size_t)(r0 + t) * ld + k0 + j] = sV[rr][j];
+        }
+    }
+}
+
+// L^T dc = y, from the last panel to the first (one workgroup of 1024 threads: the product over the rows below a panel is split 32 ways -- with 8 slices of
+// 256 threads a thread walked up to 92 rows of dependent loads, 160 us per solve at 768 unknowns)
+#define BA_CB_THREADS 1024
+__global__ __launch_bounds__(BA_CB_THREADS) void k_ba_chol_back(BaJob J)
 {
     ba_select_window(J, blockIdx.y);
     if (*J.done) return;
@@ -1461,26 +1645,35 @@ __global__ __launch_bounds__(256) void k_ba_chol_back(BaJob J)
     const double* A = J.Sfull;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sx = reinterpret_cast<double*>(smem);  // [nq] solution so far
-    __shared__ double sT[8][BA_CH_NB];
+    constexpr int NP = BA_CB_THREADS / BA_CH_NB;   // row slices
+    __shared__ double sT[NP][BA_CH_NB + 1];
     __shared__ double sD[BA_CH_NB][BA_CH_NB + 1];
     __shared__ double st[BA_CH_NB];
     const int npan = (nq + BA_CH_NB - 1) / BA_CH_NB;
     for (int p = npan - 1; p >= 0; p--) {
         const int k0 = p * BA_CH_NB, nb = min(BA_CH_NB, nq - k0), r0 = k0 + nb;
-        // t[j] = y[k0 + j] - sum_{i >= r0} L[i][k0 + j] x[i]: 8 row slices x 32 columns
+        // t[j] = y[k0 + j] - sum_{i >= r0} L[i][k0 + j] x[i]: NP row slices x 32 columns, four independent chains per thread
         const int j = tid & (BA_CH_NB - 1), part = tid >> 5;
-        double acc = 0.0;
-        if (j < nb)
-            for (int i = r0 + part; i < nq; i += 8) acc = __builtin_fma(A[(size_t)i * ld + k0 + j], sx[i], acc);
-        sT[part][j] = acc;
-        for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += 256) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (j < nb) {
+            int i = r0 + part;
+            for (; i + 3 * NP < nq; i += 4 * NP) {
+                const double l0 = A[(size_t)i * ld + k0 + j], l1 = A[(size_t)(i + NP) * ld + k0 + j], l2 = A[(size_t)(i + 2 * NP) * ld + k0 + j],
+                             l3 = A[(size_t)(i + 3 * NP) * ld + k0 + j];
+                a0 = __builtin_fma(l0, sx[i], a0); a1 = __builtin_fma(l1, sx[i + NP], a1);
+                a2 = __builtin_fma(l2, sx[i + 2 * NP], a2); a3 = __builtin_fma(l3, sx[i + 3 * NP], a3);
+            }
+            for (; i < nq; i += NP) a0 = __builtin_fma(A[(size_t)i * ld + k0 + j], sx[i], a0);
+        }
+        sT[part][j] = (a0 + a1) + (a2 + a3);
+        for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += BA_CB_THREADS) {
             const int i = e / BA_CH_NB, jj = e - i * BA_CH_NB;
             sD[i][jj] = (i < nb && jj <= i) ? A[(size_t)(k0 + i) * ld + k0 + jj] : (i == jj ? 1.0 : 0.0);
         }
         __syncthreads();
         if (tid < BA_CH_NB) {
             double t = tid < nb ? A[(size_t)(k0 + tid) * ld + nq] : 0.0;
-            for (int q = 0; q < 8; q++) t -= sT[q][tid];
+            for (int q = 0; q < NP; q++) t -= sT[q][tid];
             st[tid] = t;
         }
         __syncthreads();
@@ -1504,7 +1697,7 @@ __global__ __launch_bounds__(256) void k_ba_chol_back(BaJob J)
         if (tid < nb) sx[k0 + tid] = st[tid];
         __syncthreads();
     }
-    for (int q = tid; q < nq; q += 256) J.dc[q] = sx[q];
+    for (int q = tid; q < nq; q += BA_CB_THREADS) J.dc[q] = sx[q];
 }
 
 // back-substitution dp = tp - Y dc, update x += 0.9 delta, rms(delta) and the stop flag (NLS.py:235-240)
@@ -1705,7 +1898,9 @@ size_t vh_ba_workspace_bytes(int nt, int nc, int nparts)
     const size_t nf = nc + 1, nq = 6 * (size_t)nc, m = (size_t)nt * nf;
     size_t b = 0;
     auto add = [&](size_t n) { b += (n * sizeof(double) + 255) / 256 * 256; };
-    add(36 * nf); add(2 * m); add(6 * m); add(12 * m); add(3 * (size_t)nt); add(6 * (size_t)nt); add(3 * nq * nt); add(nparts * nq * nq); add(nparts * nq);
+    const bool big = nq > 252;  // 43+ cameras: per-workgroup partials of k_ba_zbuild (see there)
+    add(36 * nf); add(2 * m); add(6 * m); add(12 * m); add(3 * (size_t)nt); add(6 * (size_t)nt); add(3 * nq * nt); add(nparts * nq * nq);
+    add((big ? std::max((size_t)nparts, (size_t)BA_ZB_MAX) : (size_t)nparts) * nq); add(big ? (size_t)BA_ZB_MAX * 36 * nc : 0);
     add(nq * (nq + 1) + 4); add(nq); add(32);
     return b + 1024;
 }
@@ -1725,7 +1920,9 @@ static void ba_layout(const BaProblem& P, BaJob& J, double*& flags)
     auto take = [&](size_t n) { double* p = reinterpret_cast<double*>(w); w += (n * sizeof(double) + 255) / 256 * 256; return p; };
     const size_t nf = nc + 1, m = (size_t)nt * nf;
     J.camR = take(36 * nf); J.r = take(2 * m); J.Jp = take(6 * m); J.Jc = take(12 * m); J.tp = take(3 * (size_t)nt); J.Lc = take(6 * (size_t)nt); J.Y = take(3 * (size_t)nq * nt);
-    J.Spart = take((size_t)nparts * nq * nq); J.Rpart = take((size_t)nparts * nq);
+    const bool big = nq > 252;
+    J.Spart = take((size_t)nparts * nq * nq); J.Rpart = take((big ? std::max((size_t)nparts, (size_t)BA_ZB_MAX) : (size_t)nparts) * nq);
+    J.Dpart = take(big ? (size_t)BA_ZB_MAX * 36 * nc : 0);
     J.Sfull = take((size_t)nq * (nq + 1) + 4);     // augmented system followed by the 4 accumulators: ONE all-reduce span
     J.acc = J.Sfull + (size_t)nq * (nq + 1);
     J.dc = take(nq);
@@ -1766,8 +1963,9 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     // first `nsplit` partial systems are used: about one resident round of workgroups (2 per CU), every split at least one LDS stage of points
     const bool use_syrk = nq > 252 && !P.force_valu && P.model == 0;
     const int nm = (nq + 127) / 128, npairs = nm * (nm + 1) / 2;
-    const int nsplit = use_syrk ? std::max(1, std::min(std::min(nparts, (512 + npairs - 1) / npairs), (nt + 10) / 11)) : nparts;
-    if (use_mfma && lds_mfma > 64 * 1024) {
+    const int nsplit = use_syrk ? std::max(1, std::min(std::min(nparts, std::max(1, 512 / (npairs * (int)std::min(J.nwin < 1 ? 1 : J.nwin, 512)))), (nt + 10) / 11)) : nparts;
+    const int nzb = use_syrk ? std::max(1, std::min(BA_ZB_MAX, (nt + 2 * BA_ZB_PL - 1) / (2 * BA_ZB_PL))) : 0;  // workgroups of k_ba_zbuild: at least two rounds of points each
+    if ((use_mfma && lds_mfma > 64 * 1024) || nq > BA_GJ_MAXQ) {
         // the attribute is per function AND per device: one bit per device ordinal, set with an atomic OR (two host threads, or a process that drives
         // a second GPU, each set it for their device; setting it twice is harmless)
         static std::atomic<unsigned long long> attr_devs{0};
@@ -1777,6 +1975,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_schur_mfma<256, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_schur_mfma<256, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_chol_left), hipFuncAttributeMaxDynamicSharedMemorySize, BA_CL_LDS);
             if (e != hipSuccess) return (int)e;
             attr_devs.fetch_or(bit, std::memory_order_release);
         }
@@ -1812,7 +2011,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
             hipLaunchKernelGGL(k_ba_jac<true>, dim3((nt + ppb - 1) / ppb, nw), dim3(BA_THREADS), 0, s, J);
             vh_prof_stop(pc, rec, VH_PROF_BA_JAC, s);
             rec = vh_prof_start(pc, s);
-            hipLaunchKernelGGL(k_ba_zbuild, dim3(nsplit, (nq + 255) / 256, nw), dim3(256, BA_ZB_PL), 0, s, J);
+            hipLaunchKernelGGL(k_ba_zbuild, dim3(nzb, (nq + 255) / 256, nw), dim3(256, BA_ZB_PL), 0, s, J);
             hipLaunchKernelGGL(k_ba_syrk_mfma, dim3(npairs, nsplit, nw), dim3(256), 0, s, J, nm);
             vh_prof_stop(pc, rec, VH_PROF_BA_SCHUR, s);
         } else {
@@ -1825,7 +2024,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
             vh_prof_stop(pc, rec, VH_PROF_BA_SCHUR, s);
         }
         const int rec = vh_prof_start(pc, s);
-        hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((nent + nq + 63) / 64), nw), dim3(BA_THREADS), 0, s, J, nsplit);
+        hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((nent + nq + 63) / 64), nw), dim3(BA_THREADS), 0, s, J, nsplit, use_syrk ? nzb : nsplit, use_syrk ? nzb : 0);
         vh_prof_stop(pc, rec, VH_PROF_BA_REDUCE, s);
     };
     auto solve_update = [&](int it) {
@@ -1838,12 +2037,16 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
             else if (nq <= 256) hipLaunchKernelGGL((k_ba_solve<8, 9, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
             else hipLaunchKernelGGL(k_ba_solve_big, dim3(1, nw), dim3(1024), sizeof(double) * (size_t)(2 * nq + 1), s, J);
         } else {  // 125+ unknowns: blocked Cholesky, two launches per 32-column panel + the back-substitution
-            for (int k0 = 0; k0 < nq; k0 += BA_CH_NB) {
+            for (int k0 = 0; k0 < nq && !(J.dbg & 256); k0 += BA_CH_NB) {  // left-looking: one launch per panel, rows spread over workgroups
+                const int rows = nq - std::min(nq, k0 + BA_CH_NB) + 1;
+                hipLaunchKernelGGL(k_ba_chol_left, dim3((rows + BA_CL_RB - 1) / BA_CL_RB, nw), dim3(256), BA_CL_LDS, s, J, k0);
+            }
+            for (int k0 = 0; k0 < nq && (J.dbg & 256); k0 += BA_CH_NB) {  // right-looking kernels of round 4 (VH_BA_DBG=256: second implementation for the tests)
                 hipLaunchKernelGGL(k_ba_chol_panel, dim3(1, nw), dim3(256), 0, s, J, k0);
                 const int r0 = std::min(nq, k0 + BA_CH_NB), ntile = (nq - r0 + BA_CH_NB - 1) / BA_CH_NB;
                 if (ntile > 0) hipLaunchKernelGGL(k_ba_chol_update, dim3(ntile + 1, ntile, nw), dim3(256), 0, s, J, k0);
             }
-            hipLaunchKernelGGL(k_ba_chol_back, dim3(1, nw), dim3(256), sizeof(double) * (size_t)nq, s, J);
+            hipLaunchKernelGGL(k_ba_chol_back, dim3(1, nw), dim3(BA_CB_THREADS), sizeof(double) * (size_t)nq, s, J);
         }
         vh_prof_stop(pc, rec, VH_PROF_BA_SOLVE, s);
         rec = vh_prof_start(pc, s);

@@ -16,7 +16,8 @@ struct BaJob {  // passed by value to every BA kernel
     double* Lc;       // [nt][6]  lower-triangular Cholesky factor of (U+I)^-1 = L L^T (l00 l10 l11 l20 l21 l22): matrix-core path only
     double* Y;        // [nt][6 nc][3]  (U+I)^-1 W   (matrix-core path: Z = L^T W instead, zmode = 1)
     double* Spart;    // [nparts][(6 nc)^2]
-    double* Rpart;    // [nparts][6 nc]
+    double* Rpart;    // [nparts][6 nc]  (43+ cameras: [max(nparts, BA_ZB_MAX)][6 nc], one partial per k_ba_zbuild workgroup)
+    double* Dpart;    // 43+ cameras only: [BA_ZB_MAX][36 nc] partial diagonal blocks V_c of the k_ba_zbuild workgroups
     double* Sfull;    // [6 nc][6 nc + 1]
     double* dc;       // [6 nc]
     double* acc;      // [2] sum r^2, sum delta^2
@@ -30,7 +31,7 @@ struct BaJob {  // passed by value to every BA kernel
     int nq;     // reduced unknowns: 6 nc (model 0) or nc + 5 (model 1)
     int model;  // 0: fcnNLS_batch (free cameras, NLS.py:186-250); 1: fcnNLS_batch2 (joint rotation + straight-line trajectory, NLS.py:253-328)
     int add_identity, count_cams, defer_finalize;
-    int dbg;    // experiment switches (VH_BA_DBG): 1 skip MFMA, 2 skip Z / diag VALU, 4 skip global fetch, 8 skip barrier, 64 VALU Gauss-Jordan solve
+    int dbg;    // experiment switches (VH_BA_DBG): 1 skip MFMA, 2 skip Z / diag VALU, 4 skip global fetch, 8 skip barrier, 64 VALU Gauss-Jordan solve, 128 elimination kernels above 128 unknowns, 256 right-looking Cholesky (two launches per panel)
     int zmode;  // 1: Y holds Z = L^T W and Spart holds only the upper-triangle 16x16 tiles (k_ba_schur_mfma); 0: Y = (U+I)^-1 W, full Spart
     // batched independent windows (vh_nls_batch_multi): blockIdx.y selects the window; every pointer above is window 0's
     int nwin;
