@@ -267,9 +267,9 @@ def test_nls_batch_cholesky_and_wide_schur_equal_the_round3_kernels(golden, nt, 
         close(pw, outs[0][1], 1e-6, 1e-8)
 
 
-@pytest.mark.parametrize("nt,nf", [(37, 44), (50, 129), (333, 97), (1001, 65), (9, 50)])
-def test_nls_batch_43_to_128_cameras_syrk_vs_valu_and_oracle(golden, nt, nf):
-    """43..128 free cameras (258..768 reduced unknowns): Z materialised by k_ba_zbuild + the K-split matrix-core SYRK k_ba_syrk_mfma (default) against the
+@pytest.mark.parametrize("nt,nf", [(37, 44), (50, 129), (333, 97), (1001, 65), (9, 50), (39, 201), (12, 256)])
+def test_nls_batch_43_to_255_cameras_syrk_vs_valu_and_oracle(golden, nt, nf):
+    """43..255 free cameras (258..1530 reduced unknowns; the VALU kernel -- the second implementation here -- stops at 128 cameras): Z materialised by k_ba_zbuild + the K-split matrix-core SYRK k_ba_syrk_mfma (default) against the
     VALU Schur kernel (vh_debug_ba_force_valu) and the oracle's structured solve.  Point counts that are no multiple of the split / of a 4-row slab,
     a window with fewer points than an LDS stage, widths that end inside a 16-column tile (258 = 16 x 16 + 2) and the full 768."""
     from velocity_amd import _lib as L
@@ -278,16 +278,19 @@ def test_nls_batch_43_to_128_cameras_syrk_vs_valu_and_oracle(golden, nt, nf):
 
     P, pw0, cw0 = synth.ba_scene(nt, nf, seed=300 + nf)
     outs = []
-    for force_valu in (0, 1):
+    for force_valu in (0, 1) if nf <= 129 else (0,):
         L.load().vh_debug_ba_force_valu(force_valu)
         try:
             outs.append(fcnNLS_batch(golden["K32"], P.copy(), pw0, cw0, max_iter=4, return_info=True))
         finally:
             L.load().vh_debug_ba_force_valu(0)
-    (cw, pw, x, tr), (cw2, pw2, x2, tr2) = outs
-    assert np.all(np.isfinite(x)) and len(tr) == len(tr2) == 4
-    close(tr[:, 0], tr2[:, 0], 1e-8)
-    close(x, x2, 1e-6, 1e-8)
+    cw, pw, x, tr = outs[0]
+    assert np.all(np.isfinite(x)) and len(tr) == 4
+    if len(outs) > 1:
+        cw2, pw2, x2, tr2 = outs[1]
+        close(tr[:, 0], tr2[:, 0], 1e-8)
+        close(x, x2, 1e-6, 1e-8)
+    assert nt * nf <= 8000 or len(outs) > 1
     if nt * nf <= 8000:
         ecw, epw, ex, etr = O.nls_batch_schur(golden["K32"], P.copy(), pw0, cw0, max_iter=4, return_info=True)
         close(tr[:, 0], etr[:, 0], 1e-7)

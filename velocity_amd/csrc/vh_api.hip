@@ -1042,7 +1042,7 @@ extern "C" VH_API int vh_nls_batch(vh_ctx* c, const double* K_host, const double
                                    int* info, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!c || !K_host || nt < 1 || nc < 1 || max_iter < 1) return vh_fail(-1, "vh_nls_batch: bad arguments");
-    if (nc > 128) return vh_fail(-1, "vh_nls_batch: at most 128 free cameras");
+    if (nc > 255) return vh_fail(-1, "vh_nls_batch: at most 255 free cameras");
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc))) return vh_fail(-1, "vh_nls_batch: workspace too small");
     BaProblem P;
     P.graph_cache = c->ba_graph_on ? &c->ba_graphs : nullptr;
@@ -1063,7 +1063,7 @@ extern "C" VH_API int vh_nls_batch_multi(vh_ctx* c, const double* K_host, const 
                                          double* trace, int* info, void* workspace, size_t workspace_bytes_per_window, void* stream)
 {
     if (!c || !K_host || nt < 1 || nc < 1 || max_iter < 1 || nwin < 1 || nwin > 65535) return vh_fail(-1, "vh_nls_batch_multi: bad arguments");
-    if (nc > 128) return vh_fail(-1, "vh_nls_batch_multi: at most 128 free cameras");
+    if (nc > 255) return vh_fail(-1, "vh_nls_batch_multi: at most 255 free cameras");
     if (workspace_bytes_per_window < vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc)) || workspace_bytes_per_window % 256)
         return vh_fail(-1, "vh_nls_batch_multi: per-window workspace too small or not a multiple of 256 bytes");
     BaProblem P;
@@ -1088,7 +1088,7 @@ extern "C" VH_API int vh_nls_batch2(vh_ctx* c, const double* K_host, const doubl
                                     int* info, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!c || !K_host || nt < 1 || nc < 1 || max_iter < 1) return vh_fail(-1, "vh_nls_batch2: bad arguments");
-    if (nc > 128) return vh_fail(-1, "vh_nls_batch2: at most 128 free cameras");
+    if (nc > 255) return vh_fail(-1, "vh_nls_batch2: at most 255 free cameras");
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc))) return vh_fail(-1, "vh_nls_batch2: workspace too small");
     BaProblem P;
     P.graph_cache = c->ba_graph_on ? &c->ba_graphs : nullptr;
@@ -1113,7 +1113,7 @@ extern "C" VH_API int vh_nls_batch_phase(vh_ctx* c, const double* K_host, const 
                                          size_t* span_offset, size_t* span_doubles, void* stream)
 {
     if (!c || !K_host || nt < 1 || nc < 1 || nt_total < nt) return vh_fail(-1, "vh_nls_batch_phase: bad arguments");
-    if (nc > 128) return vh_fail(-1, "vh_nls_batch_phase: at most 128 free cameras");
+    if (nc > 255) return vh_fail(-1, "vh_nls_batch_phase: at most 255 free cameras");
     if (workspace_bytes < vh_ba_workspace_bytes(nt, nc, ba_parts(nt, nc))) return vh_fail(-1, "vh_nls_batch_phase: workspace too small");
     BaProblem P;
     P.graph_cache = c->ba_graph_on ? &c->ba_graphs : nullptr;

@@ -19,9 +19,10 @@
 #define BA_FD 1e-6
 #define BA_THREADS 256
 #define BA_EPT 64  // Schur entries owned by one thread per pass
-#define BA_MAX_NC 128                       // free cameras (the reference has no limit; the workspace grows with (6 nc)^2 per partial system)
+#define BA_MAX_NC 255                       // free cameras: a k_ba_jac workgroup (256 threads) owns whole points, one thread per frame (the reference has no limit)
+#define BA_MAX_NC_VALU 128                  // ... of the VALU Schur kernel (test hook / fcnNLS_batch2's trajectory model excepted: nc + 5 unknowns)
 #define BA_ZB_MAX 256                        // workgroups of k_ba_zbuild (43+ cameras): one partial right-hand side / set of diagonal blocks each
-#define BA_RQ (6 * BA_MAX_NC / BA_THREADS)  // reduced right-hand-side entries owned by one thread of the VALU Schur kernel
+#define BA_RQ ((6 * BA_MAX_NC_VALU + BA_THREADS - 1) / BA_THREADS)  // reduced right-hand-side entries owned by one thread of the VALU Schur kernel
 
 // batched windows: shift every pointer of the job to window w (the job travels by value, so this edits the kernel's own copy)
 __device__ __forceinline__ void ba_select_window(BaJob& J, int w)
@@ -1962,6 +1963,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     // 43..128 cameras: Z materialised + K-split SYRK on the matrix cores (k_ba_zbuild / k_ba_syrk_mfma).  nm macro tiles of 128 per dimension; the
     // first `nsplit` partial systems are used: about one resident round of workgroups (2 per CU), every split at least one LDS stage of points
     const bool use_syrk = nq > 252 && !P.force_valu && P.model == 0;
+    if (!use_syrk && !use_mfma && nq > 6 * BA_MAX_NC_VALU) return -3;  // the VALU Schur kernel keeps 6 nc / 256 right-hand-side entries per thread and 3 x 6 nc doubles of LDS
     const int nm = (nq + 127) / 128, npairs = nm * (nm + 1) / 2;
     const int nsplit = use_syrk ? std::max(1, std::min(std::min(nparts, std::max(1, 512 / (npairs * (int)std::min(J.nwin < 1 ? 1 : J.nwin, 512)))), (nt + 10) / 11)) : nparts;
     const int nzb = use_syrk ? std::max(1, std::min(BA_ZB_MAX, (nt + 2 * BA_ZB_PL - 1) / (2 * BA_ZB_PL))) : 0;  // workgroups of k_ba_zbuild: at least two rounds of points each
