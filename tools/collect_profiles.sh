@@ -90,6 +90,10 @@ json.dump(dur, open("$OUT/sq_ba${i}_dispatch.json", "w"))
 PY
   find $OUT/sq_ba$i -name "*kernel_trace.csv" -delete
 done
+# BA by free cameras (one window, 5000 / 1000 points): per-stage times of an LM iteration from 19 to 255 cameras + kernel stats of the 128-camera window
+BA_NF=20,26,43,51,65,97,129,201,256 python $R/tools/exp/ba_by_cameras.py 5000 1000 > $OUT/ba_by_cameras.jsonl 2> $OUT/ba_by_cameras.log
+BA_NF=129 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ba128 -- python $R/tools/exp/ba_by_cameras.py 5000 > $OUT/ba128.log 2>&1
+find $OUT/ba128 -name "*kernel_trace.csv" -delete
 # single stream: launch timeline of one steady-state frame
 rocprofv3 --kernel-trace --output-format csv -d $OUT/s1 -- python $R/bench.py --streams 1 --steps 200 --warmup 20 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/s1.log 2>&1
 python - <<PY

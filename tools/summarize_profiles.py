@@ -109,6 +109,23 @@ if lk_sq:
               open(os.path.join(DST, f"{tag}_lk_sq_pmc.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(DST, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 
+# BA by free cameras
+bc = os.path.join(SRC, "ba_by_cameras.jsonl")
+if os.path.exists(bc):
+    rows = [json.loads(l) for l in open(bc) if l.strip().startswith("{")]
+    stats128 = {}
+    for f in glob.glob(os.path.join(SRC, "ba128", "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "k_ba" in r["Name"]:
+                stats128[r["Name"].split("(")[0].replace("void ", "")] = dict(calls=int(r["Calls"]), avg_us=round(float(r["AverageNs"]) / 1e3, 2),
+                                                                                 min_us=round(float(r["MinNs"]) / 1e3, 2), max_us=round(float(r["MaxNs"]) / 1e3, 2))
+    json.dump(dict(_comment="tools/exp/ba_by_cameras.py: ONE window, 4 LM iterations; per-stage microseconds per iteration from HIP events inside the library "
+                            "(jac = k_ba_jac, schur = the Schur launches, reduce, solve = the Gauss-Jordan / Cholesky launches, update) and the whole "
+                            "iteration (us_per_iter, events around the solve).  Up to 21 cameras: k_ba_schur_mfma<128> + k_ba_solve_mfma; 22..42: "
+                            "k_ba_schur_mfma<256> in two passes + left-looking Cholesky; 43..255: k_ba_zbuild + k_ba_syrk_mfma + left-looking Cholesky.  "
+                            "kernels_128_cameras: rocprofv3 --stats of the 128-camera x 5000-point window (24 panel launches per solve)",
+                   rows=rows, kernels_128_cameras=stats128), open(os.path.join(DST, f"{tag}_ba_by_cameras.json"), "w"), indent=1)
+
 # BA: per-window-count kernel times, SQ / MFMA counters of the 64-window launches
 for name in ("ba_by_windows.json", "s1_timeline.json"):
     src = os.path.join(SRC, name)
