@@ -149,10 +149,45 @@ def bench_ba(nt=5000, nf=20, repeats=3, windows=(1, 8, 64), min_seconds=0.4):
         out["single_window_kernels_us"] = {k: round(v, 2) for k, v in k1.items()}
     except Exception as e:  # the roofline leg must never take the BA numbers down with it
         out["roofline"] = dict(error=f"{type(e).__name__}: {e}"[:300])
+    # ---- larger windows (43..255 free cameras: k_ba_zbuild + k_ba_syrk_mfma + left-looking Cholesky; round 5) ----
+    try:
+        out["by_cameras"] = {str(nfw - 1): large_window(ws, K64, nt, nfw) for nfw in (51, 129)}
+    except Exception as e:
+        out["by_cameras"] = dict(error=f"{type(e).__name__}: {e}"[:300])
     one = out["by_windows"]["1"]
     out.update(iters_per_s=one["iters_per_s"], ms_per_iter=one["ms_per_window_iter"], rms_residual_first=one["rms_residual_first"],
                rms_residual_last=one["rms_residual_last"])
     return out, first
+
+
+def large_window(ws, K64, nt, nf, iters=4, reps=4):
+    """One window of `nf` keyframes x `nt` tracks, `iters` LM iterations: microseconds per iteration (HIP events around the solve, best of `reps`)."""
+    from velocity_amd import _lib as L
+    from velocity_amd import synth
+
+    nc = nf - 1
+    z, x0 = synth.ba_pack(*synth.ba_scene(nt, nf, seed=5))[:2]
+    zd, x0d = L.to_dev(z[None], torch.float64), L.to_dev(x0[None], torch.float64)
+    nbytes = int(ws.lib.vh_nls_batch_workspace(nt, nc))
+    scratch = torch.empty((1, nbytes), dtype=torch.uint8, device="cuda")
+    trace = torch.zeros((1, iters, 2), dtype=torch.float64, device="cuda")
+    info = torch.zeros((1, 2), dtype=torch.int32, device="cuda")
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    xd, best = torch.empty_like(x0d), None
+    for _ in range(reps):
+        xd.copy_(x0d)
+        torch.cuda.synchronize()
+        ev0.record()
+        L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, 1, iters, L.dptr(trace), L.dptr(info),
+                                          L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1)
+        best = ms if best is None else min(best, ms)
+    its = max(int(info.cpu()[0, 0]), 1)
+    tr = trace.cpu().numpy()[0, :, 0]
+    return dict(keyframes=nf, tracks=nt, reduced_unknowns=6 * nc, us_per_iter=round(1e3 * best / its, 1), iters_per_s=round(1e3 * its / best, 1),
+                rms_residual_first=round(float(tr[0]), 4), rms_residual_last=round(float(tr[its - 1]), 4), workspace_mb=round(nbytes / 2 ** 20, 1))
 
 
 def bench_ba_multi_gpu(rank, world, barrier, reduce_max, nt=5000, nf=20, windows_per_gpu=8):

@@ -1,25 +1,18 @@
-"""Latency of one pyramidal LK launch sequence (quarter-scale stage: 480x270, 15x15, maxLevel 2, 10 iterations) vs the number of tracks."""
-import sys, os, ctypes as C
+"""Experiment: how a single LK launch scales with the number of tracks (one stream).  Run under rocprofv3 --kernel-trace; the LK kernels are
+identified by their grid (one workgroup per track for the small-batch routes)."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import numpy as np, torch
-from velocity_amd import synth, _lib as L
-from velocity_amd.KLT import _lk_from_cv
+import torch
+from velocity_amd import synth, KLT
 
-W, H = 480, 270
-m = synth.AffineMotion(W, H, tx=2.1, ty=-0.7)
-f0 = synth.render_frame(W, H, m, 0).cuda(); f1 = synth.render_frame(W, H, m, 1).cuda()
-lk = _lk_from_cv(dict(winSize=(15, 15), maxLevel=2, criteria=(3, 10, 0.1)))
-for n in (1, 64, 256, 1000, 2000, 4000):
-    p = torch.from_numpy(synth.grid_tracks(n, W, H)).cuda()
-    ws = L.workspace(W, H, n)
-    p2 = torch.zeros((n, 2), dtype=torch.float32, device="cuda"); v = torch.zeros(n, dtype=torch.uint8, device="cuda"); err = torch.zeros((n, 1), dtype=torch.float32, device="cuda")
-    for fbt in (-1.0, 1.0):
-        def call():
-            L.check(ws.lib.vh_pyr_lk(ws.handle, L.dptr(f0), L.dptr(f1), W, H, W, W, L.dptr(p), n, C.byref(lk), C.c_float(fbt), L.dptr(p2), L.dptr(v), None, None, L.stream_ptr()), "lk")
-        for _ in range(5): call()
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(50): call()
-        b.record(); torch.cuda.synchronize()
-        print(f"n {n:5d} fbt {fbt:4.1f}: {a.elapsed_time(b) / 50 * 1e3:8.1f} us per call (pyramid build + LK)", flush=True)
+W, H = 1920, 1080
+m = synth.PlaneMotion(synth.K_1080P, traj=synth.oscillating_traj())
+f0 = synth.render_frame(W, H, m, 3, device="cuda")
+f1 = synth.render_frame(W, H, m, 4, device="cuda")
+C, E = KLT.TERM_CRITERIA_COUNT, KLT.TERM_CRITERIA_EPS
+for n in (64, 250, 500, 1000, 2000, 4000):
+    p = torch.as_tensor(synth.grid_tracks(n, W, H), device="cuda")
+    for rep in range(3):
+        KLT.cv2calcOpticalFlowPyrLK(f0, f1, p, None, None, winSize=(15, 15), maxLevel=2, criteria=(C | E, 10, 0.1))
+        KLT.cv2calcOpticalFlowPyrLK(f0, f1, p, None, 0.3, winSize=(51, 51), maxLevel=0, criteria=(C | E, 30, 0.001))
+    torch.cuda.synchronize()

@@ -120,13 +120,28 @@ __device__ void ba_cam_tables(const BaJob& J, int c, const double* par)  // came
     }
 }
 
+// model 0, one (camera, variant) pair: variant 0 = R(rpy), 1..3 = R(rpy + dx e_k) -- the four rotation matrices of a camera are independent chains of six
+// f64 sin / cos each; one thread per pair keeps the chain of the update kernel's camera block four times shorter
+__device__ void ba_cam_table_variant(const BaJob& J, int c, int v, const double* par)
+{
+    double* out = J.camR + (size_t)c * 36 + 9 * v;
+    if (c == 0) {
+        for (int k = 0; k < 9; k++) out[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    const double* rpy = par + 3 * J.nc + 3 * (c - 1);
+    double a[3] = {rpy[0], rpy[1], rpy[2]};
+    if (v > 0) a[v - 1] += BA_FD;
+    ba_rpy2dcm(a, out);
+}
+
 // first iteration only: later iterations get their tables from block 0 of k_ba_update, right after it moved the cameras
 __global__ void k_ba_cams(BaJob J)
 {
     ba_select_window(J, blockIdx.y);
     if (*J.done) return;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c <= J.nc) ba_cam_tables(J, c, J.x + 3 * J.nt);
+    if (c <= J.nc) ba_cam_tables(J, c, J.x + 3 * J.nt);  // (once per solve: one thread per camera is fine here)
 }
 
 __device__ void inv3_sym(const double* U, double* Ui);
@@ -1701,7 +1716,55 @@ __global__ __launch_bounds__(BA_CB_THREADS) void k_ba_chol_back(BaJob J)
     for (int q = tid; q < nq; q += BA_CB_THREADS) J.dc[q] = sx[q];
 }
 
-// back-substitution dp = tp - Y dc, update x += 0.9 delta, rms(delta) and the stop flag (NLS.py:235-240)
+// tail of the update kernels: block 0 moves the cameras (and builds the rotation / offset tables of the next iteration from the LDS copy of the new
+// parameters -- saves a launch per iteration); every block adds its sum of squared steps, the last one finishes the iteration record
+template <int NT>
+__device__ __forceinline__ void ba_update_tail(BaJob& J, int it, double ss, double* s_par, double* sh)
+{
+    const int nt = J.nt, nc = J.nc, nq = J.nq, tid = threadIdx.x;
+    if (blockIdx.x == 0)
+        for (int q = tid; q < nq; q += NT) {
+            const int c = q / 6, k = q - 6 * c;
+            const double dl = J.dc[q] * 0.9;
+            // state layout: [points | camera positions | camera rpy] (NLS.py:203); model 1: [points | rpy, el, az, ranges] in reduced order
+            const size_t idx = J.model == 1 ? (size_t)3 * nt + q
+                                            : (k < 3 ? (size_t)3 * nt + 3 * c + k : (size_t)3 * nt + 3 * nc + 3 * c + (k - 3));
+            const double nv = J.x[idx] + dl;
+            J.x[idx] = nv;
+            s_par[idx - (size_t)3 * nt] = nv;
+            if (J.count_cams) ss += dl * dl;  // sharded runs: the (replicated) camera update is counted by rank 0 only
+        }
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        if (J.model == 0) for (int cv = tid; cv < 4 * (nc + 1); cv += NT) ba_cam_table_variant(J, cv >> 2, cv & 3, s_par);
+        else for (int c = tid; c <= nc; c += NT) ba_cam_tables(J, c, s_par);
+    }
+    ss = vh_wave_sum_f64(ss);
+    if ((tid & 63) == 0) sh[tid >> 6] = ss;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int k = 0; k < NT / 64; k++) s += sh[k];
+        atomicAdd(J.acc + 1, s);
+        __threadfence();
+        const unsigned prev = atomicAdd(J.ticket, 1u);
+        if (prev == gridDim.x - 1 && J.defer_finalize) *J.ticket = 0u;
+        if (prev == gridDim.x - 1 && !J.defer_finalize) {  // last block: finish the iteration record
+            const double nz = J.nz_total, nx = J.nx_total;
+            const double sumr = atomicAdd(J.acc, 0.0), sumd = atomicAdd(J.acc + 1, 0.0);
+            const double f = sqrt(sumr / nz), xr = sqrt(sumd / nx);
+            J.trace[2 * it] = f;
+            J.trace[2 * it + 1] = xr;
+            J.info[0] = it + 1;
+            if (xr < 1e-7) { J.info[1] = 1; *J.done = 1; }
+            J.acc[0] = 0.0; J.acc[1] = 0.0;
+            *J.ticket = 0u;
+            __threadfence();
+        }
+    }
+}
+
+// back-substitution dp = tp - Y dc, update x += 0.9 delta, rms(delta) and the stop flag (NLS.py:235-240): VALU Schur path (zmode = 0; k_ba_update_z otherwise)
 __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
 {
     ba_select_window(J, blockIdx.y);
@@ -1711,41 +1774,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
     __shared__ double s_par[6 * BA_MAX_NC];  // new camera-side parameters (block 0)
     double ss = 0.0;
     const int lane = tid & 63, wave = tid >> 6;
-    if (J.zmode) {
-        // matrix-core path: dp_i = tp_i - (U_i+I)^-1 W_i dc with W_i dc = sum_c Jp_c^T (Jc_c dc_c) recomputed from the compact Jacobians (the same
-        // bytes a stored Y / Z would cost to read, and nothing to write in the Schur kernel); 4 lanes share a point (cameras c = 1 + sub, 5 + sub, ...)
-        for (int q = tid; q < nq; q += BA_THREADS) s_par[q] = J.dc[q];
-        __syncthreads();
-        const int total = 4 * ((nt + 15) / 16) * 16;  // whole waves run the loop together (the shuffles below need their 4 partners)
-        for (int p4 = blockIdx.x * BA_THREADS + tid; p4 < total; p4 += gridDim.x * BA_THREADS) {
-            const int i = min(p4 >> 2, nt - 1), sub = p4 & 3;
-            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
-            for (int c = 1 + sub; c <= nc; c += 4) {
-                const size_t m = (size_t)i * (nc + 1) + c;
-                const double* Jc = J.Jc + 12 * m;
-                const double* Jp = J.Jp + 6 * m;
-                const double* dq = s_par + 6 * (c - 1);
-                double su = 0.0, sv = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) { su += Jc[k] * dq[k]; sv += Jc[6 + k] * dq[k]; }
-                e0 += Jp[0] * su + Jp[3] * sv; e1 += Jp[1] * su + Jp[4] * sv; e2 += Jp[2] * su + Jp[5] * sv;
-            }
-            e0 += __shfl_xor(e0, 1, 64); e1 += __shfl_xor(e1, 1, 64); e2 += __shfl_xor(e2, 1, 64);
-            e0 += __shfl_xor(e0, 2, 64); e1 += __shfl_xor(e1, 2, 64); e2 += __shfl_xor(e2, 2, 64);
-            if (sub == 0 && (p4 >> 2) < nt) {
-                const double* Lp = J.Lc + 6 * (size_t)i;  // (U+I)^-1 = L L^T, L = l00 l10 l11 l20 l21 l22
-                const double z0 = Lp[0] * e0 + Lp[1] * e1 + Lp[3] * e2, z1 = Lp[2] * e1 + Lp[4] * e2, z2 = Lp[5] * e2;  // L^T e
-                const double d0 = Lp[0] * z0, d1 = Lp[1] * z0 + Lp[2] * z1, d2 = Lp[3] * z0 + Lp[4] * z1 + Lp[5] * z2;  // L (L^T e)
-                const double d[3] = {J.tp[3 * (size_t)i] - d0, J.tp[3 * (size_t)i + 1] - d1, J.tp[3 * (size_t)i + 2] - d2};
-                for (int k = 0; k < 3; k++) {
-                    const double dl = d[k] * 0.9;
-                    J.x[3 * (size_t)i + k] += dl;
-                    ss += dl * dl;
-                }
-            }
-        }
-        __syncthreads();  // s_par is reused for the camera parameters below
-    } else {
+    {
         // VALU path: one wavefront per point: the lanes split the 6nc columns of the point's 3 x 6nc block of Y (consecutive lanes read
         // consecutive 24-byte column triples -> coalesced; a thread-per-point walk of the 2.7 KB rows ran at 0.3 TB/s)
         for (int i = blockIdx.x * (BA_THREADS / 64) + wave; i < nt; i += gridDim.x * (BA_THREADS / 64)) {
@@ -1766,47 +1795,107 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_update(BaJob J, int it)
             }
         }
     }
-    if (blockIdx.x == 0)
-        for (int q = tid; q < nq; q += BA_THREADS) {
-            const int c = q / 6, k = q - 6 * c;
-            const double dl = J.dc[q] * 0.9;
-            // state layout: [points | camera positions | camera rpy] (NLS.py:203); model 1: [points | rpy, el, az, ranges] in reduced order
-            const size_t idx = J.model == 1 ? (size_t)3 * nt + q
-                                            : (k < 3 ? (size_t)3 * nt + 3 * c + k : (size_t)3 * nt + 3 * nc + 3 * c + (k - 3));
-            const double nv = J.x[idx] + dl;
-            J.x[idx] = nv;
-            s_par[idx - (size_t)3 * nt] = nv;
-            if (J.count_cams) ss += dl * dl;  // sharded runs: the (replicated) camera update is counted by rank 0 only
-        }
-    if (blockIdx.x == 0) {
-        // the cameras of the next iteration are final now: build their rotation / offset tables here, from the LDS copy of the
-        // new parameters (saves a launch per iteration)
-        __syncthreads();
-        for (int c = tid; c <= nc; c += BA_THREADS) ba_cam_tables(J, c, s_par);
-    }
-    ss = vh_wave_sum_f64(ss);
-    if ((tid & 63) == 0) sh[tid >> 6] = ss;
+    ba_update_tail<BA_THREADS>(J, it, ss, s_par, sh);
+}
+
+// matrix-core paths (zmode = 1): dp_i = tp_i - (U_i+I)^-1 W_i dc with W_i dc = sum_c Jp_c^T (Jc_c dc_c) recomputed from the compact Jacobians (the same bytes a
+// stored Y / Z would cost to read).  32 lanes share a point, ONE camera per lane and pass (cameras c = 1 + sub, 33 + sub, ...): the 18 doubles of a
+// measurement arrive as nine 16-byte loads issued together -- one memory round trip per point instead of the five dependent ones of the 4-lanes-per-point
+// loop (round 5: 20 -> ~9 us for one C5 window, whose Jacobians were written by other XCDs in the previous launch and come from the infinity cache / HBM)
+// Up to 20 000 points per launch (latency regime); more take k_ba_update_z4.
+#define BA_UZ_LPP 32  // lanes per point
+template <int BA_UZ_THREADS>
+__global__ __launch_bounds__(BA_UZ_THREADS) void k_ba_update_z(BaJob J, int it)
+{
+    ba_select_window(J, blockIdx.y);
+    if (*J.done) return;
+    const int nt = J.nt, nc = J.nc, nq = J.nq, tid = threadIdx.x;
+    __shared__ double sh[BA_UZ_THREADS / 64];
+    __shared__ double s_par[6 * BA_MAX_NC];  // dc, then the new camera-side parameters (block 0)
+    double ss = 0.0;
+    for (int q = tid; q < nq; q += BA_UZ_THREADS) s_par[q] = J.dc[q];
     __syncthreads();
-    if (tid == 0) {
-        double s = 0.0;
-        for (int k = 0; k < BA_THREADS / 64; k++) s += sh[k];
-        atomicAdd(J.acc + 1, s);
-        __threadfence();
-        const unsigned prev = atomicAdd(J.ticket, 1u);
-        if (prev == gridDim.x - 1 && J.defer_finalize) *J.ticket = 0u;
-        if (prev == gridDim.x - 1 && !J.defer_finalize) {  // last block: finish the iteration record
-            const double nz = J.nz_total, nx = J.nx_total;
-            const double sumr = atomicAdd(J.acc, 0.0), sumd = atomicAdd(J.acc + 1, 0.0);
-            const double f = sqrt(sumr / nz), xr = sqrt(sumd / nx);
-            J.trace[2 * it] = f;
-            J.trace[2 * it + 1] = xr;
-            J.info[0] = it + 1;
-            if (xr < 1e-7) { J.info[1] = 1; *J.done = 1; }
-            J.acc[0] = 0.0; J.acc[1] = 0.0;
-            *J.ticket = 0u;
-            __threadfence();
+    typedef double double2v __attribute__((ext_vector_type(2)));
+    constexpr int PPB = BA_UZ_THREADS / BA_UZ_LPP;  // points per block and pass
+    const int sub = tid & (BA_UZ_LPP - 1), pl = tid / BA_UZ_LPP;
+    // block 0 owns the cameras and no point: its chain (dc -> new parameters -> 6 sin / cos per rotation table) runs beside the point blocks, not after
+    // block 0's share of them
+    const int npb = (int)gridDim.x - 1, pb = (int)blockIdx.x - 1;
+    const int npass = pb < 0 ? 0 : (nt + PPB * npb - 1) / (PPB * npb);  // whole blocks run the loop together (the shuffles below need their partners)
+    for (int ps = 0; ps < npass; ps++) {
+        const int ip = (ps * npb + pb) * PPB + pl, i = min(ip, nt - 1);
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+        for (int c = 1 + sub; c <= nc; c += BA_UZ_LPP) {
+            const size_t m = (size_t)i * (nc + 1) + c;
+            const double2v* Jc = reinterpret_cast<const double2v*>(J.Jc + 12 * m);  // 96 m bytes: 16-byte aligned
+            const double2v* Jp = reinterpret_cast<const double2v*>(J.Jp + 6 * m);   // 48 m bytes
+            const double2v a0 = Jc[0], a1 = Jc[1], a2 = Jc[2], b0 = Jc[3], b1 = Jc[4], b2 = Jc[5], p0 = Jp[0], p1 = Jp[1], p2 = Jp[2];
+            const double* dq = s_par + 6 * (c - 1);
+            const double su = a0.x * dq[0] + a0.y * dq[1] + a1.x * dq[2] + a1.y * dq[3] + a2.x * dq[4] + a2.y * dq[5];
+            const double sv = b0.x * dq[0] + b0.y * dq[1] + b1.x * dq[2] + b1.y * dq[3] + b2.x * dq[4] + b2.y * dq[5];
+            // Jp = [du/dX du/dY du/dZ | dv/dX dv/dY dv/dZ]
+            e0 += p0.x * su + p1.y * sv; e1 += p0.y * su + p2.x * sv; e2 += p1.x * su + p2.y * sv;
+        }
+#pragma unroll
+        for (int o = 1; o < BA_UZ_LPP; o <<= 1) { e0 += __shfl_xor(e0, o, 64); e1 += __shfl_xor(e1, o, 64); e2 += __shfl_xor(e2, o, 64); }
+        if (sub == 0 && ip < nt) {
+            const double* Lp = J.Lc + 6 * (size_t)i;  // (U+I)^-1 = L L^T, L = l00 l10 l11 l20 l21 l22
+            const double z0 = Lp[0] * e0 + Lp[1] * e1 + Lp[3] * e2, z1 = Lp[2] * e1 + Lp[4] * e2, z2 = Lp[5] * e2;  // L^T e
+            const double d0 = Lp[0] * z0, d1 = Lp[1] * z0 + Lp[2] * z1, d2 = Lp[3] * z0 + Lp[4] * z1 + Lp[5] * z2;  // L (L^T e)
+            const double d[3] = {J.tp[3 * (size_t)i] - d0, J.tp[3 * (size_t)i + 1] - d1, J.tp[3 * (size_t)i + 2] - d2};
+            for (int k = 0; k < 3; k++) {
+                const double dl = d[k] * 0.9;
+                J.x[3 * (size_t)i + k] += dl;
+                ss += dl * dl;
+            }
         }
     }
+    __syncthreads();  // s_par is reused for the camera parameters
+    ba_update_tail<BA_UZ_THREADS>(J, it, ss, s_par, sh);
+}
+
+// zmode = 1, more than 20 000 points per launch (bandwidth regime): 4 lanes share a point (cameras c = 1 + sub, 5 + sub, ...), every lane busy.  (k_ba_update_z with its
+// 19 of 32 lanes at C5 ran 282 us against 241 at 64 windows.)
+__global__ __launch_bounds__(BA_THREADS) void k_ba_update_z4(BaJob J, int it)
+{
+    ba_select_window(J, blockIdx.y);
+    if (*J.done) return;
+    const int nt = J.nt, nc = J.nc, nq = J.nq, tid = threadIdx.x;
+    __shared__ double sh[BA_THREADS / 64];
+    __shared__ double s_par[6 * BA_MAX_NC];
+    double ss = 0.0;
+    for (int q = tid; q < nq; q += BA_THREADS) s_par[q] = J.dc[q];
+    __syncthreads();
+    const int total = 4 * ((nt + 15) / 16) * 16;  // whole waves run the loop together (the shuffles below need their 4 partners)
+    for (int p4 = blockIdx.x * BA_THREADS + tid; p4 < total; p4 += gridDim.x * BA_THREADS) {
+        const int i = min(p4 >> 2, nt - 1), sub = p4 & 3;
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+        for (int c = 1 + sub; c <= nc; c += 4) {
+            const size_t m = (size_t)i * (nc + 1) + c;
+            const double* Jc = J.Jc + 12 * m;
+            const double* Jp = J.Jp + 6 * m;
+            const double* dq = s_par + 6 * (c - 1);
+            double su = 0.0, sv = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { su += Jc[k] * dq[k]; sv += Jc[6 + k] * dq[k]; }
+            e0 += Jp[0] * su + Jp[3] * sv; e1 += Jp[1] * su + Jp[4] * sv; e2 += Jp[2] * su + Jp[5] * sv;
+        }
+        e0 += __shfl_xor(e0, 1, 64); e1 += __shfl_xor(e1, 1, 64); e2 += __shfl_xor(e2, 1, 64);
+        e0 += __shfl_xor(e0, 2, 64); e1 += __shfl_xor(e1, 2, 64); e2 += __shfl_xor(e2, 2, 64);
+        if (sub == 0 && (p4 >> 2) < nt) {
+            const double* Lp = J.Lc + 6 * (size_t)i;  // (U+I)^-1 = L L^T, L = l00 l10 l11 l20 l21 l22
+            const double z0 = Lp[0] * e0 + Lp[1] * e1 + Lp[3] * e2, z1 = Lp[2] * e1 + Lp[4] * e2, z2 = Lp[5] * e2;  // L^T e
+            const double d0 = Lp[0] * z0, d1 = Lp[1] * z0 + Lp[2] * z1, d2 = Lp[3] * z0 + Lp[4] * z1 + Lp[5] * z2;  // L (L^T e)
+            const double d[3] = {J.tp[3 * (size_t)i] - d0, J.tp[3 * (size_t)i + 1] - d1, J.tp[3 * (size_t)i + 2] - d2};
+            for (int k = 0; k < 3; k++) {
+                const double dl = d[k] * 0.9;
+                J.x[3 * (size_t)i + k] += dl;
+                ss += dl * dl;
+            }
+        }
+    }
+    __syncthreads();  // s_par is reused for the camera parameters
+    ba_update_tail<BA_THREADS>(J, it, ss, s_par, sh);
 }
 
 // iteration record from the (all-reduced) sums of a sharded run
@@ -1986,7 +2075,9 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     { const char* e = getenv("VH_BA_DBG"); J.dbg = e ? atoi(e) : 0; }
     // one wavefront per point, grid-strided: every block ends with an atomic on one address, so keep the block count low
     const int upd_cap = J.nwin > 1 ? std::max(16, 1024 / J.nwin) : 256;
-    const int upd_blocks = std::min((use_mfma || use_syrk) ? (4 * nt + BA_THREADS - 1) / BA_THREADS : (nt + BA_THREADS / 64 - 1) / (BA_THREADS / 64), upd_cap);
+    const bool uz_latency = (long long)J.nwin * nt <= 20000;  // few points in flight: the 32-lanes-per-point kernel (one memory round trip); else every lane busy
+    const int uz_ppb = uz_latency ? 1024 / BA_UZ_LPP : BA_THREADS / 4;  // points per block and pass of k_ba_update_z / k_ba_update_z4
+    const int upd_blocks = std::min((use_mfma || use_syrk) ? (nt + uz_ppb - 1) / uz_ppb : (nt + BA_THREADS / 64 - 1) / (BA_THREADS / 64), upd_cap);
     const unsigned nw = (unsigned)J.nwin;
     auto init = [&]() -> int {
         hipLaunchKernelGGL(k_ba_init, dim3(1, nw), dim3(64), 0, s, J, flags);
@@ -2052,7 +2143,9 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
         }
         vh_prof_stop(pc, rec, VH_PROF_BA_SOLVE, s);
         rec = vh_prof_start(pc, s);
-        hipLaunchKernelGGL(k_ba_update, dim3(upd_blocks, nw), dim3(BA_THREADS), 0, s, J, it);
+        if (J.zmode && uz_latency) hipLaunchKernelGGL(k_ba_update_z<1024>, dim3(upd_blocks + 1, nw), dim3(1024), 0, s, J, it);  // (+ 1: the camera block)
+        else if (J.zmode) hipLaunchKernelGGL(k_ba_update_z4, dim3(upd_blocks, nw), dim3(BA_THREADS), 0, s, J, it);
+        else hipLaunchKernelGGL(k_ba_update, dim3(upd_blocks, nw), dim3(BA_THREADS), 0, s, J, it);
         vh_prof_stop(pc, rec, VH_PROF_BA_UPDATE, s);
     };
     switch (P.phase) {
