@@ -186,7 +186,16 @@ def large_window(ws, K64, nt, nf, iters=4, reps=4):
         best = ms if best is None else min(best, ms)
     its = max(int(info.cpu()[0, 0]), 1)
     tr = trace.cpu().numpy()[0, :, 0]
-    return dict(keyframes=nf, tracks=nt, reduced_unknowns=6 * nc, us_per_iter=round(1e3 * best / its, 1), iters_per_s=round(1e3 * its / best, 1),
+    # per-stage times of one more (profiled) solve: HIP events around every kernel inside the library
+    xd.copy_(x0d)
+    L.check(ws.lib.vh_profile_begin(ws.handle, 200), "vh_profile_begin")
+    L.check(ws.lib.vh_nls_batch_multi(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(zd), L.dptr(xd), nt, nc, 1, iters, L.dptr(trace), L.dptr(info),
+                                      L.dptr(scratch), nbytes, L.stream_ptr()), "vh_nls_batch_multi")
+    ms, n = (C.c_double * 16)(), (C.c_int * 16)()
+    L.check(ws.lib.vh_profile_end_stages(ws.handle, 16, ms, n), "vh_profile_end_stages")
+    stages = {k: round(1e3 * ms[i] / max(n[i], 1), 1) for k, i in (("jac", 8), ("schur", 9), ("reduce", 10), ("solve", 11), ("update", 12))}
+    return dict(keyframes=nf, tracks=nt, reduced_unknowns=6 * nc, us_per_iter=round(1e3 * best / its, 1), iters_per_s=round(1e3 * its / best, 1), stages_us=stages,
+                syrk_flop_per_iter=float((-(-6 * nc // 128)) * (-(-6 * nc // 128) + 1) // 2) * 128 * 128 * 3 * nt * 2,
                 rms_residual_first=round(float(tr[0]), 4), rms_residual_last=round(float(tr[its - 1]), 4), workspace_mb=round(nbytes / 2 ** 20, 1))
 
 

@@ -116,4 +116,6 @@ for s in 1 8 64; do
 done
 # VALU issue rates per instruction class
 timeout 600 $R/tools/ubench/valu_rate > $OUT/valu_rate.json 2> $OUT/valu_rate.err
+# f64 MFMA next to LDS operand reads (the step structure of k_ba_syrk_mfma / k_ba_chol_left)
+[ -x $R/tools/ubench/mfma_lds ] && timeout 120 $R/tools/ubench/mfma_lds > $OUT/mfma_lds.json 2> $OUT/mfma_lds.err
 du -sh $OUT; tail -2 $OUT/bench_default.err; ls $OUT | head -60

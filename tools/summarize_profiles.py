@@ -109,6 +109,15 @@ if lk_sq:
               open(os.path.join(DST, f"{tag}_lk_sq_pmc.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(DST, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 
+ml = os.path.join(SRC, "mfma_lds.json")
+if os.path.exists(ml) and os.path.getsize(ml) > 10:
+    try:
+        rows = [r for r in json.load(open(ml)) if r]
+        json.dump(dict(_comment="tools/ubench/mfma_lds.hip on one MI355X: one wavefront per SIMD, steps of R ds_read_b64 (operands of the NEXT step) then M independent "
+                                "v_mfma_f64_16x16x4_f64; ns / cycles per MFMA.  Alone: ~68 cycles; a step costs ~30 ns more than its MFMAs whatever R is",
+                       rows=rows), open(os.path.join(DST, f"{tag}_mfma_lds.json"), "w"), indent=1)
+    except Exception as e:
+        print("mfma_lds:", e)
 # BA by free cameras
 bc = os.path.join(SRC, "ba_by_cameras.jsonl")
 if os.path.exists(bc):

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_jac(BaJob J)
         if (t != 0.0) atomicAdd(J.rslot + (blockIdx.x & 15), t);
     }
     // coalesced write-out of the block's contiguous spans: r [2 x nval], Jp [6 x nval], Jc [12 x nval] doubles
+    // (round 5 ablation, one C5 window: 17.1 us in all = 6.1 launch / LDS / atomics + 1 arithmetic + 8.6 the 16 MB of stores and their write-back + 1.4 the tail below)
     const size_t m0 = (size_t)i0 * nf;
     const int nval = npts * nf;
     const int tid = threadIdx.x;
@@ -945,7 +946,10 @@ __global__ __launch_bounds__(256, 2) void k_ba_syrk_mfma(BaJob J, int nm)
 // entries; each of its 4 wavefronts sums a fixed slice of the partials (512-byte coalesced reads, 8 in flight), then the
 // slices are combined in a fixed order (deterministic).
 // nparts_r / ndpart (43+ cameras): partial right-hand sides and partial diagonal blocks V_c of the k_ba_zbuild workgroups (otherwise nparts and 0)
-__global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts, int nparts_r, int ndpart)
+// NS = slices (wavefronts) per block: 4, or 16 when a window has many partials (one C5 window: 256 -- a wavefront then sums 16 of them in two rounds of
+// eight loads in flight instead of 64 in eight rounds: the kernel is bound by those dependent round trips, not by its 19 MB)
+template <int NS>
+__global__ __launch_bounds__(64 * NS) void k_ba_reduce(BaJob J, int nparts, int nparts_r, int ndpart)
 {
     ba_select_window(J, blockIdx.y);
     if (*J.done) return;
@@ -953,7 +957,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts, i
     const long long nent = (long long)nq * nq, ntot = nent + nq;
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const long long e = (long long)blockIdx.x * 64 + lane;
-    __shared__ double sh[BA_THREADS / 64][64];
+    __shared__ double sh[NS][64];
     double s = 0.0;
     // zmode: only the tiles with tile(row) <= tile(col) were written; the owners of those entries also write the mirrored one, the
     // entries below do nothing (reading the partials transposed instead cost 3.5x the kernel)
@@ -963,7 +967,6 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts, i
         lower = (a >> 4) > (b >> 4);
     }
     if (e < ntot && !lower) {
-        constexpr int NS = BA_THREADS / 64;
         const int np = e < nent ? nparts : nparts_r;
         const int per = (np + NS - 1) / NS, p0 = slice * per, p1 = min(np, p0 + per);
         const double* src = e < nent ? J.Spart + e : J.Rpart + (e - nent);
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_reduce(BaJob J, int nparts, i
     __syncthreads();
     if (slice == 0 && e < ntot && !lower) {
         double t = 0.0;
-        for (int k = 0; k < BA_THREADS / 64; k++) t += sh[k][lane];
+        for (int k = 0; k < NS; k++) t += sh[k][lane];
         if (e < nent) {
             const int a = (int)(e / nq), b = (int)(e - (long long)a * nq);
             J.Sfull[(size_t)a * ld + b] = t + ((a == b && J.add_identity) ? 1.0 : 0.0);  // sharded runs: rank 0 adds the +I
@@ -2117,7 +2120,8 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
             vh_prof_stop(pc, rec, VH_PROF_BA_SCHUR, s);
         }
         const int rec = vh_prof_start(pc, s);
-        hipLaunchKernelGGL(k_ba_reduce, dim3((unsigned)((nent + nq + 63) / 64), nw), dim3(BA_THREADS), 0, s, J, nsplit, use_syrk ? nzb : nsplit, use_syrk ? nzb : 0);
+        if (nsplit >= 128) hipLaunchKernelGGL(k_ba_reduce<16>, dim3((unsigned)((nent + nq + 63) / 64), nw), dim3(1024), 0, s, J, nsplit, use_syrk ? nzb : nsplit, use_syrk ? nzb : 0);
+        else hipLaunchKernelGGL(k_ba_reduce<4>, dim3((unsigned)((nent + nq + 63) / 64), nw), dim3(256), 0, s, J, nsplit, use_syrk ? nzb : nsplit, use_syrk ? nzb : 0);
         vh_prof_stop(pc, rec, VH_PROF_BA_REDUCE, s);
     };
     auto solve_update = [&](int it) {
