@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(const void* pb_tab, size_t ws_
     if (lvl + 1 >= P.nlevels) return;
     const ImgDesc s = P.lv[lvl];
     const ImgDesc d = P.lv[lvl + 1];
-    const int ox0 = (int)(bx * 64 + threadIdx.x) * 4, oy0 = (int)(by * 4 + threadIdx.y) * RB;
+    const int ox0 = (int)(bx * blockDim.x + threadIdx.x) * 4, oy0 = (int)(by * blockDim.y + threadIdx.y) * RB;
     if (oy0 >= d.h) return;            // wave-uniform
     const bool live = ox0 < d.w;       // dead lanes stay for the DPP exchange, they load and store nothing
     const int sx0 = 2 * ox0 - 2, cnt = min(4, d.w - ox0);
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(const void* pb_tab, size_t ws_
     const bool left = ox0 == 0, right = sx0 + 16 > s.w;     // right: the 16-byte read passes the end of the row
     const bool dwords = live && wide;
     // an interior lane always loads its own 8 bytes: only such a right neighbour can provide my second half
-    const bool next_interior = threadIdx.x != 63 && ox0 + 4 < d.w && sx0 + 8 + 16 <= s.w;
+    const bool next_interior = threadIdx.x != blockDim.x - 1 && ox0 + 4 < d.w && sx0 + 8 + 16 <= s.w;  // (lane + 1 is my right neighbour only inside a block row)
     const bool own_ext = dwords && !next_interior;
     // per-lane byte selectors: stream position p takes position src(p) (mirror about column 0 / column w-1)
     unsigned sel0 = 0x03020100u, sel1 = 0x07060504u, sel2 = 0x07060504u;
@@ -602,20 +602,23 @@ void vh_launch_pyr_down_ws(const void* pb_tab, size_t ws_stride, int batch, int 
     // dims of level lvl+1 when level 0 is max_w0 x max_h0
     int w = max_w0, h = max_h0;
     for (int l = 0; l <= lvl; l++) { w = (w + 1) / 2; h = (h + 1) / 2; }
-    dim3 blk(64, 4);
+    // 64 x 4 threads: a wavefront is ONE row of 256 output pixels.  Wavefronts of 16 x 4 or 32 x 2 threads (fewer idle lanes in the last column of
+    // workgroups: 818 output pixels are 3.2 wavefronts of 256) measured SLOWER -- 451 / 454 against 405 us for pyrDown + rings at 256 streams: a
+    // thread's 19 source rows are shared with no other row of its wavefront, and narrower row segments coalesce worse
+    const dim3 blk(64, 4);
     // 8 output rows per thread (19 source rows in flight, 136 VGPRs) once a launch is far beyond the chip (19 rows read per 16 produced instead of
     // 11 per 8: 271 -> 250 us for the 766 x 451 level of 256 streams; no gain below), 4 rows from ~1 Mpx, 2 for single-stream latency
     const long long px = (long long)w * h * batch;
     const int forced_rows = g_pyr_rows.load(std::memory_order_relaxed);
     const int rb = forced_rows ? forced_rows : (px >= (1ll << 25) ? 8 : px >= (1ll << 20) ? 4 : 2);
     if (rb == 8) {
-        dim3 grd((w + 255) / 256, (h + 31) / 32, batch * 2);
+        dim3 grd((w + 4 * blk.x - 1) / (4 * blk.x), (h + 8 * blk.y - 1) / (8 * blk.y), batch * 2);
         hipLaunchKernelGGL(k_pyr_down<8>, grd, blk, 0, s, pb_tab, ws_stride, lvl);
     } else if (rb == 4) {
-        dim3 grd((w + 255) / 256, (h + 15) / 16, batch * 2);
+        dim3 grd((w + 4 * blk.x - 1) / (4 * blk.x), (h + 4 * blk.y - 1) / (4 * blk.y), batch * 2);
         hipLaunchKernelGGL(k_pyr_down<4>, grd, blk, 0, s, pb_tab, ws_stride, lvl);
     } else {
-        dim3 grd((w + 255) / 256, (h + 7) / 8, batch * 2);
+        dim3 grd((w + 4 * blk.x - 1) / (4 * blk.x), (h + 2 * blk.y - 1) / (2 * blk.y), batch * 2);
         hipLaunchKernelGGL(k_pyr_down<2>, grd, blk, 0, s, pb_tab, ws_stride, lvl);
     }
     // border ring of the new level when it is a small one (decided per image on the device).  The launch covers the worst small level inside w x h:
@@ -632,6 +635,10 @@ void vh_launch_pyr_down_ws(const void* pb_tab, size_t ws_stride, int batch, int 
 
 void vh_launch_roi_warp(const void* job_tab, size_t tab_stride, int batch, int max_w, int max_h, hipStream_t s)
 {
-    dim3 blk(64, 4), grd((max_w + 64 * RW_PX - 1) / (64 * RW_PX), (max_h + 4 * RW_ROWS * RW_LOOP - 1) / (4 * RW_ROWS * RW_LOOP), batch);
+    // 16 x 16 threads: a wavefront covers 4 consecutive ROI rows of 128 pixels, so the bottom source row of one thread row is the top source row of
+    // the next INSIDE the wavefront (one L1 fetch instead of two) and the last column of workgroups idles 28 of 1636 pixels instead of 412.  Measured at
+    // 256 streams (A/B on one box): 64 x 4 threads (one 512-pixel row per wavefront) 370 us, 32 x 8 375, 16 x 16 301, 16 x 8 292-302, 8 x 32 305
+    const dim3 blk(16, 16);
+    const dim3 grd((max_w + blk.x * RW_PX - 1) / (blk.x * RW_PX), (max_h + blk.y * RW_ROWS * RW_LOOP - 1) / (blk.y * RW_ROWS * RW_LOOP), batch);
     hipLaunchKernelGGL(k_roi_warp, grd, blk, 0, s, job_tab, tab_stride);
 }
