@@ -1359,7 +1359,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
     if ((int)blk_x >= n) return;
-    const int pt = job.order ? job.order[blk_x] : (int)blk_x;  // launch slot -> point (LKJob::order)
+    // the point index and the start position are workgroup uniform and live until the epilogue: as SCALARS (the loads below come back in vector registers,
+    // and hipcc then parks them in scratch for the length of the kernel: 7 spilled registers, 28 bytes of scratch traffic per lane and track)
+    const int pt = __builtin_amdgcn_readfirstlane(job.order ? job.order[blk_x] : (int)blk_x);  // launch slot -> point (LKJob::order)
     const int tid = threadIdx.x;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int max_count = job.max_count;
@@ -1367,8 +1369,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
     const float fbt = job.fbt;
 
     const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];
-    const float px = __fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]);
-    const float py = __fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]);
+    const float px = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]))));
+    const float py = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]))));
 
     // forward pass, then (fbt >= 0) the backward pass from its result: ONE copy of the track code in a loop over the direction -- two inlined copies
     // doubled the kernel and recomputed the per-lane mapping / masks of lk3_level in each
