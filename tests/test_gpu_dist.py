@@ -76,14 +76,17 @@ def test_sharded_ba_with_30_cameras_world2(tmp_path):
         "from velocity_amd.dist import fcnNLS_batch_sharded\n"
         "g = np.load(os.path.join(os.environ['VH_REPO'], 'tests', 'golden', 'nls_golden.npz'))\n"
         "P, pw0, cw0 = synth.ba_scene(150, 31, seed=91)\n"
-        "cw2, pw2, tr2 = fcnNLS_batch_sharded(g['K32'], P.copy(), pw0, cw0)\n"
         "import io, contextlib\n"
         "with contextlib.redirect_stdout(io.StringIO()):\n"
         "    cw, pw, x, tr = fcnNLS_batch(g['K32'], P.copy(), pw0, cw0, return_info=True)\n"
-        "assert len(tr2) == len(tr)\n"
-        "np.testing.assert_allclose(tr2[:, 0], tr[:, 0], rtol=1e-8)\n"
-        "np.testing.assert_allclose(cw2, cw, rtol=1e-6, atol=1e-7)\n"
-        "np.testing.assert_allclose(pw2, pw, rtol=1e-6, atol=1e-7)\n"
+        # repeated: two processes share the device here, so workgroups start late at random -- the left-looking Cholesky of round 5 once wrote a diagonal
+        # factor block over entries a late workgroup had still to read, and ~30 % of single solves took another LM path (tools/exp/ba_sharded_repeat.py)
+        "for rep in range(12):\n"
+        "    cw2, pw2, tr2 = fcnNLS_batch_sharded(g['K32'], P.copy(), pw0, cw0)\n"
+        "    assert len(tr2) == len(tr), rep\n"
+        "    np.testing.assert_allclose(tr2[:, 0], tr[:, 0], rtol=1e-8, err_msg=f'repetition {rep}')\n"
+        "    np.testing.assert_allclose(cw2, cw, rtol=1e-6, atol=1e-7)\n"
+        "    np.testing.assert_allclose(pw2, pw, rtol=1e-6, atol=1e-7)\n"
     )
     _run_ranks(tmp_path, body, world=2)
 

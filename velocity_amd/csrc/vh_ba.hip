@@ -1624,10 +1624,13 @@ __global__ __launch_bounds__(256) void k_ba_chol_left(BaJob J, int k0)
         }
     }
     __syncthreads();
+    // The factor of the diagonal block goes to a block array of its own (J.Spart is free once k_ba_reduce has run), NOT back into A: every workgroup of
+    // this launch reads the ORIGINAL block from A, and a workgroup that starts late -- another process's kernels on the device are enough -- would find
+    // workgroup 0's factor there instead (a race the point-sharded two-rank test hit in ~30 % of its runs).  k_ba_chol_back reads the blocks from here.
     if (blockIdx.x == 0)
         for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += 256) {
             const int i = e / BA_CH_NB, j = e - i * BA_CH_NB;
-            if (i < nb && j <= i) A[(size_t)(k0 + i) * ld + k0 + j] = sD[i][j];
+            J.Spart[(size_t)k0 * BA_CH_NB + e] = (i < nb && j <= i) ? sD[i][j] : (i == j ? 1.0 : 0.0);
         }
     // own rows: v <- v L_D^-T, one thread per row, right-looking (see k_ba_chol_panel)
     if (tid < cnt) {
@@ -1656,7 +1659,7 @@ __global__ __launch_bounds__(256) void k_ba_chol_left(BaJob J, int k0)
 // L^T dc = y, from the last panel to the first (one workgroup of 1024 threads: the product over the rows below a panel is split 32 ways -- with 8 slices of
 // 256 threads a thread walked up to 92 rows of dependent loads, 160 us per solve at 768 unknowns)
 #define BA_CB_THREADS 1024
-__global__ __launch_bounds__(BA_CB_THREADS) void k_ba_chol_back(BaJob J)
+__global__ __launch_bounds__(BA_CB_THREADS) void k_ba_chol_back(BaJob J, int blocks_apart)
 {
     ba_select_window(J, blockIdx.y);
     if (*J.done) return;
@@ -1687,7 +1690,8 @@ __global__ __launch_bounds__(BA_CB_THREADS) void k_ba_chol_back(BaJob J)
         sT[part][j] = (a0 + a1) + (a2 + a3);
         for (int e = tid; e < BA_CH_NB * BA_CH_NB; e += BA_CB_THREADS) {
             const int i = e / BA_CH_NB, jj = e - i * BA_CH_NB;
-            sD[i][jj] = (i < nb && jj <= i) ? A[(size_t)(k0 + i) * ld + k0 + jj] : (i == jj ? 1.0 : 0.0);
+            // diagonal factor blocks: in their own array after k_ba_chol_left (see there), in place after the right-looking kernels
+            sD[i][jj] = blocks_apart ? J.Spart[(size_t)k0 * BA_CH_NB + e] : ((i < nb && jj <= i) ? A[(size_t)(k0 + i) * ld + k0 + jj] : (i == jj ? 1.0 : 0.0));
         }
         __syncthreads();
         if (tid < BA_CH_NB) {
@@ -2143,7 +2147,7 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
                 const int r0 = std::min(nq, k0 + BA_CH_NB), ntile = (nq - r0 + BA_CH_NB - 1) / BA_CH_NB;
                 if (ntile > 0) hipLaunchKernelGGL(k_ba_chol_update, dim3(ntile + 1, ntile, nw), dim3(256), 0, s, J, k0);
             }
-            hipLaunchKernelGGL(k_ba_chol_back, dim3(1, nw), dim3(BA_CB_THREADS), sizeof(double) * (size_t)nq, s, J);
+            hipLaunchKernelGGL(k_ba_chol_back, dim3(1, nw), dim3(BA_CB_THREADS), sizeof(double) * (size_t)nq, s, J, (J.dbg & 256) ? 0 : 1);
         }
         vh_prof_stop(pc, rec, VH_PROF_BA_SOLVE, s);
         rec = vh_prof_start(pc, s);

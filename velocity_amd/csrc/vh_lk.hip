@@ -933,10 +933,13 @@ struct LK3 {
     static constexpr int OFF_PI = 0;
     static constexpr int OFF_PJ = OFF_PI + (PI_ROWS + PAD_ROWS) * PI_PITCH + 8;
     static constexpr int OFF_RED = ((OFF_PJ + (RJ + PAD_ROWS) * PJ_PITCH + 16 + 15) / 16) * 16;
-    static constexpr int LDS_BYTES = OFF_RED + 2 * NW * 4 * 8;
+    static constexpr int MAX_TPW = 8;                           // launch slots one workgroup may solve one after the other (k_lk3)
+    static constexpr int OFF_RES = OFF_RED + 2 * NW * 4 * 8;   // their result records (8 dwords each), written out after the last one
+    static constexpr int LDS_BYTES = OFF_RES + MAX_TPW * 32;
 };
 
 typedef const uint2 __attribute__((address_space(1)))* gptr_u32x2;
+typedef int __attribute__((address_space(3)))* lds_i32;
 
 // stage ROWS x PITCH bytes of image `im` starting at pixel (rx, ry) into LDS (region-aligned rows).  Compile-time
 // extents: the loop is fully unrolled and every global load of the batch is issued before the first LDS store, so a
@@ -1352,21 +1355,30 @@ __device__ __forceinline__ void lk3_track(const PyrDesc& PI, const PyrDesc& PJ, 
 // (forcing 5 or 6 workgroups per CU through the second launch bound spills and measured 3-8 % slower; a 128-VGPR cap
 // + a 3-pixel search margin to fit 7 workgroups of the 2-wave variant per CU: 11 spilled registers, 5 % slower: not used)
 template <int WIN, int NW, int M>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? 3 : 4))) void k_lk3(const void* job_tab, size_t tab_stride, unsigned grp)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? 3 : 4))) void k_lk3(const void* job_tab, size_t tab_stride, unsigned grp, unsigned tpw)
 {
-    unsigned blk_x, blk_y;
-    lk_block_xy<true>(blk_x, blk_y, grp);
+    unsigned blk_x0, blk_y0;
+    lk_block_xy<true>(blk_x0, blk_y0, grp);
+    const unsigned blk_x = (unsigned)__builtin_amdgcn_readfirstlane((int)blk_x0), blk_y = (unsigned)__builtin_amdgcn_readfirstlane((int)blk_y0);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int phase = 0, tot_iter = 0, tot_setup = 0;
+    unsigned ndone = 0;
+    // A workgroup solves `tpw` consecutive launch slots one after the other (tracks that are neighbours in the launch order): fewer, longer-lived
+    // workgroups.  Everything but the slot counter is re-derived per track (scalar loads of the job descriptor): values kept live across the loop cost
+    // scalar registers the track code spills
+#pragma unroll 1
+    for (unsigned ti = 0; ti < tpw; ti++) {
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = job.n_ptr ? *job.n_ptr : job.n;
-    if ((int)blk_x >= n) return;
-    // the point index and the start position are workgroup uniform and live until the epilogue: as SCALARS (the loads below come back in vector registers,
-    // and hipcc then parks them in scratch for the length of the kernel: 7 spilled registers, 28 bytes of scratch traffic per lane and track)
-    const int pt = __builtin_amdgcn_readfirstlane(job.order ? job.order[blk_x] : (int)blk_x);  // launch slot -> point (LKJob::order)
+    const unsigned slot = blk_x * tpw + ti;
+    if ((int)slot >= n) break;
     const int tid = threadIdx.x;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int max_count = job.max_count;
     const double eps2 = job.eps2;
     const float fbt = job.fbt;
+    // the point index and the start position are workgroup uniform and live until the epilogue: as SCALARS (the loads below come back in vector registers,
+    // and hipcc then parks them in scratch for the length of the kernel: 7 spilled registers, 28 bytes of scratch traffic per lane and track)
+    const int pt = __builtin_amdgcn_readfirstlane(job.order ? job.order[slot] : (int)slot);  // launch slot -> point (LKJob::order)
 
     const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];
     const float px = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]))));
@@ -1375,7 +1387,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
     // forward pass, then (fbt >= 0) the backward pass from its result: ONE copy of the track code in a loop over the direction -- two inlined copies
     // doubled the kernel and recomputed the per-lane mapping / masks of lk3_level in each
     float fx = 0.f, fy = 0.f, err = 0.f, bx = 0.f, by = 0.f;
-    int st = 0, st2 = 0, n_iter = 0, n_setup = 0, phase = 0;
+    int st = 0, st2 = 0, n_iter = 0, n_setup = 0;
     const int ndir = fbt >= 0.f ? 2 : 1;
     const bool want_err = job.err_out != nullptr;
 #pragma unroll 1
@@ -1395,7 +1407,27 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
         fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
         st = st && st2 && (fbe < fbt);
     }
+    // the track's results wait in LDS: a global store inside this loop would make every descriptor load of the NEXT track a possibly-clobbered load,
+    // i.e. a vector load instead of a scalar one (the same effect as the volatile asm of DESIGN.md section 9)
     if (tid == 0) {
+        // (an explicit LDS pointer: through a generic one hipcc counts these stores as possible writes to the job descriptors too)
+        lds_i32 rec = (lds_i32)(smem + LK3<WIN, NW, M>::OFF_RES) + 8 * ti;
+        rec[0] = pt; rec[1] = __float_as_int(fx); rec[2] = __float_as_int(fy); rec[3] = st != 0;
+        rec[4] = __float_as_int(err); rec[5] = __float_as_int(fbe);
+    }
+    tot_iter += n_iter; tot_setup += n_setup;
+    ndone = ti + 1;
+    // The LAST memory operation of the loop body must not be a plain store: hipcc's scalar-load test (is a load clobbered anywhere in the function?) takes
+    // whatever definition reaches the loop header over the back edge at face value when it is a store -- LDS or not -- and only looks through fences
+    // and barriers with alias analysis.  With the record stores last, every descriptor load of the track code became a vector load.
+    __syncthreads();
+    }
+    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
+    if (threadIdx.x < ndone) {
+        const int* rec = reinterpret_cast<const int*>(smem + LK3<WIN, NW, M>::OFF_RES) + 8 * threadIdx.x;
+        const int pt = rec[0];
+        const float fx = __int_as_float(rec[1]), fy = __int_as_float(rec[2]), err = __int_as_float(rec[4]), fbe = __int_as_float(rec[5]);
+        const int st = rec[3];
         float ox, oy;
         if (job.out_mode == VH_OUT_SCALE) {
             ox = __fdiv_rn(fx, job.out_scale);
@@ -1416,10 +1448,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
         if (job.err_out) job.err_out[pt] = err;
         if (job.fbe_out) job.fbe_out[pt] = fbe;
         if (job.praw_out) { job.praw_out[2 * pt] = fx; job.praw_out[2 * pt + 1] = fy; }
-        if (job.stats) {
-            atomicAdd(&job.stats[0], (unsigned long long)n_iter);
-            atomicAdd(&job.stats[1], (unsigned long long)n_setup);
-        }
+    }
+    if (threadIdx.x == 0 && job.stats && ndone) {
+        atomicAdd(&job.stats[0], (unsigned long long)tot_iter);
+        atomicAdd(&job.stats[1], (unsigned long long)tot_setup);
     }
 }
 
@@ -2168,7 +2200,14 @@ static int launch_lk3(const void* job_tab, size_t tab_stride, int batch, int max
     static const int pad = [] { const char* e = getenv("VH_LK_LDS_PAD"); return e ? atoi(e) : 0; }();
     const int lds = LK3<WIN, NW, M>::LDS_BYTES + pad;
     static const unsigned grp = getenv("VH_LK3_G") ? (unsigned)atoi(getenv("VH_LK3_G")) : 16u;  // (environment: experiments only)
-    hipLaunchKernelGGL((k_lk3<WIN, NW, M>), dim3(max_n, batch), dim3(64 * NW), lds, s, job_tab, tab_stride, lk_group_arg(grp, batch));
+    // Launch slots per workgroup (one-wavefront kernel): a 51 x 51 track keeps a workgroup for ~22 us, and starting one (dispatch, LDS allocation, the block
+    // remap, the first descriptor loads) is not free: 4 consecutive slots per workgroup measured 3620 -> 3520 us per launch at 512 000 tracks (2: 3580,
+    // 8: 3545; A/B on one box).  Only where the launch still has many workgroups per resident slot (256 CUs x 12): below that the tail would cost more.
+    static const int tpw_env = getenv("VH_LK3_TPW") ? atoi(getenv("VH_LK3_TPW")) : 0;  // (environment: experiments only)
+    const long long tracks = (long long)max_n * batch;
+    const int tpw_auto = NW != 1 ? 1 : tracks >= 98304 ? 4 : tracks >= 49152 ? 2 : 1;
+    const unsigned tpw = (unsigned)std::min(NW == 1 && tpw_env > 0 ? tpw_env : tpw_auto, LK3<WIN, NW, M>::MAX_TPW);
+    hipLaunchKernelGGL((k_lk3<WIN, NW, M>), dim3((max_n + tpw - 1) / tpw, batch), dim3(64 * NW), lds, s, job_tab, tab_stride, lk_group_arg(grp, batch), tpw);
     return 0;
 }
 

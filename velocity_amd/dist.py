@@ -186,13 +186,18 @@ def fcnNLS_batch_sharded(K, P, pw, cw, max_iter=10, group=None, timing=None):
     if timing is not None:
         ev0, ev1 = tc.cuda.Event(enable_timing=True), tc.cuda.Event(enable_timing=True)
         ev0.record()
+    dbg_sync = bool(os.environ.get("VH_AR_SYNC"))
     for it in range(max_iter):
         phase(1, it)
         if collective:
+            if dbg_sync: tc.cuda.synchronize()
             dist.all_reduce(span, group=group)
+            if dbg_sync: tc.cuda.synchronize()
         phase(2, it)
         if collective:
+            if dbg_sync: tc.cuda.synchronize()
             dist.all_reduce(sum_delta, group=group)
+            if dbg_sync: tc.cuda.synchronize()
         phase(3, it)
     if timing is not None:
         ev1.record()
