@@ -59,6 +59,13 @@ __global__ __launch_bounds__(256) void k_resize_quarter(const void* src_tab, con
 // ---------------------------------------------------------------------------------------------------------------
 typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
 typedef const unsigned __attribute__((address_space(1)))* pd_gptr;
+typedef const PyrDesc __attribute__((address_space(1)))* pd_gdesc;
+__device__ __forceinline__ ImgDesc pd_level(pd_gdesc P, int l)
+{
+    ImgDesc d;
+    d.p = P->lv[l].p; d.w = P->lv[l].w; d.h = P->lv[l].h; d.stride = P->lv[l].stride; d.pad = P->lv[l].pad;
+    return d;
+}
 
 struct PdRow { unsigned s0, s1, s2; };  // source bytes sx0 .. sx0+11 of one row
 
@@ -109,10 +116,12 @@ __global__ __launch_bounds__(256) void k_pyr_down(const void* pb_tab, size_t ws_
     const unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     const PyrBuild& pb = reinterpret_cast<const PyrBuild*>(reinterpret_cast<const char*>(pb_tab) + (size_t)(bz >> 1) * ws_stride)[bz & 1];
     if (!pb.enable || pb.pyr == nullptr) return;
-    const PyrDesc& P = *pb.pyr;
-    if (lvl + 1 >= P.nlevels) return;
-    const ImgDesc s = P.lv[lvl];
-    const ImgDesc d = P.lv[lvl + 1];
+    // the pyramid descriptor hangs off a pointer that was itself loaded: as a GLOBAL pointer its fields come through the scalar cache (a generic one made
+    // every wavefront start with a chain of three dependent flat loads before its first image row was requested -- of a workgroup that lives ~6 us)
+    const pd_gdesc Pg = (pd_gdesc)pb.pyr;
+    if (lvl + 1 >= Pg->nlevels) return;
+    const ImgDesc s = pd_level(Pg, lvl);
+    const ImgDesc d = pd_level(Pg, lvl + 1);
     const int ox0 = (int)(bx * blockDim.x + threadIdx.x) * 4, oy0 = (int)(by * blockDim.y + threadIdx.y) * RB;
     if (oy0 >= d.h) return;            // wave-uniform
     const bool live = ox0 < d.w;       // dead lanes stay for the DPP exchange, they load and store nothing
@@ -566,9 +575,9 @@ __global__ __launch_bounds__(256) void k_pyr_pad(const void* pb_tab, size_t ws_s
 {
     const PyrBuild& pb = reinterpret_cast<const PyrBuild*>(reinterpret_cast<const char*>(pb_tab) + (size_t)(blockIdx.z >> 1) * ws_stride)[blockIdx.z & 1];
     if (!pb.enable || pb.pyr == nullptr) return;
-    const PyrDesc& P = *pb.pyr;
-    if (lvl + 1 >= P.nlevels) return;
-    const ImgDesc d = P.lv[lvl + 1];
+    const pd_gdesc Pg = (pd_gdesc)pb.pyr;  // (global, not generic: scalar loads, see k_pyr_down)
+    if (lvl + 1 >= Pg->nlevels) return;
+    const ImgDesc d = pd_level(Pg, lvl + 1);
     const int B = d.pad;
     if (B <= 0) return;
     const int wq = (d.w + 2 * B + 3) >> 2;        // dwords of a full-width ring row (columns -B .. w+B-1, rounded up: the pitch has 4 spare bytes)

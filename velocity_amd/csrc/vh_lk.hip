@@ -19,6 +19,13 @@
 
 // (float)v for |v| < 2^53 with ONE rounding: hi * 2^32 + lo is exact in float64, the final conversion rounds once --
 // identical to the int64 -> float32 conversion, in 5 instructions instead of the compiler's ~15-instruction sequence
+// The per-track inputs of a launch (count, launch order, start points) hang off pointers that were themselves loaded from the job descriptor: read through a
+// GLOBAL pointer (where the address is workgroup uniform they then come through the scalar cache), not through the generic one hipcc assumes -- a
+// workgroup otherwise starts with a chain of three dependent flat loads before its first image row is requested
+typedef const int __attribute__((address_space(1)))* gptr_i32;
+typedef const float __attribute__((address_space(1)))* gptr_f32;
+#define LK_N_OF(job) ((job).n_ptr ? *(gptr_i32)(job).n_ptr : (job).n)
+
 __device__ __forceinline__ float i64_to_f32(long long v)
 {
     const double d = __dadd_rn(__dmul_rn((double)(int)(v >> 32), 4294967296.0), (double)(unsigned)(v & 0xffffffffll));
@@ -232,7 +239,7 @@ __device__ void lk_track(const PyrDesc& PI, const PyrDesc& PJ, int win, int max_
 __global__ __launch_bounds__(64) void k_lk(const void* job_tab, size_t tab_stride)
 {
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
-    const int n = job.n_ptr ? *job.n_ptr : job.n;
+    const int n = LK_N_OF(job);
     if ((int)blockIdx.x >= n) return;
     const int pt = job.order ? job.order[blockIdx.x] : (int)blockIdx.x;  // launch slot -> point (LKJob::order)
     const int lane = threadIdx.x;
@@ -833,7 +840,7 @@ __global__ __launch_bounds__(64) void k_lk_strip(const void* job_tab, size_t tab
     unsigned blk_x, blk_y;
     lk_block_xy<false>(blk_x, blk_y);
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
-    const int n = job.n_ptr ? *job.n_ptr : job.n;
+    const int n = LK_N_OF(job);
     if ((int)blk_x >= n) return;
     const int pt = job.order ? job.order[blk_x] : (int)blk_x;  // launch slot -> point (LKJob::order)
     const int lane = threadIdx.x;
@@ -1369,7 +1376,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
 #pragma unroll 1
     for (unsigned ti = 0; ti < tpw; ti++) {
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
-    const int n = job.n_ptr ? *job.n_ptr : job.n;
+    const int n = LK_N_OF(job);
     const unsigned slot = blk_x * tpw + ti;
     if ((int)slot >= n) break;
     const int tid = threadIdx.x;
@@ -1378,9 +1385,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
     const float fbt = job.fbt;
     // the point index and the start position are workgroup uniform and live until the epilogue: as SCALARS (the loads below come back in vector registers,
     // and hipcc then parks them in scratch for the length of the kernel: 7 spilled registers, 28 bytes of scratch traffic per lane and track)
-    const int pt = __builtin_amdgcn_readfirstlane(job.order ? job.order[slot] : (int)slot);  // launch slot -> point (LKJob::order)
+    const int pt = __builtin_amdgcn_readfirstlane(job.order ? ((gptr_i32)job.order)[slot] : (int)slot);  // launch slot -> point (LKJob::order)
 
-    const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];
+    const float qx = ((gptr_f32)job.p_in)[2 * pt], qy = ((gptr_f32)job.p_in)[2 * pt + 1];
     const float px = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]))));
     const float py = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]))));
 
@@ -1763,13 +1770,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
     unsigned blk_x, blk_y;
     lk_block_xy<true>(blk_x, blk_y, grp);
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
-    const int n = job.n_ptr ? *job.n_ptr : job.n;
+    const int n = LK_N_OF(job);
     const int slot = (int)blk_x * 4 + (threadIdx.x >> 4);
     if (slot >= n) return;
-    const int pt = job.order ? job.order[slot] : slot;  // launch slot -> point (LKJob::order)  // whole 16-lane rows leave together
+    const int pt = job.order ? ((gptr_i32)job.order)[slot] : slot;  // launch slot -> point (LKJob::order)  // whole 16-lane rows leave together
     const int r = threadIdx.x & 15;
 
-    const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];
+    const float qx = ((gptr_f32)job.p_in)[2 * pt], qy = ((gptr_f32)job.p_in)[2 * pt + 1];
     const float px = __fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]);
     const float py = __fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]);
 
@@ -2127,13 +2134,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     unsigned blk_x, blk_y;
     lk_block_xy<true>(blk_x, blk_y, grp);
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
-    const int n = job.n_ptr ? *job.n_ptr : job.n;
+    const int n = LK_N_OF(job);
     const int slot = (int)blk_x * 8 + (threadIdx.x >> 3);
     if (slot >= n) return;  // whole 8-lane groups leave together
-    const int pt = job.order ? job.order[slot] : slot;  // launch slot -> point (LKJob::order)
+    const int pt = job.order ? ((gptr_i32)job.order)[slot] : slot;  // launch slot -> point (LKJob::order)
     const int r = threadIdx.x & 7;
 
-    const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];
+    const float qx = ((gptr_f32)job.p_in)[2 * pt], qy = ((gptr_f32)job.p_in)[2 * pt + 1];
     const float px = __fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]);
     const float py = __fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]);
 
