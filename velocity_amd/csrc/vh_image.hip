@@ -18,31 +18,46 @@ __device__ __forceinline__ const ImgDesc& desc_at(const void* base, size_t strid
 // one thread = 4 consecutive output pixels (one packed dword store when the row is aligned)
 // ---------------------------------------------------------------------------------------------------------------
 // Descriptor tables: entry z belongs to stream z / per_stream and is its (z % per_stream)-th descriptor.
+#define RQ_ROWS 4  // output rows per thread: a thread's whole work used to be one 16-byte load and one dword store -- workgroups that live ~1 us
 __global__ __launch_bounds__(256) void k_resize_quarter(const void* src_tab, const void* dst_tab, size_t tab_stride, int per_stream)
 {
     const int b = blockIdx.z / per_stream, k = blockIdx.z - b * per_stream;
     const ImgDesc s = desc_at(reinterpret_cast<const ImgDesc*>(src_tab) + k, tab_stride, b);
     const ImgDesc d = desc_at(reinterpret_cast<const ImgDesc*>(dst_tab) + k, tab_stride, b);
-    int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (y >= d.h || x4 >= d.w) return;
-    int sy = min(4 * y, s.h - 1);
-    const uint8_t* srow = s.p + (size_t)sy * s.stride;
-    uint8_t* drow = const_cast<uint8_t*>(d.p) + (size_t)y * d.stride;
-    uint32_t pack = 0;
-    int cnt = min(4, d.w - x4);
-    const uint8_t* sp = srow + 4 * (size_t)x4;
-    if (cnt == 4 && 4 * (x4 + 3) <= s.w - 1 && (reinterpret_cast<uintptr_t>(sp) & 3) == 0) {
-        // the four samples are byte 0 of four consecutive dwords: one 16-byte load and two v_perm instead of four dependent byte loads
-        const uint4 q = *reinterpret_cast<const uint4*>(sp);
-        pack = __builtin_amdgcn_perm(q.y, q.x, 0x0c0c0400u) | __builtin_amdgcn_perm(q.w, q.z, 0x04000c0cu);
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y0 = (blockIdx.y * blockDim.y + threadIdx.y) * RQ_ROWS;
+    if (y0 >= d.h || x4 >= d.w) return;
+    const int cnt = min(4, d.w - x4);
+    const bool quad = cnt == 4 && 4 * (x4 + 3) <= s.w - 1 && ((reinterpret_cast<uintptr_t>(s.p) | (uintptr_t)s.stride) & 3) == 0;  // (x4 is a multiple of 4: 16-byte steps on dword rows)
+    uint32_t pack[RQ_ROWS];
+    if (quad) {
+        // the four samples are byte 0 of four consecutive dwords: one 16-byte load and two v_perm instead of four dependent byte loads; all rows' loads first
+        uint4 q[RQ_ROWS];
+#pragma unroll
+        for (int r = 0; r < RQ_ROWS; r++) {
+            const int sy = min(4 * min(y0 + r, d.h - 1), s.h - 1);
+            q[r] = *reinterpret_cast<const uint4*>(s.p + (size_t)sy * s.stride + 4 * (size_t)x4);
+        }
+#pragma unroll
+        for (int r = 0; r < RQ_ROWS; r++) pack[r] = __builtin_amdgcn_perm(q[r].y, q[r].x, 0x0c0c0400u) | __builtin_amdgcn_perm(q[r].w, q[r].z, 0x04000c0cu);
     } else {
-        for (int k = 0; k < cnt; k++) pack |= (uint32_t)srow[min(4 * (x4 + k), s.w - 1)] << (8 * k);
+#pragma unroll
+        for (int r = 0; r < RQ_ROWS; r++) {
+            const int sy = min(4 * min(y0 + r, d.h - 1), s.h - 1);
+            const uint8_t* srow = s.p + (size_t)sy * s.stride;
+            pack[r] = 0;
+            for (int k = 0; k < cnt; k++) pack[r] |= (uint32_t)srow[min(4 * (x4 + k), s.w - 1)] << (8 * k);
+        }
     }
-    if (cnt == 4 && ((reinterpret_cast<uintptr_t>(drow + x4) & 3) == 0)) {
-        *reinterpret_cast<uint32_t*>(drow + x4) = pack;
-    } else {
-        for (int k = 0; k < cnt; k++) drow[x4 + k] = (uint8_t)(pack >> (8 * k));
+#pragma unroll
+    for (int r = 0; r < RQ_ROWS; r++) {
+        if (y0 + r >= d.h) break;
+        uint8_t* drow = const_cast<uint8_t*>(d.p) + (size_t)(y0 + r) * d.stride;
+        if (cnt == 4 && ((reinterpret_cast<uintptr_t>(drow + x4) & 3) == 0)) {
+            *reinterpret_cast<uint32_t*>(drow + x4) = pack[r];
+        } else {
+            for (int k = 0; k < cnt; k++) drow[x4 + k] = (uint8_t)(pack[r] >> (8 * k));
+        }
     }
 }
 
@@ -564,7 +579,7 @@ void vh_launch_resize_nearest(const uint8_t* src, int w, int h, size_t sstride, 
 void vh_launch_resize_quarter(const void* src_tab, const void* dst_tab, size_t tab_stride, int per_stream, int batch, int max_dw, int max_dh,
                               hipStream_t s)
 {
-    dim3 blk(64, 4), grd((max_dw + 255) / 256, (max_dh + 3) / 4, batch * per_stream);
+    dim3 blk(64, 4), grd((max_dw + 255) / 256, (max_dh + 4 * RQ_ROWS - 1) / (4 * RQ_ROWS), batch * per_stream);
     hipLaunchKernelGGL(k_resize_quarter, grd, blk, 0, s, src_tab, dst_tab, tab_stride, per_stream);
 }
 
