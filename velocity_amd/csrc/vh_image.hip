@@ -598,24 +598,26 @@ __global__ __launch_bounds__(256) void k_pyr_pad(const void* pb_tab, size_t ws_s
     const int wq = (d.w + 2 * B + 3) >> 2;        // dwords of a full-width ring row (columns -B .. w+B-1, rounded up: the pitch has 4 spare bytes)
     const int rq = ((d.w & 3) + B + 3) >> 2;       // dwords of the right band of an image row, starting at column w & ~3
     const int band = wq * 2 * B, side = (B / 4) + rq;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    int x, y;
-    if (t < band) {  // the 2 B full-width rows above and below
-        const int q = t / wq;
-        x = 4 * (t - q * wq) - B;
-        y = q < B ? q - B : d.h + q - B;
-    } else {         // left (B / 4 dwords) and right (rq dwords) of the image rows
-        const int u = t - band;
-        if (u >= d.h * side) return;
-        y = u / side;
-        const int q = u - y * side;
-        x = q < B / 4 ? 4 * q - B : (d.w & ~3) + 4 * (q - B / 4);
-    }
-    const uint8_t* srow = d.p + (ptrdiff_t)vh_reflect101(y, d.h) * d.stride;
-    uint32_t v = 0;
+    // A FIXED small grid per image (gridDim.x workgroups, each walks the ring with a stride of gridDim.x x 256 dwords) and a loop, not one thread per ring dword of the largest bordered level: most launches of a step find levels
+    // without a ring (the ROI pyramids' levels are large) and used to dispatch ~12 000 workgroups that left at once -- 10 us per launch, four per step
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < band + d.h * side; t += (int)gridDim.x * 256) {
+        int x, y;
+        if (t < band) {  // the 2 B full-width rows above and below
+            const int q = t / wq;
+            x = 4 * (t - q * wq) - B;
+            y = q < B ? q - B : d.h + q - B;
+        } else {         // left (B / 4 dwords) and right (rq dwords) of the image rows
+            const int u = t - band;
+            y = u / side;
+            const int q = u - y * side;
+            x = q < B / 4 ? 4 * q - B : (d.w & ~3) + 4 * (q - B / 4);
+        }
+        const uint8_t* srow = d.p + (ptrdiff_t)vh_reflect101(y, d.h) * d.stride;
+        uint32_t v = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) v |= (uint32_t)srow[vh_reflect101(x + k, d.w)] << (8 * k);
-    *reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(d.p) + (ptrdiff_t)y * d.stride + x) = v;
+        for (int k = 0; k < 4; k++) v |= (uint32_t)srow[vh_reflect101(x + k, d.w)] << (8 * k);
+        *reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(d.p) + (ptrdiff_t)y * d.stride + x) = v;
+    }
 }
 
 static std::atomic<int> g_pyr_rows{0};  // PROCESS-WIDE test hook (include/velocity_hip.h): 2 / 4 / 8 output rows per thread whatever the launch size (0: by size)
@@ -645,16 +647,10 @@ void vh_launch_pyr_down_ws(const void* pb_tab, size_t ws_stride, int batch, int 
         dim3 grd((w + 4 * blk.x - 1) / (4 * blk.x), (h + 2 * blk.y - 1) / (2 * blk.y), batch * 2);
         hipLaunchKernelGGL(k_pyr_down<2>, grd, blk, 0, s, pb_tab, ws_stride, lvl);
     }
-    // border ring of the new level when it is a small one (decided per image on the device).  The launch covers the worst small level inside w x h:
-    // the ring dword count grows linearly with each dimension, so over {w' <= w, h' <= h, w' h' <= VH_LV_PAD_MAX_PIXELS} it peaks in a corner --
-    // the widest level with the rows that still fit (e.g. 8192 x 8) or the tallest one
-    {
-        auto ring_dwords = [](int ww, int hh) { return ((ww + 2 * VH_LV_PAD + 3) / 4) * 2 * VH_LV_PAD + hh * (VH_LV_PAD / 4 + (VH_LV_PAD + 6) / 4); };
-        const int wa = std::min(w, VH_LV_PAD_MAX_PIXELS), ha = std::min(h, std::max(1, VH_LV_PAD_MAX_PIXELS / wa));
-        const int hb = std::min(h, VH_LV_PAD_MAX_PIXELS), wb = std::min(w, std::max(1, VH_LV_PAD_MAX_PIXELS / hb));
-        const int ring = std::max(ring_dwords(wa, ha), ring_dwords(wb, hb));
-        hipLaunchKernelGGL(k_pyr_pad, dim3((ring + 255) / 256, 1, batch * 2), dim3(256), 0, s, pb_tab, ws_stride, lvl);
-    }
+    // border ring of the new level when it is a small one (decided per image on the device): a few workgroups per image, each loops over its share --
+    // 4 when the launch has many images (327 against 338 us for pyrDown + rings at 256 streams), 32 for a few streams (a ring of <= ~7000 dwords in one pass:
+    // with 4 a single-stream step took 6 us longer)
+    hipLaunchKernelGGL(k_pyr_pad, dim3(batch >= 16 ? 4 : 32, 1, batch * 2), dim3(256), 0, s, pb_tab, ws_stride, lvl);
 }
 
 void vh_launch_roi_warp(const void* job_tab, size_t tab_stride, int batch, int max_w, int max_h, hipStream_t s)
