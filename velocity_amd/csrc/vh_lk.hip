@@ -241,14 +241,14 @@ __global__ __launch_bounds__(64) void k_lk(const void* job_tab, size_t tab_strid
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.y * tab_stride);
     const int n = LK_N_OF(job);
     if ((int)blockIdx.x >= n) return;
-    const int pt = job.order ? job.order[blockIdx.x] : (int)blockIdx.x;  // launch slot -> point (LKJob::order)
+    const int pt = job.order ? ((gptr_i32)job.order)[blockIdx.x] : (int)blockIdx.x;  // launch slot -> point (LKJob::order)
     const int lane = threadIdx.x;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int kmax = (job.win * job.win + 63) / 64;
     int* ldsD = reinterpret_cast<int*>(smem);
     short* ldsI = reinterpret_cast<short*>(smem + (size_t)kmax * 64 * 4);
 
-    const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];
+    const float qx = ((gptr_f32)job.p_in)[2 * pt], qy = ((gptr_f32)job.p_in)[2 * pt + 1];
     const float px = __fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]);
     const float py = __fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]);
 
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(64) void k_lk_strip(const void* job_tab, size_t tab
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     const int n = LK_N_OF(job);
     if ((int)blk_x >= n) return;
-    const int pt = job.order ? job.order[blk_x] : (int)blk_x;  // launch slot -> point (LKJob::order)
+    const int pt = job.order ? ((gptr_i32)job.order)[blk_x] : (int)blk_x;  // launch slot -> point (LKJob::order)
     const int lane = threadIdx.x;
     const int win = WIN_T ? WIN_T : job.win;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(64) void k_lk_strip(const void* job_tab, size_t tab
     uint2* tX = tI + kmax * 64;
     uint2* tY = tX + kmax * 64;
 
-    const float qx = job.p_in[2 * pt], qy = job.p_in[2 * pt + 1];
+    const float qx = ((gptr_f32)job.p_in)[2 * pt], qy = ((gptr_f32)job.p_in)[2 * pt + 1];
     const float px = __fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]);
     const float py = __fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]);
 
@@ -1375,59 +1375,59 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
     // scalar registers the track code spills
 #pragma unroll 1
     for (unsigned ti = 0; ti < tpw; ti++) {
-    const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
-    const int n = LK_N_OF(job);
-    const unsigned slot = blk_x * tpw + ti;
-    if ((int)slot >= n) break;
-    const int tid = threadIdx.x;
-    const int max_count = job.max_count;
-    const double eps2 = job.eps2;
-    const float fbt = job.fbt;
-    // the point index and the start position are workgroup uniform and live until the epilogue: as SCALARS (the loads below come back in vector registers,
-    // and hipcc then parks them in scratch for the length of the kernel: 7 spilled registers, 28 bytes of scratch traffic per lane and track)
-    const int pt = __builtin_amdgcn_readfirstlane(job.order ? ((gptr_i32)job.order)[slot] : (int)slot);  // launch slot -> point (LKJob::order)
+        const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
+        const int n = LK_N_OF(job);
+        const unsigned slot = blk_x * tpw + ti;
+        if ((int)slot >= n) break;
+        const int tid = threadIdx.x;
+        const int max_count = job.max_count;
+        const double eps2 = job.eps2;
+        const float fbt = job.fbt;
+        // the point index and the start position are workgroup uniform and live until the epilogue: as SCALARS (the loads below come back in vector registers,
+        // and hipcc then parks them in scratch for the length of the kernel: 7 spilled registers, 28 bytes of scratch traffic per lane and track)
+        const int pt = __builtin_amdgcn_readfirstlane(job.order ? ((gptr_i32)job.order)[slot] : (int)slot);  // launch slot -> point (LKJob::order)
 
-    const float qx = ((gptr_f32)job.p_in)[2 * pt], qy = ((gptr_f32)job.p_in)[2 * pt + 1];
-    const float px = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]))));
-    const float py = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]))));
+        const float qx = ((gptr_f32)job.p_in)[2 * pt], qy = ((gptr_f32)job.p_in)[2 * pt + 1];
+        const float px = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__fsub_rn(__fmul_rn(qx, job.in_scale), job.in_off[0]))));
+        const float py = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__fsub_rn(__fmul_rn(qy, job.in_scale), job.in_off[1]))));
 
-    // forward pass, then (fbt >= 0) the backward pass from its result: ONE copy of the track code in a loop over the direction -- two inlined copies
-    // doubled the kernel and recomputed the per-lane mapping / masks of lk3_level in each
-    float fx = 0.f, fy = 0.f, err = 0.f, bx = 0.f, by = 0.f;
-    int st = 0, st2 = 0, n_iter = 0, n_setup = 0;
-    const int ndir = fbt >= 0.f ? 2 : 1;
-    const bool want_err = job.err_out != nullptr;
-#pragma unroll 1
-    for (int dir = 0; dir < ndir; dir++) {
-        if (dir == 1 && !st && !job.fbe_out) break;  // forward status 0 (block uniform): the backward pass cannot change v or p (see k_lk)
-        const PyrDesc& PA = dir ? job.J : job.I;
-        const PyrDesc& PB = dir ? job.I : job.J;
-        float ox, oy, e;
-        int s;
-        lk3_track<WIN, NW, M>(PA, PB, max_count, eps2, dir ? fx : px, dir ? fy : py, ox, oy, s, e, smem, tid, phase, n_iter, n_setup, want_err && dir == 0);
-        if (dir == 0) { fx = ox; fy = oy; st = s; err = e; }
-        else { bx = ox; by = oy; st2 = s; }
-    }
-    float fbe = 0.f;
-    if (fbt >= 0.f) {
-        const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
-        fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
-        st = st && st2 && (fbe < fbt);
-    }
-    // the track's results wait in LDS: a global store inside this loop would make every descriptor load of the NEXT track a possibly-clobbered load,
-    // i.e. a vector load instead of a scalar one (the same effect as the volatile asm of DESIGN.md section 9)
-    if (tid == 0) {
-        // (an explicit LDS pointer: through a generic one hipcc counts these stores as possible writes to the job descriptors too)
-        lds_i32 rec = (lds_i32)(smem + LK3<WIN, NW, M>::OFF_RES) + 8 * ti;
-        rec[0] = pt; rec[1] = __float_as_int(fx); rec[2] = __float_as_int(fy); rec[3] = st != 0;
-        rec[4] = __float_as_int(err); rec[5] = __float_as_int(fbe);
-    }
-    tot_iter += n_iter; tot_setup += n_setup;
-    ndone = ti + 1;
-    // The LAST memory operation of the loop body must not be a plain store: hipcc's scalar-load test (is a load clobbered anywhere in the function?) takes
-    // whatever definition reaches the loop header over the back edge at face value when it is a store -- LDS or not -- and only looks through fences
-    // and barriers with alias analysis.  With the record stores last, every descriptor load of the track code became a vector load.
-    __syncthreads();
+        // forward pass, then (fbt >= 0) the backward pass from its result: ONE copy of the track code in a loop over the direction -- two inlined copies
+        // doubled the kernel and recomputed the per-lane mapping / masks of lk3_level in each
+        float fx = 0.f, fy = 0.f, err = 0.f, bx = 0.f, by = 0.f;
+        int st = 0, st2 = 0, n_iter = 0, n_setup = 0;
+        const int ndir = fbt >= 0.f ? 2 : 1;
+        const bool want_err = job.err_out != nullptr;
+    #pragma unroll 1
+        for (int dir = 0; dir < ndir; dir++) {
+            if (dir == 1 && !st && !job.fbe_out) break;  // forward status 0 (block uniform): the backward pass cannot change v or p (see k_lk)
+            const PyrDesc& PA = dir ? job.J : job.I;
+            const PyrDesc& PB = dir ? job.I : job.J;
+            float ox, oy, e;
+            int s;
+            lk3_track<WIN, NW, M>(PA, PB, max_count, eps2, dir ? fx : px, dir ? fy : py, ox, oy, s, e, smem, tid, phase, n_iter, n_setup, want_err && dir == 0);
+            if (dir == 0) { fx = ox; fy = oy; st = s; err = e; }
+            else { bx = ox; by = oy; st2 = s; }
+        }
+        float fbe = 0.f;
+        if (fbt >= 0.f) {
+            const float ddx = __fsub_rn(px, bx), ddy = __fsub_rn(py, by);
+            fbe = vh_sqrtf(__fadd_rn(__fmul_rn(ddx, ddx), __fmul_rn(ddy, ddy)));
+            st = st && st2 && (fbe < fbt);
+        }
+        // the track's results wait in LDS: a global store inside this loop would make every descriptor load of the NEXT track a possibly-clobbered load,
+        // i.e. a vector load instead of a scalar one (the same effect as the volatile asm of DESIGN.md section 9)
+        if (tid == 0) {
+            // (an explicit LDS pointer: through a generic one hipcc counts these stores as possible writes to the job descriptors too)
+            lds_i32 rec = (lds_i32)(smem + LK3<WIN, NW, M>::OFF_RES) + 8 * ti;
+            rec[0] = pt; rec[1] = __float_as_int(fx); rec[2] = __float_as_int(fy); rec[3] = st != 0;
+            rec[4] = __float_as_int(err); rec[5] = __float_as_int(fbe);
+        }
+        tot_iter += n_iter; tot_setup += n_setup;
+        ndone = ti + 1;
+        // The LAST memory operation of the loop body must not be a plain store: hipcc's scalar-load test (is a load clobbered anywhere in the function?) takes
+        // whatever definition reaches the loop header over the back edge at face value when it is a store -- LDS or not -- and only looks through fences
+        // and barriers with alias analysis.  With the record stores last, every descriptor load of the track code became a vector load.
+        __syncthreads();
     }
     const LKJob& job = *reinterpret_cast<const LKJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blk_y * tab_stride);
     if (threadIdx.x < ndone) {
