@@ -4,6 +4,7 @@
 // every image / track kernel is launched over the maximum extent and reads its extent from there.  A frame is thus a
 // fixed sequence of launches with no host round trip (hipGraph-capturable), for any number of streams per launch.
 #include <atomic>
+#include <vector>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -281,7 +282,7 @@ __device__ void klt_setup_descriptors(StreamWS& ws, const SessStream* ss_all, co
     J.fbt = -1.f;
     J.in_scale = 0.25f; J.in_off[0] = 0.f; J.in_off[1] = 0.f;
     J.out_mode = VH_OUT_SCALE; J.out_scale = 0.25f;
-    J.stats = ws.lk_stats[0];
+    J.stats = &ws.lk_stats[0][0][0];
     // RANSAC 1: inliers gate the status (KLT.py:116-117)
     RansacJob& R = ws.ransac;
     R.from = io.p0; R.to = B.p_small; R.valid = B.v_small; R.n_ptr = nullptr; R.n = n;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void k_klt_glue1(StreamWS* ws_all)
     J.fbt = io.fbt_coarse;
     J.in_scale = 1.f; J.in_off[0] = (float)x0; J.in_off[1] = (float)y0;
     J.out_mode = VH_OUT_TRANSLATE; J.out_off[0] = (float)dx; J.out_off[1] = (float)dy;
-    J.stats = ws.lk_stats[1];
+    J.stats = &ws.lk_stats[1][0][0];
     // RANSAC 2: affine from the survivors, only when more than 10 of them (KLT.py:126-127)
     RansacJob& R = ws.ransac;
     R.to = B.p_coarse; R.valid = B.v_coarse; R.min_valid = 10; R.gate_valid = 0;
@@ -436,7 +437,7 @@ __global__ void k_klt_glue2(StreamWS* ws_all)
     J.in_scale = 1.f; J.in_off[0] = (float)x0; J.in_off[1] = (float)y0;
     J.out_mode = VH_OUT_AFFINE;
     for (int k = 0; k < 6; k++) J.T[k] = T[k];
-    J.stats = ws.lk_stats[2];
+    J.stats = &ws.lk_stats[2][0][0];
     if (io.flags) *io.flags = ws.flags;
 }
 
@@ -526,9 +527,11 @@ extern "C" VH_API int vh_profile_end(vh_ctx* c, double* ms_sum, int* launches, u
         launches[c->prof_stage[k]]++;
     }
     for (int b = 0; b < c->batch; b++) {
-        unsigned long long st[3][2];
-        VH_CHECK(hipMemcpy(st, c->d_ws[b].lk_stats, sizeof(st), hipMemcpyDeviceToHost));
-        for (int k = 0; k < 3; k++) { iters[k] += st[k][0]; setups[k] += st[k][1]; }
+        static_assert(sizeof(c->d_ws[b].lk_stats) == sizeof(unsigned long long) * 3 * VH_LK_STAT_SLOTS * 16, "lk_stats layout");
+        std::vector<unsigned long long> st((size_t)3 * VH_LK_STAT_SLOTS * 16);
+        VH_CHECK(hipMemcpy(st.data(), c->d_ws[b].lk_stats, sizeof(c->d_ws[b].lk_stats), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 3; k++)
+            for (int q = 0; q < VH_LK_STAT_SLOTS; q++) { iters[k] += st[((size_t)k * VH_LK_STAT_SLOTS + q) * 16]; setups[k] += st[((size_t)k * VH_LK_STAT_SLOTS + q) * 16 + 1]; }
     }
     return 0;
 }
@@ -788,7 +791,7 @@ extern "C" VH_API int vh_pyr_lk(vh_ctx* c, const uint8_t* im1, const uint8_t* im
     J.fbt = fbt;
     J.in_scale = 1.f; J.out_mode = VH_OUT_SCALE; J.out_scale = 1.f;
     StreamWS* ws = c->d_ws;
-    J.stats = ws->lk_stats[0];  // Newton iterations / template set-ups of this call (vh_profile_begin zeroes them, vh_profile_end reads them)
+    J.stats = &ws->lk_stats[0][0][0];  // Newton iterations / template set-ups of this call (vh_profile_begin zeroes them, vh_profile_end reads them)
     VH_CHECK(vh_store(&ws->lk, J, s));
     VH_CHECK(vh_store(&ws->pb[0], PyrBuild{&ws->lk.I, 1, 0}, s));
     VH_CHECK(vh_store(&ws->pb[1], PyrBuild{&ws->lk.J, 1, 0}, s));

@@ -22,6 +22,7 @@ void vh_set_error(const char* what, hipError_t e, const char* file, int line);
 // border) carry a REFLECT_101 border of VH_LV_PAD pixels on every side (rows VH_LV_STRIDE(w) bytes apart, >= 4 spare bytes per row), filled by
 // k_pyr_pad right after the level is built: the row loads of windows at the border of such a level are then plain dword loads.  On large levels
 // border windows are rare and a border ring would cost more to write than it saves.
+#define VH_LK_STAT_SLOTS 64  // LKJob::stats points at [VH_LK_STAT_SLOTS][16] counters: a workgroup uses slot (launch slot & 63), entries 0 / 1 (see StreamWS::lk_stats)
 #define VH_LV_PAD 24
 #define VH_LV_PAD_MAX_PIXELS 65536
 #define VH_LV_STRIDE(w) (((((w) + 2 * VH_LV_PAD) + 3) & ~3) + 4)

@@ -289,8 +289,9 @@ __global__ __launch_bounds__(64) void k_lk(const void* job_tab, size_t tab_strid
         if (job.fbe_out) job.fbe_out[pt] = fbe;
         if (job.praw_out) { job.praw_out[2 * pt] = fx; job.praw_out[2 * pt + 1] = fy; }
         if (job.stats) {
-            atomicAdd(&job.stats[0], (unsigned long long)n_iter);
-            atomicAdd(&job.stats[1], (unsigned long long)n_setup);
+            unsigned long long* st = job.stats + (size_t)(blockIdx.x & (VH_LK_STAT_SLOTS - 1)) * 16;  // (counters spread over VH_LK_STAT_SLOTS lines: see StreamWS::lk_stats)
+            atomicAdd(&st[0], (unsigned long long)n_iter);
+            atomicAdd(&st[1], (unsigned long long)n_setup);
         }
     }
 }
@@ -889,8 +890,9 @@ __global__ __launch_bounds__(64) void k_lk_strip(const void* job_tab, size_t tab
         if (job.fbe_out) job.fbe_out[pt] = fbe;
         if (job.praw_out) { job.praw_out[2 * pt] = fx; job.praw_out[2 * pt + 1] = fy; }
         if (job.stats) {
-            atomicAdd(&job.stats[0], (unsigned long long)n_iter);
-            atomicAdd(&job.stats[1], (unsigned long long)n_setup);
+            unsigned long long* st = job.stats + (size_t)(blk_x & (VH_LK_STAT_SLOTS - 1)) * 16;  // (counters spread over VH_LK_STAT_SLOTS lines: see StreamWS::lk_stats)
+            atomicAdd(&st[0], (unsigned long long)n_iter);
+            atomicAdd(&st[1], (unsigned long long)n_setup);
         }
     }
 }
@@ -1457,8 +1459,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
         if (job.praw_out) { job.praw_out[2 * pt] = fx; job.praw_out[2 * pt + 1] = fy; }
     }
     if (threadIdx.x == 0 && job.stats && ndone) {
-        atomicAdd(&job.stats[0], (unsigned long long)tot_iter);
-        atomicAdd(&job.stats[1], (unsigned long long)tot_setup);
+        unsigned long long* st = job.stats + (size_t)(blk_x & (VH_LK_STAT_SLOTS - 1)) * 16;  // (counters spread over VH_LK_STAT_SLOTS lines: see StreamWS::lk_stats)
+        atomicAdd(&st[0], (unsigned long long)tot_iter);
+        atomicAdd(&st[1], (unsigned long long)tot_setup);
     }
 }
 
@@ -1814,8 +1817,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_
         if (job.fbe_out) job.fbe_out[pt] = fbe;
         if (job.praw_out) { job.praw_out[2 * pt] = fx; job.praw_out[2 * pt + 1] = fy; }
         if (job.stats) {
-            atomicAdd(&job.stats[0], (unsigned long long)n_iter);
-            atomicAdd(&job.stats[1], (unsigned long long)n_setup);
+            unsigned long long* st = job.stats + (size_t)((unsigned)slot & (VH_LK_STAT_SLOTS - 1)) * 16;  // (counters spread over VH_LK_STAT_SLOTS lines: see StreamWS::lk_stats)
+            atomicAdd(&st[0], (unsigned long long)n_iter);
+            atomicAdd(&st[1], (unsigned long long)n_setup);
         }
     }
 }
@@ -2178,8 +2182,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
         if (job.fbe_out) job.fbe_out[pt] = fbe;
         if (job.praw_out) { job.praw_out[2 * pt] = fx; job.praw_out[2 * pt + 1] = fy; }
         if (job.stats) {
-            atomicAdd(&job.stats[0], (unsigned long long)n_iter);
-            atomicAdd(&job.stats[1], (unsigned long long)n_setup);
+            unsigned long long* st = job.stats + (size_t)((unsigned)slot & (VH_LK_STAT_SLOTS - 1)) * 16;  // (counters spread over VH_LK_STAT_SLOTS lines: see StreamWS::lk_stats)
+            atomicAdd(&st[0], (unsigned long long)n_iter);
+            atomicAdd(&st[1], (unsigned long long)n_setup);
         }
     }
 }

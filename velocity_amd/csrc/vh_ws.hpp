@@ -53,7 +53,10 @@ struct StreamWS {
     double t_trans[2];
     int roi[4];
     int dxy[2];
-    unsigned long long lk_stats[3][2];  // per KLTmain stage: Newton iterations, template set-ups (profiling aid)
+    // per KLTmain stage: Newton iterations ([slot][0]) and template set-ups ([slot][1]), summed over VH_LK_STAT_SLOTS slots of one 128-byte line each.  A
+    // workgroup adds to slot (its launch slot mod VH_LK_STAT_SLOTS): with ONE pair of counters per stream the 2 x 2000 same-address atomics of a single-stream
+    // launch serialised in the L2 -- ~45 us of every ~62 us LK launch, 0.33 -> 0.21 ms per single-stream frame step once they were spread out
+    unsigned long long lk_stats[3][VH_LK_STAT_SLOTS][16];
     int n, m, rstatus, flags, pp, rbound;
     const int* order;  // bufs.order when this call launches its LK kernels in spatial order, else null
 };
