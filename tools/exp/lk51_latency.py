@@ -11,7 +11,7 @@ f0 = synth.render_frame(W, H, m, 0).cuda(); f1 = synth.render_frame(W, H, m, 1).
 lk = _lk_from_cv(dict(winSize=(51, 51), maxLevel=0, criteria=(3, 30, 0.001)))
 for mode in (5, 6, 7):
     L.load().vh_debug_force_generic_lk(mode)
-    for n in (1, 256, 1024, 2000, 3072, 4096):
+    for n in (1, 64, 128, 278, 512, 768, 1024, 1500, 2000, 3072):
         p = torch.from_numpy(synth.grid_tracks(n, W, H)).cuda()
         ws = L.workspace(W, H, n)
         p2 = torch.zeros((n, 2), dtype=torch.float32, device="cuda"); v = torch.zeros(n, dtype=torch.uint8, device="cuda")

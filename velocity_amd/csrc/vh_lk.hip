@@ -2242,18 +2242,18 @@ static int launch_strip(const void* job_tab, size_t tab_stride, int batch, int m
 // bit-identical implementations, never a torn value) -- a test / experiment switch, not a per-stream control.
 static std::atomic<int> g_lk_force_generic{getenv("VH_LK_FORCE") ? atoi(getenv("VH_LK_FORCE")) : 0};  // (environment: experiments only)
 void vh_lk_force_generic(int on) { g_lk_force_generic.store(on, std::memory_order_relaxed); }
-static const long long g_lko_min_tracks = getenv("VH_LKO_MIN") ? atoll(getenv("VH_LKO_MIN")) : 30000;  // (environment: experiments only)
+static const long long g_lko_min_tracks = getenv("VH_LKO_MIN") ? atoll(getenv("VH_LKO_MIN")) : 10000;  // (environment: experiments only)
 
 // Which kernel a launch of `batch` streams x `max_n` track slots with window `win` takes (the ids of the test hook above; 2 = the strip kernel of any
 // window <= 63, 1 = the per-sample kernel).  vh_launch_lk follows exactly this decision, and the profiling records report it (vh_profile_lk_routes), so
 // nobody has to mirror the thresholds.
 //
-// Default routing (measured on MI355X, profiles/): 51x51 fine stage -- the LDS-staged kernel; ONE wavefront per track (no barrier, no LDS exchange of
-// the window sums, the wave-uniform work done once per track) wins from ~3000 tracks in flight (2.32 ms vs 2.99 ms (2 per track) vs 4.5 ms (4 per
-// track) at 256 000 tracks); 2 and 4 per track shorten the critical path of a single track and are used below that (67 us vs 72 us for 2000 tracks).
-// 15x15 coarse stages -- 8 tracks per wavefront once the launch fills the chip at 8 per wavefront (>= 30 000 tracks), 4 per wavefront from ~3000
-// (53 / 89 us vs 55 / 99 us at 4000 tracks, 0.43 / 0.81 ms vs 0.9 / 1.7 ms at 256 000), below that the one-wave-per-track strip kernel has the
-// shorter critical path (43 / 73 us vs 51 / 82 us at 2000 tracks; the LDS-staged variant is 2.5x slower there).
+// Default routing, re-measured late in round 5 -- the earlier thresholds had been measured while every LK launch carried ~45 us of serialised statistics
+// atomics (StreamWS::lk_stats), which hid what the kernels themselves cost at a few thousand tracks.  51x51 fine stage: the LDS-staged kernel with ONE
+// wavefront per track from 640 tracks in flight (2000 tracks: 28.8 us against 33.2 / 43.2 with 2 / 4 wavefronts per track; 768: 37.1 / 39.7 / 41.1 for
+// the whole vh_pyr_lk call), 4 wavefronts per track below (128 tracks: 30.8 against 35.3); 2 per track is never the fastest and is kept for the tests.
+// 15x15 coarse stages: the one-wave-per-track strip kernel up to 3000 tracks (2000: 20.2 / 27.9 us against 22.2 / 29.4 for 4 tracks per wavefront; 4000:
+// 25.6 / 36.6 against 23.1 / 29.2), 4 tracks per wavefront up to 10 000, 8 per wavefront above (12 000: 33.6 / 50.2 against 35.4 / 55.9 us; 8000: a tie).
 int vh_lk_route(int batch, int max_n, int win)
 {
     const int force = g_lk_force_generic.load(std::memory_order_relaxed);
@@ -2262,7 +2262,7 @@ int vh_lk_route(int batch, int max_n, int win)
     if (force == 0 || force == 3 || (force_nw && win == 51)) {
         if (win == 15 && force == 3) return 3;
         if (win == 51) {
-            const int nw = force_nw ? (1 << (force - 5)) : (force == 3 ? 4 : tracks >= 3000 ? 1 : tracks >= 1024 ? 2 : 4);
+            const int nw = force_nw ? (1 << (force - 5)) : (force == 3 ? 4 : tracks >= 640 ? 1 : 4);
             return nw == 1 ? 5 : nw == 2 ? 6 : 7;
         }
     }
