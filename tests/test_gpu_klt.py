@@ -461,6 +461,7 @@ def test_backward_pass_is_skipped_for_tracks_whose_forward_status_is_zero(lk, fb
     a, b, p = torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda(), torch.from_numpy(p0).cuda()
     prm = L.lk_params(lk)
     routes = (1, 2, 3, 4, 8) if lk["win"] == 15 else (1, 2, 5, 6, 7)
+    counts = {}
     for mode in routes:
         ws.lib.vh_debug_force_generic_lk(mode)
         got = {}
@@ -482,6 +483,10 @@ def test_backward_pass_is_skipped_for_tracks_whose_forward_status_is_zero(lk, fb
         assert np.array_equal(pa, pb) and np.array_equal(va, vb) and np.array_equal(ea, eb), f"route {mode}: the skip changed a result"
         assert np.array_equal(pa, ep2) and np.array_equal(va, ev) and np.array_equal(ea, eerr), f"route {mode} differs from the oracle"
         assert sua < sub and ita <= itb, f"route {mode}: the backward pass of the forward-dead tracks still ran ({sua} vs {sub} set-ups)"
+        counts[mode] = (sua, ita, sub, itb)
+    # the statistics counters are spread over VH_LK_STAT_SLOTS cache lines per stream and stage (a workgroup adds to slot = launch slot mod 64) and summed by
+    # vh_profile_end: every route is the same algorithm on the same tracks, so every route must report the same totals
+    assert len(set(counts.values())) == 1, counts
 
 
 def test_klt_main_failure_path_matches(seq):
