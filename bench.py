@@ -45,9 +45,109 @@ from benchlib.workload import EpisodeWorkload, Workload  # noqa: E402
 _T0 = time.perf_counter()
 
 
+VERBOSE = False
+COMPACT_MAX_BYTES = 4096  # the driver keeps a bounded tail of stdout: the contract line has to fit it whole (BENCH_r05.json: a 27.9 KB line did not parse)
+
+
 def stamp(what):
-    """Wall-clock mark on stderr (the JSON line on stdout stays alone): where a default run spends its minutes."""
-    print(f"[bench {time.perf_counter() - _T0:7.1f} s] {what}", file=sys.stderr, flush=True)
+    """Wall-clock mark on stderr, only with --verbose (the JSON line on stdout stays alone): where a default run spends its minutes."""
+    if VERBOSE:
+        print(f"[bench {time.perf_counter() - _T0:7.1f} s] {what}", file=sys.stderr, flush=True)
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _all_verified(legs):
+    """True when every extras leg that carries a `verified` object says bit_exact (None when none does)."""
+    flags = [v["verified"].get("bit_exact") for v in legs.values() if isinstance(v, dict) and isinstance(v.get("verified"), dict) and "bit_exact" in v["verified"]]
+    return bool(all(flags)) if flags else None
+
+
+def compact_line(out, detail_path=None):
+    """The ONE stdout line of a run: the contract's fields, `roofline`, `cpu_baseline`, `verified`, `build_id` and few-number summaries of `ba`, `extras`
+    and (N > 1) `multi_gpu` -- at most COMPACT_MAX_BYTES bytes.  Everything else (`roofline_detail`, the full `extras` / `ba` legs, `headline_hbm`,
+    `build`) is written to the detail file.  Optional summaries are dropped, last first, should the line ever outgrow the limit; the contract's fields
+    never are (a line that still does not fit raises: better a red run than an unparsable record)."""
+    line = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "timed_steps", "tracks_alive_frac", "higher_is_better", "scaling")
+    line["vs_baseline"] = out.get("vs_baseline")
+    line.update(_pick(out, "dtype", "data"))
+    line["config"] = _pick(out.get("config", {}), "workload", "params", "scene", "streams_per_gpu", "tracks", "parallelism")
+    r = out.get("roofline") or {}
+    line["roofline"] = dict(_pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_class_peak", "us_per_launch"), traffic=r.get("traffic"),
+                            **_pick(r, "lk_kernels", "lk_us_per_launch", "newton_iters_per_track_dir"))
+    if isinstance(r.get("step_hbm"), dict):
+        line["roofline"]["step_hbm_gbs"] = r["step_hbm"].get("gbs")
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = _pick(out["cpu_baseline"], "value", "unit", "cores", "kind", "sample")
+        line.update(_pick(out, "gpu_over_cpu"))
+        if "cpu_baseline_1core" in out:
+            line["cpu_baseline_1core"] = out["cpu_baseline_1core"].get("value")
+    if "verified" in out:
+        line["verified"] = _pick(out["verified"], "bit_exact", "pose_within_1e5", "streams", "frames", "skipped")
+    line.update(_pick(out, "build_id"))
+    optional = []
+    if isinstance(out.get("multi_gpu"), dict):
+        line["multi_gpu"] = out["multi_gpu"]
+    ba = out.get("ba")
+    if isinstance(ba, dict):
+        b = _pick(ba, "iters_per_s", "ms_per_iter", "gpu_over_cpu")
+        bw = ba.get("by_windows", {})
+        if "64" in bw:
+            b["iters_per_s_64_windows"] = bw["64"].get("iters_per_s")
+        if isinstance(ba.get("roofline_one_window"), dict):
+            b["roofline_frac_one_window"] = ba["roofline_one_window"].get("frac")
+        if isinstance(ba.get("roofline"), dict) and "frac" in ba["roofline"]:
+            b["roofline"] = _pick(ba["roofline"], "bound", "kernel", "achieved", "peak", "unit", "frac")
+        if isinstance(ba.get("cpu_baseline"), dict):
+            b["cpu_baseline"] = _pick(ba["cpu_baseline"], "value", "unit", "cores", "kind")
+        for k in ("replicas", "point_sharded"):
+            if isinstance(ba.get(k), dict):
+                b[k + "_iters_per_s"] = ba[k].get("iters_per_s")
+        line["ba"] = b
+        optional.append("ba")
+    ex = out.get("extras")
+    if isinstance(ex, dict):
+        def g(leg, key):
+            v = ex.get(leg)
+            return v.get(key) if isinstance(v, dict) else None
+        e = dict(hard_scene_fps=g("hard_scene", "value"), hard_scene_vs_headline=g("hard_scene", "vs_headline"), real_texture_fps=g("real_texture", "value"),
+                 single_stream_ms=g("single_stream", "ms_per_step"), drop_in_ms=g("drop_in_route", "ms_per_frame"), ref_params_fps=g("ref_params", "value"),
+                 c3_fps=g("other_config", "value"), c3_cpu_fps=(ex.get("other_config") or {}).get("cpu_baseline", {}).get("value") if isinstance(ex.get("other_config"), dict) else None,
+                 all_bit_exact=_all_verified(ex), errors=[k for k, v in ex.items() if isinstance(v, dict) and "error" in v] or None)
+        line["extras"] = {k: v for k, v in e.items() if v is not None}
+        optional.append("extras")
+    if detail_path:
+        line["detail"] = os.path.basename(detail_path)
+    text = json.dumps(line, separators=(",", ":"))
+    trims = [("cpu_baseline", "sample"), ("roofline", "lk_kernels"), ("roofline", "lk_us_per_launch")]
+    while len(text.encode()) > COMPACT_MAX_BYTES and (optional or trims):
+        if optional:
+            line.pop(optional.pop(), None)
+        else:
+            a_, b_ = trims.pop(0)
+            if isinstance(line.get(a_), dict):
+                line[a_].pop(b_, None)
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text.encode()) > COMPACT_MAX_BYTES:
+        raise RuntimeError(f"bench.py: the contract line is {len(text.encode())} bytes (> {COMPACT_MAX_BYTES})")
+    return text
+
+
+def write_detail(out, path):
+    """The full record (every leg, every note) next to the script; tools/collect_profiles.sh files it as profiles/rNN_bench_default.json."""
+    if not path or path == os.devnull:
+        return None
+    try:
+        tmp = path + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(out, f, indent=1)
+        os.replace(tmp, path)
+        return path
+    except OSError as e:  # a read-only checkout must not cost the run its line
+        print(f"bench.py: cannot write {path}: {e}", file=sys.stderr)
+        return None
 
 
 def host_cores():
@@ -105,6 +205,9 @@ def parse():
                     help="frames start in pinned HOST memory and are uploaded every step (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the track-state exchange even with one rank (smoke test of the N>1 path)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for tests)")
+    ap.add_argument("--verbose", action="store_true", help="wall-clock stamps of the legs on stderr")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="file that receives the FULL record (roofline_detail, every extras / BA leg); stdout carries only the compact contract line")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: allow more ranks than visible GPUs (ranks share devices round-robin; needs --backend gloo, RCCL refuses duplicate devices)")
     return ap.parse_args()
@@ -310,7 +413,7 @@ def _kernel_table(r):
     return t
 
 
-def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev, track_order=None):
+def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev, track_order=None, cpu_seconds=0.0):
     """One more single-GPU workload next to the headline one; returns its summary (None when it does not fit / fails)."""
     try:
         if track_order:
@@ -327,6 +430,9 @@ def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev, track_orde
                    lk_us_per_launch=[round(1e3 * m["prof"]["ms_sum"][k] / max(m["prof"]["launches"][k], 1), 2) for k in range(3)])
         if a.verify_frames > 0:
             out["verified"] = verify(wl, wl.done_steps + 1, nframes=min(a.verify_frames, 2))
+        if cpu_seconds > 0:  # the CPU port on the same workload, all granted cores (north_star: 1080p AND 4K beside the CPU path)
+            out["cpu_baseline"] = cpu_baseline(CONFIGS[cfg_key], wl.K, wl.frames[: a.ring], wl.p0, wl.p3, wl.vp, wl.lkc, wl.lkf, cpu_seconds, 0)
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         wl.close()
         return out
     except Exception as e:  # an extra leg must never take the headline number down with it
@@ -393,7 +499,9 @@ def dropin_leg(a, cfg, dev, frames=24):
 
 
 def main():
+    global VERBOSE
     a = parse()
+    VERBOSE = a.verbose
     cfg = CONFIGS[a.config]
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -456,7 +564,6 @@ def main():
     if rank == 0:
         elapsed, timed = m["elapsed"], m["timed_steps"]
         value = S * world * timed / elapsed
-        # the head of the line is what a truncated record keeps: metric ... roofline, cpu_baseline first, the long objects after
         out = dict(metric="tracked frames/sec (KLT 2000 tracks + NLS pose, 1080p)" if a.config == "c2" else "tracked frames/sec (KLT 5000 tracks + NLS pose, 4K)",
                    value=round(value, 2), unit="frames/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=round(1e3 * elapsed / timed, 4), timed_steps=timed, timed_seconds=round(elapsed, 3),
@@ -474,7 +581,7 @@ def main():
                 "setups_per_launch", "newton_iters_per_launch", "newton_iters_per_track_dir", "lk_kernels", "lk_us_per_launch", "lk_newton_iters_per_setup",
                 "step_hbm", "peak_source", "peak_class_source")
         out["roofline"] = {k: full_roofline.get(k) for k in keys}
-        out["roofline"]["detail"] = "roofline_detail (same line, further down): hbm view, opcode mix, one row per kernel family, notes"
+        out["roofline"]["detail"] = "roofline_detail (detail file): hbm view, opcode mix, one row per kernel family, notes"
         out["headline_hbm"] = headline_hbm(cfg, value / world)
         out["build"] = L.build_info()  # which binary ran: vh_build_id() of the loaded library vs the hash of the tree's sources
         out["build_id"] = out["build"]["build_id"]
@@ -482,12 +589,14 @@ def main():
         if a.verify_frames > 0:
             out["verified"] = verify(wl, wl.done_steps + 1, nframes=a.verify_frames)
     if use_dist and ex is not None:
+        last = ex.wait().clone()  # the LAST exchange of the timed run, read before anything else touches the process group
         desc = ex.describe()  # collective (all_gather_object): every rank calls it
+        desc["exchange_device_us_idle"] = ex.measure_idle_latency()  # collective too; scratch buffers, None under gloo
         if rank == 0:
-            g = vdist.unpack_state(ex.wait()[0, 0], N)
+            g = vdist.unpack_state(last[0, 0], N)
             assert g["n_cur"] == st["n_cur"] or g["frame_i"] <= st["frame_i"], "exchanged track state is inconsistent"
-            # every rank's last gathered record must be a live tracker state (proof that the collective really carried N ranks' data)
-            seen = [vdist.unpack_state(ex.gathered[r, 0], N) for r in range(world)]
+            # every rank's last gathered record must be a live tracker state (proof that the timed collective really carried N ranks' data)
+            seen = [vdist.unpack_state(last[r, 0], N) for r in range(world)]
             desc["ranks_seen_in_last_gather"] = sum(1 for q in seen if q["frame_i"] > 0 and q["n_cur"] > 0)
             desc["exchange_every_frames"] = a.exchange_every
             out["dist"] = desc
@@ -530,7 +639,8 @@ def main():
             legs["roll_scene"] = extra_leg(a, a.config, a.params, "roll" if a.scene == "plane" else "plane", S, 60, 10, dev)
             # the headline scene hands its tracks over in raster order; goodFeaturesToTrack sorts by corner response (spatially at random): same work, the other order
             stamp("leg other_config ...")
-            legs["other_config"] = extra_leg(a, "c3" if c2 else "c2", a.params, a.scene, 64 if c2 else 128, 24 if c2 else 60, 6, dev)  # 64 4K streams = 320 000 tracks in flight
+            legs["other_config"] = extra_leg(a, "c3" if c2 else "c2", a.params, a.scene, 64 if c2 else 128, 24 if c2 else 60, 6, dev,
+                                              cpu_seconds=a.cpu_seconds)  # 64 4K streams = 320 000 tracks in flight; CPU port timed on the same frames
             out["extras"] = legs
         if not a.no_ba and world == 1:
             stamp("extras done; BA ...")
@@ -540,7 +650,7 @@ def main():
             out["ba"] = ba
         stamp("BA done")
         out["roofline_detail"] = full_roofline
-        if world > 1:  # what the 8-GPU run is for, where a truncated record still shows it: exchange cost and both BA modes
+        if "dist" in out:  # what the 8-GPU run is for, in the compact line: exchange cost and both BA modes
             d, b = out.get("dist", {}), out.get("ba", {})
             out["multi_gpu"] = dict(backend=d.get("backend"), world_size=d.get("world_size"), exchanges=d.get("exchanges"),
                                     exchange_bytes_per_rank=d.get("bytes_per_rank_per_exchange"), exchange_host_ms_total=d.get("exchange_host_ms_total"),
@@ -548,12 +658,8 @@ def main():
                                     ba_point_sharded_iters_per_s=b.get("point_sharded", {}).get("iters_per_s"),
                                     ba_point_sharded_ms_per_iter=b.get("point_sharded", {}).get("ms_per_iter"),
                                     ba_replicas_iters_per_s=b.get("replicas", {}).get("iters_per_s"))
-        # the head of the line is what a truncated record keeps (BENCH_rNN.json's tail cut round 4's line): the contract's fields, the multi-GPU summary,
-        # roofline and cpu_baseline first; the long objects after
-        head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "multi_gpu",
-                "config", "roofline", "cpu_baseline", "verified", "build_id")
-        out = {**{k: out[k] for k in head if k in out}, **{k: v for k, v in out.items() if k not in head}}
-        print(json.dumps(out))
+        # stdout: ONE compact contract line (<= 4 KB); the full record goes to the detail file
+        print(compact_line(out, write_detail(out, a.detail)), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -106,12 +106,15 @@ def bench_ba(nt=5000, nf=20, repeats=3, windows=(1, 8, 64), min_seconds=0.4):
         kus = profiled(nwr)
         # launch shape of k_ba_schur_mfma (velocity_amd/csrc/vh_api.hip::vh_nls_batch_multi): nparts workgroups per window, each walks its chunk of tie
         # points in groups of 4; a group = 27 v_mfma_f64_16x16x4_f64 (2048 flop each) on each of the 4 consumer wavefronts
-        parts = max(1, min(256, nt // 16))
-        cap = max(16, 512 // nwr)
-        nparts = cap if (nwr > 1 and parts > cap) else parts
-        chunk = -(-nt // nparts)
-        groups = sum(-(-max(0, min(nt, (b + 1) * chunk) - b * chunk) // 4) for b in range(nparts))
-        mfma = nwr * groups * 4 * 27
+        def schur_mfma(nw_):
+            parts = max(1, min(256, nt // 16))
+            cap = max(16, 512 // nw_)
+            nparts_ = cap if (nw_ > 1 and parts > cap) else parts
+            chunk = -(-nt // nparts_)
+            groups = sum(-(-max(0, min(nt, (b + 1) * chunk) - b * chunk) // 4) for b in range(nparts_))
+            return nw_ * groups * 4 * 27, nparts_
+
+        mfma, nparts = schur_mfma(nwr)
         flop = mfma * 2048.0
         t = kus["k_ba_schur_mfma"] * 1e-6
         tf = flop / t / 1e12
@@ -147,6 +150,16 @@ def bench_ba(nt=5000, nf=20, repeats=3, windows=(1, 8, 64), min_seconds=0.4):
                                kernels=rows, us_per_iteration_all_windows=round(sum(r["us"] for r in rows), 1))
         k1 = profiled(1)
         out["single_window_kernels_us"] = {k: round(v, 2) for k, v in k1.items()}
+        # the configuration BASELINE names is ONE window: the same figure for it (in-kernel: flop of its Schur launch / that launch's time; and over the
+        # whole LM iteration: the same flop / the sum of the five launches)
+        m1, np1 = schur_mfma(1)
+        tf1 = m1 * 2048.0 / (k1["k_ba_schur_mfma"] * 1e-6) / 1e12
+        it_us = sum(k1.values())
+        out["roofline_one_window"] = dict(bound="mfma", kernel="k_ba_schur_mfma (1 window per launch)", achieved=round(tf1, 2), peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s",
+                                          frac=round(tf1 / MFMA_F64_PEAK_TFLOPS, 4), us_per_launch=round(k1["k_ba_schur_mfma"], 2), mfma_instr_per_launch=int(m1),
+                                          nparts_per_window=np1, us_per_iteration=round(it_us, 1),
+                                          frac_over_iteration=round(m1 * 2048.0 / (it_us * 1e-6) / 1e12 / MFMA_F64_PEAK_TFLOPS, 4),
+                                          note="one C5 window is latency bound: five dependent launches per LM iteration, 256 workgroups in the Schur launch")
     except Exception as e:  # the roofline leg must never take the BA numbers down with it
         out["roofline"] = dict(error=f"{type(e).__name__}: {e}"[:300])
     # ---- larger windows (43..255 free cameras: k_ba_zbuild + k_ba_syrk_mfma + left-looking Cholesky; round 5) ----

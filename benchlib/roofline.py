@@ -60,14 +60,6 @@ def lk_valu_model():
         return None
 
 
-def fallback_lk_names(tracks):
-    """Kernel names when a measurement carries no library-reported routes (the fake measurements of tests/test_bench_cpu.py only): the live bench asks
-    the library which kernel it launched (vh_profile_lk_routes) instead of mirroring vh_lk_route's thresholds."""
-    coarse = "k_lk_o<15>" if tracks >= 30000 else ("k_lk_q<15>" if tracks >= 3000 else "k_lk_strip<15>")
-    fine = "k_lk3<51, 1, 4>" if tracks >= 3000 else ("k_lk3<51, 2, 4>" if tracks >= 1024 else "k_lk3<51, 4, 4>")
-    return [coarse, coarse, fine]
-
-
 def valu_rates():
     """opcode -> measured lanes / clk / SIMD (best over 1-4 waves per SIMD, 16 independent chains), from the newest profiles/rNN_valu_rate.json"""
     import glob
@@ -169,9 +161,9 @@ def roofline_of(wl, m, world):
     it_f = iters[2] / max(launches[2], 1)
     su_f = setups[2] / max(launches[2], 1)
     ops_fine = wf * wf * (47.0 * su_f + 12.0 * it_f)  # SURVEY §8d op model: 47 op/px set-up, 12 op/px per Newton iteration
-    # the kernels the library says it launched (vh_profile_lk_routes); only the fake measurements of the CPU tests fall back to a name table
-    names = m.get("lk_kernels") or fallback_lk_names(N * SG)
-    names_src = "vh_profile_lk_routes (the launcher's own routing decision)" if m.get("lk_kernels") else "name table (no library report in this measurement)"
+    # the kernels the library says it launched (vh_profile_lk_routes): nobody mirrors vh_lk_route's thresholds
+    names = m["lk_kernels"]
+    names_src = "vh_profile_lk_routes (the launcher's own routing decision)"
     fine_kernel = names[2]
     # HBM bytes of that kernel are NOT measured by this run: they come from the PMC passes committed under profiles/ (collected at the stream count
     # stored in the file, scaled linearly); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes

@@ -283,6 +283,10 @@ VH_API int vh_session_pack_state(vh_session* s, float* out, void* stream);
  * wavefronts per track (other windows: default routing), 0: default routing per window and load.  All are bit-identical. */
 VH_API void vh_debug_force_generic_lk(int on);
 
+/* test hook (vh_version >= 105): launch slots one workgroup of the one-wavefront LDS-staged LK kernel (k_lk3<.., 1, ..>, routes 3 and 5) solves one after the
+ * other -- 0: chosen by load (1 below 49 152 tracks in flight, 2 from there, 4 from 98 304), n > 0: n (clamped to 8).  Bit-identical results. */
+VH_API void vh_debug_lk3_tpw(int n);
+
 /* test hook: estimateAffine2D stand-in -- 1: always the three-kernel path (hypotheses spread over the chip), 2: the fused
  * one-workgroup-per-stream kernel whenever the problem fits it (latency path), 0: default routing by batch size.  Bit-identical results. */
 VH_API void vh_debug_ransac_path(int mode);
@@ -307,6 +311,9 @@ VH_API int vh_profile_end_stages(vh_ctx* ctx, int nstages, double* ms_sum, int* 
 /* the kernel each of the three LK launches of the last vh_klt_main / vh_session_step took (the launcher's own routing decision, so nobody mirrors its
  * thresholds): routes_host int[3] (ids of vh_debug_force_generic_lk), names_host char[3][32] (may be NULL) */
 VH_API int vh_profile_lk_routes(vh_ctx* ctx, int* routes_host, char* names_host);
+/* (vh_version >= 105) launch slots per workgroup of the same three launches (see vh_debug_lk3_tpw): tpw_host int[3]; a stateless vh_pyr_lk call reports
+ * its route and slot count through entry 0 (like its iteration counters) */
+VH_API int vh_profile_lk_tpw(vh_ctx* ctx, int* tpw_host);
 /* host copy of every stream's ROI (x0, x1, y0, y1) of the last KLTmain call (images.py:9-19 as KLT.py:121-123 applies it): 4 ints per stream */
 VH_API int vh_klt_rois(vh_ctx* ctx, int* roi_host);
 

@@ -26,7 +26,9 @@ def _fake_measurement(S, N, steps):
                 iters=[int(2.03 * 3 * N * S) * steps, int(1.6 * 6 * N * S) * steps, int(2.25 * 2 * N * S) * steps],
                 setups=[3 * N * S * steps, 6 * N * S * steps, 2 * N * S * steps])
     rois = np.tile(np.int32([190, 1722, 90, 992]), (S, 1))
-    return dict(prof=prof, stage_ms=stage_ms, stage_n=stage_n, rois=rois)
+    # what vh_profile_lk_routes reports at this load (the live bench asks the library; a fake measurement has to say it)
+    names = ["k_lk_o<15>", "k_lk_o<15>", "k_lk3<51, 1, 4>"] if N * S >= 10000 else ["k_lk_strip<15>", "k_lk_strip<15>", "k_lk3<51, 1, 4>"]
+    return dict(prof=prof, stage_ms=stage_ms, stage_n=stage_n, rois=rois, lk_kernels=names)
 
 
 def test_roofline_object_is_recomputable_from_its_own_fields():
@@ -132,3 +134,50 @@ def test_the_line_cites_the_newest_profile_round():
     for kind in ("valu_rate.json", "lk_valu_model.json", "lk_isa_mix.json", "hbm_traffic.json", "ba_pmc.json"):
         assert os.path.exists(os.path.join(ROOT, "profiles", f"r{newest:02d}_{kind}")), f"profiles/r{newest:02d}_{kind} is missing from the newest collection"
     assert r["step_hbm"] is not None and r["step_hbm"]["gbs"] > 0
+
+
+def _full_record():
+    """A realistic full record: the newest committed default run (every leg, every note: the 28 KB object that did not parse as a stdout line)."""
+    import glob
+
+    return json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_default.json")))[-1]))
+
+
+def test_compact_line_fits_4k_and_carries_the_contract():
+    """the stdout line is one JSON object of <= 4096 bytes with the contract's fields, `roofline` and `cpu_baseline`; the long objects
+    live in the detail file."""
+    b = _bench()
+    full = _full_record()
+    assert len(json.dumps(full)) > 8192  # the input really is the oversized record
+    text = b.compact_line(full, "/tmp/bench_detail.json")
+    assert "\n" not in text and len(text.encode()) <= 4096 == b.COMPACT_MAX_BYTES
+    d = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "verified", "build_id"):
+        assert k in d, k
+    assert d["value"] == full["value"] and d["vs_baseline"] is None and d["config"]["workload"].startswith("C2") and d["config"]["streams_per_gpu"] == 256
+    r = d["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "tracked frames/s"
+    assert d["verified"]["bit_exact"] is True
+    assert d["ba"]["iters_per_s"] == full["ba"]["iters_per_s"] and d["ba"]["cpu_baseline"]["value"] > 0
+    assert d["extras"]["hard_scene_fps"] == full["extras"]["hard_scene"]["value"] and d["extras"]["all_bit_exact"] is True
+    assert d["detail"] == "bench_detail.json"
+    assert "roofline_detail" not in d and "headline_hbm" not in d and "build" not in d
+
+
+def test_compact_line_with_multi_gpu_summary_and_oversized_extras_still_fits():
+    b = _bench()
+    full = _full_record()
+    full["n_gpus"] = 8
+    full["multi_gpu"] = dict(backend="nccl", world_size=8, exchanges=7, exchange_bytes_per_rank=6152192, exchange_host_ms_total=1.234, exchange_device_us_idle=55.5,
+                             ranks_seen_in_last_gather=8, ba_point_sharded_iters_per_s=9000.1, ba_point_sharded_ms_per_iter=0.1111, ba_replicas_iters_per_s=300000.5)
+    full["ba"] = dict(workload="C5", replicas=dict(iters_per_s=300000.5), point_sharded=dict(iters_per_s=9000.1, ms_per_iter=0.1111))
+    full["cpu_baseline"]["sample"] = "x" * 5000  # whatever grows: optional parts go, the contract stays
+    text = b.compact_line(full, None)
+    d = json.loads(text)
+    assert len(text.encode()) <= 4096
+    assert d["multi_gpu"]["ranks_seen_in_last_gather"] == 8 and d["roofline"]["frac"] and d["cpu_baseline"]["value"] > 0 and "sample" not in d["cpu_baseline"]

@@ -128,20 +128,24 @@ def test_track_state_exchange_world2_real_sessions(tmp_path):
     _run_ranks(tmp_path, body)
 
 
-def test_bench_self_launches_two_ranks_on_one_device():
+def test_bench_self_launches_two_ranks_on_one_device(tmp_path):
     """`python bench.py --gpus 2` without a torchrun environment starts its own two ranks and reports n_gpus = 2 (here: both on
     cuda:0 over gloo); the whole-job value counts the frames of both ranks."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--oversubscribe", "--streams", "2", "--steps", "6",
-           "--warmup", "2", "--no-ba", "--cpu-seconds", "0", "--exchange-every", "3", "--min-seconds", "0", "--no-extras"]
+           "--warmup", "2", "--no-ba", "--cpu-seconds", "0", "--exchange-every", "3", "--min-seconds", "0", "--no-extras", "--detail", str(tmp_path / "detail.json")]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.returncode == 0 and len(lines) == 1 and len(lines[0].encode()) <= 4096, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["streams_per_gpu"] == 2 and out["scaling"] == "weak"
     assert out["tracks_alive_frac"] > 0.9
-    # the record itself says what the process group was: backend, world size, one device entry per rank, exchanges done and seen
-    d = out["dist"]
+    # the compact line carries the multi-GPU summary ...
+    mg = out["multi_gpu"]
+    assert mg["backend"] == "gloo" and mg["world_size"] == 2 and mg["ranks_seen_in_last_gather"] == 2 and mg["exchanges"] >= 2
+    assert mg["exchange_device_us_idle"] is None  # gloo stages through the host: a device-side latency would mean nothing
+    # ... and the detail file says what the process group was: backend, world size, one device entry per rank, exchanges done and seen
+    d = json.load(open(tmp_path / "detail.json"))["dist"]
     assert d["backend"] == "gloo" and d["world_size"] == 2 and len(d["devices"]) == 2 and [q["rank"] for q in d["devices"]] == [0, 1]
     assert d["exchanges"] >= 2 and d["ranks_seen_in_last_gather"] == 2 and d["exchange_host_ms_total"] >= 0
     assert out["verified"]["bit_exact"] is True and out["verified"]["pose_within_1e5"] is True
@@ -257,19 +261,22 @@ def test_c4_full_size_two_ranks_exchange_at_frame_30(tmp_path):
     assert "C4_FULL" in out
 
 
-def test_bench_eight_ranks_oversubscribed_prints_n_gpus_8():
+def test_bench_eight_ranks_oversubscribed_prints_n_gpus_8(tmp_path):
     """`python bench.py --gpus 8 --oversubscribe --backend gloo`: the driver's 8-GPU launch shape (8 ranks, weak scaling, exchange every 30
     frames) on one device; the line says n_gpus 8 and its dist record shows 8 ranks seen in the last gather."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--oversubscribe", "--streams", "1", "--steps", "32",
-           "--warmup", "2", "--no-ba", "--cpu-seconds", "0", "--exchange-every", "30", "--min-seconds", "0", "--no-extras", "--verify-frames", "2"]
+           "--warmup", "2", "--no-ba", "--cpu-seconds", "0", "--exchange-every", "30", "--min-seconds", "0", "--no-extras", "--verify-frames", "2",
+           "--detail", str(tmp_path / "detail.json")]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.returncode == 0 and len(lines) == 1 and len(lines[0].encode()) <= 4096, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["config"]["streams_per_gpu"] == 1 and out["scaling"] == "weak"
-    d = out["dist"]
+    assert out["multi_gpu"]["world_size"] == 8 and out["multi_gpu"]["ranks_seen_in_last_gather"] == 8
+    full = json.load(open(tmp_path / "detail.json"))
+    d = full["dist"]
     assert d["backend"] == "gloo" and d["world_size"] == 8 and len(d["devices"]) == 8
     assert d["exchanges"] >= 1 and d["ranks_seen_in_last_gather"] == 8
     assert out["verified"]["bit_exact"] is True
-    assert out["build"]["matches_source"] is True
+    assert full["build"]["matches_source"] is True and full["build_id"] == out["build_id"]

@@ -145,7 +145,7 @@ def test_bench_distributed_path_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29622", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--streams", "4", "--steps", "35", "--warmup", "2",
-                        "--cpu-seconds", "0", "--no-ba", "--exchange-every", "10"], env=env, capture_output=True, text=True, timeout=600)
+                        "--cpu-seconds", "0", "--no-ba", "--no-extras", "--exchange-every", "10", "--detail", os.devnull], env=env, capture_output=True, text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert lines, r.stdout[-1500:] + r.stderr[-1500:]
     d = json.loads(lines[-1])
@@ -153,3 +153,32 @@ def test_bench_distributed_path_one_rank():
     assert "RCCL" in d["config"]["parallelism"]
     for key in ("metric", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "roofline"):
         assert key in d
+
+
+def test_bench_prints_exactly_one_compact_contract_line(tmp_path):
+    """`python bench.py` writes ONE stdout line, a JSON object of <= 4096 bytes that carries the contract's fields with `roofline` and
+    `cpu_baseline`; nothing on stderr without --verbose apart from warnings; the long objects are in the detail file."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    detail = tmp_path / "bench_detail.json"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--no-extras", "--no-ba", "--cpu-seconds", "1",
+                        "--detail", str(detail)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{") and len(lines[0].encode()) <= 4096, r.stdout[:600]
+    assert "[bench" not in r.stderr
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline", "verified", "build_id"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["streams_per_gpu"] == 256 and d["config"]["tracks"] == 2000
+    assert d["roofline"]["bound"] == "valu" and 0.2 < d["roofline"]["frac"] < 1.0 and d["roofline"]["kernel"].startswith("k_lk3<51, 1, 4>")
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["verified"]["bit_exact"] is True and d["verified"]["pose_within_1e5"] is True
+    full = json.load(open(detail))
+    assert full["value"] == d["value"] and "roofline_detail" in full and full["roofline_detail"]["kernels"]

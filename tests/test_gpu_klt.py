@@ -728,3 +728,142 @@ def test_klt_main_fuzz_vs_oracle():
         assert np.array_equal(v, ev), ctx
         assert np.array_equal(p_all, S["p_all"]), ctx
         assert np.array_equal(p, ep), ctx
+
+
+def _pyr_lk_raw(ws, a, b, W, H, pts, lk, fbt, want_err=True, want_fbe=False):
+    """vh_pyr_lk through the C ABI with optional err / fbe outputs; returns (p2, v, err | None, fbe | None, route, tpw) of that call."""
+    L, C, torch = _lib()
+    n = len(pts)
+    p = torch.from_numpy(np.ascontiguousarray(pts, np.float32)).cuda()
+    p2 = torch.zeros((n, 2), dtype=torch.float32, device="cuda")
+    v = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    err = torch.zeros(n, dtype=torch.float32, device="cuda") if want_err else None
+    fbe = torch.zeros(n, dtype=torch.float32, device="cuda") if want_fbe else None
+    prm = L.lk_params(lk)
+    L.check(ws.lib.vh_pyr_lk(ws.handle, L.dptr(a), L.dptr(b), W, H, W, W, L.dptr(p), n, C.byref(prm), C.c_float(-1.0 if fbt is None else fbt), L.dptr(p2), L.dptr(v),
+                             L.dptr(err), L.dptr(fbe), L.stream_ptr()), "vh_pyr_lk")
+    routes, tpw = (C.c_int * 3)(), (C.c_int * 3)()
+    L.check(ws.lib.vh_profile_lk_routes(ws.handle, routes, None), "vh_profile_lk_routes")
+    L.check(ws.lib.vh_profile_lk_tpw(ws.handle, tpw), "vh_profile_lk_tpw")
+    return (p2.cpu().numpy(), v.cpu().numpy().astype(bool), None if err is None else err.cpu().numpy(), None if fbe is None else fbe.cpu().numpy(),
+            int(routes[0]), int(tpw[0]))
+
+
+@pytest.mark.parametrize("mode, lk", [(5, dict(win=51, max_level=0, max_count=30, eps=0.001)), (3, dict(win=15, max_level=4, max_count=10, eps=0.1)),
+                                      (5, dict(win=51, max_level=2, max_count=12, eps=0.01))])
+def test_lk3_slot_loop_is_bit_exact_for_every_slot_count(seq, mode, lk):
+    """the one-wavefront LDS-staged kernel k_lk3<.., 1, ..> solves `tpw` consecutive launch slots per workgroup (results parked in LDS,
+    stored after the last one; tpw = 4 is what the 256-stream headline runs).  Every slot count -- through vh_debug_lk3_tpw -- must give the oracle's bits:
+    n not a multiple of tpw, n < tpw, border / out-of-frame tracks, the gate scene (forward-dead tracks in the middle of a workgroup's slots), with and
+    without the err / fbe outputs, with and without the forward-backward gate; and the launch must report the slot count it really used."""
+    L, C, torch = _lib()
+    W, H, m, f0, f1, p0 = seq
+    rng = np.random.default_rng(77)
+    edge = np.concatenate([rng.uniform(-30, 40, (41, 2)), rng.uniform([W - 40, H - 40], [W + 30, H + 30], (41, 2)),
+                           np.stack([rng.uniform(0, W, 41), rng.uniform(-10, 10, 41)], 1)]).astype(np.float32)
+    mixed = np.concatenate([p0, edge])
+    mixed = mixed[rng.permutation(len(mixed))]  # dead (out-of-frame) tracks anywhere inside a workgroup's run of slots
+    assert len(mixed) % 8 == 3
+    g0, g1, gp = synth.gate_scene()
+    cases = [("mixed", f0, f1, mixed), ("three", f0, f1, mixed[:3]), ("one", f0, f1, mixed[:1]), ("seven", f0, f1, mixed[5:12]), ("gate", g0, g1, gp)]
+    lib = L.load()
+    try:
+        lib.vh_debug_force_generic_lk(mode)
+        for name, a_np, b_np, pts in cases:
+            h, w = a_np.shape
+            ws = L.workspace(w, h, len(pts))
+            a, b = torch.from_numpy(a_np).cuda(), torch.from_numpy(b_np).cuda()
+            for fbt in (None, 0.3 if lk["win"] == 51 else 1.0):
+                e2, ev, eerr = KO.lk_fb(a_np, b_np, pts, fbt=fbt, **lk)
+                if name == "gate":
+                    assert (~KO.pyr_lk(a_np, b_np, pts, **lk)[1]).sum() >= 5
+                for tpw in (1, 2, 3, 4, 8):
+                    lib.vh_debug_lk3_tpw(tpw)
+                    for want_err, want_fbe in ((True, False), (False, False), (True, True)):
+                        if want_fbe and fbt is None:
+                            continue
+                        p2, v, err, fbe, route, used = _pyr_lk_raw(ws, a, b, w, h, pts, lk, fbt, want_err, want_fbe)
+                        ctx = (name, fbt, tpw, want_err, want_fbe)
+                        assert route == mode and used == tpw, (ctx, route, used)
+                        assert np.array_equal(v, ev) and np.array_equal(p2, e2), ctx
+                        if want_err:
+                            assert np.array_equal(err, eerr), ctx
+                        if want_fbe:  # fbe requested: the backward pass of forward-dead tracks runs too; the gate and the point stay the oracle's
+                            assert np.isfinite(fbe[v]).all() and (fbe[v] < fbt).all(), ctx
+    finally:
+        lib.vh_debug_lk3_tpw(0)
+        lib.vh_debug_force_generic_lk(0)
+
+
+def test_lk3_slot_count_hook_is_clamped_and_default_is_one_for_small_launches(seq):
+    L, C, torch = _lib()
+    W, H, m, f0, f1, p0 = seq
+    ws = L.workspace(W, H, len(p0))
+    a, b = torch.from_numpy(f0).cuda(), torch.from_numpy(f1).cuda()
+    lk = dict(win=51, max_level=0, max_count=30, eps=0.001)
+    lib = L.load()
+    try:
+        lib.vh_debug_force_generic_lk(5)
+        assert _pyr_lk_raw(ws, a, b, W, H, p0, lk, 0.3)[5] == 1  # 600 tracks in flight: one slot per workgroup
+        lib.vh_debug_lk3_tpw(100)
+        ref = _pyr_lk_raw(ws, a, b, W, H, p0, lk, 0.3)
+        assert ref[5] == 8  # LK3::MAX_TPW
+        lib.vh_debug_lk3_tpw(-5)
+        assert _pyr_lk_raw(ws, a, b, W, H, p0, lk, 0.3)[5] == 1
+        lib.vh_debug_force_generic_lk(6)  # two wavefronts per track: no slot loop whatever the hook says
+        lib.vh_debug_lk3_tpw(4)
+        two = _pyr_lk_raw(ws, a, b, W, H, p0, lk, 0.3)
+        assert two[4] == 6 and two[5] == 1 and np.array_equal(two[0], ref[0]) and np.array_equal(two[1], ref[1])
+    finally:
+        lib.vh_debug_lk3_tpw(0)
+        lib.vh_debug_force_generic_lk(0)
+
+
+def test_klt_main_reuses_the_previous_upload_and_notices_a_refilled_buffer(seq):
+    """The drop-in KLTmain keeps the device copy of the frame it uploaded and of the quarter image it returned; when those very arrays come back as
+    im0 / im0_small (the reference's `im0 = im`) they are not uploaded again.  The results must be the oracle's either way, and a frame BUFFER that is
+    refilled in place between calls (same object, new pixels) must be uploaded again."""
+    from velocity_amd import KLT
+
+    W, H, m, f0, f1, p0 = seq
+    f2 = synth.render_frame(W, H, m, 2).numpy()
+    pts = p0[:300]
+    e1 = KO.klt_main(f1, f0, None, pts)
+    e2 = KO.klt_main(f2, f1, e1[2], e1[0])
+    KLT._uploaded.clear()
+    a1 = KLT.KLTmain(f1, f0, None, pts)
+    assert KLT._uploaded["im"][0][0] == id(f1) and KLT._uploaded["small"][0][0] == id(a1[2])
+    dev_f1, dev_small = KLT._uploaded["im"][1], KLT._uploaded["small"][1]
+    seen = set()
+    real = KLT.L.img_dev
+
+    def counting(x):
+        seen.add(id(x))
+        return real(x)
+
+    KLT.L.img_dev = counting
+    try:
+        a2 = KLT.KLTmain(f2, f1, a1[2], a1[0])  # im0 = the array uploaded one call earlier, im0_small = the array returned one call earlier
+    finally:
+        KLT.L.img_dev = real
+    assert id(f1) not in seen and id(a1[2]) not in seen and id(f2) in seen, "the previous frame / quarter image must come from the device copies"
+    assert KLT._uploaded["im"][1] is not dev_f1 and dev_small is not None
+    for got, exp in ((a1, e1), (a2, e2)):
+        assert np.array_equal(got[1], exp[1]) and np.array_equal(got[0], exp[0]) and np.array_equal(got[2], exp[2])
+    # one buffer refilled in place: the same object now holds other pixels -> uploaded again, results still the oracle's
+    buf = f1.copy()
+    b1 = KLT.KLTmain(buf, f0, None, pts)
+    prev = buf.copy()
+    buf[:] = f2
+    b2 = KLT.KLTmain(buf, prev, b1[2], b1[0])
+    assert np.array_equal(b2[0], e2[0]) and np.array_equal(b2[1], e2[1])
+    stale = buf  # and the degenerate call "both arguments are the refilled buffer" must see the NEW pixels for both
+    c = KLT.KLTmain(stale, stale, None, pts)
+    ec = KO.klt_main(f2, f2, None, pts)
+    assert np.array_equal(c[0], ec[0]) and np.array_equal(c[1], ec[1])
+    KLT.UPLOAD_CACHE = False
+    try:
+        d = KLT.KLTmain(f2, f1, a1[2], a1[0])
+    finally:
+        KLT.UPLOAD_CACHE = True
+    assert np.array_equal(d[0], e2[0]) and np.array_equal(d[1], e2[1])

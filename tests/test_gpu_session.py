@@ -281,8 +281,9 @@ def test_session_on_a_rolling_zooming_scene():
 @pytest.mark.parametrize("params,scene", [("baseline", "plane"), ("ref", "plane"), ("baseline", "roll")])
 def test_session_at_the_measured_configuration(params, scene):
     """The configuration bench.py's headline number is measured on (BASELINE config 2): 1080p, 2000 tracks per stream, SEVERAL streams in one
-    session, so that >= 3000 tracks are in flight and vh_launch_lk routes to k_lk3<51,1,4> (fine stage) and k_lk_q<15> (coarse stages), RANSAC
-    to k_ransac_fused and the bookkeeping + pose to the fused k_sess_frame -- exactly the kernels the benchmark times.  Every stream must equal
+    session, so that >= 3000 tracks are in flight and vh_launch_lk routes to k_lk3<51,1,4> (fine stage, one slot per workgroup) and k_lk_q<15>
+    (coarse stages), RANSAC to k_ransac_fused and the bookkeeping + pose to the fused k_sess_frame.  (The 256-stream headline itself takes k_lk_o<15>
+    and k_lk3<51,1,4> with FOUR slots per workgroup: test_session_at_the_headline_load_takes_the_headline_routes below.)  Every stream must equal
     its own reference loop: bit-exact vg / vp / ids / p, pose and residual to 1e-5 (north_star: 1e-4)."""
     import torch
 
@@ -324,6 +325,60 @@ def test_session_at_the_measured_configuration(params, scene):
         assert np.abs(st["t"] - truth).max() < 2e-3
         for r in (0, 1, 4):
             assert np.array_equal(st["P"][r], orcs[b].P[r], equal_nan=True)
+
+
+def test_session_at_the_headline_load_takes_the_headline_routes():
+    """the kernel configuration the headline number times, reached by NATURAL routing (no debug hook): >= 98 304 tracks in flight in
+    one launch sequence -- 256 streams x 400 tracks on 640 x 360 frames = 102 400 -- so that vh_lk_route picks k_lk_o<15> for both coarse stages (8 tracks
+    per wavefront, spatial launch order) and k_lk3<51, 1, 4> with FOUR launch slots per workgroup for the fine stage, as vh_session_step does at 256 C2
+    streams.  The first, a middle and the last stream (each with its own texture and motion phase) are held against SessionOracle for 4 frames: vg / vp /
+    ids / p bit for bit, pose and residual to 1e-5; the library's own launch record must name those kernels and slots."""
+    import torch
+
+    from velocity_amd.driver import TrackerSession
+
+    W, H, N, B, nframes, ring = 640, 360, 400, 256, 5, 60
+    K = synth.K_1080P.copy()
+    K[:2, :2] *= W / 1920.0
+    K[2, 0], K[2, 1] = W / 2 + 0.5, H / 2 + 0.5
+    m = synth.PlaneMotion(K, z0=3.6, traj=synth.oscillating_traj(period=float(ring)))
+    lkc = dict(max_level=2)
+    checked = {0: (0, 11), 131: (9, 22), 255: (31, 33)}  # stream -> (motion phase, texture); every other stream replays one of three filler clips
+    filler = [(3, 44), (17, 55), (40, 66)]
+    clips = {}
+
+    def clip(ph, tex):
+        if (ph, tex) not in clips:
+            clips[(ph, tex)] = [synth.render_frame(W, H, m, ph + k, seed=0xC0FFEE + 104729 * tex, device="cuda") for k in range(nframes)]
+        return clips[(ph, tex)]
+
+    of = [checked.get(b, filler[b % 3]) for b in range(B)]
+    p0 = synth.grid_tracks(N, W, H, seed=0xEF)
+    p3 = m.world_points(p0)
+    vp = np.ones(N, bool)
+    ses = TrackerSession(K, W, H, N, nhist=nframes + 1, batch=B, lk_coarse=lkc, lk_fine={}, msv_frame=0)
+    orcs = {}
+    for b, (ph, tex) in enumerate(of):
+        pb = m.apply(ph, p0.astype(float)).astype(np.float32)
+        p3b = p3 + m.t(ph)
+        ses.init_stream(b, clip(ph, tex)[0], pb, p3b, vp, np.float32([0, 0, 0]))
+        if b in checked:
+            orcs[b] = SessionOracle(K, clip(ph, tex)[0].cpu().numpy(), pb, p3b, vp, np.float32([0, 0, 0]), nhist=nframes + 1, lk_coarse=lkc, lk_fine={}, msv_frame=0)
+    for i in range(1, nframes):
+        ts = np.float32(i / 30.0)
+        ses.step([clip(*of[b])[i] for b in range(B)], time_s=ts, frame_no=i)
+        rec = ses.lk_launches()
+        assert rec["kernels"] == ["k_lk_o<15>", "k_lk_o<15>", "k_lk3<51, 1, 4>"], rec
+        assert rec["slots_per_workgroup"] == [1, 1, 4], rec
+        for b, o in orcs.items():
+            o.step(clip(*of[b])[i].cpu().numpy(), ts, i)
+            st = ses.state(b)
+            assert np.array_equal(st["vg"], o.vg) and np.array_equal(st["vp"], o.vp), (i, b)
+            assert np.array_equal(st["ids"], np.nonzero(o.vg)[0]) and np.array_equal(st["p"], o.p), (i, b)
+            np.testing.assert_allclose(st["t"], o.t, rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(st["res"], o.residuals, rtol=1e-5)
+    for b in orcs:
+        assert ses.state(b)["n_cur"] > 0.9 * N  # the tracker really follows the scene
 
 
 def test_session_stays_on_the_reference_loop_for_2000_frames():

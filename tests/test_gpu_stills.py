@@ -73,15 +73,16 @@ def test_real_stills_full_loop_matches_oracle_and_the_labelled_speed(stills):
 
 
 def test_run_sequence_drop_in_route_prints_the_same_table(stills):
-    """The same clip through the reference's own loop body on the drop-in functions (what INTEGRATION.md's import switch gives a maintainer): same table,
+    """The same clip through a host loop on the drop-in functions (tools/dropin_loop.py: what INTEGRATION.md's import switch gives a maintainer): same table,
     and the per-frame time of both routes side by side."""
     from oracle import driver_oracle as DO
+    from tools.dropin_loop import run_sequence_dropin
     from velocity_amd.driver import run_sequence
 
     frames, times, q, K = stills["b_frames"], stills["b_times"], stills["b_q"], stills["b_K"]
     with np.errstate(all="ignore"):
         ref = DO.run_sequence(frames, q, K, times, roi_border=(180, 140))
-    dropin = run_sequence(frames, q, K, times=times, roi_border=(180, 140), route="dropin", clock=lambda: 0.0, out=None)
+    dropin = run_sequence_dropin(frames, q, K, times=times, roi_border=(180, 140), clock=lambda: 0.0, out=None)
     _same_table(dropin["lines"][:-1], ref["lines"])
     assert np.array_equal(dropin["vg"], ref["vg"]) and np.array_equal(dropin["p"], ref["p"])
     for r in (0, 1, 4):
@@ -89,7 +90,7 @@ def test_run_sequence_drop_in_route_prints_the_same_table(stills):
     # timing (real clock), second pass of each route (the first pays allocations / first launches)
     for _ in range(2):
         a = run_sequence(frames, q, K, times=times, roi_border=(180, 140), route="session", live=False, out=None)
-        b = run_sequence(frames, q, K, times=times, roi_border=(180, 140), route="dropin", out=None)
+        b = run_sequence_dropin(frames, q, K, times=times, roi_border=(180, 140), out=None)
     print(f"per tracked frame on the real stills (1024 x 768, 278 tracks): session route {a['ms_per_frame']:.3f} ms, drop-in route {b['ms_per_frame']:.3f} ms")
     assert 0 < a["ms_per_frame"] < 50 and 0 < b["ms_per_frame"] < 50
 

@@ -30,15 +30,15 @@ cd /tmp && export TMPDIR=/tmp
 bash $R/tools/pmc_lk_calib.sh $S > $OUT/lk_calib.log 2>&1
 M=$(ls $R/profiles/r[0-9][0-9]_lk_valu_model.json 2>/dev/null | tail -1)
 if [ -s $R/gpurun_out/lk_valu_model.json ]; then cp $R/gpurun_out/lk_valu_model.json $OUT/lk_valu_model.json; [ -n "$M" ] && cp $R/gpurun_out/lk_valu_model.json $M; fi
-python $R/bench.py --streams $S > $OUT/bench_default.json 2> $OUT/bench_default.err
+python $R/bench.py --streams $S --verbose --detail $OUT/bench_default.json > $OUT/bench_default.line 2> $OUT/bench_default.err
 for s in 1 2 4 8 16 32 64 128 256; do
-  python $R/bench.py --streams $s --steps 60 --warmup 10 --cpu-seconds 0 --no-ba --no-extras --min-seconds 1 2>/dev/null | tail -1 > $OUT/sweep_$s.json
+  python $R/bench.py --streams $s --steps 60 --warmup 10 --cpu-seconds 0 --no-ba --no-extras --min-seconds 1 --detail /dev/null 2>/dev/null | tail -1 > $OUT/sweep_$s.json
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --streams $S --steps 40 --warmup 5 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --streams $S --steps 40 --warmup 5 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null > $OUT/stats.log 2>&1
 find $OUT/stats -name "*kernel_trace.csv" -delete   # tens of MB; the per-kernel summary is what is kept
 # HBM traffic of EVERY library kernel of a step (roofline.step_hbm sums them): FETCH_SIZE and WRITE_SIZE in separate passes
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --kernel-include-regex '^(void )?k_' --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --streams $S --steps 6 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --kernel-include-regex '^(void )?k_' --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --streams $S --steps 6 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null > $OUT/pmc_$c.log 2>&1
   find $OUT/pmc_$c -name "*kernel_trace.csv" -delete
 done
 # the loads that look like the reference's data: both episode legs + the kernel stats of the hard scene
@@ -54,7 +54,7 @@ P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_I
 i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_o|k_lk_q' --pmc $P --output-format csv -d $OUT/sq_lk$i -- python $R/bench.py --streams $S --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/sq_lk$i.log 2>&1
+  rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_o|k_lk_q' --pmc $P --output-format csv -d $OUT/sq_lk$i -- python $R/bench.py --streams $S --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null > $OUT/sq_lk$i.log 2>&1
   find $OUT/sq_lk$i -name "*kernel_trace.csv" -delete
 done
 # BA (C5): per-kernel stats of bench.bench_ba() (1, 8 and 64 windows) + SQ / MFMA counters of its kernels
@@ -95,7 +95,7 @@ BA_NF=20,26,43,51,65,97,129,201,256 python $R/tools/exp/ba_by_cameras.py 5000 10
 BA_NF=129 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ba128 -- python $R/tools/exp/ba_by_cameras.py 5000 > $OUT/ba128.log 2>&1
 find $OUT/ba128 -name "*kernel_trace.csv" -delete
 # single stream: launch timeline of one steady-state frame
-rocprofv3 --kernel-trace --output-format csv -d $OUT/s1 -- python $R/bench.py --streams 1 --steps 200 --warmup 20 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/s1.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/s1 -- python $R/bench.py --streams 1 --steps 200 --warmup 20 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null > $OUT/s1.log 2>&1
 python - <<PY
 import csv, glob, json
 f = glob.glob("$OUT/s1/**/*kernel_trace.csv", recursive=True)[0]
@@ -112,7 +112,7 @@ PY
 rm -rf $OUT/s1
 # PCIe-inclusive rate (frames uploaded from pinned host memory every step)
 for s in 1 8 64; do
-  python $R/bench.py --streams $s --steps 60 --warmup 10 --cpu-seconds 0 --no-ba --no-extras --min-seconds 1 --host-frames 2>/dev/null | tail -1 > $OUT/hostframes_$s.json
+  python $R/bench.py --streams $s --steps 60 --warmup 10 --cpu-seconds 0 --no-ba --no-extras --min-seconds 1 --host-frames --detail /dev/null 2>/dev/null | tail -1 > $OUT/hostframes_$s.json
 done
 # VALU issue rates per instruction class
 timeout 600 $R/tools/ubench/valu_rate > $OUT/valu_rate.json 2> $OUT/valu_rate.err

@@ -28,5 +28,6 @@ for rep in range(3):
 for rep in range(2):
     r = run_sequence(dev, q, K, times=times, roi_border=(180, 140), route="session", live=False, out=None)
     print("live=False ms/frame", round(r["ms_per_frame"], 3))
-    r = run_sequence(frames, q, K, times=times, roi_border=(180, 140), route="dropin", out=None)
+    from tools.dropin_loop import run_sequence_dropin
+    r = run_sequence_dropin(frames, q, K, times=times, roi_border=(180, 140), out=None)
     print("dropin ms/frame", round(r["ms_per_frame"], 3), [round(1e3 * float(x), 3) for x in r["S"][:, 1]])

@@ -7,7 +7,7 @@ S=${1:-256}
 R=/root/repo; OUT=$R/gpurun_out/pmc_calib; rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 run() {  # tag, extra bench flags
   rocprofv3 --kernel-trace --kernel-include-regex "k_lk3|k_lk_o|k_lk_q" --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/$1 -- \
-    python $R/bench.py --streams $S --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --verify-frames 0 $2 > $OUT/$1.log 2>&1
+    python $R/bench.py --streams $S --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null --verify-frames 0 $2 > $OUT/$1.log 2>&1
 }
 run default ""
 run cap1 "--fine-max-count 1"

@@ -2,7 +2,7 @@
 # launch timeline of ONE steady-state frame step (rocprofv3 --kernel-trace); run on the GPU box.  Usage: bash tools/step_timeline.sh [streams]
 S=${1:-128}
 R=/root/repo; OUT=$R/gpurun_out/timeline; rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python $R/bench.py --streams $S --steps 30 --warmup 5 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python $R/bench.py --streams $S --steps 30 --warmup 5 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null > $OUT/log.txt 2>&1
 python - <<PY
 import csv, glob, json
 f = glob.glob("$OUT/**/*kernel_trace.csv", recursive=True)[0]

@@ -28,9 +28,12 @@ def last_json(path):
     return json.loads(lines[-1])
 
 
-bench = last_json(os.path.join(SRC, "bench_default.json"))
+bench = json.load(open(os.path.join(SRC, "bench_default.json")))  # the FULL record (bench.py --detail); the compact stdout line is bench_default.line
 S = bench["config"]["streams_per_gpu"]
 json.dump(bench, open(os.path.join(DST, f"{tag}_bench_default.json"), "w"), indent=1)
+line = os.path.join(SRC, "bench_default.line")
+if os.path.exists(line):
+    json.dump(last_json(line), open(os.path.join(DST, f"{tag}_bench_line.json"), "w"), indent=1)
 
 sweep = {}
 for f in sorted(glob.glob(os.path.join(SRC, "sweep_*.json")), key=lambda p: int(p.split("_")[-1].split(".")[0])):

@@ -89,6 +89,8 @@ _SIGS = {
     "vh_debug_ba_force_valu": (None, [C.c_int]),
     "vh_debug_pyr_rows": (None, [C.c_int]),
     "vh_debug_klt_order": (None, [C.c_int]),
+    "vh_debug_lk3_tpw": (None, [C.c_int]),
+    "vh_profile_lk_tpw": (C.c_int, [vp, i32p]),
     "vh_profile_begin": (C.c_int, [vp, C.c_int]),
     "vh_profile_end": (C.c_int, [vp, f64p, i32p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "vh_profile_end_stages": (C.c_int, [vp, C.c_int, f64p, i32p]),

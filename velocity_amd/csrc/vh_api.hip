@@ -29,7 +29,7 @@ int vh_fail(int code, const char* msg)
 }
 #define VH_LAUNCH_CHECK() VH_CHECK(hipGetLastError())
 
-extern "C" VH_API int vh_version(void) { return 104; }
+extern "C" VH_API int vh_version(void) { return 105; }
 void vh_lk_force_generic(int on);
 extern "C" VH_API void vh_debug_force_generic_lk(int on) { vh_lk_force_generic(on); }
 void vh_ransac_force_path(int mode);
@@ -444,9 +444,9 @@ __global__ void k_klt_glue2(StreamWS* ws_all)
 static int launch_lk_profiled(vh_ctx* c, int stage, const void* tab, size_t st, int count, int win, hipStream_t s, int mn)
 {
     const int rec = vh_prof_start(c, s, 1);
-    int route = 0;
-    const int r = vh_launch_lk(tab, st, count, mn, win, s, &route);
-    if (c && stage >= 0 && stage < 3) { c->lk_route[stage] = route; c->lk_win[stage] = win; }
+    int route = 0, tpw = 1;
+    const int r = vh_launch_lk(tab, st, count, mn, win, s, &route, &tpw);
+    if (c && stage >= 0 && stage < 3) { c->lk_route[stage] = route; c->lk_win[stage] = win; c->lk_tpw[stage] = tpw; }
     vh_prof_stop(c, rec, stage, s);
     return r;
 }
@@ -580,6 +580,18 @@ extern "C" VH_API int vh_klt_rois(vh_ctx* c, int* roi_host)
 
 // which kernel each of the three LK launches of the last KLTmain / session step took (the launcher's own decision, vh_lk_route): ids as
 // vh_debug_force_generic_lk, names as in DESIGN.md / rocprofv3 traces; names_host: 3 x 32 chars (may be null)
+// launch slots per workgroup of the same three launches (1 unless the one-wavefront LDS-staged kernel looped over consecutive slots, launch_lk3); a
+// stateless vh_pyr_lk call reports through entry 0, like its iteration counters
+extern "C" VH_API int vh_profile_lk_tpw(vh_ctx* c, int* tpw_host)
+{
+    if (!c || !tpw_host) return vh_fail(-1, "vh_profile_lk_tpw: bad arguments");
+    for (int k = 0; k < 3; k++) tpw_host[k] = c->lk_tpw[k];
+    return 0;
+}
+
+void vh_lk3_set_tpw(int n);
+extern "C" VH_API void vh_debug_lk3_tpw(int n) { vh_lk3_set_tpw(n); }
+
 extern "C" VH_API int vh_profile_lk_routes(vh_ctx* c, int* routes_host, char* names_host)
 {
     if (!c || !routes_host) return vh_fail(-1, "vh_profile_lk_routes: bad arguments");
@@ -604,7 +616,7 @@ extern "C" VH_API int vh_klt_main(vh_ctx* c, int slot, const uint8_t* im, const 
     io.im = im; io.im0 = im0; io.im0_small = im0_small; io.p0 = p0; io.n_ptr = nullptr; io.p_all = p_all; io.v = v;
     io.im_small = im_small; io.flags = flags; io.w = w; io.h = h; io.stride = stride; io.stride0 = stride0; io.n = n;
     io.reuse_prev_small = 0; io.coarse = *coarse; io.fine = *fine; io.fbt_coarse = 1.0f; io.fbt_fine = 0.3f;
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     hipStream_t s = bound_.s;
     VH_CHECK(vh_store(&c->d_ws[slot].io, io, s));
     return vh_run_klt_main(c, slot, 1, s, *coarse, *fine, nullptr, nullptr, n);
@@ -626,7 +638,7 @@ extern "C" VH_API int vh_klt_stage_ptrs(vh_ctx* c, int slot, vh_klt_stages* out)
 extern "C" VH_API int vh_resize_quarter(vh_ctx* c, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream)
 {
     if (!c) return vh_fail(-1, "null ctx");
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     hipStream_t s = bound_.s;
     const int dw = (int)lrint(w * 0.25), dh = (int)lrint(h * 0.25);
     StreamWS* ws = c->d_ws;
@@ -659,7 +671,7 @@ extern "C" VH_API int vh_bgr2gray(vh_ctx* c, const uint8_t* bgr, int w, int h, i
 extern "C" VH_API int vh_ingest_bgr(vh_ctx* c, const uint8_t* bgr, int w, int h, int stride_bytes, uint8_t* gray, int gray_stride, uint8_t* small, void* stream)
 {
     if (!c || !bgr || !gray || w < 1 || h < 1 || stride_bytes < 3 * w || gray_stride < w) return vh_fail(-1, "vh_ingest_bgr: bad arguments");
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     hipStream_t s = bound_.s;
     IngestJob J;
     memset(&J, 0, sizeof(J));
@@ -676,7 +688,7 @@ extern "C" VH_API int vh_ingest_bgr(vh_ctx* c, const uint8_t* bgr, int w, int h,
 extern "C" VH_API int vh_pyr_down(vh_ctx* c, const uint8_t* src, int w, int h, int stride, uint8_t* dst, void* stream)
 {
     if (!c) return vh_fail(-1, "null ctx");
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     hipStream_t s = bound_.s;
     StreamWS* ws = c->d_ws;
     PyrDesc P;
@@ -776,7 +788,7 @@ extern "C" VH_API int vh_pyr_lk(vh_ctx* c, const uint8_t* im1, const uint8_t* im
         return vh_fail(-1, "vh_pyr_lk: bad arguments (need win >= 3, max_level >= 0, w, h >= 4, strides >= w)");
     if (w > c->max_w || h > c->max_h || n > c->max_pts) return vh_fail(-1, "vh_pyr_lk: image or point count exceeds the workspace");
     if (n <= 0) return 0;
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     hipStream_t s = bound_.s;
     const StreamBufs& B = c->h_bufs[0];
     LKJob J;
@@ -791,13 +803,16 @@ extern "C" VH_API int vh_pyr_lk(vh_ctx* c, const uint8_t* im1, const uint8_t* im
     J.fbt = fbt;
     J.in_scale = 1.f; J.out_mode = VH_OUT_SCALE; J.out_scale = 1.f;
     StreamWS* ws = c->d_ws;
-    J.stats = &ws->lk_stats[0][0][0];  // Newton iterations / template set-ups of this call (vh_profile_begin zeroes them, vh_profile_end reads them)
+    // Newton iterations / template set-ups of this call, ONLY between vh_profile_begin (zeroes them) and vh_profile_end (reads them, as stage 0): an
+    // unprofiled call issues no statistics atomics at all
+    J.stats = c->prof_on ? &ws->lk_stats[0][0][0] : nullptr;
     VH_CHECK(vh_store(&ws->lk, J, s));
     VH_CHECK(vh_store(&ws->pb[0], PyrBuild{&ws->lk.I, 1, 0}, s));
     VH_CHECK(vh_store(&ws->pb[1], PyrBuild{&ws->lk.J, 1, 0}, s));
     const int lv = lk->max_level < VH_MAX_LEVELS - 1 ? lk->max_level : VH_MAX_LEVELS - 1;
     for (int l = 0; l < lv; l++) vh_launch_pyr_down_ws(&ws->pb[0], sizeof(StreamWS), 1, l, w, h, s);
-    int r = vh_launch_lk(&ws->lk, sizeof(StreamWS), 1, n, lk->win, s);
+    int r = vh_launch_lk(&ws->lk, sizeof(StreamWS), 1, n, lk->win, s, &c->lk_route[0], &c->lk_tpw[0]);
+    c->lk_win[0] = lk->win;
     if (r) return vh_fail(r, "vh_launch_lk failed (window too large for LDS?)");
     VH_LAUNCH_CHECK();
     return 0;
@@ -807,7 +822,7 @@ extern "C" VH_API int vh_ransac_affine(vh_ctx* c, const float* from, const float
                                        int* status, void* stream)
 {
     if (!c || n < 0 || n > c->max_pts) return vh_fail(-1, "vh_ransac_affine: bad arguments");
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     hipStream_t s = bound_.s;
     const StreamBufs& B = c->h_bufs[0];
     RansacJob R;
@@ -888,7 +903,7 @@ extern "C" VH_API int vh_klt_regional(vh_ctx* c, const uint8_t* im0, const uint8
     if (!c || !lk || !T_host || lk->win < 3 || lk->max_level < 0 || n < 1 || w < 4 || h < 4 || stride0 < w || stride < w)
         return vh_fail(-1, "vh_klt_regional: bad arguments (need win >= 3, max_level >= 0, w, h >= 4, strides >= w)");
     if (w > c->max_w || h > c->max_h || n > c->max_pts) return vh_fail(-1, "vh_klt_regional: image or point count exceeds the workspace");
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     hipStream_t s = bound_.s;
     RegionalIO io;
     memset(&io, 0, sizeof(io));
@@ -932,7 +947,7 @@ extern "C" VH_API int vh_pose(vh_ctx* c, const double* K, const float* p, const 
                               int findR, float* t_out, double* R_out, double* res_out, double* p_proj, int* info, void* stream)
 {
     if (!c || !K || !x0 || !R || n < 0) return vh_fail(-1, "vh_pose: bad arguments");
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     hipStream_t s = bound_.s;
     PoseJob J;
     memset(&J, 0, sizeof(J));
@@ -952,7 +967,7 @@ extern "C" VH_API int vh_pose(vh_ctx* c, const double* K, const float* p, const 
 extern "C" VH_API int vh_world2image(vh_ctx* c, const double* C_host, const double* pw, int n, double* out, void* stream)
 {
     if (!c || !C_host) return vh_fail(-1, "vh_world2image: bad arguments");
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     hipStream_t s = bound_.s;
     int r = store_doubles(c->d_small, C_host, 12, s);
     if (r) return r;
@@ -964,7 +979,7 @@ extern "C" VH_API int vh_world2image(vh_ctx* c, const double* C_host, const doub
 extern "C" VH_API int vh_image2world(vh_ctx* c, const double* Hi_host, const double* p, int n, double* out, void* stream)
 {
     if (!c || !Hi_host) return vh_fail(-1, "vh_image2world: bad arguments");
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     hipStream_t s = bound_.s;
     int r = store_doubles(c->d_small + 16, Hi_host, 9, s);
     if (r) return r;

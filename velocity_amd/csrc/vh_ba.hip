@@ -2055,10 +2055,13 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     const size_t lds = sizeof(double) * (size_t)(6 * nq + 12 * (nc + 1) + 16);
     const int npad = nq <= BA_NPAD ? BA_NPAD : 2 * BA_NPAD;  // matrix-core Schur kernel: 128-wide (<= 21 cameras) or 256-wide in two passes (<= 42)
     const size_t lds_mfma = sizeof(double) * (size_t)(24 * npad + 2 * 4 * (20 * nc + 10) + 4 * npad);
-    const bool use_mfma = nq <= 252 && !P.force_valu && P.model == 0;  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
+    // the VALU test hook (vh_debug_ba_force_valu) is honoured where the VALU Schur kernel exists (<= BA_MAX_NC_VALU cameras) and ignored above: a flag
+    // left set by another test or thread must not turn a valid call into a failure
+    const bool force_valu = P.force_valu && nq <= 6 * BA_MAX_NC_VALU;
+    const bool use_mfma = nq <= 252 && !force_valu && P.model == 0;  // model 1 has nc + 5 unknowns: nothing for the matrix cores to do
     // 43..128 cameras: Z materialised + K-split SYRK on the matrix cores (k_ba_zbuild / k_ba_syrk_mfma).  nm macro tiles of 128 per dimension; the
     // first `nsplit` partial systems are used: about one resident round of workgroups (2 per CU), every split at least one LDS stage of points
-    const bool use_syrk = nq > 252 && !P.force_valu && P.model == 0;
+    const bool use_syrk = nq > 252 && !force_valu && P.model == 0;
     if (!use_syrk && !use_mfma && nq > 6 * BA_MAX_NC_VALU) return -3;  // the VALU Schur kernel keeps 6 nc / 256 right-hand-side entries per thread and 3 x 6 nc doubles of LDS
     const int nm = (nq + 127) / 128, npairs = nm * (nm + 1) / 2;
     const int nsplit = use_syrk ? std::max(1, std::min(std::min(nparts, std::max(1, 512 / (npairs * (int)std::min(J.nwin < 1 ? 1 : J.nwin, 512)))), (nt + 10) / 11)) : nparts;

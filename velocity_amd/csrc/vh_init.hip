@@ -237,7 +237,7 @@ static int init_reserve(vh_ctx* c, size_t pixels, hipStream_t s)
 extern "C" VH_API int vh_init_reserve(vh_ctx* c, int w, int h, void* stream)
 {
     if (!c || w < 1 || h < 1) return vh_fail(-1, "vh_init_reserve: bad arguments");
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     return init_reserve(c, (size_t)w * h, bound_.s);
 }
 
@@ -269,7 +269,7 @@ extern "C" VH_API int vh_good_features(vh_ctx* c, const uint8_t* im, int w, int 
                                        double k, float* corners, int* count, void* stream)
 {
     if (!c || w < 3 || h < 3 || max_corners < 1 || block < 1 || block > 15) return vh_fail(-1, "vh_good_features: bad arguments");
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     return good_features_run(c, im, w, h, stride, max_corners, quality, block, k, 0.f, 0.f, corners, count, bound_.s);
 }
 
@@ -291,7 +291,7 @@ extern "C" VH_API int vh_corner_subpix(vh_ctx* c, const uint8_t* im, int w, int 
 {
     if (!c || win < 1 || win > SUBPIX_MAXWIN || n < 0) return vh_fail(-1, "vh_corner_subpix: bad arguments (window half-size 1..7)");
     if (n == 0) return 0;
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     return corner_subpix_run(c, im, w, h, stride, pts, n, nullptr, win, max_iter, eps, bound_.s);
 }
 
@@ -372,7 +372,7 @@ extern "C" VH_API int vh_frame0_init(vh_ctx* c, const uint8_t* im, int w, int h,
         return vh_fail(-1, "vh_frame0_init: null argument");
     if (w < 3 || h < 3 || stride < w || max_corners < 1 || block < 1 || block > 15 || subpix_win < 1 || subpix_win > SUBPIX_MAXWIN)
         return vh_fail(-1, "vh_frame0_init: bad arguments");
-    vh_ctx_bind bound_(c, stream);
+    VH_BIND(c, stream);
     hipStream_t s = bound_.s;
     Frame0Job J;
     memset(&J, 0, sizeof(J));

@@ -56,7 +56,7 @@ struct IngestJob {
 void vh_launch_ingest_bgr(const IngestJob* jobs_dev, int count, int max_w, int max_h, hipStream_t s);
 void vh_pyr_force_rows(int rb);
 void vh_launch_roi_warp(const void* job_tab, size_t tab_stride, int batch, int max_w, int max_h, hipStream_t s);
-int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s, int* route_out = nullptr);
+int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s, int* route_out = nullptr, int* tpw_out = nullptr);
 int vh_lk_route(int batch, int max_n, int win);           // the kernel such a launch takes (ids of vh_debug_force_generic_lk)
 const char* vh_lk_route_name(int route, int win);
 void vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s);

@@ -2205,8 +2205,13 @@ static int launch_lkq(const void* job_tab, size_t tab_stride, int batch, int max
     return 0;
 }
 
+// test hook (vh_debug_lk3_tpw): launch slots per workgroup of the one-wavefront LDS-staged kernel -- 0 = chosen by load, n > 0 = n (clamped to MAX_TPW).
+// PROCESS-WIDE atomic like the other hooks; every value gives bit-identical results (VH_LK3_TPW: experiments only, the initial value).
+static std::atomic<int> g_lk3_tpw{getenv("VH_LK3_TPW") ? atoi(getenv("VH_LK3_TPW")) : 0};
+void vh_lk3_set_tpw(int n) { g_lk3_tpw.store(n < 0 ? 0 : n, std::memory_order_relaxed); }
+
 template <int WIN, int NW, int M>
-static int launch_lk3(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
+static int launch_lk3(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s, int* tpw_out)
 {
     // VH_LK_LDS_PAD (experiments only): extra dynamic LDS per workgroup = fewer resident wavefronts per SIMD (the occupancy sensitivity behind DESIGN.md section 9)
     static const int pad = [] { const char* e = getenv("VH_LK_LDS_PAD"); return e ? atoi(e) : 0; }();
@@ -2215,10 +2220,11 @@ static int launch_lk3(const void* job_tab, size_t tab_stride, int batch, int max
     // Launch slots per workgroup (one-wavefront kernel): a 51 x 51 track keeps a workgroup for ~22 us, and starting one (dispatch, LDS allocation, the block
     // remap, the first descriptor loads) is not free: 4 consecutive slots per workgroup measured 3620 -> 3520 us per launch at 512 000 tracks (2: 3580,
     // 8: 3545; A/B on one box).  Only where the launch still has many workgroups per resident slot (256 CUs x 12): below that the tail would cost more.
-    static const int tpw_env = getenv("VH_LK3_TPW") ? atoi(getenv("VH_LK3_TPW")) : 0;  // (environment: experiments only)
+    const int tpw_env = g_lk3_tpw.load(std::memory_order_relaxed);
     const long long tracks = (long long)max_n * batch;
     const int tpw_auto = NW != 1 ? 1 : tracks >= 98304 ? 4 : tracks >= 49152 ? 2 : 1;
     const unsigned tpw = (unsigned)std::min(NW == 1 && tpw_env > 0 ? tpw_env : tpw_auto, LK3<WIN, NW, M>::MAX_TPW);
+    if (tpw_out) *tpw_out = (int)tpw;
     hipLaunchKernelGGL((k_lk3<WIN, NW, M>), dim3((max_n + tpw - 1) / tpw, batch), dim3(64 * NW), lds, s, job_tab, tab_stride, lk_group_arg(grp, batch), tpw);
     return 0;
 }
@@ -2287,17 +2293,18 @@ const char* vh_lk_route_name(int route, int win)
     }
 }
 
-int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s, int* route_out)
+int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s, int* route_out, int* tpw_out)
 {
     if (route_out) *route_out = 0;
+    if (tpw_out) *tpw_out = 1;
     if (max_n <= 0) return 0;
     const int route = vh_lk_route(batch, max_n, win);
     if (route_out) *route_out = route;
     switch (route) {
-    case 3: return launch_lk3<15, 1, 6>(job_tab, tab_stride, batch, max_n, s);
-    case 5: return launch_lk3<51, 1, 4>(job_tab, tab_stride, batch, max_n, s);
-    case 6: return launch_lk3<51, 2, 4>(job_tab, tab_stride, batch, max_n, s);
-    case 7: return launch_lk3<51, 4, 4>(job_tab, tab_stride, batch, max_n, s);
+    case 3: return launch_lk3<15, 1, 6>(job_tab, tab_stride, batch, max_n, s, tpw_out);
+    case 5: return launch_lk3<51, 1, 4>(job_tab, tab_stride, batch, max_n, s, tpw_out);
+    case 6: return launch_lk3<51, 2, 4>(job_tab, tab_stride, batch, max_n, s, tpw_out);
+    case 7: return launch_lk3<51, 4, 4>(job_tab, tab_stride, batch, max_n, s, tpw_out);
     case 8: return launch_lko<15>(job_tab, tab_stride, batch, max_n, s);
     case 4: return launch_lkq<15>(job_tab, tab_stride, batch, max_n, s);
     case 2:

@@ -319,7 +319,7 @@ static int session_init(vh_session* s, int slot, const uint8_t* frame0, int stri
                         void* stream)
 {
     if (stride != s->w) return vh_fail(-1, "vh_session_init: frames must be dense (stride == width)");
-    vh_ctx_bind bound_(s->ctx, stream);
+    VH_BIND(s->ctx, stream);
     hipStream_t st = bound_.s;
     hipLaunchKernelGGL(k_sess_init, dim3(1), dim3(256), 0, st, s->d_ss + slot, p, p3, vp, frame0, t0_host ? t0_host[0] : 0.f, t0_host ? t0_host[1] : 0.f,
                        t0_host ? t0_host[2] : 0.f, time0, frame_no, res0, t0_dev, res0_dev, n_dev);
@@ -350,7 +350,7 @@ static int session_step(vh_session* s, const uint8_t* const* frames_dev, float t
                         const float* frame_nos_dev, void* stream)
 {
     if (!s || !frames_dev) return vh_fail(-1, "vh_session_step: bad arguments");
-    vh_ctx_bind bound_(s->ctx, stream);
+    VH_BIND(s->ctx, stream);
     hipStream_t st = bound_.s;
     vh_ctx* c = s->ctx;
     const int nb = s->batch;
@@ -428,7 +428,7 @@ __global__ void k_sess_ingest_jobs(SessStream* ss_all, IngestJob* jobs, const ui
 extern "C" VH_API int vh_session_ingest_bgr(vh_session* s, const uint8_t* const* bgr_frames_dev, int bgr_stride, uint8_t* const* gray_frames_dev, void* stream)
 {
     if (!s || !bgr_frames_dev || !gray_frames_dev || bgr_stride < 3 * s->w) return vh_fail(-1, "vh_session_ingest_bgr: bad arguments");
-    vh_ctx_bind bound_(s->ctx, stream);
+    VH_BIND(s->ctx, stream);
     hipStream_t st = bound_.s;
     hipLaunchKernelGGL(k_sess_ingest_jobs, dim3((s->batch + 63) / 64), dim3(64), 0, st, s->d_ss, s->d_ingest, bgr_frames_dev, bgr_stride, gray_frames_dev, s->batch);
     vh_launch_ingest_bgr(s->d_ingest, s->batch, s->w, s->h, st);

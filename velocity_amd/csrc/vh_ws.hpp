@@ -90,6 +90,7 @@ struct vh_ctx {
     hipStream_t bound_stream;  // the stream whose work may still read this context's job descriptors (vh_ctx_bind)
     hipEvent_t bound_ev;       // recorded on bound_stream by vh_ctx_release at the end of every entry point: what a rebind waits for
     int bound;                 // 0: never used, 1: bound
+    int lk_tpw[3];             // launch slots per workgroup of those launches (1 unless the one-wavefront LDS-staged kernel looped; vh_profile_lk_tpw)
     int lk_route[3];           // kernel route (vh_lk_route ids) the last KLTmain took for its three LK launches (vh_profile_lk_routes)
     int lk_win[3];
     InitScratch init;          // created by the first frame-0 call (vh_init.hip)
@@ -99,17 +100,26 @@ struct vh_ctx {
 // with vh_ctx_release (an event record on its stream); an entry point that arrives with another stream makes that stream wait for the event
 // (hipStreamWaitEvent) before it rebinds.  No host blocking, legal under stream capture, and the previous stream handle is never touched again (it
 // may have been destroyed: only the event is used).
-static inline hipStream_t vh_ctx_bind_raw(vh_ctx* c, void* stream)
+static inline hipStream_t vh_ctx_bind_raw(vh_ctx* c, void* stream, int* err = nullptr)
 {
     hipStream_t s = (hipStream_t)stream;
+    if (err) *err = 0;
     if (c) {
         if (c->bound && c->bound_stream != s && c->bound_ev) {
             // A capturing stream must not wait for an event recorded OUTSIDE its capture (an isolation violation that can invalidate the caller's
-            // capture): the wait is skipped there, and the rule is the caller's -- a context does not change stream inside a capture (the work it
-            // queued on its previous stream must have been ordered before the capture began; include/velocity_hip.h "Conventions").
+            // capture), so there is nothing to wait with there.  The rule is the caller's -- a context does not change stream inside a capture (the
+            // work it queued on its previous stream must have been ordered before the capture began; include/velocity_hip.h "Conventions") -- and it is
+            // CHECKED: the rebind is accepted only when the earlier work has provably completed (hipEventQuery); otherwise the entry point fails
+            // instead of letting the captured launches overwrite job descriptors the previous stream may still be reading.
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-            if (cs == hipStreamCaptureStatusNone && hipStreamWaitEvent(s, c->bound_ev, 0) != hipSuccess) (void)hipGetLastError();
+            if (cs == hipStreamCaptureStatusNone) {
+                if (hipStreamWaitEvent(s, c->bound_ev, 0) != hipSuccess) (void)hipGetLastError();
+            } else if (hipEventQuery(c->bound_ev) != hipSuccess) {
+                (void)hipGetLastError();
+                if (err) *err = 1;
+                return s;  // (the context stays bound to its previous stream)
+            }
         }
         c->bound_stream = s;
         c->bound = 1;
@@ -132,14 +142,21 @@ static inline void vh_ctx_release(vh_ctx* c)
 // scope of one entry point: binds on construction, releases (event record) when the entry point returns, whichever return path it takes
 struct vh_ctx_bind {
     vh_ctx* c;
+    int err;  // 1: the context was asked to change stream inside a stream capture while its earlier work is still running (see vh_ctx_bind_raw)
     hipStream_t s;
-    vh_ctx_bind(vh_ctx* ctx, void* stream) : c(ctx), s(vh_ctx_bind_raw(ctx, stream)) {}
-    ~vh_ctx_bind() { vh_ctx_release(c); }
+    vh_ctx_bind(vh_ctx* ctx, void* stream) : c(ctx), err(0), s(vh_ctx_bind_raw(ctx, stream, &err)) {}
+    ~vh_ctx_bind() { if (!err) vh_ctx_release(c); }
     vh_ctx_bind(const vh_ctx_bind&) = delete;
     vh_ctx_bind& operator=(const vh_ctx_bind&) = delete;
     operator hipStream_t() const { return s; }
 };
 
+
+#define VH_BIND(ctx_, stream_)                                                                                                                              \
+    vh_ctx_bind bound_(ctx_, stream_);                                                                                                                     \
+    if (bound_.err)                                                                                                                                        \
+        return vh_fail(-6, "the context was handed another stream inside a stream capture while work it queued on its previous stream is still running: " \
+                           "order that work before the capture begins (include/velocity_hip.h, Conventions)")
 
 // tracker-session state of one video stream (vh_session.hip); declared here because the KLTmain set-up kernel (vh_api.hip) fetches a
 // frame's inputs straight from it (one launch less per frame than a separate "prepare" kernel)

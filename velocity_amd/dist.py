@@ -97,23 +97,28 @@ class TrackStateExchange:
             me.update(device=d, name=pr.name, pci_bus_id=getattr(pr, "pci_bus_id", None), gcn_arch=getattr(pr, "gcnArchName", None))
         devs = [None] * self.world
         dist.all_gather_object(devs, me, group=self.group)
-        # one more exchange on an otherwise idle device, bracketed by events on the current stream: the collective's own device latency (every rank
-        # takes part; not counted in `exchanges`)
-        dev_us = None
-        if self.local.is_cuda:
-            n, hs = self.count, self.host_seconds
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            self.start()
-            self.wait()
-            e1.record()
-            torch.cuda.synchronize()
-            dev_us = round(1e3 * e0.elapsed_time(e1), 1)
-            self.count, self.host_seconds = n, hs
         return dict(backend=dist.get_backend(self.group), world_size=self.world, devices=devs, exchanges=self.count,
-                    exchange_host_ms_total=round(1e3 * self.host_seconds, 3), bytes_per_rank_per_exchange=int(self.local.numel() * 4),
-                    exchange_device_us_idle=dev_us)
+                    exchange_host_ms_total=round(1e3 * self.host_seconds, 3), bytes_per_rank_per_exchange=int(self.local.numel() * 4))
+
+    def measure_idle_latency(self):
+        """Device latency of ONE more all-gather of the same size on an otherwise idle device, bracketed by events on the current stream.  Collective:
+        every rank calls it.  It runs on scratch buffers of its own -- `gathered`, `count` and `host_seconds` of the timed run are left untouched -- and
+        refuses to run while an exchange is in flight.  Returns microseconds, or None where a device-side figure means nothing (gloo stages the copy on
+        the host and its wait blocks the host; no process group; CPU tensors)."""
+        if self._work is not None:
+            raise RuntimeError("TrackStateExchange.measure_idle_latency: an exchange is still in flight (call wait() first)")
+        if not dist.is_initialized() or self._host or not self.local.is_cuda:
+            return None
+        src = torch.zeros_like(self.local)
+        dst = torch.zeros_like(self.gathered)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.all_gather_into_tensor(dst.view(-1), src.view(-1), group=self.group)  # warm-up (communicator set-up is not latency)
+        torch.cuda.synchronize()
+        e0.record()
+        dist.all_gather_into_tensor(dst.view(-1), src.view(-1), group=self.group)
+        e1.record()
+        torch.cuda.synchronize()
+        return round(1e3 * e0.elapsed_time(e1), 1)
 
 
 # ----------------------------------------------------------------------------------------------------------------

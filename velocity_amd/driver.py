@@ -116,6 +116,14 @@ class TrackerSession:
             L.check(self.lib.vh_copy_to_host(out.ctypes.data, ptr, out.nbytes, L.stream_ptr()), "vh_copy_to_host")
         return out
 
+    def lk_launches(self):
+        """What the library says the three LK launches of the last step were (the launcher's own decisions): kernel names (vh_profile_lk_routes) and launch
+        slots per workgroup (vh_profile_lk_tpw) of stage 0 (quarter scale), 1 (coarse ROI), 2 (fine)."""
+        routes, names, tpw = (C.c_int * 3)(), C.create_string_buffer(96), (C.c_int * 3)()
+        L.check(self.lib.vh_profile_lk_routes(self.ws.handle, routes, names), "vh_profile_lk_routes")
+        L.check(self.lib.vh_profile_lk_tpw(self.ws.handle, tpw), "vh_profile_lk_tpw")
+        return dict(kernels=[names.raw[32 * k:32 * k + 32].split(b"\0")[0].decode() for k in range(3)], routes=list(routes), slots_per_workgroup=list(tpw))
+
     def state(self, slot=0):
         """Host copy of the stream state: dict(vg, vp, p, P, B, S, p3, t, res, n_cur, n_pose, frame_i, klt_flags).
         P comes back in the reference's [5, N0, nhist] layout (the device keeps it frame-major, [nhist, 5, N0]: include/velocity_hip.h)."""
@@ -248,9 +256,9 @@ def run_sequence(frames, q, K, fps=None, times=None, frame_numbers=None, plate="
     K       the camera's 3 x 3 intrinsic matrix, reference layout (images.py:148-151)
     fps / times / frame_numbers   B[i, 12] (seconds; `CAP_PROP_POS_MSEC / 1000` or the EXIF time) and B[i, 13] per frame: either `times` or `fps`
     route   "session": frame 0 through vh_frame0_init (Harris -> cornerSubPix -> plate pose -> image2world -> insidebbox, ONE device sequence) straight
-            into a device-resident TrackerSession -- nothing but the frames goes up and nothing but the printed rows comes down;
-            "dropin": the reference's own loop body on the drop-in functions (KLT.KLTmain, NLS.estimateWorldCameraPose, MSV.fcnMSV1_t, images.*),
-            i.e. what INTEGRATION.md's import switch gives a maintainer: host arrays in and out of every call.
+            into a device-resident TrackerSession -- nothing but the frames goes up and nothing but the printed rows comes down (the only route of the
+            product; a host loop on the drop-in functions -- what INTEGRATION.md's import switch gives a maintainer -- lives in tools/dropin_loop.py as a
+            measurement harness).
     live    True prints every row as its frame finishes (one small read-back per frame, like the reference); False runs the whole clip first.
     out     line sink (default print); clock: time source for the procTime column / fps line (default time.perf_counter).
 
@@ -277,14 +285,11 @@ def run_sequence(frames, q, K, fps=None, times=None, frame_numbers=None, plate="
     emit(f"Starting image processing on {name} ...")  # vidExample.py:50
     emit(TABLE_HEADER)
     t_begin = clock()
-    if route == "dropin":
-        res = _run_dropin(frames, q, K, times, frame_numbers, plate, roi_border, max_corners, quality, block, harris_k, subpix, msv_frame, lk_coarse,
-                          lk_fine, emit, clock)
-    elif route == "session":
+    if route == "session":
         res = _run_session(frames, q, K, times, frame_numbers, plate, roi_border, max_corners, quality, block, harris_k, subpix, msv_frame, lk_coarse,
                            lk_fine, emit, clock, live)
     else:
-        raise ValueError("route must be 'session' or 'dropin'")
+        raise ValueError("route must be 'session' (the host loop on the drop-in functions is a measurement harness: tools/dropin_loop.py::run_sequence_dropin)")
     seconds = clock() - t_begin
     for line in summary_lines(res["S"], n, frame_numbers, seconds):
         emit(line)
@@ -367,70 +372,6 @@ def _run_session(frames, q, K, times, frame_numbers, plate, roi_border, max_corn
                 loop_seconds=loop_seconds, klt_flags=st["klt_flags"])
 
 
-def _run_dropin(frames, q, K, times, frame_numbers, plate, roi_border, max_corners, quality, block, harris_k, subpix, msv_frame, lk_coarse, lk_fine,
-                emit, clock):
-    """vidExample.py:75-165 statement by statement on the drop-in functions (numpy in / numpy out of every call)."""
-    from . import KLT, MSV, NLS
-    from .common import addcol0, image2world, norm
-    from .images import boundingRect, cornerSubPix, goodFeaturesToTrack, insidebbox
-
-    torch = L.torch_cuda()
-    frames = [f.cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f) for f in frames]
-    n = len(frames)
-    B = np.zeros([n, 14], np.float32)
-    S = np.zeros([n, 9], np.float32)
-    proc_dt = np.zeros(n)
-    t_loop = None
-    for i in range(n):
-        tic = clock()
-        if i == 1:
-            t_loop = tic
-        B[i, 12], B[i, 13] = times[i], frame_numbers[i]
-        im = frames[i]
-        if i == 0:
-            boxa = boundingRect(q, im.shape, border=(0, 0))
-            boxb = boundingRect(q, im.shape, border=tuple(roi_border))
-            roi = im[boxb[2]:boxb[3], boxb[0]:boxb[1]]
-            p = goodFeaturesToTrack(roi, max_corners, quality, 0, blockSize=block, useHarrisDetector=True, k=harris_k).reshape(-1, 2) + np.float32([boxb[0], boxb[2]])
-            p = cornerSubPix(im, p, (subpix[0], subpix[0]), (-1, -1), (3, subpix[1], subpix[2]))
-            p = np.concatenate((q, p))
-            t, R, residuals, _ = NLS.estimateWorldCameraPose(K, q, _plate_points(plate), findR=True)
-            p3 = addcol0(image2world(K, R, t, p).astype(float)) @ R + t
-            R = np.eye(3)
-            B[0, 0:3] = t
-            vg = np.ones(p.shape[0], dtype=bool)
-            vp = insidebbox(p, boxa)
-            p_ = p[vp]
-            P = np.full([5, p.shape[0], n], np.nan, np.float32)
-            im0_small, dt, dr, r, t0 = None, np.nan, 0, 0, B[0, 12]
-            n_tr, t_plate, R_plate, res_plate = len(p), t, None, residuals
-        else:
-            p, v, im0_small = KLT.KLTmain(im, im0, im0_small, p, lk_coarse=lk_coarse, lk_fine=lk_fine)
-            vg[vg] = v
-            vp = vp & vg
-            t, R, residuals, p_ = NLS.estimateWorldCameraPose(K, p[vp[vg]], p3[vp], R=R, findR=False)
-            dt = B[i, 12] - B[i - 1, 12]
-            dr = norm(t + B[0, 0:3] - B[i - 1, 0:3])
-            r += dr
-            B[i, 3:6] = t
-            B[i, 0:3] = B[0, 0:3] + t
-        im0 = im  # (the reference never assigns im0: SURVEY App. B intent)
-        P[0:2, vg, i] = p.T
-        P[2:4, vp, i] = p_.T
-        P[4, vg, i] = i
-        if i == msv_frame:
-            _tmsv, p3hatmsv = MSV.fcnMSV1_t(K, P, B, vg, i)
-            p3[vg] = p3hatmsv - t
-            vp = vg.copy()
-        proc_dt[i] = clock() - tic
-        with np.errstate(all="ignore"):
-            S[i, :] = (i, proc_dt[i], vg.sum(), residuals, dt, B[i, 12] - t0, dr, r, dr / dt * 3.6)
-        emit(table_row(S[i]))
-    loop_seconds = clock() - t_loop
-    return dict(S=S, B=B, P=P, vg=vg, vp=vp, p=p, p3=p3, ids=np.nonzero(vg)[0].astype(np.int32), n_tracks0=n_tr, t0=np.asarray(t_plate), R0=R_plate,
-                res0=float(res_plate), boxa=tuple(boxa), boxb=tuple(boxb), loop_seconds=loop_seconds, klt_flags=0)
-
-
 def run_sequences(clips, K, plate="Chile", roi_border=(700, 500), max_corners=1000, quality=0.01, block=5, harris_k=0.04, subpix=(5, 100, 0.001),
                   msv_frame=5, lk_coarse=None, lk_fine=None, out=None):
     """Many clips at once: the throughput form of run_sequence.  `clips` = list of dict(frames, q, times[, frame_numbers, name]) of ONE frame size and
@@ -498,7 +439,7 @@ def run_sequences(clips, K, plate="Chile", roi_border=(700, 500), max_corners=10
 
 
 def main(argv=None):
-    """`python -m velocity_amd.driver clip.npz [--seq b] [--route session|dropin]`: the reference's run (`python vidExample.py`) on a decoded clip.
+    """`python -m velocity_amd.driver clip.npz [--seq b]`: the reference's run (`python vidExample.py`) on a decoded clip.
     clip.npz holds `<seq>_frames` uint8 [n, H, W], `<seq>_times` [n] seconds, `<seq>_q` [4, 2] plate corners and `<seq>_K` [3, 3] (the format of
     tests/golden/stills_gray.npz); decoding videos is out of scope (no decoder in the image)."""
     import argparse
@@ -506,14 +447,13 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=main.__doc__)
     ap.add_argument("clip")
     ap.add_argument("--seq", default="b")
-    ap.add_argument("--route", default="session", choices=["session", "dropin"])
     ap.add_argument("--border", type=int, nargs=2, default=None, help="ROI border around the plate (vidExample.py:108 uses 700 500; the 1024 x 768 stills fixture needs 180 140)")
     ap.add_argument("--msv-frame", type=int, default=5)
     a = ap.parse_args(argv)
     d = np.load(a.clip)
     fr = d[f"{a.seq}_frames"]
     border = tuple(a.border) if a.border else ((700, 500) if fr.shape[2] >= 1900 else (180, 140))
-    run_sequence(fr, d[f"{a.seq}_q"], d[f"{a.seq}_K"], times=d[f"{a.seq}_times"], roi_border=border, msv_frame=a.msv_frame, route=a.route,
+    run_sequence(fr, d[f"{a.seq}_q"], d[f"{a.seq}_K"], times=d[f"{a.seq}_times"], roi_border=border, msv_frame=a.msv_frame,
                  name=f"{a.clip}:{a.seq}")
 
 
