@@ -776,7 +776,7 @@ def test_lk3_slot_loop_is_bit_exact_for_every_slot_count(seq, mode, lk):
             for fbt in (None, 0.3 if lk["win"] == 51 else 1.0):
                 e2, ev, eerr = KO.lk_fb(a_np, b_np, pts, fbt=fbt, **lk)
                 if name == "gate":
-                    assert (~KO.pyr_lk(a_np, b_np, pts, **lk)[1]).sum() >= 5
+                    assert (~KO.pyr_lk(a_np, b_np, pts, **lk)[1]).sum() >= 3  # forward-dead tracks inside the workgroups' runs of slots
                 for tpw in (1, 2, 3, 4, 8):
                     lib.vh_debug_lk3_tpw(tpw)
                     for want_err, want_fbe in ((True, False), (False, False), (True, True)):

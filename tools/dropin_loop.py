@@ -22,7 +22,7 @@ class DropinLoop:
 
     def __init__(self, K, n_frames, plate="Chile", roi_border=(700, 500), detector=None, msv_frame=5, lk_coarse=None, lk_fine=None):
         self.K, self.n, self.plate, self.roi_border = K, int(n_frames), plate, tuple(roi_border)
-        self.detector = dict(max_corners=1000, quality=0.01, block=5, harris_k=0.04, subpix=(5, 100, 0.001), **(detector or {}))
+        self.detector = {**dict(max_corners=1000, quality=0.01, block=5, harris_k=0.04, subpix=(5, 100, 0.001)), **(detector or {})}
         self.msv_frame, self.lk_coarse, self.lk_fine = msv_frame, lk_coarse, lk_fine
         self.poses = np.zeros((self.n, 14), np.float32)  # the reference's B: world position, relative position, ..., time, frame number
         self.stats = np.zeros((self.n, 9), np.float32)   # the reference's S: one table row per frame

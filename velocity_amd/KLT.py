@@ -97,7 +97,7 @@ def KLTregional(im0, im, p0, T, lk_param, fbt=1.0, translateFlag=False):
 # ---- the frame the previous KLTmain call uploaded, kept on the device ----------------------------------------------------------------
 # The reference's loop hands the SAME array back one call later (`im0 = im`; `im0_small` is the quarter image KLTmain itself returned):
 # uploading it a second time is half of the drop-in route's PCIe traffic.  A host array is recognised by identity -- (id, data pointer, shape, strides) --
-# AND by a checksum of a strided sample of its pixels (every 8th pixel of every 8th row), so a frame buffer that was refilled in place (a capture loop
+# AND by a checksum of a strided sample of its pixels (every 16th pixel of every 16th row), so a frame buffer that was refilled in place (a capture loop
 # that reuses one array) is uploaded again.  What the sample cannot see: an in-place edit that touches none of the sampled pixels; set
 # `KLT.UPLOAD_CACHE = False` for such callers.  One entry per role; nothing is cached for CUDA-tensor inputs (nothing to upload).
 UPLOAD_CACHE = True
@@ -107,7 +107,7 @@ _uploaded = {}  # role -> (key, device tensor)
 def _host_key(a):
     import zlib
 
-    return (id(a), a.ctypes.data, a.shape, a.strides, zlib.crc32(np.ascontiguousarray(a[::8, ::8])))
+    return (id(a), a.ctypes.data, a.shape, a.strides, zlib.crc32(a[::16, ::16].tobytes()))
 
 
 def _img_dev_cached(a, roles):
@@ -148,11 +148,12 @@ def KLTmain(im, im0, im0_small, p0, lk_coarse=None, lk_fine=None, return_all=Fal
         small0 = small0.contiguous()
         if (sh0, sw0) != (dh, dw):
             raise ValueError("im0_small has the wrong shape")
-    small = torch.empty((dh, dw), dtype=torch.uint8, device="cuda")
-    # p_all (n x 2 float32) | v (n uint8, padded to 4) | flags (int32) in one allocation: one copy brings all three to the host
+    # p_all (n x 2 float32) | v (n uint8, padded to 4) | flags (int32) | quarter image (dh x dw uint8) in one allocation: one copy brings all of it to the host
     nv = (n + 3) & ~3
-    rec = torch.zeros(8 * n + nv + 4, dtype=torch.uint8, device="cuda")
-    p_all, v, flags = rec[: 8 * n].view(torch.float32).view(n, 2), rec[8 * n: 8 * n + n], rec[8 * n + nv:].view(torch.int32)
+    o_small = 8 * n + nv + 4
+    rec = torch.zeros(o_small + dh * dw, dtype=torch.uint8, device="cuda")
+    p_all, v, flags = rec[: 8 * n].view(torch.float32).view(n, 2), rec[8 * n: 8 * n + n], rec[8 * n + nv: o_small].view(torch.int32)
+    small = rec[o_small:].view(dh, dw)
     lc = L.lk_params(dict(L.LK_COARSE, **(lk_coarse or {})))
     lf = L.lk_params(dict(L.LK_FINE, **(lk_fine or {})))
     L.check(ws.lib.vh_klt_main(ws.handle, 0, L.dptr(a), L.dptr(b), L.dptr(small0), w, h, sa, sb, L.dptr(p), n, C.byref(lc), C.byref(lf),
@@ -169,8 +170,8 @@ def KLTmain(im, im0, im0_small, p0, lk_coarse=None, lk_fine=None, return_all=Fal
         host = rec.cpu().numpy()  # the one host sync of the call
         p_host = host[: 8 * n].view(np.float32).reshape(n, 2)
         vb = host[8 * n: 8 * n + n].astype(bool)
-        fl = int(host[8 * n + nv:].view(np.int32)[0])
-        small_host = small.cpu().numpy()
+        fl = int(host[8 * n + nv: o_small].view(np.int32)[0])
+        small_host = host[o_small:].reshape(dh, dw)
         if UPLOAD_CACHE:
             _uploaded["small"] = (_host_key(small_host), small)
         res = (p_host[vb], vb, small_host)

@@ -18,26 +18,35 @@ def _scratch(torch, shape):
 
 
 def _pose(K, p, pw, x0, R, findR, want_proj=True):
+    """vh_pose with ONE upload (p and pw packed into one host buffer when both are host arrays) and ONE download (R | res | proj | t | info packed into one
+    device record): the drop-in call costs two PCIe transfers and one host synchronisation, not seven."""
     torch = L.torch_cuda()
     K64 = L.host_K(K)
-    pd = L.to_dev(np.asarray(p, np.float32) if not hasattr(p, "is_cuda") else p, torch.float32).reshape(-1, 2)
-    pwd = L.to_dev(np.asarray(pw, np.float64) if not hasattr(pw, "is_cuda") else pw, torch.float64).reshape(-1, 3)
+    if hasattr(p, "is_cuda") or hasattr(pw, "is_cuda"):
+        pd = L.to_dev(np.asarray(p, np.float32) if not hasattr(p, "is_cuda") else p, torch.float32).reshape(-1, 2)
+        pwd = L.to_dev(np.asarray(pw, np.float64) if not hasattr(pw, "is_cuda") else pw, torch.float64).reshape(-1, 3)
+    else:
+        ph = np.ascontiguousarray(np.asarray(p, np.float32).reshape(-1, 2))
+        pwh = np.ascontiguousarray(np.asarray(pw, np.float64).reshape(-1, 3))
+        both = torch.from_numpy(np.concatenate((pwh.reshape(-1).view(np.uint8), ph.reshape(-1).view(np.uint8)))).cuda()
+        pwd = both[: pwh.nbytes].view(torch.float64).view(-1, 3)
+        pd = both[pwh.nbytes:].view(torch.float32).view(-1, 2)
     n = pd.shape[0]
     if pwd.shape[0] != n:
         raise ValueError("p and pw must have the same number of rows")
     x0 = np.ascontiguousarray(np.asarray(x0, np.float64).reshape(6))
     R = np.ascontiguousarray(np.asarray(R, np.float64).reshape(9))
-    t = torch.zeros(3, dtype=torch.float32, device="cuda")
-    Rout = torch.zeros(9, dtype=torch.float64, device="cuda")
-    res = torch.zeros(1, dtype=torch.float64, device="cuda")
-    proj = torch.zeros((n, 2), dtype=torch.float64, device="cuda") if want_proj else None
-    info = torch.zeros(2, dtype=torch.int32, device="cuda")
+    npj = 2 * n if want_proj else 0
+    rec = torch.zeros(10 + npj + 3, dtype=torch.float64, device="cuda")  # R 9 | res 1 | proj 2n | t (3 x f32 in 2 doubles) | info (2 x i32 in 1 double)
+    Rout, res, proj = rec[0:9], rec[9:10], (rec[10: 10 + npj].view(n, 2) if want_proj else None)
+    t, info = rec[10 + npj: 12 + npj].view(torch.float32)[:3], rec[12 + npj:].view(torch.int32)
     ws = L.workspace()
     L.check(ws.lib.vh_pose(ws.handle, K64.ctypes.data_as(L.f64p), L.dptr(pd), L.dptr(pwd), n, x0.ctypes.data_as(L.f64p),
                            R.ctypes.data_as(L.f64p), int(bool(findR)), L.dptr(t), L.dptr(Rout), L.dptr(res), L.dptr(proj), L.dptr(info),
                            L.stream_ptr()), "vh_pose")
-    info = info.cpu().numpy()
-    return t.cpu().numpy(), Rout.cpu().numpy().reshape(3, 3), float(res.item()), (proj.cpu().numpy() if want_proj else None), info
+    h = rec.cpu().numpy()  # the one host synchronisation of the call
+    return (h[10 + npj: 12 + npj].view(np.float32)[:3].copy(), h[0:9].reshape(3, 3).copy(), float(h[9]), (h[10: 10 + npj].reshape(n, 2).copy() if want_proj else None),
+            h[12 + npj:].view(np.int32).copy())
 
 
 def estimateWorldCameraPose(K, p, p3, t=np.array([0, 0, 1]), R=np.eye(3), findR=False):

@@ -180,17 +180,29 @@ def check(rc, what=""):
         raise RuntimeError(f"libvelocity_hip {what} failed (rc={rc}): {msg}")
 
 
-def torch_cuda():
-    import torch
+_torch_ok = None
 
-    if not torch.cuda.is_available():
-        raise RuntimeError("velocity_amd needs a visible MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    return torch
+
+def torch_cuda():
+    """torch, once a visible MI355X has been confirmed (checked once per process: torch.cuda.is_available() costs microseconds on every call)."""
+    global _torch_ok
+    if _torch_ok is None:
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("velocity_amd needs a visible MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+        _torch_ok = torch
+    return _torch_ok
+
+
+def _raw_stream():
+    """Handle of torch's current HIP stream on the current device (the raw query: torch.cuda.current_stream() builds a Stream object, ~12 us a call)."""
+    torch = torch_cuda()
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def stream_ptr():
-    torch = torch_cuda()
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream())
 
 
 def dptr(t):
@@ -258,7 +270,7 @@ def workspace(w=0, h=0, n=0):
     workspace must never be shared by two HIP streams: calls issued on different streams (or from different threads, each with its own
     current stream) get different workspaces here.  Growing replaces the workspace after a stream synchronisation."""
     torch = torch_cuda()
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    key = (torch.cuda.current_device(), _raw_stream())
     with _lock:
         old = _default_ws.get(key)
         if old is None or not old.fits(w, h, n):
