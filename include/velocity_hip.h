@@ -151,9 +151,10 @@ VH_API int vh_msv1_t(vh_ctx* ctx, const double* K_host, const float* P, const fl
  *   z [2*nt*(nc+1)] float64 = [all u | all v], camera-major / track-minor;  x [3 nt + 6 nc] = points | cam pos | cam rpy.
  * x is updated in place.  trace [max_iter][2] = (rms(z - zhat), rms(delta)) per iteration (what NLS.py:238 prints),
  * info int[2] = {iterations, converged}.  workspace: vh_nls_batch_workspace(nt, nc) bytes of device memory.
- * nc <= 255 free cameras (the reference has no limit; -1 above).  Up to 21 cameras the reduced camera system is formed and solved in two launches on the
- * matrix cores, 22..42 by a 256-wide two-pass Schur kernel, 43..255 by a materialised Z + K-split SYRK; 22+ cameras solve it by a left-looking Cholesky,
- * one launch per 32 columns.  The workspace grows with (6 nc)^2 per partial system: ask vh_nls_batch_workspace, never guess. */
+ * nc <= 255 free cameras (the reference has no limit; -1 above).  The reduced camera system is FORMED on the matrix cores -- one 128-wide Schur launch up
+ * to 21 cameras, a 256-wide two-pass Schur kernel for 22..42, a materialised Z + K-split SYRK for 43..255 -- and SOLVED by a matrix-core block
+ * Gauss-Jordan up to 20 cameras (124 unknowns), a register-resident VALU Gauss-Jordan at 21 cameras (126 unknowns), and from 22 cameras by a
+ * left-looking Cholesky, one launch per 32 columns.  The workspace grows with (6 nc)^2 per partial system: ask vh_nls_batch_workspace, never guess. */
 VH_API size_t vh_nls_batch_workspace(int nt, int nc);
 /* Opt-in (default OFF): replay a repeated whole solve as ONE hipGraph launch.  A captured sequence bakes the device pointers it was captured with
  * (z, x, trace, info, workspace), so the caller promises POINTER STABILITY: the same buffers are passed on every call (a sliding-window solver that

@@ -240,16 +240,16 @@ def test_nls_batch_many_cameras_vs_oracle(golden, nt, nf):
 
 @pytest.mark.parametrize("nt,nf", [(300, 25), (200, 43), (120, 51), (60, 129)])
 def test_nls_batch_cholesky_and_wide_schur_equal_the_round3_kernels(golden, nt, nf, monkeypatch):
-    """Second implementation check for 22+ cameras: blocked Cholesky + 256-wide matrix-core Schur (default) against the elimination kernels of rounds 2-3
-    (VH_BA_DBG=128), the right-looking two-launch Cholesky of round 4 (VH_BA_DBG=256; default since round 5: left-looking, one launch per panel) and against
-    the VALU Schur kernel (vh_debug_ba_force_valu) -- same trace and state to rounding."""
+    """Second implementation check for 22+ cameras: left-looking blocked Cholesky + 256-wide matrix-core Schur (default) against the right-looking two-launch
+    Cholesky of round 4 (VH_BA_DBG=256) and against the VALU Schur kernel (vh_debug_ba_force_valu) -- same trace and state to rounding.  (The spilling
+    elimination kernels of rounds 2-3, VH_BA_DBG=128, were removed in round 6; test_nls_batch_many_cameras_vs_oracle and test_nls_batch_43_to_255_cameras_syrk_vs_valu_and_oracle hold these sizes against the oracle.)"""
     from velocity_amd import _lib as L
     from velocity_amd import synth
     from velocity_amd.NLS import fcnNLS_batch
 
     P, pw0, cw0 = synth.ba_scene(nt, nf, seed=60 + nf)
     outs = []
-    for dbg, valu in ((None, 0), ("128", 0), (None, 1), ("256", 0)):
+    for dbg, valu in ((None, 0), (None, 1), ("256", 0)):
         if dbg is None:
             monkeypatch.delenv("VH_BA_DBG", raising=False)
         else:

@@ -1284,39 +1284,6 @@ __global__ __launch_bounds__(64 * BA_GJ_WAVES) void k_ba_solve_mfma(BaJob J)
     }
 }
 
-// Schur stage 2b for MANY cameras (6 nc > 256: more unknowns than the register-resident kernels hold): Gauss-Jordan without pivoting (S is SPD) on the
-// augmented system in place in global memory -- it stays in L2 (nq = 360: 1 MB) --, one workgroup, scalar pivots; the pivot row and the multipliers
-// of a round travel through LDS.  Columns left of the pivot are already zero in the pivot row and are skipped.  A slow path by design (one CU, L2
-// bandwidth bound: ~5 ms per solve at 60 cameras); windows of up to 42 cameras take the register-resident kernels above.
-__global__ __launch_bounds__(1024) void k_ba_solve_big(BaJob J)
-{
-    ba_select_window(J, blockIdx.y);
-    if (*J.done) return;
-    const int nq = J.nq, ld = nq + 1, tid = threadIdx.x;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* s_row = reinterpret_cast<double*>(smem);  // [ld] pivot row
-    double* s_f = s_row + ld;                          // [nq] multipliers a[r][c] / a[c][c] (0 for the pivot row)
-    double* A = J.Sfull;
-    for (int c = 0; c < nq; c++) {
-        __syncthreads();  // the updates of the previous round are complete (same workgroup: global writes are visible after the barrier + fence)
-        const double piv = A[(size_t)c * ld + c];
-        for (int k = c + tid; k < ld; k += 1024) s_row[k] = A[(size_t)c * ld + k];
-        const double ip = 1.0 / piv;
-        for (int r = tid; r < nq; r += 1024) s_f[r] = r == c ? 0.0 : A[(size_t)r * ld + c] * ip;
-        __syncthreads();
-        // columns c+1 .. nq (rhs included); column c itself becomes zero off the pivot and is never read again.  Half-wavefronts walk a row (256-byte segments)
-        for (int r = tid >> 5; r < nq; r += 32) {
-            const double f = s_f[r];
-            if (f == 0.0) continue;
-            double* Ar = A + (size_t)r * ld;
-            for (int k = c + 1 + (tid & 31); k < ld; k += 32) Ar[k] = __builtin_fma(-f, s_row[k], Ar[k]);
-        }
-        __threadfence();  // the round's stores must be visible to the whole workgroup's next loads (L1 is not coherent with its own write-through)
-    }
-    __syncthreads();
-    for (int q = tid; q < nq; q += 1024) J.dc[q] = A[(size_t)q * ld + nq] / A[(size_t)q * ld + q];
-}
-
 // Schur stage 2b for more than 124 unknowns (21+ cameras): BLOCKED CHOLESKY across launches.  The augmented system of 125..768 unknowns does not fit the
 // register file of one CU (252 x 253 doubles = 510 KB of its 512 KB), which is what made the register-resident Gauss-Jordan of round 2 spill (620 VGPRs,
 // 1.3 ms per solve at 36-42 cameras) and the in-L2 elimination crawl (5 ms at 50).  S is SPD (Schur complement of J^T J + I), so S = L L^T, right-looking,
@@ -2133,14 +2100,10 @@ int vh_ba_run(const BaProblem& P, hipStream_t s)
     };
     auto solve_update = [&](int it) {
         int rec = vh_prof_start(pc, s);
-        // up to 124 unknowns: block Gauss-Jordan on the matrix cores; above: register-resident VALU Gauss-Jordan (256 threads x 64 doubles, then 1024 threads)
+        // up to 124 unknowns (20 cameras): block Gauss-Jordan on the matrix cores; 125..127 (21 cameras: 126): the register-resident VALU Gauss-Jordan
         if (nq <= BA_GJ_MAXQ && !(J.dbg & 64)) hipLaunchKernelGGL(k_ba_solve_mfma, dim3(1, nw), dim3(64 * BA_GJ_WAVES), 0, s, J);
         else if (nq + 1 <= 128) hipLaunchKernelGGL((k_ba_solve<8, 8, 16>), dim3(1, nw), dim3(256), 0, s, J, nparts);
-        else if (J.dbg & 128) {  // the elimination kernels of rounds 2-3, kept as a second implementation for the tests (VH_BA_DBG=128)
-            if (nq <= 192) hipLaunchKernelGGL((k_ba_solve<6, 7, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
-            else if (nq <= 256) hipLaunchKernelGGL((k_ba_solve<8, 9, 32>), dim3(1, nw), dim3(1024), 0, s, J, nparts);
-            else hipLaunchKernelGGL(k_ba_solve_big, dim3(1, nw), dim3(1024), sizeof(double) * (size_t)(2 * nq + 1), s, J);
-        } else {  // 125+ unknowns: blocked Cholesky, two launches per 32-column panel + the back-substitution
+        else {  // 128+ unknowns (22+ cameras): left-looking blocked Cholesky, ONE launch per 32-column panel, + the back-substitution
             for (int k0 = 0; k0 < nq && !(J.dbg & 256); k0 += BA_CH_NB) {  // left-looking: one launch per panel, rows spread over workgroups
                 const int rows = nq - std::min(nq, k0 + BA_CH_NB) + 1;
                 hipLaunchKernelGGL(k_ba_chol_left, dim3((rows + BA_CL_RB - 1) / BA_CL_RB, nw), dim3(256), BA_CL_LDS, s, J, k0);

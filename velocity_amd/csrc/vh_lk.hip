@@ -1767,7 +1767,7 @@ __device__ __forceinline__ void lkq_track(const PyrDesc& PI, const PyrDesc& PJ, 
 }
 
 template <int WIN>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void k_lk_q(const void* job_tab, size_t tab_stride, unsigned grp)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_lk_q(const void* job_tab, size_t tab_stride, unsigned grp)
 {
     static_assert(WIN <= 15, "lane WIN of every 16-lane row carries the extra bottom row");
     unsigned blk_x, blk_y;
