@@ -241,9 +241,9 @@ def roofline_of(wl, m, world):
     # HBM traffic of the WHOLE step: the PMC bytes of every kernel of a step (committed collection, scaled to this run's streams) over this run's step time
     step_hbm = None
     if tj is not None and tj.get("step_total_kib") and m.get("step_us"):
-        b = float(tj["step_total_kib"]) * 1024.0 * SG / tj["streams"]
+        b = float(tj["step_total_kib"]) * 1024.0 * SG * int(getattr(wl, "G", 1)) / tj["streams"]  # (every session group of the step)
         step_hbm = dict(bytes_per_step=int(b), gbs=round(b / (m["step_us"] * 1e-6) / 1e9, 1), frac_of_hbm_peak=round(b / (m["step_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                        step_us=round(m["step_us"], 1), source=f"{tname}: sum over every kernel of a step of (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches per step, scaled to {SG} streams; step time of THIS run")
+                        step_us=round(m["step_us"], 1), source=f"{tname}: sum over every kernel of a step of (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches per step, scaled to {SG * int(getattr(wl, 'G', 1))} streams; step time of THIS run")
     out = dict(bound="valu", kernel=fine_kernel + " (fine stage: 51x51 window, level 0, fwd+bwd)", kernel_source=names_src,
                achieved=round(issued_tops, 3) if issued_tops else None, peak=round(abs_peak, 1), unit="T lane-instr/s",
                frac=round(issued_tops / abs_peak, 4) if issued_tops else None,
@@ -251,7 +251,9 @@ def roofline_of(wl, m, world):
                frac_of_class_peak=round(issued_tops / class_tops, 4) if issued_tops else None, peak_class=round(class_tops, 1),
                peak_class_lanes_per_clk_per_simd=lanes, peak_class_source=class_src,
                frac_of_mix_ceiling=(round(issued_tops / (N_SIMD * mix["mix_ceiling_lanes_per_clk_per_simd"] * CLOCK_GHZ * 1e9 / 1e12), 4) if issued_tops and mix else None),
-               mix=mix, us_per_launch=round(us_fine, 2),
+               mix=mix, us_per_launch=round(us_fine, 2), launches_per_step=int(getattr(wl, "G", 1)), streams_per_launch=int(SG),
+               concurrency=(None if getattr(wl, "G", 1) == 1 else f"{wl.G} sessions on {wl.G} HIP streams: the launch durations (HIP events on session 0's stream, and rocprofv3 "
+                            "alike) are measured while the other session's kernels share the chip"),
                issued_ginstr_per_launch=round(issued / 1e9, 3) if issued else None, issued_source=isrc, issued_model_tolerance=tol,
                setups_per_launch=int(su_f), newton_iters_per_launch=int(it_f), simds=N_SIMD, clock_ghz=CLOCK_GHZ,
                note="track solve is VALU-issue bound (SURVEY §8d): frac = issued lane-instructions / launch time / (1024 SIMDs x 32 lanes x 2.4 GHz), the guide's SIMD-32 "

@@ -867,3 +867,49 @@ def test_klt_main_reuses_the_previous_upload_and_notices_a_refilled_buffer(seq):
     finally:
         KLT.UPLOAD_CACHE = True
     assert np.array_equal(d[0], e2[0]) and np.array_equal(d[1], e2[1])
+
+
+def test_context_refuses_to_change_stream_inside_a_capture_while_its_earlier_work_runs():
+    """A vh_ctx that is handed another stream makes that stream wait for the work it queued on the previous one -- except inside a stream capture, where a
+    wait on an outside event would break the capture.  There the rebind is accepted only when the earlier work has provably finished (hipEventQuery);
+    otherwise the entry point FAILS (-6) instead of letting the captured launches overwrite job descriptors that are still being read (advisor r5).
+    Once the earlier work is done the same capture is legal and replays the oracle's corners."""
+    L, C, torch = _lib()
+    W, H, nmax = 640, 360, 200
+    f = synth.render_frame(W, H, synth.AffineMotion(W, H), 0, seed=78).numpy()
+    e = KO.good_features(f, nmax, 0.01, 5, 0.04)
+    ws = L.Workspace(1, W, H, 1024)
+    img = torch.from_numpy(f).cuda()
+    out = torch.zeros((nmax, 2), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(a):
+        L.check(ws.lib.vh_init_reserve(ws.handle, W, H, L.stream_ptr()), "vh_init_reserve")
+    torch.cuda.synchronize()
+
+    def features():
+        return ws.lib.vh_good_features(ws.handle, L.dptr(img), W, H, W, nmax, 0.01, 5, 0.04, L.dptr(out), L.dptr(cnt), L.stream_ptr())
+
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(int(2.0e9))  # ~1 s of device time in front of the call: its kernels and the context's release event wait behind it
+        L.check(features(), "vh_good_features")
+    marker = torch.zeros(1, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(b):
+        g.capture_begin()  # (the raw call: torch.cuda.graph() synchronises the device first, which would finish stream a's work)
+        marker.add_(1.0)   # (the capture is never empty)
+        rc = features()
+        g.capture_end()
+    assert rc == -6 and b"stream capture" in ws.lib.vh_last_error(), (rc, ws.lib.vh_last_error())
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == len(e) and np.array_equal(out.cpu().numpy()[: len(e)], e)  # the call on stream a was not disturbed
+    out.zero_()
+    cnt.zero_()
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=b):
+        rc = features()
+    assert rc == 0, ws.lib.vh_last_error()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == len(e) and np.array_equal(out.cpu().numpy()[: len(e)], e)

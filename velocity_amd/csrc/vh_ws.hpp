@@ -115,10 +115,17 @@ static inline hipStream_t vh_ctx_bind_raw(vh_ctx* c, void* stream, int* err = nu
             if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
             if (cs == hipStreamCaptureStatusNone) {
                 if (hipStreamWaitEvent(s, c->bound_ev, 0) != hipSuccess) (void)hipGetLastError();
-            } else if (hipEventQuery(c->bound_ev) != hipSuccess) {
-                (void)hipGetLastError();
-                if (err) *err = 1;
-                return s;  // (the context stays bound to its previous stream)
+            } else {
+                // (an event query counts as a "potentially unsafe" call while a capture in global / thread-local mode is under way: relaxed for the query only)
+                hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+                const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+                const hipError_t q = hipEventQuery(c->bound_ev);
+                if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
+                if (q != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (err) *err = 1;
+                    return s;  // (the context stays bound to its previous stream)
+                }
             }
         }
         c->bound_stream = s;
