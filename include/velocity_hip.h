@@ -247,7 +247,8 @@ typedef struct {
 
 /* K_host: 9 doubles; k_is_float32 != 0: the caller's K array is float32 (vidExample.py:29-33), so fcnMSV1_t builds its rays in
  * float32 like numpy does.  n0 = number of initial tracks, nhist = number of frames of history (P, B, S rows),
- * msv_frame = frame index at which fcnMSV1_t re-triangulates (vidExample.py:155; <= 0 disables). */
+ * msv_frame = frame index at which fcnMSV1_t re-triangulates (vidExample.py:155; <= 0 disables; a frame the history reaches -- < nhist -- must be below
+ * 2048: -1 otherwise, the limit of vh_msv1_t). */
 VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, int nhist, int w, int h, const double* K_host,
                              int k_is_float32, const vh_lk_params* coarse_host, const vh_lk_params* fine_host, int msv_frame);
 VH_API void vh_session_destroy(vh_session* s);

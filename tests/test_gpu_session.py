@@ -504,3 +504,15 @@ def test_session_with_a_never_msv_sentinel_allocates_no_msv_history():
     ses = TrackerSession(K, W, H, n0, nhist=6, batch=2, msv_frame=1 << 24)  # 24 B * 2^24 * 512 = 206 GB per stream if it were carved
     ses.init_stream(0, frames[0], p, p3, vp, np.float32([1.5, 0.45, 3.6]))
     assert ses.state(0)["n_cur"] == n0
+
+
+def test_session_rejects_a_reachable_msv_frame_beyond_the_2048_frame_limit():
+    """fcnMSV1_t keeps one table entry per history frame in LDS: 2048 frames at most (the reference has no limit).  A session whose history reaches an
+    MSV frame beyond that must fail at creation with a message, not silently skip the re-triangulation; an unreachable or disabled MSV frame is fine."""
+    from velocity_amd.driver import TrackerSession
+
+    K = synth.K_1080P.copy()
+    with pytest.raises(RuntimeError, match="2048"):
+        TrackerSession(K, 64, 64, 8, nhist=3000, batch=1, msv_frame=2500)
+    TrackerSession(K, 64, 64, 8, nhist=100, batch=1, msv_frame=2500)  # never reached: allowed
+    TrackerSession(K, 64, 64, 8, nhist=3000, batch=1, msv_frame=0)     # disabled: allowed

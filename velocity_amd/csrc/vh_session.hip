@@ -247,6 +247,10 @@ extern "C" VH_API int vh_session_create(vh_session** out, vh_ctx* ctx, int n0, i
 {
     if (!out || !ctx || !K_host || !coarse || !fine || n0 < 1 || nhist < 2) return vh_fail(-1, "vh_session_create: bad arguments");
     if (n0 > ctx->max_pts || w > ctx->max_w || h > ctx->max_h) return vh_fail(-1, "vh_session_create: exceeds the workspace");
+    // a re-triangulation frame the session COULD reach (< nhist) but fcnMSV1_t cannot serve is an error, not a silently skipped step
+    if (msv_frame >= 1 && msv_frame < nhist && msv_frame + 1 > 2048)
+        return vh_fail(-1, "vh_session_create: msv_frame + 1 > 2048 frames (fcnMSV1_t keeps one ray table entry per frame of the history in LDS; the "
+                           "reference has no such limit -- pass msv_frame <= 0 to run without the re-triangulation, or a frame below 2048)");
     vh_session* s = new (std::nothrow) vh_session();
     if (!s) return vh_fail(-1, "out of host memory");
     s->ctx = ctx; s->batch = ctx->batch; s->N0 = n0; s->nhist = nhist; s->w = w; s->h = h; s->msv_frame = msv_frame; s->k_is_f32 = k_is_float32 ? 1 : 0;
