@@ -115,7 +115,7 @@ def compact_line(out, detail_path=None):
             return v.get(key) if isinstance(v, dict) else None
         e = dict(hard_scene_fps=g("hard_scene", "value"), hard_scene_vs_headline=g("hard_scene", "vs_headline"), real_texture_fps=g("real_texture", "value"),
                  single_stream_ms=g("single_stream", "ms_per_step"), drop_in_ms=g("drop_in_route", "ms_per_frame"), ref_params_fps=g("ref_params", "value"),
-                 c3_fps=g("other_config", "value"), c3_cpu_fps=(ex.get("other_config") or {}).get("cpu_baseline", {}).get("value") if isinstance(ex.get("other_config"), dict) else None,
+                 single_session_fps=g("single_session", "value"), c3_fps=g("other_config", "value"), c3_cpu_fps=(ex.get("other_config") or {}).get("cpu_baseline", {}).get("value") if isinstance(ex.get("other_config"), dict) else None,
                  all_bit_exact=_all_verified(ex), errors=[k for k, v in ex.items() if isinstance(v, dict) and "error" in v] or None)
         line["extras"] = {k: v for k, v in e.items() if v is not None}
         optional.append("extras")
@@ -416,14 +416,14 @@ def _kernel_table(r):
     return t
 
 
-def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev, track_order=None, cpu_seconds=0.0):
+def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev, track_order=None, cpu_seconds=0.0, groups=None, kernels=False):
     """One more single-GPU workload next to the headline one; returns its summary (None when it does not fit / fails)."""
     try:
         if track_order:
             import copy
             a = copy.copy(a)
             a.track_order = track_order
-        wl = Workload(a, CONFIGS[cfg_key], params, scene, streams, steps, warmup, dev, rank=0, groups=a.groups if streams == a.streams else 1)
+        wl = Workload(a, CONFIGS[cfg_key], params, scene, streams, steps, warmup, dev, rank=0, groups=groups if groups else (a.groups if streams == a.streams else 1))
         m = wl.measure(steps, warmup, 1.0, torch.cuda.synchronize, lambda t: t)
         fps = wl.S * m["timed_steps"] / m["elapsed"]
         out = dict(workload=f"{cfg_key} / params {params} / scene {scene}" + (f" / tracks {track_order}" if track_order else ""), streams=streams, value=round(fps, 2),
@@ -431,6 +431,10 @@ def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev, track_orde
                    pose_t=[round(float(x), 5) for x in m["st"]["t"]], pose_t_truth=[round(float(x), 5) for x in m["truth"]],
                    rms_residual_px=round(m["st"]["res"], 5), lk_kernels=m["lk_kernels"],
                    lk_us_per_launch=[round(1e3 * m["prof"]["ms_sum"][k] / max(m["prof"]["launches"][k], 1), 2) for k in range(3)])
+        if kernels:  # per-kernel microseconds of a step (HIP events inside the library) and the VALU fraction of the fine launch, of THIS leg
+            r = roofline_of(wl, m, 1)
+            out.update(stream_groups=wl.G, kernels_us_per_step=_kernel_table(r), step_us_accounted=r["step_us_accounted"], valu_frac_fine=r["frac"],
+                       valu_frac_fine_of_class_peak=r["frac_of_class_peak"], kernels=r["kernels"], fine_us_per_launch=r["us_per_launch"])
         if a.verify_frames > 0:
             out["verified"] = verify(wl, wl.done_steps + 1, nframes=min(a.verify_frames, 2))
         if cpu_seconds > 0:  # the CPU port on the same workload, all granted cores (north_star: 1080p AND 4K beside the CPU path)
@@ -624,6 +628,12 @@ def main():
         if not a.no_extras and world == 1 and not a.host_frames:
             c2 = a.config == "c2"
             legs = {}
+            if wl.G > 1:
+                # the headline runs as wl.G sessions on wl.G HIP streams, so its per-launch durations include the time a launch shares the chip with the
+                # other session's kernels (a one-workgroup-per-stream kernel then waits for slots the other session's LK launch holds).  The same streams as
+                # ONE session: every kernel alone on the chip -- the per-kernel table DESIGN.md quotes
+                stamp("leg single_session ...")
+                legs["single_session"] = extra_leg(a, a.config, a.params, a.scene, S, 60, 10, dev, groups=1, kernels=True)
             # the load that looks like the reference's data: both at the headline's stream count and at 8 streams
             stamp("leg hard_scene ...")
             legs["hard_scene"] = episode_leg(a, "hard_scene", S, dev, headline_fps=out["value"])

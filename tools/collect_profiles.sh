@@ -29,6 +29,7 @@ cd /tmp && export TMPDIR=/tmp
 # as gpurun_out/prof/lk_valu_model.json and summarize_profiles.py files it as profiles/rNN_lk_valu_model.json
 bash $R/tools/pmc_lk_calib.sh $S > $OUT/lk_calib.log 2>&1
 M=$(ls $R/profiles/r[0-9][0-9]_lk_valu_model.json 2>/dev/null | tail -1)
+if ! [ -s $R/gpurun_out/lk_valu_model.json ]; then echo "collect_profiles: the instruction-cost fit FAILED (see lk_calib.log): the bench line will price with the previous round's model"; tail -5 $OUT/lk_calib.log; fi
 if [ -s $R/gpurun_out/lk_valu_model.json ]; then cp $R/gpurun_out/lk_valu_model.json $OUT/lk_valu_model.json; [ -n "$M" ] && cp $R/gpurun_out/lk_valu_model.json $M; fi
 python $R/bench.py --streams $S --verbose --detail $OUT/bench_default.json > $OUT/bench_default.line 2> $OUT/bench_default.err
 for s in 1 2 4 8 16 32 64 128 256; do
@@ -36,9 +37,11 @@ for s in 1 2 4 8 16 32 64 128 256; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --streams $S --steps 40 --warmup 5 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null > $OUT/stats.log 2>&1
 find $OUT/stats -name "*kernel_trace.csv" -delete   # tens of MB; the per-kernel summary is what is kept
+# (counter passes run ONE session -- --groups 1 -- so that a launch is 256 streams and launches do not overlap; the stats pass above and the bench line run the
+# headline's own shape, two sessions on two HIP streams: their per-launch durations agree with each other)
 # HBM traffic of EVERY library kernel of a step (roofline.step_hbm sums them): FETCH_SIZE and WRITE_SIZE in separate passes
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --kernel-include-regex '^(void )?k_' --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --streams $S --steps 6 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --kernel-include-regex '^(void )?k_' --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --streams $S --groups 1 --steps 6 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null > $OUT/pmc_$c.log 2>&1
   find $OUT/pmc_$c -name "*kernel_trace.csv" -delete
 done
 # the loads that look like the reference's data: both episode legs + the kernel stats of the hard scene
@@ -54,7 +57,7 @@ P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_I
 i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_o|k_lk_q' --pmc $P --output-format csv -d $OUT/sq_lk$i -- python $R/bench.py --streams $S --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null > $OUT/sq_lk$i.log 2>&1
+  rocprofv3 --kernel-trace --kernel-include-regex 'k_lk3|k_lk_o|k_lk_q' --pmc $P --output-format csv -d $OUT/sq_lk$i -- python $R/bench.py --streams $S --groups 1 --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null > $OUT/sq_lk$i.log 2>&1
   find $OUT/sq_lk$i -name "*kernel_trace.csv" -delete
 done
 # BA (C5): per-kernel stats of bench.bench_ba() (1, 8 and 64 windows) + SQ / MFMA counters of its kernels

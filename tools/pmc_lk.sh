@@ -7,7 +7,7 @@ P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_I
 i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --kernel-include-regex "${VH_PMC_REGEX:-k_lk3|k_lk_o|k_lk_q}" --pmc $P --output-format csv -d $OUT/p$i -- python $R/bench.py --streams $S --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --kernel-include-regex "${VH_PMC_REGEX:-k_lk3|k_lk_o|k_lk_q}" --pmc $P --output-format csv -d $OUT/p$i -- python $R/bench.py --streams $S --groups 1 --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null > $OUT/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, json

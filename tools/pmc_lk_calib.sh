@@ -4,10 +4,10 @@
 # line prints them), and a check run (the roll scene) that states the model's error.  Run on the GPU box; writes gpurun_out/lk_valu_model.json
 # (copy to profiles/r03_lk_valu_model.json).  Usage: bash tools/pmc_lk_calib.sh [streams]
 S=${1:-256}
-R=/root/repo; OUT=$R/gpurun_out/pmc_calib; rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+R=/root/repo; OUT=$R/gpurun_out/pmc_calib; rm -rf $OUT $R/gpurun_out/lk_valu_model.json; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 run() {  # tag, extra bench flags
   rocprofv3 --kernel-trace --kernel-include-regex "k_lk3|k_lk_o|k_lk_q" --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/$1 -- \
-    python $R/bench.py --streams $S --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail /dev/null --verify-frames 0 $2 > $OUT/$1.log 2>&1
+    python $R/bench.py --streams $S --groups 1 --steps 4 --warmup 2 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0 --detail $OUT/$1.json --verify-frames 0 $2 > $OUT/$1.log 2>&1
 }
 run default ""
 run cap1 "--fine-max-count 1"
@@ -20,9 +20,8 @@ import csv, glob, json
 import numpy as np
 pts, cpts = {}, {}
 for tag in ("default", "cap1", "cap3", "roll", "ccap1", "ccap2"):
-    line = [l for l in open("$OUT/%s.log" % tag) if l.startswith("{")][-1]
-    j = json.loads(line)
-    rf = j.get("roofline_detail", j["roofline"])
+    j = json.load(open("$OUT/%s.json" % tag))  # the FULL record of that run (bench.py --detail); stdout carries only the compact line
+    rf = j["roofline_detail"]
     vals, cvals = {}, {}
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % tag, recursive=True):
         for r in csv.DictReader(open(f)):

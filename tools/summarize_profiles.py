@@ -237,7 +237,8 @@ if hs:
 
 # ---- human-readable summary
 lib = sum(float(r["TotalDurationNs"]) for r in keep if not r["Name"].startswith("k_sess_init"))
-steps = [int(r["Calls"]) for r in keep if "k_lk3" in r["Name"]][0]
+G = int(bench["config"].get("stream_groups", 1) or 1)  # sessions per step (each on its own HIP stream): a frame step of S streams = G launch sequences
+steps = [int(r["Calls"]) for r in keep if "k_lk3" in r["Name"]][0] // G
 rf, cb = bench.get("roofline_detail", bench["roofline"]), bench["cpu_baseline"]
 cb1 = bench.get("cpu_baseline_1core", {})
 kname = rf["kernel"].split(" (")[0]
@@ -255,8 +256,9 @@ o = [f"# Round {tag[1:]} profiles (1x MI355X)\n",
      f"frames), CPU port {cb['value']:.1f} frames/s on {cb['cores']} host cores ({bench['gpu_over_cpu']}x), {cb1.get('value', 0):.1f} frames/s on 1 core; "
      f"BA {bench['ba']['iters_per_s']:.0f} LM iterations/s (one window), CPU {bench['ba'].get('cpu_baseline', {}).get('value', 0):.1f} it/s.\n",
      f"`rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --streams {S} --steps 40 --warmup 5 --cpu-seconds 0 --no-ba --no-extras --min-seconds 0` -> "
-     f"`profiles/{tag}_kernel_stats.csv`\n({steps} frame steps of {S} streams incl. warm-up; library kernels only, the `at::native::*` rows that render "
-     "the synthetic frame rings before the timed region are dropped.)\n",
+     f"`profiles/{tag}_kernel_stats.csv`\n({steps} frame steps of {S} streams incl. warm-up" + (f", each {G} launch sequences of {S // G} streams on {G} HIP streams: a launch's "
+     "duration below includes the time it shares the chip with the other session's kernels -- a one-workgroup-per-stream kernel waits for slots the other session's LK launch holds" if G > 1 else "")
+     + "; library kernels only, the `at::native::*` rows that render the synthetic frame rings before the timed region are dropped.)\n",
      "| kernel | calls | total ms | avg us | % of library time |\n|---|---|---|---|---|"]
 for r in keep:
     t = float(r["TotalDurationNs"])
@@ -266,8 +268,8 @@ for r in keep:
 k = [r for r in keep if "k_lk3" in r["Name"]][0]
 kk = traffic[kname]
 ksq = lk_sq.get(kname, {})
-o.append(f"\nLibrary kernel time {lib / 1e6:.1f} ms over {steps} steps = {lib / 1e3 / steps:.0f} us per step; bench wall {1e3 * bench['ms_per_step']:.0f} us per "
-         "step -> launches run back to back.")
+o.append(f"\nLibrary kernel time {lib / 1e6:.1f} ms over {steps} steps = {lib / 1e3 / steps:.0f} us of kernel time per step" + (f" on {G} concurrent HIP streams" if G > 1 else "")
+         + f"; bench wall {1e3 * bench['ms_per_step']:.0f} us per step" + (" -> launches run back to back." if G == 1 else f" -> {lib / 1e3 / steps / (1e3 * bench['ms_per_step']):.2f} launches in flight on average."))
 o.append(f"Dominant kernel `{kname}` (fine LK stage): {float(k['AverageNs']) / 1e3:.1f} us average in the trace vs {rf['us_per_launch']} us from the HIP events "
          "inside bench.py (`roofline.us_per_launch`).")
 hb = rf["hbm"]
@@ -281,9 +283,15 @@ o.append(f"HBM traffic of that kernel (`profiles/{tag}_hbm_traffic.json`, separa
          f"issue rate gives -> `roofline.frac` {rf['frac']} ({rf.get('frac_of_class_peak')} of the {rf.get('peak_class')} T/s of the 4-cycle opcode class the kernel is made of); SQ issue utilisation {100 * ksq.get('valu_issue_utilisation', 0):.0f} % "
          f"(`profiles/{tag}_valu_rate.json` settles the issue rates; SQ counters in `profiles/{tag}_lk_sq_pmc.json`). "
          f"SURVEY's op model (47 op/px set-up, 12 op/px/iteration) prices the same launch at {rf['op_model']['gops_per_launch']} G operations.\n")
-o.append("Per-kernel rows of the bench line (`roofline.kernels`: HIP-event time inside the library, algorithmic bytes, HBM fraction):\n")
+ss = (bench.get("extras") or {}).get("single_session") or {}
+if G > 1 and ss.get("kernels"):
+    o.append(f"Per-kernel rows of `extras.single_session` -- the same {S} streams as ONE session, {ss['value']:.0f} frames/s, every kernel alone on the chip (HIP-event time inside "
+             f"the library, algorithmic bytes, HBM fraction; fine LK launch {ss['fine_us_per_launch']} us, `frac` {ss['valu_frac_fine']}); the headline's own rows "
+             "(`roofline_detail.kernels`) carry the waiting described above:\n")
+else:
+    o.append("Per-kernel rows of the bench line (`roofline.kernels`: HIP-event time inside the library, algorithmic bytes, HBM fraction):\n")
 o.append("| kernel | us per step | algorithmic MB per step | GB/s | of 8 TB/s |\n|---|---|---|---|---|")
-for r in rf["kernels"]:
+for r in (ss["kernels"] if G > 1 and ss.get("kernels") else rf["kernels"]):
     o.append(f"| {r['kernel'][:90]} | {r['us_per_step']} | {r['alg_bytes_per_step'] / 1e6:.0f} | {r['hbm_gbs']} | {100 * r['hbm_frac']:.1f} % |")
 o.append("")
 o.append(f"Throughput vs resident streams (`profiles/{tag}_stream_sweep.json`, 60 steps each): "
