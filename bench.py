@@ -170,6 +170,14 @@ def host_cores():
     return n
 
 
+def auto_groups(S, host_frames=False):
+    """Sessions (HIP streams) the resident streams of one GPU are split into: the library's own rule (velocity_amd.driver.session_groups, where the
+    measurements behind it are listed); the PCIe-inclusive mode is measured with one session."""
+    from velocity_amd.driver import session_groups
+
+    return 1 if host_frames else session_groups(S)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,8 +210,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (single stream, reference parameters, C3, roll scene)")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("VH_BENCH_GROUPS", 0)),
                     help="split the resident streams into this many sessions, each on its own HIP stream: the one-workgroup-per-stream stages of one session "
-                         "(RANSAC, bookkeeping + pose, glue) run while the other's LK launches fill the chip.  0 = auto: 2 from 64 streams (measured on one box: "
-                         "44.5 k frames/s with 1, 45.6 k with 2, 45.5 k with 4), else 1")
+                         "(RANSAC, bookkeeping + pose, glue) run while the other's LK launches fill the chip.  0 = auto: 2 sessions for 2-4 and from 64 streams, 4 for "
+                         "8-32 streams (+3 % at 256 streams, +15 % at 8)")
     ap.add_argument("--host-frames", action="store_true",
                     help="frames start in pinned HOST memory and are uploaded every step (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the track-state exchange even with one rank (smoke test of the N>1 path)")
@@ -423,7 +431,8 @@ def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev, track_orde
             import copy
             a = copy.copy(a)
             a.track_order = track_order
-        wl = Workload(a, CONFIGS[cfg_key], params, scene, streams, steps, warmup, dev, rank=0, groups=groups if groups else (a.groups if streams == a.streams else 1))
+        wl = Workload(a, CONFIGS[cfg_key], params, scene, streams, steps, warmup, dev, rank=0, groups=groups if groups else (a.groups if (streams == a.streams or not getattr(a, "groups_auto", False)) and streams % max(a.groups, 1) == 0
+                                                   else auto_groups(streams)))
         m = wl.measure(steps, warmup, 1.0, torch.cuda.synchronize, lambda t: t)
         fps = wl.S * m["timed_steps"] / m["elapsed"]
         out = dict(workload=f"{cfg_key} / params {params} / scene {scene}" + (f" / tracks {track_order}" if track_order else ""), streams=streams, value=round(fps, 2),
@@ -548,7 +557,8 @@ def main():
         return
     S, N = a.streams, cfg["n"]
     if a.groups <= 0:
-        a.groups = 2 if (S >= 64 and S % 2 == 0 and not a.host_frames) else 1
+        a.groups = auto_groups(S, a.host_frames)
+        a.groups_auto = True
     wl = Workload(a, cfg, a.params, a.scene, S, a.steps, a.warmup, dev, rank, groups=a.groups, host_frames=a.host_frames)
     ex = vdist.TrackStateExchange(S, N, every=a.exchange_every, device=dev) if use_dist else None
 

@@ -150,7 +150,16 @@ def test_run_sequences_batches_clips_like_single_runs(stills):
     clips = [dict(frames=frames, q=q, times=times, name="b"),
              dict(frames=frames, q=q, times=times * np.float32(1.5) + np.float32(2.0), frame_numbers=list(range(100, 100 + len(frames))), name="b slow"),
              dict(frames=np.ascontiguousarray(frames[:, :, ::-1]), q=qm[[1, 0, 3, 2]], times=times, name="b mirrored")]
-    got = run_sequences(clips, K, roi_border=(180, 140))
+    got = run_sequences(clips, K, roi_border=(180, 140), sessions=1)
+    assert got[0]["sessions"] == 1
+    # the same clips split over two / three sessions on their own HIP streams (what run_sequences does by itself from two clips on): same results
+    for ns in (2, 3, 0):
+        split = run_sequences(clips, K, roi_border=(180, 140), sessions=ns)
+        assert split[0]["sessions"] == (ns if ns else 1)  # (auto: three clips do not split evenly)
+        for g, h in zip(got, split):
+            for key in ("vg", "vp", "p", "ids", "B"):
+                assert np.array_equal(g[key], h[key]), (ns, key)
+            assert np.array_equal(g["P"], h["P"], equal_nan=True) and g["lines"][-2] == h["lines"][-2]
     for c, g in zip(clips, got):
         one = run_sequence(c["frames"], c["q"], K, times=c["times"], frame_numbers=c.get("frame_numbers"), roi_border=(180, 140), out=None, live=False, name=c["name"])
         assert g["n_tracks0"] == one["n_tracks0"] > 100 and g["boxb"] == one["boxb"]

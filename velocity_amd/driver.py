@@ -372,13 +372,26 @@ def _run_session(frames, q, K, times, frame_numbers, plate, roi_border, max_corn
                 loop_seconds=loop_seconds, klt_flags=st["klt_flags"])
 
 
+def session_groups(streams):
+    """How many TrackerSessions (each on its own HIP stream) to split `streams` resident video streams of one GPU into.  The stages of a frame step that run
+    ONE workgroup per stream (RANSAC, bookkeeping + pose, the glue kernels) leave the chip nearly idle; with a second session on another HIP stream they run
+    while that session's LK launches fill it.  Measured on one MI355X, C2 streams, frames/s with 1 / 2 / 4 sessions: 2 streams 8.4 / 8.9 k, 4: 14.0 / 15.1 /
+    15.0 k, 8: 20.4 / 22.4 / 23.6 k, 16: 28.5 / 30.6 / 31.3 k, 32: 35.0 / 37.7 / 38.1 k, 64: 40.4 / 41.9 / 41.3 k, 128: - / 44.8 / 43.6 k, 256: 44.5 / 45.7 /
+    45.7 k; 8 sessions lose everywhere (a session of one or two streams falls back to the one-track-per-wavefront kernels)."""
+    if streams < 2:
+        return 1
+    return 4 if (8 <= streams < 64 and streams % 4 == 0) else (2 if streams % 2 == 0 else 1)
+
+
 def run_sequences(clips, K, plate="Chile", roi_border=(700, 500), max_corners=1000, quality=0.01, block=5, harris_k=0.04, subpix=(5, 100, 0.001),
-                  msv_frame=5, lk_coarse=None, lk_fine=None, out=None):
+                  msv_frame=5, lk_coarse=None, lk_fine=None, out=None, sessions=0):
     """Many clips at once: the throughput form of run_sequence.  `clips` = list of dict(frames, q, times[, frame_numbers, name]) of ONE frame size and
-    length; every clip is a stream of one device-resident TrackerSession, so a frame step is one launch sequence for all of them (vh_session_step_v: each
-    stream has its own clock).  Frame 0 of every clip runs through vh_frame0_init on the device, its outputs feed vh_session_init_dev directly; nothing is
-    read back before the last frame.  Returns one result dict per clip (the keys of run_sequence; `lines` = that clip's table and summary, printed through
-    `out` if given), each equal to what run_sequence returns for the clip alone."""
+    length; every clip is a stream of a device-resident TrackerSession, so a frame step is one launch sequence for all the clips of a session
+    (vh_session_step_v: each stream has its own clock).  `sessions`: the clips are split into this many sessions, each on its own HIP stream (0 = auto,
+    session_groups(len(clips)): their one-workgroup-per-stream stages overlap the others' LK launches); results do not depend on it.  Frame 0 of every clip
+    runs through vh_frame0_init on the device, its outputs feed vh_session_init_dev directly; nothing is read back before the last frame.  Returns one
+    result dict per clip (the keys of run_sequence; `lines` = that clip's table and summary, printed through `out` if given), each equal to what
+    run_sequence returns for the clip alone."""
     import time as _time
 
     torch = L.torch_cuda()
@@ -389,8 +402,19 @@ def run_sequences(clips, K, plate="Chile", roi_border=(700, 500), max_corners=10
     H, W = dev[0][0].shape
     assert all(len(d) == n and d[0].shape == (H, W) for d in dev), "clips must share frame size and length"
     cap = 4 + int(max_corners)
-    ses = TrackerSession(K, W, H, cap, nhist=n, batch=nclip, lk_coarse=lk_coarse, lk_fine=lk_fine, msv_frame=msv_frame)
-    lib, ws = ses.lib, ses.ws
+    G = int(sessions) if sessions and sessions > 0 else session_groups(nclip)
+    G = max(1, min(G, nclip))
+    owner = [b * G // nclip for b in range(nclip)]                    # clip -> session (contiguous blocks)
+    members = [[b for b in range(nclip) if owner[b] == g] for g in range(G)]
+    slot = {b: members[owner[b]].index(b) for b in range(nclip)}
+    main = torch.cuda.current_stream()
+    hip_streams = [main] + [torch.cuda.Stream() for _ in range(G - 1)]
+    for st_ in hip_streams[1:]:
+        st_.wait_stream(main)  # the frame uploads above ran on the current stream
+    sess = []
+    for g in range(G):
+        with torch.cuda.stream(hip_streams[g]):  # (a session's context serves one HIP stream: everything of session g is issued on stream g)
+            sess.append(TrackerSession(K, W, H, cap, nhist=n, batch=len(members[g]), lk_coarse=lk_coarse, lk_fine=lk_fine, msv_frame=msv_frame))
     plate_w = np.ascontiguousarray(np.asarray(_plate_points(plate), np.float64).reshape(12))
     win, it, eps = subpix
     times = np.stack([np.asarray(c["times"], np.float32) for c in clips])  # [clip, frame]
@@ -398,30 +422,35 @@ def run_sequences(clips, K, plate="Chile", roi_border=(700, 500), max_corners=10
     keep = []
     t_begin = _time.perf_counter()
     for b, c in enumerate(clips):
-        q = np.ascontiguousarray(np.asarray(c["q"], np.float32).reshape(4, 2))
-        bufs = (torch.empty((cap, 2), dtype=torch.float32, device="cuda"), torch.empty((cap, 3), dtype=torch.float64, device="cuda"),
-                torch.empty(cap, dtype=torch.uint8, device="cuda"), torch.empty(3, dtype=torch.float32, device="cuda"),
-                torch.empty(9, dtype=torch.float64, device="cuda"), torch.empty(1, dtype=torch.float64, device="cuda"),
-                torch.empty(1, dtype=torch.int32, device="cuda"))
-        p, p3, vp, t0, R0, res0, n0 = bufs
-        rois = (C.c_int * 8)()
-        L.check(lib.vh_frame0_init(ws.handle, L.dptr(dev[b][0]), W, H, W, q.ctypes.data_as(L.f32p), ses.K64.ctypes.data_as(L.f64p), plate_w.ctypes.data_as(L.f64p),
-                                   int(roi_border[0]), int(roi_border[1]), int(max_corners), float(quality), int(block), float(harris_k), int(win), int(it),
-                                   float(eps), L.dptr(p), L.dptr(p3), L.dptr(vp), L.dptr(t0), L.dptr(R0), L.dptr(res0), L.dptr(n0), rois, L.stream_ptr()),
-                "vh_frame0_init")
-        L.check(lib.vh_session_init_dev(ses.handle, b, L.dptr(dev[b][0]), W, L.dptr(p), L.dptr(p3), L.dptr(vp), L.dptr(t0), L.dptr(res0), L.dptr(n0),
-                                        float(times[b, 0]), float(fnos[b, 0]), L.stream_ptr()), "vh_session_init_dev")
-        ses._keep[b] = dev[b][0]
+        ses = sess[owner[b]]
+        lib, ws = ses.lib, ses.ws
+        with torch.cuda.stream(hip_streams[owner[b]]):
+            q = np.ascontiguousarray(np.asarray(c["q"], np.float32).reshape(4, 2))
+            bufs = (torch.empty((cap, 2), dtype=torch.float32, device="cuda"), torch.empty((cap, 3), dtype=torch.float64, device="cuda"),
+                    torch.empty(cap, dtype=torch.uint8, device="cuda"), torch.empty(3, dtype=torch.float32, device="cuda"),
+                    torch.empty(9, dtype=torch.float64, device="cuda"), torch.empty(1, dtype=torch.float64, device="cuda"),
+                    torch.empty(1, dtype=torch.int32, device="cuda"))
+            p, p3, vp, t0, R0, res0, n0 = bufs
+            rois = (C.c_int * 8)()
+            L.check(lib.vh_frame0_init(ws.handle, L.dptr(dev[b][0]), W, H, W, q.ctypes.data_as(L.f32p), ses.K64.ctypes.data_as(L.f64p), plate_w.ctypes.data_as(L.f64p),
+                                       int(roi_border[0]), int(roi_border[1]), int(max_corners), float(quality), int(block), float(harris_k), int(win), int(it),
+                                       float(eps), L.dptr(p), L.dptr(p3), L.dptr(vp), L.dptr(t0), L.dptr(R0), L.dptr(res0), L.dptr(n0), rois, L.stream_ptr()),
+                    "vh_frame0_init")
+            L.check(lib.vh_session_init_dev(ses.handle, slot[b], L.dptr(dev[b][0]), W, L.dptr(p), L.dptr(p3), L.dptr(vp), L.dptr(t0), L.dptr(res0), L.dptr(n0),
+                                            float(times[b, 0]), float(fnos[b, 0]), L.stream_ptr()), "vh_session_init_dev")
+            ses._keep[slot[b]] = dev[b][0]
         keep.append((bufs, tuple(rois)))
     t_loop = _time.perf_counter()
     for i in range(1, n):
-        ses.step([dev[b][i] for b in range(nclip)], time_s=times[:, i], frame_no=fnos[:, i])
+        for g in range(G):
+            with torch.cuda.stream(hip_streams[g]):
+                sess[g].step([dev[b][i] for b in members[g]], time_s=times[members[g], i], frame_no=fnos[members[g], i])
     torch.cuda.synchronize()
     loop_seconds = _time.perf_counter() - t_loop
     seconds = _time.perf_counter() - t_begin
     results = []
     for b, c in enumerate(clips):
-        st = ses.state(b)
+        st = sess[owner[b]].state(slot[b])
         (p, p3, vp, t0, R0, res0, n0), rois = keep[b]
         k = int(n0.item())
         S = st["S"].copy()
@@ -434,7 +463,7 @@ def run_sequences(clips, K, plate="Chile", roi_border=(700, 500), max_corners=10
                 out(ln)
         results.append(dict(S=S, B=st["B"], P=st["P"][:, :k, :], vg=st["vg"][:k], vp=st["vp"][:k], p=st["p"], p3=st["p3"][:k], ids=st["ids"], n_tracks0=k,
                             t0=t0.cpu().numpy(), R0=R0.cpu().numpy().reshape(3, 3), res0=float(res0.item()), boxa=rois[0:4], boxb=rois[4:8],
-                            klt_flags=st["klt_flags"], lines=lines, seconds=seconds, ms_per_frame=1e3 * loop_seconds / (n - 1)))
+                            klt_flags=st["klt_flags"], lines=lines, seconds=seconds, ms_per_frame=1e3 * loop_seconds / (n - 1), sessions=G))
     return results
 
 
