@@ -113,7 +113,7 @@ def compact_line(out, detail_path=None):
         def g(leg, key):
             v = ex.get(leg)
             return v.get(key) if isinstance(v, dict) else None
-        e = dict(hard_scene_fps=g("hard_scene", "value"), hard_scene_vs_headline=g("hard_scene", "vs_headline"), real_texture_fps=g("real_texture", "value"),
+        e = dict(hard_scene_fps=g("hard_scene", "value"), hard_scene_vs_headline=g("hard_scene", "vs_headline"), hard_scene_vs_single_session=g("hard_scene", "vs_single_session"), real_texture_fps=g("real_texture", "value"),
                  single_stream_ms=g("single_stream", "ms_per_step"), drop_in_ms=g("drop_in_route", "ms_per_frame"), ref_params_fps=g("ref_params", "value"),
                  single_session_fps=g("single_session", "value"), c3_fps=g("other_config", "value"), c3_cpu_fps=(ex.get("other_config") or {}).get("cpu_baseline", {}).get("value") if isinstance(ex.get("other_config"), dict) else None,
                  all_bit_exact=_all_verified(ex), errors=[k for k, v in ex.items() if isinstance(v, dict) and "error" in v] or None)
@@ -647,6 +647,9 @@ def main():
             # the load that looks like the reference's data: both at the headline's stream count and at 8 streams
             stamp("leg hard_scene ...")
             legs["hard_scene"] = episode_leg(a, "hard_scene", S, dev, headline_fps=out["value"])
+            if isinstance(legs.get("single_session"), dict) and legs["single_session"].get("value") and "value" in legs["hard_scene"]:
+                # like with like: the episode legs run ONE session, so the ratio that says what the harder scene costs is against the one-session rate
+                legs["hard_scene"]["vs_single_session"] = round(legs["hard_scene"]["value"] / legs["single_session"]["value"], 4)
             stamp("leg hard_scene_8 ...")
             legs["hard_scene_8"] = episode_leg(a, "hard_scene", 8, dev)
             stamp("leg real_texture ...")

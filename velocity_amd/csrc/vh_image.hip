@@ -468,17 +468,29 @@ __device__ __forceinline__ void rw_thread(const WarpJob& J, const ImgDesc& s, in
 }
 
 #define RW_LOOP 1  // row groups a thread walks one after the other (4: 533 us against 483 -- the loop serialises the load round trips; wave start-up is not the cost)
-__global__ __launch_bounds__(256) void k_roi_warp(const void* job_tab, size_t tab_stride)
+__global__ __launch_bounds__(256) void k_roi_warp(const void* job_tab, size_t tab_stride, int xcd_bands)
 {
     // (an XCD-contiguous block remap measured 478 -> 628 us here: the dispatcher's round robin spreads every ROI over all channels)
     const WarpJob J = *reinterpret_cast<const WarpJob*>(reinterpret_cast<const char*>(job_tab) + (size_t)blockIdx.z * tab_stride);
     if (J.mode < 0) return;
     const int rw = J.x1 - J.x0, rh = J.y1 - J.y0;
-    const int x8 = (int)(blockIdx.x * blockDim.x + threadIdx.x) * RW_PX;
+    // EXPERIMENT SWITCH (VH_RW_XCD=1, off by default; round 6): XCD-aware tile order.  A workgroup's 128-px tile row is one 128-byte line only when the
+    // source column is line aligned; an ROI starts at any column, so nearly every tile row straddles two lines and shares each with its left / right
+    // neighbour -- and the dispatcher deals consecutive workgroups (x fastest) round-robin to the 8 XCDs, so the two workgroups that share a line sit on
+    // different L2s and both fetch it from the fabric.  With xcd_bands the linear workgroup id L (gridDim.y padded to a multiple of 8: L mod 8 is the XCD)
+    // is re-indexed so that XCD q walks tile row band 8 m + q from left to right.  Measured: the fabric reads fall as predicted,
+    // the kernel gets SLOWER -- it is latency / issue bound, not traffic bound -- so the natural order stays the default.
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (xcd_bands) {
+        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, k = L >> 3, band = k / gridDim.x;
+        bx = k - band * gridDim.x;
+        by = band * 8u + (L & 7u);
+    }
+    const int x8 = (int)(bx * blockDim.x + threadIdx.x) * RW_PX;
     if (x8 >= rw) return;
     const ImgDesc s = J.src;
     // consecutive rows of a block stay adjacent (threadIdx.y), the RW_LOOP passes of a block are blockDim.y * RW_ROWS rows apart
-    const int yb = (int)blockIdx.y * (int)blockDim.y * RW_ROWS * RW_LOOP + (int)threadIdx.y * RW_ROWS;
+    const int yb = (int)by * (int)blockDim.y * RW_ROWS * RW_LOOP + (int)threadIdx.y * RW_ROWS;
     if (yb >= rh) return;
 #pragma unroll 1
     for (int l = 0; l < RW_LOOP; l++) rw_thread(J, s, rw, rh, x8, yb + l * (int)blockDim.y * RW_ROWS);
@@ -659,6 +671,8 @@ void vh_launch_roi_warp(const void* job_tab, size_t tab_stride, int batch, int m
     // the next INSIDE the wavefront (one L1 fetch instead of two) and the last column of workgroups idles 28 of 1636 pixels instead of 412.  Measured at
     // 256 streams (A/B on one box): 64 x 4 threads (one 512-pixel row per wavefront) 370 us, 32 x 8 375, 16 x 16 301, 16 x 8 292-302, 8 x 32 305
     const dim3 blk(16, 16);
-    const dim3 grd((max_w + blk.x * RW_PX - 1) / (blk.x * RW_PX), (max_h + blk.y * RW_ROWS * RW_LOOP - 1) / (blk.y * RW_ROWS * RW_LOOP), batch);
-    hipLaunchKernelGGL(k_roi_warp, grd, blk, 0, s, job_tab, tab_stride);
+    static const int xcd_bands = getenv("VH_RW_XCD") ? atoi(getenv("VH_RW_XCD")) : 0;  // (environment: experiments only; see the kernel)
+    const unsigned rows = (max_h + blk.y * RW_ROWS * RW_LOOP - 1) / (blk.y * RW_ROWS * RW_LOOP);
+    const dim3 grd((max_w + blk.x * RW_PX - 1) / (blk.x * RW_PX), xcd_bands ? (rows + 7u) & ~7u : rows, batch);  // (padded rows: workgroups beyond the ROI leave at once)
+    hipLaunchKernelGGL(k_roi_warp, grd, blk, 0, s, job_tab, tab_stride, xcd_bands);
 }
