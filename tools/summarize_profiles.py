@@ -276,7 +276,7 @@ hb = rf["hbm"]
 o.append(f"HBM traffic of that kernel (`profiles/{tag}_hbm_traffic.json`, separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes at {traffic['streams']} streams, "
          f"FETCH_SIZE doubled per MI355X_MICROARCH.md): {(2 * kk['fetch_kib'] + kk['write_kib']) * 1024 / traffic['streams'] / 1e6:.1f} MB per stream and launch vs "
          f"22.05 MB algorithmic gather bytes; `roofline.hbm.achieved` = {hb['achieved']} GB/s of gather bytes ({100 * hb['frac']:.1f} % of 8 TB/s) - the kernel is VALU "
-         f"bound (`roofline.bound = valu`): {ksq.get('valu_insts_per_wave', 0):.0f} VALU instructions per wavefront (a wavefront solves {rf['setups_per_launch'] / 2 / max(ksq.get('SQ_WAVES', 0), 1):.0f} tracks, both directions each) in the PMC pass, "
+         f"bound (`roofline.bound = valu`): {ksq.get('valu_insts_per_wave', 0):.0f} VALU instructions per wavefront (a wavefront solves {rf['setups_per_launch'] * S / rf.get('streams_per_launch', S) / 2 / max(ksq.get('SQ_WAVES', 0), 1):.0f} tracks, both directions each) in the PMC pass (one session of {S} streams per launch), "
          f"{64e-9 * ksq.get('SQ_INSTS_VALU', 0):.1f} G lane-instructions per launch; the bench line derives the same figure LIVE from the kernel's own counters "
          f"({rf['setups_per_launch']} set-ups, {rf['newton_iters_per_launch']} Newton iterations per launch) through the calibrated costs of "
          f"`profiles/{tag}_lk_valu_model.json`: {rf['issued_ginstr_per_launch']} G = {rf['achieved']} T/s of the {rf['peak']} T lane-instruction/s the guide's SIMD-32 "
