@@ -156,3 +156,19 @@ def test_ctypes_structs_have_the_size_of_the_c_structs(tmp_path):
     subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
     a, b, c = (int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
     assert (a, b, c) == (C.sizeof(_lib.LKParams), C.sizeof(_lib.KltStages), C.sizeof(_lib.SessionView))
+
+
+def test_session_groups_rule_and_product_has_no_dropin_loop():
+    """driver.session_groups: how many sessions (HIP streams) resident streams are split into -- always a divisor of the stream count,
+    1 for a single stream, never 8; and the product's driver no longer carries the host loop on the drop-in functions (tools/dropin_loop.py has it)."""
+    from velocity_amd import driver
+
+    assert [driver.session_groups(s) for s in (1, 2, 3, 4, 8, 16, 32, 48, 64, 128, 256, 255)] == [1, 2, 1, 2, 4, 4, 4, 4, 2, 2, 2, 1]
+    assert all(s % driver.session_groups(s) == 0 for s in range(1, 600))
+    assert not hasattr(driver, "_run_dropin")
+    src = open(driver.__file__).read()
+    assert "def _run_dropin" not in src and "vg[vg] = v" not in src
+    import pytest
+
+    with pytest.raises(ValueError, match="dropin_loop"):
+        driver.run_sequence([None, None], [[0, 0]] * 4, None, fps=30.0, route="dropin", out=None)
