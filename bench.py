@@ -113,7 +113,7 @@ def compact_line(out, detail_path=None):
         def g(leg, key):
             v = ex.get(leg)
             return v.get(key) if isinstance(v, dict) else None
-        e = dict(hard_scene_fps=g("hard_scene", "value"), hard_scene_vs_headline=g("hard_scene", "vs_headline"), hard_scene_vs_single_session=g("hard_scene", "vs_single_session"), real_texture_fps=g("real_texture", "value"),
+        e = dict(hard_scene_fps=g("hard_scene", "value"), hard_scene_vs_headline=g("hard_scene", "vs_headline"), real_texture_fps=g("real_texture", "value"),
                  single_stream_ms=g("single_stream", "ms_per_step"), drop_in_ms=g("drop_in_route", "ms_per_frame"), ref_params_fps=g("ref_params", "value"),
                  single_session_fps=g("single_session", "value"), c3_fps=g("other_config", "value"), c3_cpu_fps=(ex.get("other_config") or {}).get("cpu_baseline", {}).get("value") if isinstance(ex.get("other_config"), dict) else None,
                  all_bit_exact=_all_verified(ex), errors=[k for k, v in ex.items() if isinstance(v, dict) and "error" in v] or None)
@@ -170,12 +170,12 @@ def host_cores():
     return n
 
 
-def auto_groups(S, host_frames=False):
+def auto_groups(S, host_frames=False, tracks=2000):
     """Sessions (HIP streams) the resident streams of one GPU are split into: the library's own rule (velocity_amd.driver.session_groups, where the
     measurements behind it are listed); the PCIe-inclusive mode is measured with one session."""
     from velocity_amd.driver import session_groups
 
-    return 1 if host_frames else session_groups(S)
+    return 1 if host_frames else session_groups(S, tracks)
 
 
 def parse():
@@ -399,7 +399,7 @@ def verify_episode(wl, nframes=3, which=None):
                 orcs[b].step(wl.frames[wl.frame_index(b, e, j)].cpu().numpy(), np.float32(wl.time_of(j)), j)
         for b in which:
             o = orcs.get(b, next(iter(orcs.values())))
-            st = wl.session.state(b)
+            st = wl.state(b)
             same, dt, dres = _compare(st, o, ids0)
             res["ok"] = res["ok"] and same
             if o.vp.sum() >= 3:
@@ -432,7 +432,7 @@ def extra_leg(a, cfg_key, params, scene, streams, steps, warmup, dev, track_orde
             a = copy.copy(a)
             a.track_order = track_order
         wl = Workload(a, CONFIGS[cfg_key], params, scene, streams, steps, warmup, dev, rank=0, groups=groups if groups else (a.groups if (streams == a.streams or not getattr(a, "groups_auto", False)) and streams % max(a.groups, 1) == 0
-                                                   else auto_groups(streams)))
+                                                   else auto_groups(streams, False, CONFIGS[cfg_key]["n"])))
         m = wl.measure(steps, warmup, 1.0, torch.cuda.synchronize, lambda t: t)
         fps = wl.S * m["timed_steps"] / m["elapsed"]
         out = dict(workload=f"{cfg_key} / params {params} / scene {scene}" + (f" / tracks {track_order}" if track_order else ""), streams=streams, value=round(fps, 2),
@@ -459,12 +459,13 @@ def episode_leg(a, kind, streams, dev, headline_fps=None):
     """The hard scene / the reference's real stills as short clips (benchlib.workload.EpisodeWorkload): frames/s, Newton iterations per set-up and stage,
     tracks alive per frame of the clip, per-kernel microseconds, the VALU fractions of the LK launches, and its own `verified`."""
     try:
-        wl = EpisodeWorkload(kind, a, streams, dev)
+        wl = EpisodeWorkload(kind, a, streams, dev, groups=(a.groups if a.groups > 0 and not getattr(a, "groups_auto", False) and streams % a.groups == 0 else 0))
         m = wl.measure(min_seconds=1.0)
         fps = wl.S * m["timed_steps"] / m["elapsed"]
         r = roofline_of(wl, m, 1)
         coarse = [k for k in r["kernels"] if k["kernel"].startswith("k_lk")]
         out = dict(workload=wl.cfg["name"] + f"; clips of {wl.E} tracked frames, every stream re-initialised (untimed) between clips", streams=streams,
+                   stream_groups=wl.G,
                    value=round(fps, 2), unit="frames/s", ms_per_step=round(1e3 * m["elapsed"] / m["timed_steps"], 4), timed_steps=m["timed_steps"],
                    episodes=m["episodes"], tracks=wl.N, tracks_alive_by_frame=m["alive_by_frame"],
                    tracks_alive_frac_end=round(m["alive_by_frame"][-1] / wl.N, 4),
@@ -557,7 +558,7 @@ def main():
         return
     S, N = a.streams, cfg["n"]
     if a.groups <= 0:
-        a.groups = auto_groups(S, a.host_frames)
+        a.groups = auto_groups(S, a.host_frames, cfg["n"])
         a.groups_auto = True
     wl = Workload(a, cfg, a.params, a.scene, S, a.steps, a.warmup, dev, rank, groups=a.groups, host_frames=a.host_frames)
     ex = vdist.TrackStateExchange(S, N, every=a.exchange_every, device=dev) if use_dist else None
@@ -647,9 +648,6 @@ def main():
             # the load that looks like the reference's data: both at the headline's stream count and at 8 streams
             stamp("leg hard_scene ...")
             legs["hard_scene"] = episode_leg(a, "hard_scene", S, dev, headline_fps=out["value"])
-            if isinstance(legs.get("single_session"), dict) and legs["single_session"].get("value") and "value" in legs["hard_scene"]:
-                # like with like: the episode legs run ONE session, so the ratio that says what the harder scene costs is against the one-session rate
-                legs["hard_scene"]["vs_single_session"] = round(legs["hard_scene"]["value"] / legs["single_session"]["value"], 4)
             stamp("leg hard_scene_8 ...")
             legs["hard_scene_8"] = episode_leg(a, "hard_scene", 8, dev)
             stamp("leg real_texture ...")

@@ -192,10 +192,10 @@ class EpisodeWorkload:
       kind "real_texture": the reference's real stills (tests/golden/stills_gray.npz sequence B: 7 frames at 1024 x 768), Harris + cornerSubPix tracks
                            and the plate pose from vh_frame0_init, the reference's own LK parameters and its fcnMSV1_t at frame 5."""
 
-    def __init__(self, kind, a, streams, dev, episode=None):
+    def __init__(self, kind, a, streams, dev, episode=None, groups=0):
         from velocity_amd import _lib as L
         from velocity_amd import synth
-        from velocity_amd.driver import TrackerSession
+        from velocity_amd.driver import TrackerSession, session_groups
 
         self.kind, self.a, self.S, self.dev = kind, a, streams, dev
         S = streams
@@ -252,9 +252,14 @@ class EpisodeWorkload:
             self.fps = None
         else:
             raise ValueError(kind)
-        self.N, self.W, self.H, self.SG, self.G = N, W, H, S, 1
-        self.session = TrackerSession(self.K, W, H, N, nhist=self.E + 2, batch=S, lk_coarse=self.lkc, lk_fine=self.lkf, msv_frame=self.msv_frame)
-        self.sessions = [self.session]
+        # the streams run as G sessions on G HIP streams like the headline's (driver.session_groups; 0 = that rule)
+        G = groups if groups and groups > 0 else session_groups(S, N)
+        G = G if S % G == 0 else 1
+        self.N, self.W, self.H, self.SG, self.G = N, W, H, S // G, G
+        self.sessions = [TrackerSession(self.K, W, H, N, nhist=self.E + 2, batch=self.SG, lk_coarse=self.lkc, lk_fine=self.lkf, msv_frame=self.msv_frame)
+                         for _ in range(G)]
+        self.session = self.sessions[0]
+        self.hip_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(G - 1)]
         base, fbytes, ring = self.frames.data_ptr(), W * H, self.ring
         # tables[j][b] = pointer to frame (clip start + j) of stream b, for every clip start this workload uses
         self.episodes = 0
@@ -285,12 +290,16 @@ class EpisodeWorkload:
             self._tab_cache[key] = t.to(self.dev)
         return self._tab_cache[key]
 
+    def state(self, b):
+        """Host copy of stream b's tracker state (whichever session holds it)."""
+        return self.sessions[b // self.SG].state(b % self.SG)
+
     def init_episode(self, e):
-        ses = self.session
         for b in range(self.S):
             f = self.start_index(b, e) if self.kind == "hard_scene" else 0
-            ses.init_stream(b, self.frames[self.frame_index(b, e, 0)], self.p_ring[f], self.p3_ring[f], self.vp, self.t0, time0=self.time_of(0),
-                            res0=getattr(self, "res0", 0.0))
+            with torch.cuda.stream(self.hip_streams[b // self.SG]):
+                self.sessions[b // self.SG].init_stream(b % self.SG, self.frames[self.frame_index(b, e, 0)], self.p_ring[f], self.p3_ring[f], self.vp, self.t0,
+                                                        time0=self.time_of(0), res0=getattr(self, "res0", 0.0))
 
     def run_episode(self, e, sync_each=None):
         """E tracked frames for every stream; returns the wall time between the two synchronisations."""
@@ -299,7 +308,9 @@ class EpisodeWorkload:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for j in range(1, self.E + 1):
-            self.session.step(frames_table=tabs[j], time_s=self.time_of(j), frame_no=float(j))
+            for g in range(self.G):
+                with torch.cuda.stream(self.hip_streams[g]):
+                    self.sessions[g].step(frames_table=tabs[j][g * self.SG:(g + 1) * self.SG], time_s=self.time_of(j), frame_no=float(j))
             if sync_each is not None:
                 torch.cuda.synchronize()
                 sync_each(j)
@@ -312,7 +323,7 @@ class EpisodeWorkload:
         ses = self.session
         for e in range(warm_episodes):
             self.run_episode(e)
-        L.check(ses.lib.vh_profile_detail(ses.ws.handle, 1 if self.N * self.S >= 3000 else 0), "vh_profile_detail")
+        L.check(ses.lib.vh_profile_detail(ses.ws.handle, 1 if self.N * self.SG >= 3000 else 0), "vh_profile_detail")
         est = max_episodes * self.E
         L.check(ses.lib.vh_profile_begin(ses.ws.handle, 40 * est + 64), "vh_profile_begin")
         elapsed, eps, e = 0.0, 0, warm_episodes
@@ -325,11 +336,11 @@ class EpisodeWorkload:
         L.check(ses.lib.vh_profile_end(ses.ws.handle, prof["ms_sum"], prof["launches"], prof["iters"], prof["setups"]), "vh_profile_end")
         stage_ms, stage_n = (C.c_double * 16)(), (C.c_int * 16)()
         L.check(ses.lib.vh_profile_end_stages(ses.ws.handle, 16, stage_ms, stage_n), "vh_profile_end_stages")
-        rois = np.zeros((self.S, 4), np.int32)
+        rois = np.zeros((self.SG, 4), np.int32)
         L.check(ses.lib.vh_klt_rois(ses.ws.handle, rois.ctypes.data_as(L.i32p)), "vh_klt_rois")
         # tracks alive per frame of the clip (S column 2 = vg.sum(), vidExample.py:164), mean over a few streams of the last episode
         pick = sorted(set([0, self.S // 3, (2 * self.S) // 3, self.S - 1]))
-        tab = np.stack([ses.state(b)["S"][: self.E + 1, 2] for b in pick])
+        tab = np.stack([self.state(b)["S"][: self.E + 1, 2] for b in pick])
         steps = eps * self.E
         routes, names = (C.c_int * 3)(), C.create_string_buffer(96)
         L.check(ses.lib.vh_profile_lk_routes(ses.ws.handle, routes, names), "vh_profile_lk_routes")

@@ -165,6 +165,7 @@ def test_session_groups_rule_and_product_has_no_dropin_loop():
 
     assert [driver.session_groups(s) for s in (1, 2, 3, 4, 8, 16, 32, 48, 64, 128, 256, 255)] == [1, 2, 1, 2, 4, 4, 4, 4, 2, 2, 2, 1]
     assert all(s % driver.session_groups(s) == 0 for s in range(1, 600))
+    assert driver.session_groups(8, 278) == 1 and driver.session_groups(256, 278) == 2 and driver.session_groups(16, 278) == 2 and driver.session_groups(2, 500) == 1
     assert not hasattr(driver, "_run_dropin")
     src = open(driver.__file__).read()
     assert "def _run_dropin" not in src and "vg[vg] = v" not in src

@@ -372,15 +372,20 @@ def _run_session(frames, q, K, times, frame_numbers, plate, roi_border, max_corn
                 loop_seconds=loop_seconds, klt_flags=st["klt_flags"])
 
 
-def session_groups(streams):
-    """How many TrackerSessions (each on its own HIP stream) to split `streams` resident video streams of one GPU into.  The stages of a frame step that run
-    ONE workgroup per stream (RANSAC, bookkeeping + pose, the glue kernels) leave the chip nearly idle; with a second session on another HIP stream they run
-    while that session's LK launches fill it.  Measured on one MI355X, C2 streams, frames/s with 1 / 2 / 4 sessions: 2 streams 8.4 / 8.9 k, 4: 14.0 / 15.1 /
-    15.0 k, 8: 20.4 / 22.4 / 23.6 k, 16: 28.5 / 30.6 / 31.3 k, 32: 35.0 / 37.7 / 38.1 k, 64: 40.4 / 41.9 / 41.3 k, 128: - / 44.8 / 43.6 k, 256: 44.5 / 45.7 /
-    45.7 k; 8 sessions lose everywhere (a session of one or two streams falls back to the one-track-per-wavefront kernels)."""
+def session_groups(streams, tracks=2000):
+    """How many TrackerSessions (each on its own HIP stream) to split `streams` resident video streams of ~`tracks` tracks each into.  The stages of a frame
+    step that run ONE workgroup per stream (RANSAC, bookkeeping + pose, the glue kernels) leave the chip nearly idle; with a second session on another HIP
+    stream they run while that session's LK launches fill it.  Measured on one MI355X, C2 streams (2000 tracks), frames/s with 1 / 2 / 4 sessions: 2 streams 8.4 /
+    8.9 k, 4: 14.0 / 15.1 / 15.0 k, 8: 20.4 / 22.4 / 23.6 k, 16: 28.5 / 30.6 / 31.3 k, 32: 35.0 / 37.7 / 38.1 k, 64: 40.4 / 41.9 / 41.3 k, 128: - / 44.8 / 43.6 k,
+    256: 44.5 / 45.7 / 45.7 k; 8 sessions lose everywhere (a session of one or two streams falls back to the one-track-per-wavefront kernels).  A session
+    needs enough tracks for the batched kernels: 8 streams of the real stills (278 tracks) LOSE 13 % as four sessions (19.8 -> 17.2 k), so the count is halved
+    until a session holds at least 2000 tracks."""
     if streams < 2:
         return 1
-    return 4 if (8 <= streams < 64 and streams % 4 == 0) else (2 if streams % 2 == 0 else 1)
+    g = 4 if (8 <= streams < 64 and streams % 4 == 0) else (2 if streams % 2 == 0 else 1)
+    while g > 1 and (streams // g) * max(int(tracks), 1) < 2000:
+        g //= 2
+    return g
 
 
 def run_sequences(clips, K, plate="Chile", roi_border=(700, 500), max_corners=1000, quality=0.01, block=5, harris_k=0.04, subpix=(5, 100, 0.001),
@@ -402,7 +407,7 @@ def run_sequences(clips, K, plate="Chile", roi_border=(700, 500), max_corners=10
     H, W = dev[0][0].shape
     assert all(len(d) == n and d[0].shape == (H, W) for d in dev), "clips must share frame size and length"
     cap = 4 + int(max_corners)
-    G = int(sessions) if sessions and sessions > 0 else session_groups(nclip)
+    G = int(sessions) if sessions and sessions > 0 else session_groups(nclip, max_corners)
     G = max(1, min(G, nclip))
     owner = [b * G // nclip for b in range(nclip)]                    # clip -> session (contiguous blocks)
     members = [[b for b in range(nclip) if owner[b] == g] for g in range(G)]
