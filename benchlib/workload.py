@@ -69,7 +69,9 @@ class Workload:
         self.G, self.SG = G, S // G
         SG = self.SG
         self.sessions = [TrackerSession(self.K, W, H, N, nhist=nhist, batch=SG, lk_coarse=self.lkc, lk_fine=self.lkf, msv_frame=0) for _ in range(G)]
-        self.hip_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(G - 1)]
+        from velocity_amd.driver import session_streams
+
+        self.hip_streams = session_streams(G)  # (a fixed set per process: see driver.session_streams)
         # streams of one texture set share its ring but run at different phases, so every launch sees S different frame pairs
         self.phase = [(7 * b) % a.ring for b in range(S)]
         fset = [0 if host_frames else b // a.ring for b in range(S)]
@@ -259,7 +261,9 @@ class EpisodeWorkload:
         self.sessions = [TrackerSession(self.K, W, H, N, nhist=self.E + 2, batch=self.SG, lk_coarse=self.lkc, lk_fine=self.lkf, msv_frame=self.msv_frame)
                          for _ in range(G)]
         self.session = self.sessions[0]
-        self.hip_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(G - 1)]
+        from velocity_amd.driver import session_streams
+
+        self.hip_streams = session_streams(G)
         base, fbytes, ring = self.frames.data_ptr(), W * H, self.ring
         # tables[j][b] = pointer to frame (clip start + j) of stream b, for every clip start this workload uses
         self.episodes = 0

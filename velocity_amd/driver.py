@@ -388,6 +388,22 @@ def session_groups(streams, tracks=2000):
     return g
 
 
+_SIDE_STREAMS = {}
+
+
+def session_streams(n):
+    """The HIP streams `n` concurrent sessions run on: torch's current stream + n - 1 side streams that are created ONCE per device and handed out again on
+    every call.  The runtime multiplexes HIP streams onto a few hardware queues (4 by default, GPU_MAX_HW_QUEUES); a process that keeps creating streams ends
+    up with two "concurrent" sessions on one queue -- measured: a two-session leg that ran after a dozen earlier streams had been created fell from 38.7 k to
+    36.2 k frames/s, a four-session one from 16.4 k to 11.0 k -- so the side streams are a fixed, small set."""
+    torch = L.torch_cuda()
+    dev = torch.cuda.current_device()
+    pool = _SIDE_STREAMS.setdefault(dev, [])
+    while len(pool) < n - 1:
+        pool.append(torch.cuda.Stream(device=dev))
+    return [torch.cuda.current_stream()] + pool[: max(n - 1, 0)]
+
+
 def run_sequences(clips, K, plate="Chile", roi_border=(700, 500), max_corners=1000, quality=0.01, block=5, harris_k=0.04, subpix=(5, 100, 0.001),
                   msv_frame=5, lk_coarse=None, lk_fine=None, out=None, sessions=0):
     """Many clips at once: the throughput form of run_sequence.  `clips` = list of dict(frames, q, times[, frame_numbers, name]) of ONE frame size and
@@ -412,8 +428,8 @@ def run_sequences(clips, K, plate="Chile", roi_border=(700, 500), max_corners=10
     owner = [b * G // nclip for b in range(nclip)]                    # clip -> session (contiguous blocks)
     members = [[b for b in range(nclip) if owner[b] == g] for g in range(G)]
     slot = {b: members[owner[b]].index(b) for b in range(nclip)}
-    main = torch.cuda.current_stream()
-    hip_streams = [main] + [torch.cuda.Stream() for _ in range(G - 1)]
+    hip_streams = session_streams(G)
+    main = hip_streams[0]
     for st_ in hip_streams[1:]:
         st_.wait_stream(main)  # the frame uploads above ran on the current stream
     sess = []
