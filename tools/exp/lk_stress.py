@@ -1,5 +1,5 @@
 """One-off stress of the LK kernels' bit-identity: many random frame sizes / windows / levels / criteria / point sets (incl. points outside the frame);
-every implementation (modes 1..7) must equal the default routing, and every `oracle_every`-th case the CPU oracle as well."""
+every implementation (modes 1..8, the slot loop of routes 3 / 5 at 2 / 3 / 4 / 8 slots) must equal the default routing, and every `oracle_every`-th case the CPU oracle as well."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -24,15 +24,18 @@ for case in range(ncases):
     fbt = [None, 1.0, 0.3][int(rng.integers(0, 3))]
     kw = dict(winSize=(win, win), maxLevel=lvl, criteria=(3, cnt, eps))
     ref = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=fbt, **kw)
-    for mode in (1, 2, 3, 4, 5, 6, 7):
+    # every route; the one-wavefront LDS-staged routes (3, 5) additionally with 2 / 3 / 4 / 8 launch slots per workgroup (vh_debug_lk3_tpw, round 6)
+    for mode, tpw in [(m_, 0) for m_ in (1, 2, 3, 4, 5, 6, 7, 8)] + [(m_, t_) for m_ in (3, 5) for t_ in (2, 3, 4, 8)]:
         L.load().vh_debug_force_generic_lk(mode)
+        L.load().vh_debug_lk3_tpw(tpw)
         try:
             got = cv2calcOpticalFlowPyrLK(f0, f1, pts, None, fbt=fbt, **kw)
         finally:
             L.load().vh_debug_force_generic_lk(0)
+            L.load().vh_debug_lk3_tpw(0)
         if not all(np.array_equal(a, b) for a, b in zip(ref, got)):
             bad += 1
-            print("MISMATCH mode", mode, (case, W, H, n, win, lvl, cnt, eps, fbt), flush=True)
+            print("MISMATCH mode", mode, "slots", tpw, (case, W, H, n, win, lvl, cnt, eps, fbt), flush=True)
     if case % oracle_every == 0:
         exp = KO.lk_fb(f0, f1, pts, fbt=fbt, win=win, max_level=lvl, max_count=cnt, eps=eps)
         if not (np.array_equal(ref[0], exp[0]) and np.array_equal(ref[1], exp[1]) and np.array_equal(ref[2].ravel(), exp[2])):
