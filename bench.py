@@ -9,15 +9,17 @@ frames already in HBM when the timed region starts.
 
 N > 1: one rank per GPU over RCCL, launched either by the driver through torch.distributed.run or -- when no torchrun
 environment is present -- by bench.py itself (self_launch); every rank tracks its own S streams (weak scaling, no
-data-path collective) and all-gathers the packed track state every 30 frames (config C4).  Rank 0 prints ONE JSON line.
+data-path collective) and all-gathers the packed track state every 30 frames (config C4).  The resident streams of a rank run as the sessions
+velocity_amd.driver.session_groups gives (two from 64 streams), each on its own HIP stream (--groups).
 
-The line carries, next to the contract's fields: `roofline` (dominant kernel, measured live with HIP events inside the
-library), `cpu_baseline` (the CPU port on all host cores AND on one core), `ba` (config 5: LM iterations/s of one window
-and of 8 / 64 batched windows, with its own structured-CPU baseline), and at N = 1 the `extras` legs: the HARD SCENE
-(noise, gain drift, moving foreground, textureless band: every KLTmain gate fires) and the reference's REAL STILLS, each
-at 256 and 8 streams; one stream alone (latency); the drop-in route (KLT.KLTmain + NLS.estimateWorldCameraPose per call);
-the reference's own LK parameters (utils/KLT.py:106-107); config C3 (4K / 5000 tracks); the camera-roll scene; shuffled
-track order.
+Rank 0 prints ONE compact JSON line on stdout (compact_line: <= 4096 bytes -- the driver keeps a bounded tail of stdout and a longer line does not parse)
+with the contract's fields, `roofline` (dominant kernel, measured live with HIP events inside the library), `cpu_baseline` (the CPU port on all host
+cores; the one-core figure beside it), `verified`, `build_id` and few-number summaries of `ba`, `extras` and `multi_gpu`.  The FULL record goes to the
+detail file (--detail, default bench_detail.json): `roofline_detail`, `ba` (config 5: LM iterations/s of one window and of 8 / 64 batched windows, with its
+own structured-CPU baseline and both roofline fractions), and at N = 1 the `extras` legs in full: the same streams as ONE session (per-kernel table with every
+kernel alone on the chip), the HARD SCENE (noise, gain drift, moving foreground, textureless band: every KLTmain gate fires) and the reference's REAL STILLS,
+each at 256 and 8 streams; one stream alone (latency); the drop-in route (KLT.KLTmain + NLS.estimateWorldCameraPose per call); the reference's own LK
+parameters (utils/KLT.py:106-107); config C3 (4K / 5000 tracks, with its own CPU baseline); the camera-roll scene; shuffled track order.
 
 Support code lives in benchlib/ (workloads, roofline objects, BA legs); everything that touches oracle/ -- the CPU
 baselines and the post-run parity attestation `verified` -- is in THIS file (the only bench code allowed to import it).
