@@ -374,15 +374,37 @@ __global__ __launch_bounds__(512) void k_ransac_fused(const void* tab, size_t st
     __shared__ long long s_red[7 * 8];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) base = 0;
-    __syncthreads();
-    for (int c = 0; c < n; c += 512) {
-        const int i = c + tid;
-        const bool f = i < n && J.valid[i] != 0;
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f) {
-            const float2 a = reinterpret_cast<const float2*>(J.from)[i], b = reinterpret_cast<const float2*>(J.to)[i];
-            q = make_float4(a.x, a.y, b.x, b.y);
+    // every chunk's loads are issued before the first barrier (round 6): the compaction was a chain of one global round trip PER 512-pair chunk (four at
+    // 2000 pairs: ~6 us of a 21 us single-stream launch); the chunks themselves are then compacted from registers in the same order as before
+    constexpr int NCH = RANSAC_FUSED_MAX / 512;
+    float4 qv[NCH];
+    unsigned fbits = 0;
+#pragma unroll
+    for (int j = 0; j < NCH; j++) qv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n > 0) {
+        // unconditional loads at a clamped index (a branch around a load serialises it behind the flag it depends on): flags and pairs of all chunks
+        // travel together
+        uint8_t fl[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            if (512 * j >= n) break;  // (uniform)
+            const int ic = min(512 * j + tid, n - 1);
+            fl[j] = J.valid[ic];
+            const float2 a = reinterpret_cast<const float2*>(J.from)[ic], b = reinterpret_cast<const float2*>(J.to)[ic];
+            qv[j] = make_float4(a.x, a.y, b.x, b.y);
         }
+#pragma unroll
+        for (int j = 0; j < NCH; j++) {
+            if (512 * j >= n) break;
+            if (512 * j + tid < n && fl[j] != 0) fbits |= 1u << j;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        if (512 * j >= n) break;  // (uniform)
+        const int i = 512 * j + tid;
+        const bool f = (fbits >> j) & 1u;
         const unsigned long long bal = __ballot(f);
         const int pre = __popcll(bal & ((1ull << lane) - 1ull));
         if (lane == 0) wcount[wave] = __popcll(bal);
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(512) void k_ransac_fused(const void* tab, size_t st
             off += w < wave ? cw : 0;
             tot += cw;
         }
-        if (f) { s_idx[off + pre] = i; s_pairs[off + pre] = q; }
+        if (f) { s_idx[off + pre] = i; s_pairs[off + pre] = qv[j]; }
         __syncthreads();
         if (tid == 0) base += tot;
         __syncthreads();
