@@ -59,4 +59,7 @@ void vh_launch_roi_warp(const void* job_tab, size_t tab_stride, int batch, int m
 int vh_launch_lk(const void* job_tab, size_t tab_stride, int batch, int max_n, int win, hipStream_t s, int* route_out = nullptr, int* tpw_out = nullptr);
 int vh_lk_route(int batch, int max_n, int win);           // the kernel such a launch takes (ids of vh_debug_force_generic_lk)
 const char* vh_lk_route_name(int route, int win);
-void vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s);
+struct StreamWS;
+// returns true when the glue that follows the call in KLTmain (glue = 1: stage 1 -> 2, 2: stage 2 -> 3; glue_ws = the streams' workspaces) ran as the
+// epilogue of the fused kernel, false when the caller has to launch it (no glue asked for, or the three-kernel path was taken)
+bool vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s, StreamWS* glue_ws = nullptr, int glue = 0);

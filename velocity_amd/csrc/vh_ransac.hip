@@ -6,6 +6,7 @@
 // fixed-point sums, so the result does not depend on reduction order.
 #include <atomic>
 #include "vh_kernels.hpp"
+#include "vh_glue_dev.hpp"
 
 #define RANSAC_THRESH2 9.0f
 #define RANSAC_CONF 0.99
@@ -361,7 +362,7 @@ __device__ bool ransac_hypothesis_lds(const float4* pairs, int m, uint32_t hyp, 
     return true;
 }
 
-__global__ __launch_bounds__(512) void k_ransac_fused(const void* tab, size_t stride)
+__device__ __forceinline__ void ransac_fused_body(const void* tab, size_t stride)
 {
     const RansacJob J = rjob(tab, stride, blockIdx.x);
     const int n = J.n_ptr ? *J.n_ptr : J.n;  // <= RANSAC_FUSED_MAX (the launcher routes larger problems to the three-kernel path)
@@ -552,33 +553,56 @@ __global__ __launch_bounds__(512) void k_ransac_fused(const void* tab, size_t st
     }
 }
 
+// GLUE: the KLTmain glue that follows this RANSAC (vh_glue_dev.hpp) runs as the epilogue of the same workgroup -- 1: stage 1 -> 2 (mean translation, ROI,
+// job descriptors, the rare shifted-crop copy), 2: stage 2 -> 3 (affine or fallback, remap job, fine-stage job); 0: stand-alone (vh_ransac_affine).  The
+// glue reads what the body wrote to global memory (status, model, the gated validity flags): a workgroup-scope fence and a barrier order the two.
+template <int GLUE>
+__global__ __launch_bounds__(512) void k_ransac_fused(const void* tab, size_t stride, StreamWS* ws_all)
+{
+    ransac_fused_body(tab, stride);
+    if constexpr (GLUE != 0) {
+        __threadfence_block();  // (the same workgroup wrote and reads: one CU, one vector L1 -- as k_sess_frame orders its three parts)
+        __syncthreads();
+        if constexpr (GLUE == 1) klt_glue1_body<512>(ws_all[blockIdx.x]);
+        else klt_glue2_body(ws_all[blockIdx.x]);
+    }
+}
+
 static std::atomic<int> g_ransac_force{0};  // PROCESS-WIDE test hook (include/velocity_hip.h): 1 = always the three-kernel path, 2 = the fused kernel whenever the problem fits it
 void vh_ransac_force_path(int mode) { g_ransac_force.store(mode, std::memory_order_relaxed); }
 
-void vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s)
+bool vh_launch_ransac(const void* job_tab, size_t tab_stride, int batch, int max_n, hipStream_t s, StreamWS* glue_ws, int glue)
 {
     // up to RANSAC_FUSED_MAX pairs: one fused workgroup per stream, pairs / indices / counts resident in LDS (measured faster than the three
     // launches at every stream count, 1 .. 256: 4.53 -> 4.48 ms per step at 128 streams); more pairs: hypotheses spread over the chip
     const int force = g_ransac_force.load(std::memory_order_relaxed);
     if (max_n <= RANSAC_FUSED_MAX && (force == 2 || force == 0)) {
         const size_t lds = (size_t)RANSAC_FUSED_MAX * (16 + 4) + (size_t)VH_RANSAC_ITERS * 4;
-        // 69 KB of dynamic LDS (> the 64 KB default limit): the attribute is per device; 0 = not tried, 1 = granted, -1 = refused (three-kernel path)
+        // 69 KB of dynamic LDS (> the 64 KB default limit): the attribute is per function AND per device; 0 = not tried, 1 = granted, -1 = refused
+        // (three-kernel path)
         static std::atomic<signed char> attr_state[64];
         int dev = 0;
         (void)hipGetDevice(&dev);
         dev = dev < 0 || dev >= 64 ? 0 : dev;
         signed char st = attr_state[dev].load(std::memory_order_acquire);
         if (st == 0) {
-            st = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ransac_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 1 : -1;
+            st = 1;
+            for (const void* f : {reinterpret_cast<const void*>(k_ransac_fused<0>), reinterpret_cast<const void*>(k_ransac_fused<1>),
+                                  reinterpret_cast<const void*>(k_ransac_fused<2>)})
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) st = -1;
             if (st < 0) (void)hipGetLastError();  // refused: forget the error, the three launches below serve every size
             attr_state[dev].store(st, std::memory_order_release);
         }
         if (st > 0) {
-            hipLaunchKernelGGL(k_ransac_fused, dim3(batch), dim3(512), lds, s, job_tab, tab_stride);
-            return;
+            const int g = glue_ws ? glue : 0;
+            if (g == 1) hipLaunchKernelGGL(k_ransac_fused<1>, dim3(batch), dim3(512), lds, s, job_tab, tab_stride, glue_ws);
+            else if (g == 2) hipLaunchKernelGGL(k_ransac_fused<2>, dim3(batch), dim3(512), lds, s, job_tab, tab_stride, glue_ws);
+            else hipLaunchKernelGGL(k_ransac_fused<0>, dim3(batch), dim3(512), lds, s, job_tab, tab_stride, glue_ws);
+            return g != 0;
         }
     }
     hipLaunchKernelGGL(k_ransac_compact, dim3(batch), dim3(1024), 0, s, job_tab, tab_stride);
     hipLaunchKernelGGL(k_ransac_score, dim3((VH_RANSAC_ITERS + 3) / 4, batch), dim3(256), 0, s, job_tab, tab_stride);
     hipLaunchKernelGGL(k_ransac_select, dim3(batch), dim3(256), 0, s, job_tab, tab_stride);
+    return false;
 }
