@@ -97,15 +97,33 @@ __device__ __forceinline__ int vh_floor(float v) { return (int)floorf(v); }
 __device__ __forceinline__ int vh_round(float v) { return __float2int_rn(v); }  // round-half-even (cvRound)
 __device__ __forceinline__ int vh_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
+// Exact integer sums over the 64 lanes, uniform result.  DPP row reductions (quad_perm, quad_perm, row_half_mirror, row_mirror: after four adds every lane
+// holds its 16-lane row's total) + one v_readlane per row: ~25 / ~45 instructions and no LDS round trip, where the six-step __shfl_xor butterfly of rounds
+// 1-5 cost 6 (12 for int64) dependent ds_bpermute round trips -- 3.9 us for the seven sums of the RANSAC refit in a single-stream launch (round 6, in-kernel
+// stamps).  Integer addition is associative: bit-identical to any other order.
+template <int CTRL>
+__device__ __forceinline__ int vh_dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 __device__ __forceinline__ long long vh_wave_sum_i64(long long v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        int lo = __shfl_xor((int)(v & 0xffffffffll), o, 64);
-        int hi = __shfl_xor((int)(v >> 32), o, 64);
-        v += ((long long)hi << 32) | (unsigned int)lo;
+#define VH_I64_DPP_STEP(ctrl)                                                                                                     \
+    {                                                                                                                             \
+        const unsigned lo = (unsigned)vh_dpp_i32<ctrl>((int)(unsigned)(unsigned long long)v);                                     \
+        const unsigned hi = (unsigned)vh_dpp_i32<ctrl>((int)(unsigned)((unsigned long long)v >> 32));                             \
+        v += (long long)(((unsigned long long)hi << 32) | lo);                                                                    \
     }
-    return v;
+    VH_I64_DPP_STEP(0xB1)   // quad_perm [1,0,3,2]
+    VH_I64_DPP_STEP(0x4E)   // quad_perm [2,3,0,1]
+    VH_I64_DPP_STEP(0x141)  // row_half_mirror
+    VH_I64_DPP_STEP(0x140)  // row_mirror
+#undef VH_I64_DPP_STEP
+    long long t = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, 16 * r);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), 16 * r);
+        t += (long long)(((unsigned long long)hi << 32) | lo);
+    }
+    return t;
 }
 __device__ __forceinline__ double vh_wave_sum_f64(double v)
 {
@@ -115,9 +133,11 @@ __device__ __forceinline__ double vh_wave_sum_f64(double v)
 }
 __device__ __forceinline__ int vh_wave_sum_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += vh_dpp_i32<0xB1>(v);
+    v += vh_dpp_i32<0x4E>(v);
+    v += vh_dpp_i32<0x141>(v);
+    v += vh_dpp_i32<0x140>(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
 // fixed-point conversion used by every order-independent reduction: round-half-even of v * 2^bits

@@ -426,8 +426,12 @@ __device__ __forceinline__ void ransac_fused_body(const void* tab, size_t stride
     if (tid == 0) { *J.m_out = m; s_bound = VH_RANSAC_ITERS; }
     __syncthreads();
     const bool run = m >= 3 && m > J.min_valid;
+    // Eight hypotheses per round (one wavefront each); after EVERY round thread 0 continues the sequential selection rule (cv::RANSAC's adaptive iteration
+    // count, as k_ransac_select) over the hypotheses scored so far and publishes the count it has shrunk to: the loop ends as soon as every reachable
+    // hypothesis is scored.  (Round 5 scored a fixed head of 16 before it looked: on a clean scene hypothesis 0 already ends the search, and the second
+    // round was 4.5 of the launch's 20 us -- in-kernel stamps, round 6.)  Same hypotheses, same counts, same rule: bit-identical results.
+    int r_best = -1, best_count = 0, niters = VH_RANSAC_ITERS, it_cur = 0;  // (thread 0's replay state, carried across the rounds)
     if (run) {
-        // the head of 16 hypotheses, then the rest of the reachable ones, 8 per round (one wavefront each)
         for (int h0 = 0; h0 < s_bound; h0 += 8) {
             const int hyp = h0 + wave;
             if (hyp < VH_RANSAC_ITERS) {
@@ -437,11 +441,11 @@ __device__ __forceinline__ void ransac_fused_body(const void* tab, size_t stride
                 if (lane == 0) s_counts[hyp] = c;
             }
             __syncthreads();
-            if (h0 == RANSAC_HEAD - 8 && tid == 0) {  // bound of the reachable hypotheses after the head (as k_ransac_compact)
-                int best_count = 0, niters = VH_RANSAC_ITERS;
-                for (int it = 0; it < RANSAC_HEAD && it < niters; it++) {
-                    const int c = s_counts[it];
+            if (tid == 0) {
+                for (; it_cur < h0 + 8 && it_cur < niters; it_cur++) {
+                    const int c = s_counts[it_cur];
                     if (c > max(best_count, 2)) {
+                        r_best = it_cur;
                         best_count = c;
                         niters = ransac_update_iters(RANSAC_CONF, __ddiv_rn((double)(m - c), (double)m), niters);
                     }
@@ -451,26 +455,13 @@ __device__ __forceinline__ void ransac_fused_body(const void* tab, size_t stride
             __syncthreads();
         }
     }
-    // sequential selection rule (as k_ransac_select)
     if (tid == 0) {
-        int best = -1, best_count = 0;
-        if (run) {
-            int niters = VH_RANSAC_ITERS;
-            for (int it = 0; it < niters; it++) {
-                const int c = s_counts[it];
-                if (c > max(best_count, 2)) {
-                    best = it;
-                    best_count = c;
-                    niters = ransac_update_iters(RANSAC_CONF, __ddiv_rn((double)(m - c), (double)m), niters);
-                }
-            }
-        }
-        s_best = best;
+        s_best = r_best;
         s_count = best_count;
         *J.bound = s_bound;
-        if (best >= 0) {
+        if (r_best >= 0) {
             double M[6];
-            ransac_hypothesis_lds(s_pairs, m, (uint32_t)best, M);
+            ransac_hypothesis_lds(s_pairs, m, (uint32_t)r_best, M);
             for (int k = 0; k < 6; k++) s_M[k] = M[k];
         }
     }
